@@ -1,0 +1,76 @@
+"""ORACLE (test infrastructure only): one distillation step on the CPU.
+
+Restates `ModelWithNMSLoss(.Augmented).forward` (src/optimization/train_methods.py:310-422 /
+436-517, augment falsy as with the shipped cfg), the loss mixing + backward of
+`train_traditional` (src/optimization/traditional.py:171-190) and torch.optim.Adam as configured in
+src/optimization/train_methods.py:825-833, on top of the functional oracle net.
+Teachers iterate in the reference's ModuleDict insertion order rgb -> depth -> thermal
+(train.py:123-135).  Pinned by tests/golden/step_*.npz (reference step module run in the build
+container through tools/oracle/make_golden.py).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import effdet_ref as net
+from . import losses_ref as L
+from . import postproc_ref as P
+
+TEACHER_ORDER = ("rgb", "depth", "thermal")
+
+
+def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[str, torch.Tensor]],
+                    batch: Dict[str, torch.Tensor], image_size: int, coef: int = 2,
+                    drop_masks: Optional[Dict[int, torch.Tensor]] = None, conf_threshold: float = 0.3,
+                    nms_threshold: float = 0.5, T: float = 9.0, p: float = 2.0, training: bool = True,
+                    kd_mode: str = "pairwise", inclusive_nms: bool = False):
+    """-> dict(reg[1], cls[1], kd: list of Tensor[5] per teacher (pairwise) or [Tensor[5]] (list),
+               labels: merged [m,5] per image, logits_s, features_s)"""
+    logits_s, feats_s = net.forward(student, batch["audio"], coef, training, drop_masks)
+    per_teacher, kd, feats_all = [], [], []
+    B = batch["audio"].shape[0]
+    for mod in TEACHER_ORDER:
+        if mod not in teachers:
+            continue
+        with torch.no_grad():
+            logits_t, feats_t = net.forward(teachers[mod], batch[mod], coef, False)
+            feats_t = [f.detach() for f in feats_t]
+            per_teacher.append(P.logits_to_ground_truth(logits_t, image_size, conf_threshold, nms_threshold,
+                                                        inclusive=inclusive_nms))
+        if kd_mode == "pairwise":
+            kd.append(L.mta_loss(feats_s, feats_t, T, p))
+        else:
+            feats_all.append(feats_t)
+    if kd_mode != "pairwise":
+        kd.append(L.mta_loss(feats_s, feats_all, T, p))
+    labels = P.merge_teacher_labels(per_teacher, B, 0.5, inclusive_nms)
+    reg, cls = L.focal_loss(logits_s[0], logits_s[1], logits_s[2], labels)
+    return {"reg": reg, "cls": cls, "kd": kd, "labels": labels, "per_teacher": per_teacher,
+            "logits_s": logits_s, "features_s": feats_s}
+
+
+def total_loss(out, w_main: float = 1.0, w_kd: float = 0.005) -> torch.Tensor:
+    """traditional.py:171-181: w_main*(mean(reg)+mean(cls)) + w_kd*sum(stack(kd))."""
+    loss_main = torch.mean(torch.stack([out["reg"]])) + torch.mean(torch.stack([out["cls"]]))
+    return w_main * loss_main + w_kd * torch.sum(torch.stack(out["kd"]))
+
+
+def adam_step(params: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], state: Dict[str, Dict],
+              lr: float = 1e-4, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.Adam (no weight decay, no amsgrad), bias-corrected; parameters without a gradient
+    are skipped exactly like the optimizer skips `p.grad is None`."""
+    for k, pth in params.items():
+        g = grads.get(k)
+        if g is None:
+            continue
+        s = state.setdefault(k, {"step": 0, "m": torch.zeros_like(pth), "v": torch.zeros_like(pth)})
+        s["step"] += 1
+        s["m"].mul_(b1).add_(g, alpha=1 - b1)
+        s["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** s["step"]
+        bc2 = 1 - b2 ** s["step"]
+        denom = (s["v"].sqrt() / (bc2 ** 0.5)).add_(eps)
+        pth.addcdiv_(s["m"], denom, value=-(lr / bc1))

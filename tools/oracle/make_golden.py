@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+    python tools/oracle/make_golden.py            # writes tests/golden/
+
+The reference (read-only at /root/reference) is imported through tools/oracle/refshim.py.  Every
+fixture stores inputs that cannot be regenerated from a seed plus the reference's outputs
+(full tensors when tiny, otherwise head-slices + sums + L2 norms).  The GPU box never sees the
+reference; it only sees these vectors.  tests/test_oracle_golden.py checks oracle/ against them
+and the `-m gpu` tests check the HIP engine against both.
+"""
+import configparser
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import refshim  # noqa: E402
+
+refshim.install()
+torch.set_num_threads(8)
+
+from mm_distillnet_amd.arch import make_spec  # noqa: E402
+from mm_distillnet_amd.layout import state_layout  # noqa: E402
+from mm_distillnet_amd.synth import synth_state, synth_inputs, calibrate_bn_  # noqa: E402
+from oracle import effdet_ref as O  # noqa: E402
+
+from src.YetAnotherEfficientDet import YetAnotherEfficientDet  # noqa: E402
+import src.YetAnotherEfficientNet as REN  # noqa: E402
+from src.loss.MTALoss import MTALoss  # noqa: E402
+from src.loss.YetAnotherFocalLoss import YetAnotherFocalLoss  # noqa: E402
+import src.utils.utils as RU  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def summ(t: torch.Tensor, n=64):
+    t = t.detach().double().reshape(-1)
+    return {"head": t[:n].float().numpy(), "sum": np.float64(t.sum().item()),
+            "l2": np.float64(t.norm().item()), "absmax": np.float64(t.abs().max().item() if t.numel() else 0.0),
+            "numel": np.int64(t.numel())}
+
+
+def put(d, name, t, n=64):
+    for k, v in summ(t, n).items():
+        d[f"{name}.{k}"] = v
+
+
+def make_state(coef, cin, seed, calib_mod, cls_bias=-4.0):
+    """Shared recipe (tests repeat it): hash weights + oracle BN calibration on a 4x256^2 batch."""
+    spec = make_spec(coef, cin)
+    st = synth_state(spec, seed=seed, cls_bias=cls_bias)
+
+    def tf(state, x, mom):
+        state["_bn_momentum"] = mom
+        masks = {b.idx: torch.ones(x.shape[0]) for b in spec.blocks if b.skip}
+        with torch.no_grad():
+            O.forward(state, x, coef, True, masks)
+        del state["_bn_momentum"]
+
+    calibrate_bn_(st, tf, synth_inputs(4, 256, seed=1000 + seed)[calib_mod], seed=seed)
+    return spec, st
+
+
+class MaskedDropConnect:
+    """Replaces the reference's RNG-driven drop_connect with a recorded, replayable mask."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.calls = []
+
+    def __call__(self, inputs, p, training):
+        if not training:
+            return inputs
+        keep = 1 - p
+        mk = torch.floor(keep + torch.rand(inputs.shape[0], generator=self.g))
+        self.calls.append(mk)
+        return inputs / keep * mk.view(-1, 1, 1, 1)
+
+
+def ref_model(coef, cin, st):
+    m = YetAnotherEfficientDet(compound_coef=coef, in_channels=cin)
+    m.load_state_dict(st)
+    return m
+
+
+def cfg(image_size, student="YetAnotherEfficientDet_D2"):
+    c = configparser.ConfigParser()
+    c["DEFAULT"] = {"student": student, "image_size": str(image_size), "conf_threshold": "0.3",
+                    "nms_threshold": "0.5", "valid_labels": "car"}
+    return c["DEFAULT"]
+
+
+VALID = {"labels_txt2i": {"car": 6}, "labels_i2txt": {6: "car"},
+         "predictions_txt2i": {"car": 6}, "predictions_i2txt": {6: "car"}}
+
+
+def golden_state_keys():
+    for coef in (2, 4):
+        m = YetAnotherEfficientDet(compound_coef=coef, in_channels=8)
+        rows = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        json.dump(rows, open(os.path.join(OUT, f"state_keys_d{coef}_c8.json"), "w"))
+    print("state keys written")
+
+
+def golden_net():
+    S, B = 128, 2
+    for mod, cin, seed in [("rgb", 3, 11), ("thermal", 1, 12), ("audio", 8, 13)]:
+        spec, st = make_state(2, cin, seed, mod)
+        x = synth_inputs(B, S, seed=24)[mod]
+        m = ref_model(2, cin, st).eval()
+        d = {}
+        with torch.no_grad():
+            (c, r, a), f = m(x)
+        put(d, "cls", c); put(d, "reg", r); put(d, "anchors", a)
+        for i, u in enumerate(f):
+            put(d, f"feat{i}", u)
+        np.savez(os.path.join(OUT, f"net_d2_eval_{mod}.npz"), **d)
+        print("net eval", mod, d["cls.sum"], d["reg.l2"])
+    # anchors at 512 (full tensor is 786 KB -> keep checksums + a strided sample)
+    m = YetAnotherEfficientDet(compound_coef=2, in_channels=3)
+    a = m.anchors(torch.zeros(1, 3, 512, 512))
+    d = {}
+    put(d, "anchors512", a)
+    d["anchors512.sample"] = a[0, ::997].numpy()
+    np.savez(os.path.join(OUT, "anchors_d2_512.npz"), **d)
+
+    # training mode (student): fwd + bwd of a scalar, running-stat update, injected drop masks
+    spec, st = make_state(2, 8, 13, "audio")
+    x = synth_inputs(B, S, seed=25)["audio"]
+    dc = MaskedDropConnect(7)
+    REN.drop_connect = dc
+    m = ref_model(2, 8, st).train()
+    (c, r, a), f = m(x)
+    loss = c.sum() * 0.01 + (r ** 2).mean() + sum((u ** 2).mean() for u in f)
+    loss.backward()
+    d = {"loss": np.float64(loss.item())}
+    put(d, "cls", c); put(d, "reg", r)
+    for i, u in enumerate(f):
+        put(d, f"feat{i}", u)
+    d["drop_masks"] = torch.stack(dc.calls).numpy()
+    d["drop_blocks"] = np.array([b.idx for b in spec.blocks if b.skip], dtype=np.int64)
+    sd = m.state_dict()
+    gn = {}
+    for k, p in m.named_parameters():
+        top = ".".join(k.split(".")[:2]) if k.startswith("bifpn") else k.split(".")[0]
+        gn[top] = gn.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in gn.items():
+        d[f"gradnorm.{k}"] = np.float64(v ** 0.5)
+    for k in ["backbone_net.model._conv_stem.conv.weight", "backbone_net.model._blocks.5._depthwise_conv.conv.weight",
+              "backbone_net.model._blocks.9._se_reduce.conv.weight", "backbone_net.model._blocks.22._bn2.weight",
+              "bifpn.0.p4_w2", "bifpn.2.conv5_down.depthwise_conv.conv.weight", "bifpn.0.p5_to_p6.0.conv.weight",
+              "regressor.header.pointwise_conv.conv.bias", "classifier.conv_list.1.pointwise_conv.conv.weight",
+              "classifier.bn_list.3.2.weight"]:
+        put(d, "grad." + k, dict(m.named_parameters())[k].grad)
+    for k in ["backbone_net.model._bn0.running_mean", "backbone_net.model._blocks.10._bn1.running_var",
+              "bifpn.3.conv4_up.bn.running_var", "regressor.bn_list.4.0.running_mean"]:
+        put(d, "stat." + k, sd[k])
+    d["nbt"] = np.int64(sd["backbone_net.model._bn0.num_batches_tracked"].item())
+    np.savez(os.path.join(OUT, "net_d2_train_audio.npz"), **d)
+    print("net train", d["loss"])
+
+
+def golden_losses():
+    torch.manual_seed(3)
+    S = 128
+    anchors = YetAnotherEfficientDet(compound_coef=2, in_channels=3).anchors(torch.zeros(1, 3, S, S))
+    A = anchors.shape[1]
+    crit = YetAnotherFocalLoss()
+    cases = {
+        "mixed": [np.array([[10, 12, 60, 70, 6], [64, 30, 120, 100, 6], [5, 5, 9, 8, 6]], dtype=np.float32),
+                  np.zeros((0,), dtype=np.float32),
+                  np.array([[0, 0, 128, 128, 6]], dtype=np.float32)],
+        "all_empty": [np.zeros((0,), dtype=np.float32), [], np.zeros((0,), dtype=np.float32)],
+        "ignore_band": [np.array([[20, 20, 52, 52, 6], [21, 23, 50, 58, 3]], dtype=np.float32),
+                        np.array([[40, 8, 100, 40, 0]], dtype=np.float32),
+                        np.array([[100, 100, 101, 100, 6]], dtype=np.float32)],
+    }
+    for name, ann in cases.items():
+        B = len(ann)
+        g = torch.Generator().manual_seed(len(name))
+        cls = torch.sigmoid(torch.randn(B, A, 20, generator=g) * 2 - 2)
+        cls[0, :50] = 0.0          # exercise the clamp (zero gradient region)
+        cls[1, :50] = 1.0
+        reg = torch.randn(B, A, 4, generator=g) * 0.3
+        cls.requires_grad_(True); reg.requires_grad_(True)
+        rl, cl = crit([cls, reg, anchors], ann)
+        d = {"seed": np.int64(len(name)), "image_size": np.int64(S),
+             "reg_loss": rl.detach().numpy(), "cls_loss": cl.detach().numpy()}
+        put(d, "cls_in", cls); put(d, "reg_in", reg)
+        for i, a in enumerate(ann):
+            d[f"ann{i}"] = np.asarray(a, dtype=np.float32).reshape(-1, 5)
+        if rl.requires_grad or cl.requires_grad:
+            (rl.sum() * 1.0 + cl.sum() * 1.0).backward()
+            put(d, "dcls", cls.grad); put(d, "dreg", reg.grad)
+            d["dcls.sample"] = cls.grad.reshape(-1)[::211].numpy().copy()
+            d["dreg.sample"] = reg.grad.reshape(-1)[::53].numpy().copy()
+        np.savez_compressed(os.path.join(OUT, f"loss_focal_{name}.npz"), **d)
+        print("focal", name, rl.detach().numpy(), cl.detach().numpy())
+
+    # MTA: pairwise and list mode, stock (T=9,p=2) and a peaky variant (T=0.05) whose gradient is not ~0
+    for name, T, scale in [("stock", 9.0, 1.0), ("peaky", 0.05, 3.0)]:
+        g = torch.Generator().manual_seed(17)
+        sizes = [16, 8, 4, 2, 1]
+        fs = [(torch.randn(2, 12, s, s, generator=g) * scale).requires_grad_(True) for s in sizes]
+        fts = [[torch.randn(2, 12, s, s, generator=g) * scale for s in sizes] for _ in range(3)]
+        crit = MTALoss(T=T, p=2)
+        d = {"T": np.float64(T)}
+        for i, f in enumerate(fs):
+            d[f"fs{i}"] = f.detach().numpy()
+        for k, ft in enumerate(fts):
+            for i, f in enumerate(ft):
+                d[f"ft{k}_{i}"] = f.numpy()
+        pair = crit(fs, fts[0])
+        pair.sum().backward()
+        d["pair"] = pair.detach().numpy()
+        for i, f in enumerate(fs):
+            d[f"pair_dfs{i}"] = f.grad.numpy().copy(); f.grad = None
+        lst = crit(fs, fts)
+        lst.sum().backward()
+        d["list"] = lst.detach().numpy()
+        for i, f in enumerate(fs):
+            d[f"list_dfs{i}"] = f.grad.numpy().copy(); f.grad = None
+        np.savez_compressed(os.path.join(OUT, f"loss_mta_{name}.npz"), **d)
+        print("mta", name, d["pair"], d["list"])
+
+
+def golden_postproc():
+    S, B = 128, 3
+    anchors = YetAnotherEfficientDet(compound_coef=2, in_channels=3).anchors(torch.zeros(1, 3, S, S))
+    A = anchors.shape[1]
+    g = torch.Generator().manual_seed(5)
+    cls = torch.sigmoid(torch.randn(B, A, 20, generator=g) * 1.5 - 3.0)
+    # make class 6 win often so the class filter keeps a decent number
+    cls[:, :, 6] = torch.sigmoid(torch.randn(B, A, generator=g) * 2.0 - 1.5)
+    cls[2] = cls[2] * 0.2          # image with no candidate at all
+    reg = torch.randn(B, A, 4, generator=g) * 0.4
+    gts = RU.logits_to_ground_truth([cls, reg, anchors], None, VALID, cfg(S), include_scores=True)
+    d = {"seed": np.int64(5), "image_size": np.int64(S)}
+    put(d, "cls_in", cls); put(d, "reg_in", reg)
+    for i, gt in enumerate(gts):
+        d[f"gt{i}"] = np.asarray(gt, dtype=np.float32).reshape(-1, 6)
+        print("postproc img", i, d[f"gt{i}"].shape)
+    np.savez_compressed(os.path.join(OUT, "postproc_d2_128.npz"), **d)
+
+
+def golden_step():
+    tm = refshim.load_train_methods()
+    S, B = 256, 2
+    mods = {"rgb": (3, 21), "depth": (3, 22), "thermal": (1, 23)}
+    bias = {"rgb": -2.0, "depth": -3.2, "thermal": -2.0}     # so that every teacher contributes boxes
+    states = {k: make_state(2, cin, seed, k, cls_bias=bias[k])[1] for k, (cin, seed) in mods.items()}
+    spec, st_s = make_state(2, 8, 24, "audio")
+    batch = synth_inputs(B, S, seed=31)
+    for variant, cls_name in [("pairwise", "ModelWithNMSLoss"), ("list", "ModelWithNMSKDListLoss")]:
+        teachers = torch.nn.ModuleDict()
+        for k in ("rgb", "depth", "thermal"):        # reference insertion order (train.py:123-135)
+            teachers[k] = ref_model(2, mods[k][0], states[k])
+        teachers.eval()
+        for p_ in teachers.parameters():
+            p_.requires_grad = False
+        dc = MaskedDropConnect(9)
+        REN.drop_connect = dc
+        student = ref_model(2, 8, st_s).train()
+        model = getattr(tm, cls_name)(student, teachers, YetAnotherFocalLoss(), None, MTALoss(T="9", p="2"),
+                                       cfg(S), VALID)
+        opt = torch.optim.Adam(student.parameters(), lr=1e-4, betas=(0.9, 0.999))
+        opt.zero_grad()
+        res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"], None)
+        regl, clsl, kdl = res[0], res[1], res[2]
+        loss_main = torch.mean(torch.stack(regl)) + torch.mean(torch.stack(clsl))
+        loss = 1.0 * loss_main + 0.005 * torch.sum(torch.stack(kdl))
+        loss.backward()
+        d = {"reg": regl[0].detach().numpy(), "cls": clsl[0].detach().numpy(),
+             "kd": torch.stack(kdl).detach().numpy(), "loss": np.float64(loss.item()),
+             "drop_masks": torch.stack(dc.calls).numpy(),
+             "drop_blocks": np.array([b.idx for b in spec.blocks if b.skip], dtype=np.int64)}
+        gn = {}
+        for k, p_ in student.named_parameters():
+            if p_.grad is None:
+                continue
+            top = ".".join(k.split(".")[:2]) if k.startswith("bifpn") else k.split(".")[0]
+            gn[top] = gn.get(top, 0.0) + float(p_.grad.double().pow(2).sum())
+        for k, v in gn.items():
+            d[f"gradnorm.{k}"] = np.float64(v ** 0.5)
+        watch = ["backbone_net.model._conv_stem.conv.weight", "backbone_net.model._blocks.12._project_conv.conv.weight",
+                 "bifpn.4.conv3_up.pointwise_conv.conv.weight", "classifier.header.pointwise_conv.conv.bias",
+                 "regressor.header.pointwise_conv.conv.weight", "bifpn.1.p5_w2"]
+        named = dict(student.named_parameters())
+        for k in watch:
+            if named[k].grad is None:
+                print("no grad for", k)
+                continue
+            put(d, "grad." + k, named[k].grad)
+        opt.step()
+        for k in watch:
+            put(d, "adam." + k, named[k])
+        # merged labels as seen by the loss: recompute through the reference helpers for the record
+        with torch.no_grad():
+            per = []
+            for k in ("rgb", "depth", "thermal"):
+                pred, _ = teachers[k](batch[k])
+                per.append(RU.logits_to_ground_truth(pred, None, VALID, cfg(S), include_scores=True))
+        for ti, lab in enumerate(per):
+            for i in range(B):
+                d[f"teacher{ti}_img{i}"] = np.asarray(lab[i], dtype=np.float32).reshape(-1, 6)
+        np.savez_compressed(os.path.join(OUT, f"step_d2_256_{variant}.npz"), **d)
+        print("step", variant, d["reg"], d["cls"], d["kd"].reshape(-1)[:5], d["loss"],
+              [d[f"teacher{t}_img{i}"].shape[0] for t in range(3) for i in range(B)])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step"]
+    if "keys" in which:
+        golden_state_keys()
+    if "net" in which:
+        golden_net()
+    if "losses" in which:
+        golden_losses()
+    if "postproc" in which:
+        golden_postproc()
+    if "step" in which:
+        golden_step()
