@@ -1,0 +1,150 @@
+/* mmdistill.h — C ABI of libmmdistill_hip.so (MI355X / gfx950 kernels for the MM-DistillNet distillation step).
+ *
+ * Drop-in boundary: the reference has no FFI; its hot path is reached through Python
+ * call signatures.  Each entry point below replaces the torch/torchvision operator(s) cited above it
+ * (file:line relative to the reference tree).  Conventions: extern "C", raw DEVICE pointers + sizes,
+ * fp32 NHWC activations ("rows" = B*H*W pixels x C channels), last argument is the hipStream_t to
+ * launch on, return 0 on success / negative errno-style code on bad arguments or launch failure,
+ * the caller owns every buffer including workspaces, no hidden allocation, no host synchronisation
+ * (every entry point is hipGraph-capturable).
+ */
+#ifndef MMDISTILL_H
+#define MMDISTILL_H
+#include <hip/hip_runtime_api.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMD_ACT_NONE 0
+#define MMD_ACT_SWISH 1
+#define MMD_ACT_SIGMOID 2
+
+// BiFPN fast-attention fusion node: swish(sum_i w_i * operand_i), nearest-x2 upsample and SAME max-pool fused
+// (src/YetAnotherEfficientDet.py:338-390).
+int mmd_bifpn_fuse_fwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, float* out, int B, int H, int W, int C, hipStream_t stream);
+
+// Backward of the fusion node, part 1: dx = df*swish'(x), wdot[i] += <dx, operand_i>.
+int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W, int C, hipStream_t stream);
+
+// Backward of w = relu(theta)/(sum+1e-4).
+int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
+
+// dst (+)= w_idx(theta) * src (same-resolution operand gradient).
+int mmd_scale_acc(const float* src, float* dst, const float* theta, int ntheta, int widx, int accumulate, long long numel, hipStream_t stream);
+
+// Backward of nn.Upsample(scale_factor=2, nearest) (src/YetAnotherEfficientDet.py:223-226).
+int mmd_upsample2_bwd_acc(const float* dx, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int H, int W, int C, hipStream_t stream);
+
+// MaxPool2dStaticSamePadding(3,2) forward: zero padding takes part in the max (src/YetAnotherEfficientNet.py:68-104).
+int mmd_maxpool_same_fwd(const float* src, float* out, int B, int PH, int PW, int C, hipStream_t stream);
+
+// Backward of MaxPool2dStaticSamePadding(3,2) in gather form (first maximum in scan order wins).
+int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream);
+
+// Depthwise kxk TF-SAME conv, NHWC, fused producer BN+swish prologue, stats / eval-BN+swish / SE-pool epilogue.
+// Replaces Conv2dStaticSamePadding(groups=C) (src/YetAnotherEfficientNet.py:433-435, src/YetAnotherEfficientDet.py:169-170) incl. F.pad (:51-65).
+int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, hipStream_t stream);
+
+// Input gradient of the depthwise conv.
+int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, hipStream_t stream);
+
+// Weight gradient of the depthwise conv, tap-major dw[k*k, C] (+=).
+int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, hipStream_t stream);
+
+// Train-mode BatchNorm2d: batch statistics -> (scale, shift, mean, invstd) + running-stat update (momentum 0.01, eps 1e-3).
+// Replaces nn.BatchNorm2d forward in training (call sites SURVEY 2.1).
+int mmd_bn_finalize(const double* stats, long long count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int C, hipStream_t stream);
+
+// Eval-mode BatchNorm2d folded to per-channel (scale, shift).
+int mmd_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift, int C, hipStream_t stream);
+
+// y = act(z*scale+shift) * rowscale[image] + res : BN apply, drop-connect scaling and identity skip
+// (src/YetAnotherEfficientNet.py:173-182,479-485).
+int mmd_affine_act(const float* z, const float* scale, const float* shift, int act, const float* rowscale, int rows_per_image, const float* res, float* y, int M, int C, hipStream_t stream);
+
+// out[b,c] += s * sum_hw (g? g*a : a), a = act(z*scale+shift): SE global average pool (src/YetAnotherEfficientNet.py:470) and d(gate).
+int mmd_chan_pool(const float* z, const float* scale, const float* shift, int act, const float* g, float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream);
+
+// Squeeze-excite FCs: gate = sigmoid(We*swish(Wr*pooled+br)+be) (src/YetAnotherEfficientNet.py:471-474).
+int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
+
+// Backward of the squeeze-excite FCs (weight grads +=, dpooled scaled by dpool_scale = 1/HW).
+int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
+
+// BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat).
+int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, hipStream_t stream);
+
+// BN backward pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dgamma/dbeta +=.
+int mmd_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, long long count, float* dz, float* dgamma, float* dbeta, int M, int C, hipStream_t stream);
+
+// out[c] += sum_rows a[row,c] (bias gradients).
+int mmd_colsum(const float* a, float* out, int M, int C, hipStream_t stream);
+
+// Stem 3x3/s2 TF-SAME conv lowered to rows [B*OH*OW, Kp] (src/YetAnotherEfficientNet.py:519,603); the GEMM is mmd_pwconv_fwd.
+int mmd_stem_im2col(const float* x, float* col, int B, int Cin, int H, int W, int Kp, hipStream_t stream);
+
+// dlogit = dprob * p * (1-p) (classifier sigmoid, src/YetAnotherEfficientDet.py:529).
+int mmd_sigmoid_bwd(const float* dprob, const float* prob, float* dlogit, long long n, hipStream_t stream);
+
+// Copy one pyramid level out of a concatenated [B, A_total, C] head tensor.
+int mmd_slice_rows(const float* src, float* dst, int B, int rows, int N, long long batch_stride, long long offset, hipStream_t stream);
+
+// MTALoss.at without the normalisation: a[b,j] = mean_c f^p (src/loss/MTALoss.py:76-77).
+int mmd_mta_attention(const float* f, float* a, int rows, int C, float p, hipStream_t stream);
+
+// Per-level MTA loss (pairwise or list mode) and d/d(student attention) (src/loss/MTALoss.py:36-74).
+int mmd_mta_kl(const float* a_s, const float* a_t0, const float* a_t1, const float* a_t2, int nteachers, int B, int HW, float T, float* loss, float* da_s, float gscale, int accumulate, hipStream_t stream);
+
+// df (+)= da * p * f^(p-1) / C.
+int mmd_mta_attention_bwd(const float* f, const float* da, float* df, int rows, int C, float p, int accumulate, hipStream_t stream);
+
+// YetAnotherFocalLoss forward + gradients (src/loss/YetAnotherFocalLoss.py:27-190).
+int mmd_focal_loss(const float* cls, const float* reg, const float* anchors, const float* boxes, const int* nbox, int maxg, int B, int A, int NC, int* assign_ws, int* npos_ws, double* acc_ws, float* loss_out, float* dcls, float* dreg, float grad_scale, int to_logit, int* any_boxes, hipStream_t stream);
+
+// torch.optim.Adam step on a flat segment (src/optimization/train_methods.py:825-833, traditional.py:190).
+int mmd_adam_step(float* p, const float* g, float* m, float* v, float* state, const float* hyper, const int* active, float grad_scale, long long n, hipStream_t stream);
+
+// hipMemsetAsync wrapper (graph-capturable zeroing of stats / gradient buffers).
+int mmd_memset_async(void* p, int value, long long bytes, hipStream_t stream);
+
+// clip_grad_norm_ on the flat gradient buffer (src/optimization/traditional.py:184-188).
+int mmd_clip_grad_norm(float* g, long long n, float max_norm, double* sumsq_ws, hipStream_t stream);
+
+// Box decode + clip + conf threshold + class filter, ordered compaction
+// (src/YetAnotherEfficientDet.py:574-602, src/utils/utils.py:123-204).
+int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, int B, int A, int NC, float conf_threshold, unsigned long long valid_class_mask, float image_size, float* score_ws, unsigned char* clsid_ws, unsigned char* flags_ws, float* over_scores, float* cand, int* n_over, int* n_keep, int* overflow, hipStream_t stream);
+
+// Per-teacher batched_nms + int truncation + label remap (src/utils/utils.py:205-231,285-323).
+int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scores, const int* label_map, float nms_threshold, int inclusive, float image_size, int B, float* out, int* out_cnt, unsigned long long* mask_ws, int* overflow, hipStream_t stream);
+
+// Cross-teacher concat + nms(0.5) + drop score (src/optimization/train_methods.py:361-411).
+int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2, const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, hipStream_t stream);
+
+// Candidate capacity per image of the pseudo-label kernels.
+int mmd_pp_cap(void);
+
+// Profiling hooks for bench.py (hipEvents on the launch stream).
+int mmd_prof_is_on(int family);
+
+int mmd_prof_enable(int family, int on);
+
+int mmd_prof_collect(int family, double* out);
+
+// 1x1 conv as fp32 MFMA GEMM with fused producer-BN/swish/SE-gate prologue and bias/BN/act/residual/stats epilogue.
+// Replaces nn.Conv2d(k=1) in Conv2dStaticSamePadding (src/YetAnotherEfficientNet.py:27-65; call sites :427,446,
+// src/YetAnotherEfficientDet.py:171,238-265) + BatchNorm2d/swish that follow (:428,447,126-143).
+int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, hipStream_t stream);
+
+// dW[N,K] += dY^T * pro(X) (autograd of the 1x1 conv weight; reference: loss.backward(), src/optimization/traditional.py:182).
+int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);
+
+// dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
+int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);
+
+// dst[C,R] = src[R,C]^T (refreshes the Wt copies after an optimizer step).
+int mmd_transpose2d(const float* src, float* dst, int R, int C, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

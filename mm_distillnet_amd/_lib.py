@@ -1,0 +1,97 @@
+"""ctypes binding of libmmdistill_hip.so — the only way the Python host reaches the HIP kernels.
+
+Signatures are parsed from include/mmdistill.h (the C-ABI contract), so the binding cannot drift from
+the header.  There is NO fallback: if the library is missing the import of any compute entry point
+raises, and every call raises on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict
+
+import torch
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmmdistill_hip.so")
+HEADER = os.path.join(os.path.dirname(PKG), "include", "mmdistill.h")
+
+_CT = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
+       "unsigned long long": ctypes.c_ulonglong, "hipStream_t": ctypes.c_void_p, "double": ctypes.c_double}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, list]:
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    sigs = {}
+    for m in re.finditer(r"\bint\s+(mmd_\w+)\s*\(([^)]*)\)\s*;", text):
+        name, args = m.group(1), m.group(2).strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    types.append(ctypes.c_void_p)
+                else:
+                    t = " ".join(a.split()[:-1])
+                    types.append(_CT[t])
+        sigs[name] = types
+    return sigs
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self._sigs = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python -m mm_distillnet_amd.build` "
+                    "(there is no CPU or PyTorch fallback for the HIP path)")
+            self._dll = ctypes.CDLL(LIB_PATH)
+            self._sigs = parse_header()
+            for name, types in self._sigs.items():
+                fn = getattr(self._dll, name)
+                fn.argtypes = types
+                fn.restype = ctypes.c_int
+        return self._dll
+
+    def symbols(self):
+        self.load()
+        return dict(self._sigs)
+
+
+LIB = _Lib()
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            raise ValueError("HIP entry points take device tensors")
+        if not x.is_contiguous():
+            raise ValueError("HIP entry points take contiguous tensors")
+        return x.data_ptr()
+    return x
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Invoke `name` with tensors -> device pointers, appending the current torch HIP stream."""
+    dll = LIB.load()
+    fn = getattr(dll, name)
+    conv = [_ptr(a) for a in args]
+    if len(fn.argtypes) == len(conv) + 1:
+        conv.append(stream_ptr())
+    rc = fn(*conv)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}")
+    return rc

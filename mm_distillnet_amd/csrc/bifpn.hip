@@ -1,0 +1,307 @@
+// BiFPN fast-attention fusion nodes and the TF-SAME 3x3/s2 max-pool (zero padding participates in the
+// max) on NHWC fp32 — CDNA4 / gfx950.
+// Reference: BiFPN._forward_fast_attention (src/YetAnotherEfficientDet.py:320-392),
+// MaxPool2dStaticSamePadding (src/YetAnotherEfficientNet.py:68-104), nn.Upsample(nearest, x2) (:223-226).
+//   f = swish( w0*in0 [+ w*in1] [+ w*up2(u)] [+ w*pool(p)] ),  w = relu(theta)/(sum relu(theta) + 1e-4)
+// Weights are assigned in the order of the non-null operands (in0, in1, up, pool), which is the
+// reference's order for every node (top-down: in,up; bottom-up: in,td,pool; p7: in,pool).
+// One thread = one pixel x 4 channels (float4, channel-contiguous, coalesced).
+#include "common.h"
+
+#define FUSE_EPS 1e-4f
+
+struct FuseArgs {
+  const float* in0; const float* in1; const float* up; const float* pl;
+  const float* theta; int ntheta;
+  int B, H, W, C, PH, PW, pad_t, pad_l;
+};
+
+__device__ __forceinline__ void fuse_weights(const float* theta, int n, float* w) {
+  float r[3] = {0.f, 0.f, 0.f}, s = 0.f;
+  for (int i = 0; i < n; ++i) { r[i] = fmaxf(theta[i], 0.f); s += r[i]; }
+  for (int i = 0; i < 3; ++i) w[i] = r[i] / (s + FUSE_EPS);
+}
+
+__device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int b, int oh, int ow, int c, int PH, int PW,
+                                              int C, int pad_t, int pad_l) {
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int y = oh * 2 - pad_t + i;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int x = ow * 2 - pad_l + j;
+      float4 v = make_float4(0, 0, 0, 0);   // zero padding takes part in the max
+      if (y >= 0 && y < PH && x >= 0 && x < PW) v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  return m;
+}
+
+__device__ __forceinline__ float4 fuse_presum(const FuseArgs& a, const float* w, int b, int h, int x, int c, float4* o0,
+                                              float4* o1, float4* o2, float4* o3) {
+  size_t off = (((size_t)b * a.H + h) * a.W + x) * a.C + c;
+  int wi = 0;
+  float4 s = make_float4(0, 0, 0, 0);
+  float4 v = mmd_ld4(a.in0 + off); *o0 = v;
+  s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
+  if (a.in1) { v = mmd_ld4(a.in1 + off); *o1 = v; s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi; }
+  if (a.up) {
+    v = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (h >> 1)) * (a.W >> 1) + (x >> 1)) * a.C + c); *o2 = v;
+    s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
+  }
+  if (a.pl) {
+    v = pool_window(a.pl, b, h, x, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l); *o3 = v;
+    s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a, float* __restrict__ out) {
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
+  const int c4n = a.C >> 2;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)a.B * a.H * a.W * c4n;
+  if (idx >= total) return;
+  int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
+  int x = (int)(pix % a.W); pix /= a.W;
+  int h = (int)(pix % a.H); int b = (int)(pix / a.H);
+  float4 t0, t1, t2, t3;
+  float4 s = fuse_presum(a, w, b, h, x, c, &t0, &t1, &t2, &t3);
+  s.x = mmd_swish(s.x); s.y = mmd_swish(s.y); s.z = mmd_swish(s.z); s.w = mmd_swish(s.w);
+  mmd_st4(out + (((size_t)b * a.H + h) * a.W + x) * a.C + c, s);
+}
+
+static int fuse_fill(FuseArgs& a, const float* in0, const float* in1, const float* up, const float* pl,
+                     const float* theta, int B, int H, int W, int C) {
+  if (!in0 || !theta || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  int n = 1 + (in1 != nullptr) + (up != nullptr) + (pl != nullptr);
+  if (n < 2 || n > 3) return MMD_EINVAL;
+  if (up && ((H & 1) || (W & 1))) return MMD_EINVAL;
+  a.in0 = in0; a.in1 = in1; a.up = up; a.pl = pl; a.theta = theta; a.ntheta = n;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.PH = 2 * H; a.PW = 2 * W;
+  // SAME pool of an even-sized map: extra = 1 -> pad_lo = 0
+  a.pad_t = 0; a.pad_l = 0;
+  return MMD_OK;
+}
+
+extern "C" int mmd_bifpn_fuse_fwd(const float* in0, const float* in1, const float* up, const float* pool,
+                                  const float* theta, float* out, int B, int H, int W, int C, hipStream_t stream) {
+  FuseArgs a{};
+  int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (rc || !out) return MMD_EINVAL;
+  size_t total = (size_t)B * H * W * (C >> 2);
+  hipLaunchKernelGGL(fuse_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, out);
+  return mmd_check_launch();
+}
+
+// backward part 1: dx = df * swish'(x) (x recomputed from the operands); wdot[i] += <dx, operand_i>
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a, const float* __restrict__ df, float* __restrict__ dx,
+                                                       float* wdot) {
+  __shared__ float sred[4 * 3];
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
+  const int c4n = a.C >> 2;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)a.B * a.H * a.W * c4n;
+  float d[3] = {0.f, 0.f, 0.f};
+  if (idx < total) {
+    int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
+    int x = (int)(pix % a.W); pix /= a.W;
+    int h = (int)(pix % a.H); int b = (int)(pix / a.H);
+    float4 t[4];
+    float4 s = fuse_presum(a, w, b, h, x, c, &t[0], &t[1], &t[2], &t[3]);
+    size_t off = (((size_t)b * a.H + h) * a.W + x) * a.C + c;
+    float4 g = mmd_ld4(df + off);
+    g.x *= mmd_swish_grad(s.x); g.y *= mmd_swish_grad(s.y); g.z *= mmd_swish_grad(s.z); g.w *= mmd_swish_grad(s.w);
+    mmd_st4(dx + off, g);
+    int wi = 0;
+    d[wi++] = g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
+    if (a.in1) d[wi++] = g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
+    if (a.up) d[wi++] = g.x * t[2].x + g.y * t[2].y + g.z * t[2].z + g.w * t[2].w;
+    if (a.pl) d[wi++] = g.x * t[3].x + g.y * t[3].y + g.z * t[3].z + g.w * t[3].w;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { float v = wave_sum(d[i]); if (lane == 0) sred[wave * 3 + i] = v; }
+  __syncthreads();
+  if (threadIdx.x < a.ntheta)
+    atomicAdd(&wdot[threadIdx.x], sred[threadIdx.x] + sred[3 + threadIdx.x] + sred[6 + threadIdx.x] + sred[9 + threadIdx.x]);
+}
+extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool,
+                                  const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W,
+                                  int C, hipStream_t stream) {
+  FuseArgs a{};
+  int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (rc || !df || !dx || !wdot) return MMD_EINVAL;
+  size_t total = (size_t)B * H * W * (C >> 2);
+  hipLaunchKernelGGL(fuse_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, df, dx, wdot);
+  return mmd_check_launch();
+}
+
+// d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   
+__global__ void fuse_theta_bwd_kernel(const float* theta, const float* wdot, float* dtheta, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float r[3], S = FUSE_EPS;
+  for (int i = 0; i < n; ++i) { r[i] = fmaxf(theta[i], 0.f); S += r[i]; }
+  for (int k = 0; k < n; ++k) {
+    if (!(theta[k] > 0.f)) continue;
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += wdot[i] * ((i == k ? S : 0.f) - r[i]) / (S * S);
+    dtheta[k] += acc;
+  }
+}
+extern "C" int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream) {
+  if (!theta || !wdot || !dtheta || n < 2 || n > 3) return MMD_EINVAL;
+  hipLaunchKernelGGL(fuse_theta_bwd_kernel, dim3(1), dim3(64), 0, stream, theta, wdot, dtheta, n);
+  return mmd_check_launch();
+}
+
+__device__ __forceinline__ float theta_weight(const float* theta, int n, int idx) {
+  if (!theta) return 1.f;
+  float w[3];
+  fuse_weights(theta, n, w);
+  return w[idx];
+}
+
+// dst (+)= w * src  (same resolution operand of a fusion node)
+__global__ void scale_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, const float* theta, int n, int widx,
+                                 int accumulate, size_t n4) {
+  float w = theta_weight(theta, n, widx);
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = mmd_ld4(src + i * 4);
+  v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+  if (accumulate) { float4 p = mmd_ld4(dst + i * 4); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+  mmd_st4(dst + i * 4, v);
+}
+extern "C" int mmd_scale_acc(const float* src, float* dst, const float* theta, int ntheta, int widx, int accumulate,
+                             long long numel, hipStream_t stream) {
+  if (!src || !dst || numel <= 0 || (numel & 3) || (theta && (widx < 0 || widx >= ntheta || ntheta > 3))) return MMD_EINVAL;
+  size_t n4 = (size_t)numel / 4;
+  hipLaunchKernelGGL(scale_acc_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, stream, src, dst, theta, ntheta, widx, accumulate, n4);
+  return mmd_check_launch();
+}
+
+// nearest x2 upsample backward: dst[b,uh,uw,c] (+)= w * sum of the 2x2 children of dx[B,H,W,C]
+__global__ void up_bwd_acc_kernel(const float* __restrict__ dx, float* __restrict__ dst, const float* theta, int n, int widx,
+                                  int accumulate, int B, int H, int W, int C) {
+  float w = theta_weight(theta, n, widx);
+  const int c4n = C >> 2, UH = H >> 1, UW = W >> 1;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)B * UH * UW * c4n;
+  if (idx >= total) return;
+  int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
+  int ux = (int)(pix % UW); pix /= UW;
+  int uy = (int)(pix % UH); int b = (int)(pix / UH);
+  float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 v = mmd_ld4(dx + (((size_t)b * H + uy * 2 + i) * W + ux * 2 + j) * C + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  s.x *= w; s.y *= w; s.z *= w; s.w *= w;
+  float* o = dst + (((size_t)b * UH + uy) * UW + ux) * C + c;
+  if (accumulate) { float4 p = mmd_ld4(o); s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+  mmd_st4(o, s);
+}
+extern "C" int mmd_upsample2_bwd_acc(const float* dx, float* dst, const float* theta, int ntheta, int widx,
+                                     int accumulate, int B, int H, int W, int C, hipStream_t stream) {
+  if (!dx || !dst || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if (theta && (widx < 0 || widx >= ntheta || ntheta > 3)) return MMD_EINVAL;
+  size_t total = (size_t)B * (H / 2) * (W / 2) * (C >> 2);
+  hipLaunchKernelGGL(up_bwd_acc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, dx, dst, theta, ntheta, widx, accumulate, B, H, W, C);
+  return mmd_check_launch();
+}
+
+// standalone SAME max-pool 3x3/s2 forward: out[B,OH,OW,C], OH = ceil(PH/2)
+__global__ void maxpool_fwd_kernel(const float* __restrict__ src, float* __restrict__ out, int B, int PH, int PW, int C, int OH,
+                                   int OW, int pad_t, int pad_l) {
+  const int c4n = C >> 2;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)B * OH * OW * c4n;
+  if (idx >= total) return;
+  int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
+  int ow = (int)(pix % OW); pix /= OW;
+  int oh = (int)(pix % OH); int b = (int)(pix / OH);
+  mmd_st4(out + (((size_t)b * OH + oh) * OW + ow) * C + c, pool_window(src, b, oh, ow, c, PH, PW, C, pad_t, pad_l));
+}
+static void pool_geom(int n, int* o, int* lo) {
+  *o = (n + 1) / 2;
+  int extra = (*o - 1) * 2 - n + 3;
+  if (extra < 0) extra = 0;
+  *lo = extra / 2;
+}
+extern "C" int mmd_maxpool_same_fwd(const float* src, float* out, int B, int PH, int PW, int C, hipStream_t stream) {
+  if (!src || !out || B <= 0 || PH <= 0 || PW <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  int OH, OW, pt, pl;
+  pool_geom(PH, &OH, &pt); pool_geom(PW, &OW, &pl);
+  size_t total = (size_t)B * OH * OW * (C >> 2);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, out, B, PH, PW, C, OH, OW, pt, pl);
+  return mmd_check_launch();
+}
+
+// max-pool backward in gather form: every source pixel looks at the (<=4) windows that contain it and takes the
+// window's gradient iff it is the FIRST maximum of that window in row-major scan order (torch semantics; a
+// zero-padding element that wins swallows the gradient).
+__global__ void maxpool_bwd_acc_kernel(const float* __restrict__ src, const float* __restrict__ dout, float* __restrict__ dst,
+                                       const float* theta, int n, int widx, int accumulate, int B, int PH, int PW, int C,
+                                       int OH, int OW, int pad_t, int pad_l) {
+  float w = theta_weight(theta, n, widx);
+  const int c4n = C >> 2;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)B * PH * PW * c4n;
+  if (idx >= total) return;
+  int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
+  int x = (int)(pix % PW); pix /= PW;
+  int y = (int)(pix % PH); int b = (int)(pix / PH);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // windows o with 2o - pad <= y <= 2o - pad + 2
+  int oy_lo = (y + pad_t - 2 + 1) >> 1; if (oy_lo < 0) oy_lo = 0;
+  int oy_hi = (y + pad_t) >> 1; if (oy_hi > OH - 1) oy_hi = OH - 1;
+  int ox_lo = (x + pad_l - 2 + 1) >> 1; if (ox_lo < 0) ox_lo = 0;
+  int ox_hi = (x + pad_l) >> 1; if (ox_hi > OW - 1) ox_hi = OW - 1;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy)
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int by[4] = {-9, -9, -9, -9}, bx[4] = {-9, -9, -9, -9};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        int yy = oy * 2 - pad_t + i;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          int xx = ox * 2 - pad_l + j;
+          float4 v = make_float4(0, 0, 0, 0);
+          if (yy >= 0 && yy < PH && xx >= 0 && xx < PW) v = mmd_ld4(src + (((size_t)b * PH + yy) * PW + xx) * C + c);
+          float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (vv[q] > best[q]) { best[q] = vv[q]; by[q] = yy; bx[q] = xx; }
+        }
+      }
+      float4 g = mmd_ld4(dout + (((size_t)b * OH + oy) * OW + ox) * C + c);
+      float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (by[q] == y && bx[q] == x) acc[q] += gg[q];
+    }
+  float4 o = make_float4(acc[0] * w, acc[1] * w, acc[2] * w, acc[3] * w);
+  float* d = dst + (((size_t)b * PH + y) * PW + x) * C + c;
+  if (accumulate) { float4 p = mmd_ld4(d); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+  mmd_st4(d, o);
+}
+extern "C" int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta,
+                                        int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream) {
+  if (!src || !dout || !dst || B <= 0 || PH <= 0 || PW <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if (theta && (widx < 0 || widx >= ntheta || ntheta > 3)) return MMD_EINVAL;
+  int OH, OW, pt, pl;
+  pool_geom(PH, &OH, &pt); pool_geom(PW, &OW, &pl);
+  size_t total = (size_t)B * PH * PW * (C >> 2);
+  hipLaunchKernelGGL(maxpool_bwd_acc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, dout, dst, theta, ntheta, widx,
+                     accumulate, B, PH, PW, C, OH, OW, pt, pl);
+  return mmd_check_launch();
+}

@@ -1,0 +1,73 @@
+// Shared device helpers for the MM-DistillNet CDNA4 (gfx950) kernels.
+// Activations are NHWC fp32 ("rows" = B*H*W pixels, channels contiguous), wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MMD_OK 0
+#define MMD_EINVAL -22
+#define MMD_ELAUNCH -5
+
+#define MMD_ACT_NONE 0
+#define MMD_ACT_SWISH 1
+#define MMD_ACT_SIGMOID 2
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float mmd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float mmd_swish(float x) { return x * mmd_sigmoid(x); }
+// d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))   (reference: SwishImplementation.backward)
+__device__ __forceinline__ float mmd_swish_grad(float x) {
+  float s = mmd_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float mmd_act(float x, int act) {
+  return act == MMD_ACT_SWISH ? mmd_swish(x) : (act == MMD_ACT_SIGMOID ? mmd_sigmoid(x) : x);
+}
+__device__ __forceinline__ float4 mmd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void mmd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware 1-D block remap (8 XCDs, blocks dealt round-robin): gives each XCD a contiguous
+// chunk of the logical tile order so neighbouring tiles share one L2. Bijective only when
+// nblk % 8 == 0; otherwise identity.
+__device__ __forceinline__ int mmd_xcd_swizzle(int bid, int nblk) {
+  if ((nblk & 7) != 0) return bid;
+  int cpx = nblk >> 3;
+  return (bid & 7) * cpx + (bid >> 3);
+}
+
+static inline int mmd_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMD_OK : MMD_ELAUNCH;
+}
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- optional per-kernel event timing (bench.py roofline leg) ----
+// mmd_prof_begin/end bracket a launch with hipEvents on the launch stream when profiling of
+// that kernel family is enabled; see prof.hip.
+extern "C" int mmd_prof_is_on(int family);
+void mmd_prof_begin(int family, hipStream_t s);
+void mmd_prof_end(int family, hipStream_t s, double flops, double bytes);
+#define MMD_FAM_PW 0
+#define MMD_FAM_PW_WGRAD 1
+#define MMD_FAM_DW 2
+#define MMD_FAM_DW_BWD 3
+#define MMD_FAM_ELT 4
+#define MMD_FAM_COUNT 8

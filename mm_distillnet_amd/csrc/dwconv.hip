@@ -1,0 +1,373 @@
+// Depthwise k x k convolution (k in {3,5}, stride in {1,2}) on NHWC fp32 with TF-"SAME" zero padding
+// folded into index math — CDNA4 / gfx950.
+//
+// Reference op: Conv2dStaticSamePadding with groups=C (src/YetAnotherEfficientNet.py:27-65, call sites
+// :433-435 and src/YetAnotherEfficientDet.py:169-170); the materialised F.pad of the reference is gone.
+//
+// A block stages an input tile (+halo) for 64 channels in LDS, applying the PRODUCER's
+// BatchNorm+swish on the way in (prologue), so every input element is activated once.  Lanes map
+// to channels (float4 = 4 channels per lane, 16 lanes = 64 channels = 256 contiguous bytes per
+// pixel), 16 pixel-groups per block each own a strip of R outputs along W and reuse the LDS
+// reads in registers.  Weights live tap-major [k*k][C] so a lane's 4 channels are one float4.
+// Epilogue: raw per-channel sum / sum-of-squares for train-mode BN (double atomics), or eval-mode
+// BN+swish and the squeeze-excite average pool.
+#include "common.h"
+
+struct DwArgs {
+  const float* x; const float* w; float* y;
+  int B, H, W, C, OH, OW;
+  int pad_t, pad_l;
+  int flip;
+  const float* in_scale; const float* in_shift; int in_act;
+  const float* out_scale; const float* out_shift; int out_act;
+  double* stats; float* pool; float pool_scale;
+  int tiles_h, tiles_w, cchunks;
+};
+
+template <int K, int S> struct DwCfg {
+  static constexpr int TH = (S == 1) ? 8 : 4;
+  static constexpr int TW = 8;
+  static constexpr int R = TH * TW / 16;                   // outputs per pixel-group (along W)
+  static constexpr int IH = (TH - 1) * S + K;
+  static constexpr int IW = (TW - 1) * S + K;
+  static constexpr int SEG = (R - 1) * S + K;              // input columns one strip needs
+};
+
+template <int K, int S>
+__device__ __forceinline__ void dw_stage_input(const DwArgs& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
+  using Cf = DwCfg<K, S>;
+  const int c4 = (tid & 15) * 4;
+  const int c = c0 + c4;
+  const bool cok = c < a.C;
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+  if (a.in_scale && cok) { sc = mmd_ld4(a.in_scale + c); sh = mmd_ld4(a.in_shift + c); }
+  for (int p = tid >> 4; p < Cf::IH * Cf::IW; p += 16) {
+    int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+      v = mmd_ld4(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
+      if (a.in_scale) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
+      if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+    }
+    *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+  }
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
+  using Cf = DwCfg<K, S>;
+  __shared__ float sIn[Cf::IH * Cf::IW * 64];
+  __shared__ float sW[K * K * 64];
+  __shared__ float sRed[2 * 4 * 64];
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int cc = bid % a.cchunks; bid /= a.cchunks;
+  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
+  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  const int b = bid;
+  const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  const bool cok = c < a.C;
+  const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
+
+  for (int i = tid; i < K * K * 16; i += 256) {
+    int tap = i >> 4, q = (i & 15) * 4;
+    int src = a.flip ? (K * K - 1 - tap) : tap;
+    float4 v = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
+    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = v;
+  }
+  dw_stage_input<K, S>(a, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+  __syncthreads();
+
+  const int p = tid >> 4;
+  const int orow = p / (Cf::TW / Cf::R);
+  const int ocol0 = (p % (Cf::TW / Cf::R)) * Cf::R;
+  float4 acc[Cf::R];
+#pragma unroll
+  for (int o = 0; o < Cf::R; ++o) acc[o] = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    float4 in[Cf::SEG];
+    const float* prow = &sIn[((orow * S + i) * Cf::IW + ocol0 * S) * 64 + c4];
+#pragma unroll
+    for (int q = 0; q < Cf::SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * K + j) * 64 + c4]);
+#pragma unroll
+      for (int o = 0; o < Cf::R; ++o) {
+        acc[o].x += in[o * S + j].x * wv.x; acc[o].y += in[o * S + j].y * wv.y;
+        acc[o].z += in[o * S + j].z * wv.z; acc[o].w += in[o * S + j].w * wv.w;
+      }
+    }
+  }
+  float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
+  if (a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
+  float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
+  const int oh = oh0 + orow;
+#pragma unroll
+  for (int o = 0; o < Cf::R; ++o) {
+    int ow = ow0 + ocol0 + o;
+    if (cok && oh < a.OH && ow < a.OW) {
+      float4 v = acc[o];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+      float4 t = v;
+      if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
+      if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
+      pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
+      mmd_st4(a.y + (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + c, t);
+    }
+  }
+  if (a.stats || a.pool) {
+    // reduce over the 4 pixel-groups of a wave (lanes l, l^16, l^32, l^48 share c4), then over 4 waves in LDS
+    auto red4 = [](float4 v) {
+      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      return v;
+    };
+    const int wave = tid >> 6, lane = tid & 63;
+    if (a.stats) {
+      s = red4(s); ss = red4(ss);
+      if (lane < 16) {
+        *reinterpret_cast<float4*>(&sRed[wave * 64 + c4]) = s;
+        *reinterpret_cast<float4*>(&sRed[256 + wave * 64 + c4]) = ss;
+      }
+      __syncthreads();
+      if (tid < 64 && c0 + tid < a.C) {
+        float vs = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
+        float vq = sRed[256 + tid] + sRed[320 + tid] + sRed[384 + tid] + sRed[448 + tid];
+        atomicAdd(&a.stats[c0 + tid], (double)vs);
+        atomicAdd(&a.stats[a.C + c0 + tid], (double)vq);
+      }
+      __syncthreads();
+    }
+    if (a.pool) {
+      pl = red4(pl);
+      if (lane < 16) *reinterpret_cast<float4*>(&sRed[wave * 64 + c4]) = pl;
+      __syncthreads();
+      if (tid < 64 && c0 + tid < a.C) {
+        float v = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
+        atomicAdd(&a.pool[(size_t)b * a.C + c0 + tid], v * a.pool_scale);
+      }
+    }
+  }
+}
+
+template <int K, int S>
+static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
+  using Cf = DwCfg<K, S>;
+  a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = cdiv(a.C, 64);
+  long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
+  hipLaunchKernelGGL((dw_fwd_kernel<K, S>), dim3((unsigned)nb), dim3(256), 0, st, a);
+  return mmd_check_launch();
+}
+
+static int same_pad_lo(int n, int k, int s, int* out) {
+  int o = (n + s - 1) / s;
+  int extra = (o - 1) * s - n + k;
+  if (extra < 0) extra = 0;
+  *out = o;
+  return extra / 2;
+}
+
+// y[B,OH,OW,C] = dwconv_same(pro(x)[B,H,W,C], w[k*k,C]); OH = ceil(H/stride).
+extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
+                              const float* in_scale, const float* in_shift, int in_act,
+                              const float* out_scale, const float* out_shift, int out_act,
+                              double* stats, float* pool, hipStream_t stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
+  DwArgs a{};
+  a.x = x; a.w = w; a.y = y; a.B = B; a.H = H; a.W = W; a.C = C;
+  a.pad_t = same_pad_lo(H, k, stride, &a.OH); a.pad_l = same_pad_lo(W, k, stride, &a.OW);
+  a.flip = 0; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
+  a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
+  mmd_prof_begin(MMD_FAM_DW, stream);
+  int rc;
+  if (k == 3 && stride == 1) rc = dw_fwd_launch<3, 1>(a, stream);
+  else if (k == 3) rc = dw_fwd_launch<3, 2>(a, stream);
+  else if (stride == 1) rc = dw_fwd_launch<5, 1>(a, stream);
+  else rc = dw_fwd_launch<5, 2>(a, stream);
+  mmd_prof_end(MMD_FAM_DW, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
+               4.0 * ((double)B * H * W * C + (double)B * a.OH * a.OW * C));
+  return rc;
+}
+
+// ---- input gradient -------------------------------------------------------------------
+// stride 1: correlation with the flipped kernel and padding (k-1-pad) -> the forward kernel.
+// stride 2: gather form, <= ceil(k/2)^2 taps per input pixel.
+template <int K>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int B, int H, int W, int C,
+                                                            int OH, int OW, int pad_t, int pad_l, int accumulate) {
+  const int c4n = C >> 2;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)B * H * W * c4n;
+  if (idx >= total) return;
+  int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
+  int iw = (int)(pix % W); pix /= W;
+  int ih = (int)(pix % H); int b = (int)(pix / H);
+  float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    int t = ih + pad_t - i;
+    if (t < 0 || (t & 1)) continue;
+    int oh = t >> 1;
+    if (oh >= OH) continue;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      int u = iw + pad_l - j;
+      if (u < 0 || (u & 1)) continue;
+      int ow = u >> 1;
+      if (ow >= OW) continue;
+      float4 g = mmd_ld4(dy + (((size_t)b * OH + oh) * OW + ow) * C + c);
+      float4 wv = mmd_ld4(w + (size_t)(i * K + j) * C + c);
+      acc.x += g.x * wv.x; acc.y += g.y * wv.y; acc.z += g.z * wv.z; acc.w += g.w * wv.w;
+    }
+  }
+  float* o = dx + (((size_t)b * H + ih) * W + iw) * C + c;
+  if (accumulate) { float4 p = mmd_ld4(o); acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+  mmd_st4(o, acc);
+}
+
+// dx[B,H,W,C] (=) dwconv^T(dy[B,OH,OW,C], w)
+extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k,
+                                   int stride, hipStream_t stream) {
+  if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
+  int OH, OW;
+  int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
+  mmd_prof_begin(MMD_FAM_DW_BWD, stream);
+  int rc;
+  if (stride == 1) {
+    DwArgs a{};
+    a.x = dy; a.w = w; a.y = dx; a.B = B; a.H = H; a.W = W; a.C = C; a.OH = H; a.OW = W;
+    a.pad_t = k - 1 - pt; a.pad_l = k - 1 - pl; a.flip = 1;
+    rc = (k == 3) ? dw_fwd_launch<3, 1>(a, stream) : dw_fwd_launch<5, 1>(a, stream);
+  } else {
+    size_t total = (size_t)B * H * W * (C >> 2);
+    if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_kernel<3>, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, 0);
+    else hipLaunchKernelGGL(dw_bwd_data_s2_kernel<5>, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, 0);
+    rc = mmd_check_launch();
+  }
+  mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * B * OH * OW * (double)C * k * k, 4.0 * ((double)B * H * W * C + (double)B * OH * OW * C));
+  return rc;
+}
+
+// ---- weight gradient: dw[tap,c] += sum_{b,oh,ow} dy[b,oh,ow,c] * pro(x)[b, oh*s+i-pad, ow*s+j-pad, c]
+// Same tiling as the forward; each block walks `tiles_per_block` tiles of one (image, 64-channel chunk)
+// keeping k*k float4 partial sums in registers, then one shuffle + LDS reduction and 256-B atomics.
+struct DwWgArgs {
+  const float* x; const float* dy; float* dw;
+  int B, H, W, C, OH, OW, pad_t, pad_l;
+  const float* in_scale; const float* in_shift; int in_act;
+  int tiles_h, tiles_w, cchunks, nsplit;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
+  using Cf = DwCfg<K, S>;
+  static_assert(Cf::IH * Cf::IW >= 4 * K * K, "reduction scratch aliases the input tile");
+  __shared__ float sIn[Cf::IH * Cf::IW * 64];
+  float* sRed = sIn;                      // reused after the tile loop (behind a barrier)
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int sp = bid % a.nsplit; bid /= a.nsplit;
+  const int cc = bid % a.cchunks; bid /= a.cchunks;
+  const int b = bid;
+  const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  const bool cok = c < a.C;
+  const int p = tid >> 4;
+  const int orow = p / (Cf::TW / Cf::R);
+  const int ocol0 = (p % (Cf::TW / Cf::R)) * Cf::R;
+  DwArgs fa{};
+  fa.x = a.x; fa.H = a.H; fa.W = a.W; fa.C = a.C; fa.in_scale = a.in_scale; fa.in_shift = a.in_shift; fa.in_act = a.in_act;
+
+  float4 acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0, 0, 0, 0);
+
+  const int ntiles = a.tiles_h * a.tiles_w;
+  for (int tile = sp; tile < ntiles; tile += a.nsplit) {
+    const int th = tile / a.tiles_w, tw = tile % a.tiles_w;
+    const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
+    __syncthreads();
+    dw_stage_input<K, S>(fa, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+    __syncthreads();
+    float4 g[Cf::R];
+    const int oh = oh0 + orow;
+#pragma unroll
+    for (int o = 0; o < Cf::R; ++o) {
+      int ow = ow0 + ocol0 + o;
+      g[o] = (cok && oh < a.OH && ow < a.OW) ? mmd_ld4(a.dy + (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + c)
+                                              : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      float4 in[Cf::SEG];
+      const float* prow = &sIn[((orow * S + i) * Cf::IW + ocol0 * S) * 64 + c4];
+#pragma unroll
+      for (int q = 0; q < Cf::SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int o = 0; o < Cf::R; ++o) {
+          acc[i * K + j].x += g[o].x * in[o * S + j].x; acc[i * K + j].y += g[o].y * in[o * S + j].y;
+          acc[i * K + j].z += g[o].z * in[o * S + j].z; acc[i * K + j].w += g[o].w * in[o * S + j].w;
+        }
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    float4 v = acc[t];
+    v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+    v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+    if (lane < 16) *reinterpret_cast<float4*>(&sRed[(wave * K * K + t) * 64 + c4]) = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < K * K * 64; i += 256) {
+    int t = i >> 6, q = i & 63;
+    if (c0 + q < a.C) {
+      float v = sRed[(0 * K * K + t) * 64 + q] + sRed[(1 * K * K + t) * 64 + q] + sRed[(2 * K * K + t) * 64 + q] +
+                sRed[(3 * K * K + t) * 64 + q];
+      atomicAdd(&a.dw[(size_t)t * a.C + c0 + q], v);
+    }
+  }
+}
+
+template <int K, int S>
+static int dw_wgrad_launch(DwWgArgs& a, hipStream_t st) {
+  using Cf = DwCfg<K, S>;
+  a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = cdiv(a.C, 64);
+  int ntiles = a.tiles_h * a.tiles_w;
+  int base = a.B * a.cchunks;
+  int ns = cdiv(2048, base); if (ns > ntiles) ns = ntiles; if (ns < 1) ns = 1;
+  a.nsplit = ns;
+  hipLaunchKernelGGL((dw_wgrad_kernel<K, S>), dim3((unsigned)(base * ns)), dim3(256), 0, st, a);
+  return mmd_check_launch();
+}
+
+extern "C" int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int k,
+                                     int stride, const float* in_scale, const float* in_shift, int in_act,
+                                     hipStream_t stream) {
+  if (!x || !dy || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
+  DwWgArgs a{};
+  a.x = x; a.dy = dy; a.dw = dw; a.B = B; a.H = H; a.W = W; a.C = C;
+  a.pad_t = same_pad_lo(H, k, stride, &a.OH); a.pad_l = same_pad_lo(W, k, stride, &a.OW);
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  mmd_prof_begin(MMD_FAM_DW_BWD, stream);
+  int rc;
+  if (k == 3 && stride == 1) rc = dw_wgrad_launch<3, 1>(a, stream);
+  else if (k == 3) rc = dw_wgrad_launch<3, 2>(a, stream);
+  else if (stride == 1) rc = dw_wgrad_launch<5, 1>(a, stream);
+  else rc = dw_wgrad_launch<5, 2>(a, stream);
+  mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
+               4.0 * ((double)B * H * W * C + (double)B * a.OH * a.OW * C));
+  return rc;
+}

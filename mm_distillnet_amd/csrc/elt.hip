@@ -1,0 +1,435 @@
+// Streaming (HBM-bound) kernels on NHWC fp32 rows: BatchNorm statistics/finalize/backward, fused
+// affine+activation+residual, squeeze-excite pool and FCs, bias/column sums, stem im2col.
+// Layout rule for all "row x channel" kernels: a thread owns 4 consecutive channels (float4) and walks
+// rows; 16 lanes cover a 64-channel chunk (256 contiguous bytes), 16 row-groups per 256-thread block.
+// Per-channel reductions: shuffle over the 4 row-groups of a wave (lanes l^16, l^32), then LDS over
+// the 4 waves, then one double/float atomic per channel per block.
+#include "common.h"
+
+#define ROWS_PER_BLOCK 256
+
+__device__ __forceinline__ float4 red_rowgroups(float4 v) {
+  v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+  v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+  return v;
+}
+// block-level per-channel sum of a float4 held by every thread (fixed c4 = (tid&15)*4); result valid for tid<64
+__device__ __forceinline__ float block_chan_sum(float4 v, float* sRed /*[256]*/, int tid) {
+  v = red_rowgroups(v);
+  __syncthreads();
+  if ((tid & 63) < 16) *reinterpret_cast<float4*>(&sRed[(tid >> 6) * 64 + (tid & 15) * 4]) = v;
+  __syncthreads();
+  float r = 0.f;
+  if (tid < 64) r = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
+  return r;
+}
+
+// ---------------------------------------------------------------- BN finalize (train forward)
+// reference: nn.BatchNorm2d(momentum=0.01, eps=1e-3) in training mode
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* rmean, float* rvar, float momentum, float eps,
+                                   float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean = stats[c] / count;
+  double var = stats[C + c] / count - mean * mean;
+  if (var < 0) var = 0;
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (mean_out) { mean_out[c] = (float)mean; invstd_out[c] = invstd; }
+  if (rmean) {
+    double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" int mmd_bn_finalize(const double* stats, long long count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* mean_out, float* invstd_out, int C,
+                               hipStream_t stream) {
+  if (!stats || !gamma || !beta || !scale || !shift || C <= 0 || count <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, stats, (double)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, C);
+  return mmd_check_launch();
+}
+
+// eval-mode BN folded to scale/shift: scale = g/sqrt(rv+eps), shift = b - rm*scale
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* rm, const float* rv, float eps, float* scale,
+                               float* shift, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sc = g[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = b[c] - rm[c] * sc;
+}
+extern "C" int mmd_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                           float* scale, float* shift, int C, hipStream_t stream) {
+  if (!gamma || !beta || !rmean || !rvar || !scale || !shift || C <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, rmean, rvar, eps, scale, shift, C);
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- y = act(z*scale+shift)*rowscale[img] + res
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act,
+                                                         const float* __restrict__ rowscale, int rows_per_image,
+                                                         const float* __restrict__ res, float* __restrict__ y, int M, int C) {
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  if (c >= C) return;
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+  if (scale) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
+  const int r0 = blockIdx.y * ROWS_PER_BLOCK;
+  const int r1 = min(M, r0 + ROWS_PER_BLOCK);
+  for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+    size_t off = (size_t)row * C + c;
+    float4 v = mmd_ld4(z + off);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+    else if (act == MMD_ACT_SIGMOID) { v.x = mmd_sigmoid(v.x); v.y = mmd_sigmoid(v.y); v.z = mmd_sigmoid(v.z); v.w = mmd_sigmoid(v.w); }
+    if (rowscale) { float rs = rowscale[row / rows_per_image]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+    if (res) { float4 q = mmd_ld4(res + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    mmd_st4(y + off, v);
+  }
+}
+extern "C" int mmd_affine_act(const float* z, const float* scale, const float* shift, int act, const float* rowscale,
+                              int rows_per_image, const float* res, float* y, int M, int C, hipStream_t stream) {
+  if (!z || !y || M <= 0 || C <= 0 || (C & 3) || (rowscale && rows_per_image <= 0)) return MMD_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, z, scale, shift,
+                     act, rowscale, rows_per_image, res, y, M, C);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * (res ? 3 : 2));
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- per-(image,channel) reductions
+// out[b,c] += out_scale * sum_{rows of image b} (g ? g*a : a),  a = act(z*scale+shift)
+// (squeeze-excite average pool forward; d(gate) in the backward)
+__global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int act,
+                                                        const float* __restrict__ g, float* __restrict__ out,
+                                                        float out_scale, int rows_per_image, int C, int nsplit) {
+  __shared__ float sRed[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  const int b = blockIdx.y;
+  const bool cok = c < C;
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+  if (scale && cok) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
+  float4 acc = make_float4(0, 0, 0, 0);
+  if (cok) {
+    for (int r = blockIdx.z * 16 + (tid >> 4); r < rows_per_image; r += 16 * nsplit) {
+      size_t off = ((size_t)b * rows_per_image + r) * C + c;
+      float4 v = mmd_ld4(z + off);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      if (act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+      if (g) { float4 q = mmd_ld4(g + off); v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  float s = block_chan_sum(acc, sRed, tid);
+  if (tid < 64 && blockIdx.x * 64 + tid < C) atomicAdd(&out[(size_t)b * C + blockIdx.x * 64 + tid], s * out_scale);
+}
+extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* shift, int act, const float* g, float* out,
+                             float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
+  if (!z || !out || B <= 0 || rows_per_image <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
+  int base = cdiv(C, 64) * B;
+  int ns = cdiv(1024, base); int mx = cdiv(rows_per_image, 64); if (ns > mx) ns = mx; if (ns < 1) ns = 1;
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(chan_pool_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift, act, g, out,
+                     out_scale, rows_per_image, C, ns);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * B * (double)rows_per_image * C * (g ? 2 : 1));
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- squeeze-excite FCs (one block per image)
+// reference: src/YetAnotherEfficientNet.py:469-474.  wr [S,C], br [S], we [C,S], be [C].
+__global__ __launch_bounds__(256) void se_fc_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
+                                                        const float* __restrict__ br, const float* __restrict__ we,
+                                                        const float* __restrict__ be, float* __restrict__ hpre,
+                                                        float* __restrict__ gate, int C, int S) {
+  extern __shared__ float sm[];  // [C] pooled + [S] hidden
+  float* sp = sm; float* shid = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int c = tid; c < C; c += 256) sp[c] = pooled[(size_t)b * C + c];
+  __syncthreads();
+  for (int j = wave; j < S; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += wr[(size_t)j * C + c] * sp[c];
+    acc = wave_sum(acc);
+    if (lane == 0) { float h = acc + br[j]; hpre[(size_t)b * S + j] = h; shid[j] = mmd_swish(h); }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = be[c];
+    for (int j = 0; j < S; ++j) acc += we[(size_t)c * S + j] * shid[j];
+    gate[(size_t)b * C + c] = mmd_sigmoid(acc);
+  }
+}
+extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
+                             float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
+  if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || S <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(B), dim3(256), (C + S) * sizeof(float), stream, pooled, wr, br, we, be, hpre, gate, C, S);
+  return mmd_check_launch();
+}
+
+// backward, step 1 (one block per image): dgate[b,c] = dL/d gate ->
+//   dpe[b,c] = dgate*gate*(1-gate), dpr[b,j] = (We^T dpe)_j * swish'(hpre), dpooled[b,c] = dpool_scale * (Wr^T dpr)_c
+__global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                        const float* __restrict__ hpre, const float* __restrict__ wr,
+                                                        const float* __restrict__ we, float* __restrict__ dpe,
+                                                        float* __restrict__ dpr, float* __restrict__ dpooled,
+                                                        float dpool_scale, int C, int S) {
+  extern __shared__ float sm[];  // [C] dpe, [S] dpr
+  float* sdpe = sm; float* sdpr = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int c = tid; c < C; c += 256) {
+    float g = gate[(size_t)b * C + c];
+    float d = dgate[(size_t)b * C + c] * g * (1.f - g);
+    sdpe[c] = d;
+    dpe[(size_t)b * C + c] = d;
+  }
+  __syncthreads();
+  for (int j = wave; j < S; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += we[(size_t)c * S + j] * sdpe[c];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float d = acc * mmd_swish_grad(hpre[(size_t)b * S + j]);
+      sdpr[j] = d;
+      dpr[(size_t)b * S + j] = d;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sdpr[j];
+    dpooled[(size_t)b * C + c] = acc * dpool_scale;
+  }
+}
+// step 2 (grid over weights, sums over the batch, no atomics):
+//   dwe[c,j] += sum_b dpe[b,c]*swish(hpre[b,j]); dbe[c] += sum_b dpe[b,c]
+//   dwr[j,c] += sum_b dpr[b,j]*pooled[b,c];      dbr[j] += sum_b dpr[b,j]
+__global__ void se_fc_wgrad_kernel(const float* __restrict__ dpe, const float* __restrict__ dpr,
+                                   const float* __restrict__ hpre, const float* __restrict__ pooled, float* dwr, float* dbr,
+                                   float* dwe, float* dbe, int B, int C, int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * S) return;
+  {  // dwe laid out [C][S]
+    int c = i / S, j = i % S;
+    float acc = 0.f, accb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float d = dpe[(size_t)b * C + c];
+      acc += d * mmd_swish(hpre[(size_t)b * S + j]);
+      accb += d;
+    }
+    dwe[i] += acc;
+    if (j == 0) dbe[c] += accb;
+  }
+  {  // dwr laid out [S][C]
+    int j = i / C, c = i % C;
+    float acc = 0.f, accb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float d = dpr[(size_t)b * S + j];
+      acc += d * pooled[(size_t)b * C + c];
+      accb += d;
+    }
+    dwr[i] += acc;
+    if (c == 0) dbr[j] += accb;
+  }
+}
+extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled,
+                             const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dpooled,
+                             float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S,
+                             hipStream_t stream) {
+  if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dpooled || !dwr || !dbr || !dwe || !dbe)
+    return MMD_EINVAL;
+  if (B <= 0 || C <= 0 || S <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (C + S) * sizeof(float), stream, dgate, gate, hpre, wr, we,
+                     dpe_ws, dpr_ws, dpooled, dpool_scale, C, S);
+  hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,
+                     pooled, dwr, dbr, dwe, dbe, B, C, S);
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- BN (+activation) backward
+// pass 1: g = (g_in * mul_bc[img,c] * mul_b[img] + add_bc[img,c]) * act'(z*scale+shift); g_out = g;
+//         sums[c] += g, sums[C+c] += g * xhat,  xhat = (z-mean)*invstd          
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g_in, const float* __restrict__ z,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int act, const float* __restrict__ mul_bc,
+                                                            const float* __restrict__ mul_b, const float* __restrict__ add_bc,
+                                                            int rows_per_image, float* __restrict__ g_out, double* sums,
+                                                            int M, int C) {
+  __shared__ float sRed[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  const bool cok = c < C;
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
+  if (cok) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); mu = mmd_ld4(mean + c); is = mmd_ld4(invstd + c); }
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  const int r0 = blockIdx.y * ROWS_PER_BLOCK, r1 = min(M, r0 + ROWS_PER_BLOCK);
+  if (cok) {
+    for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+      size_t off = (size_t)row * C + c;
+      float4 g = mmd_ld4(g_in + off), zz = mmd_ld4(z + off);
+      int img = (mul_bc || mul_b || add_bc) ? row / rows_per_image : 0;
+      if (mul_bc) { float4 m = mmd_ld4(mul_bc + (size_t)img * C + c); g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w; }
+      if (mul_b) { float m = mul_b[img]; g.x *= m; g.y *= m; g.z *= m; g.w *= m; }
+      if (add_bc) { float4 m = mmd_ld4(add_bc + (size_t)img * C + c); g.x += m.x; g.y += m.y; g.z += m.z; g.w += m.w; }
+      if (act == MMD_ACT_SWISH) {
+        g.x *= mmd_swish_grad(zz.x * sc.x + sh.x); g.y *= mmd_swish_grad(zz.y * sc.y + sh.y);
+        g.z *= mmd_swish_grad(zz.z * sc.z + sh.z); g.w *= mmd_swish_grad(zz.w * sc.w + sh.w);
+      }
+      mmd_st4(g_out + off, g);
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+      s2.x += g.x * (zz.x - mu.x) * is.x; s2.y += g.y * (zz.y - mu.y) * is.y;
+      s2.z += g.z * (zz.z - mu.z) * is.z; s2.w += g.w * (zz.w - mu.w) * is.w;
+    }
+  }
+  float a = block_chan_sum(s1, sRed, tid);
+  float b2 = block_chan_sum(s2, sRed, tid);
+  if (tid < 64 && blockIdx.x * 64 + tid < C) {
+    atomicAdd(&sums[blockIdx.x * 64 + tid], (double)a);
+    atomicAdd(&sums[C + blockIdx.x * 64 + tid], (double)b2);
+  }
+}
+extern "C" int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, int act, const float* mul_bc,
+                                 const float* mul_b, const float* add_bc, int rows_per_image, float* g_out,
+                                 double* sums, int M, int C, hipStream_t stream) {
+  if (!g_in || !z || !scale || !shift || !mean || !invstd || !g_out || !sums || M <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g_in, z, scale,
+                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
+  return mmd_check_launch();
+}
+
+// pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); block row 0 also does dgamma += sum(g*xhat), dbeta += sum(g)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           double count, float* __restrict__ dz, float* dgamma, float* dbeta,
+                                                           int M, int C) {
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  if (c >= C) return;
+  float4 mu = mmd_ld4(mean + c), is = mmd_ld4(invstd + c), ga = mmd_ld4(gamma + c);
+  float m1[4], m2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m1[i] = (float)(sums[c + i] / count); m2[i] = (float)(sums[C + c + i] / count); }
+  if (blockIdx.y == 0 && (tid >> 4) == 0 && dgamma) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dgamma[c + i] += (float)sums[C + c + i]; dbeta[c + i] += (float)sums[c + i]; }
+  }
+  const int r0 = blockIdx.y * ROWS_PER_BLOCK, r1 = min(M, r0 + ROWS_PER_BLOCK);
+  for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+    size_t off = (size_t)row * C + c;
+    float4 gg = mmd_ld4(g + off), zz = mmd_ld4(z + off), o;
+    o.x = ga.x * is.x * (gg.x - m1[0] - (zz.x - mu.x) * is.x * m2[0]);
+    o.y = ga.y * is.y * (gg.y - m1[1] - (zz.y - mu.y) * is.y * m2[1]);
+    o.z = ga.z * is.z * (gg.z - m1[2] - (zz.z - mu.z) * is.z * m2[2]);
+    o.w = ga.w * is.w * (gg.w - m1[3] - (zz.w - mu.w) * is.w * m2[3]);
+    mmd_st4(dz + off, o);
+  }
+}
+extern "C" int mmd_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd,
+                                const float* gamma, const double* sums, long long count, float* dz, float* dgamma,
+                                float* dbeta, int M, int C, hipStream_t stream) {
+  if (!g || !z || !mean || !invstd || !gamma || !sums || !dz || M <= 0 || C <= 0 || (C & 3) || count <= 0) return MMD_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g, z, mean,
+                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients): out[c] += sum_rows a[row,c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* out, int M, int C) {
+  __shared__ float sRed[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  float4 acc = make_float4(0, 0, 0, 0);
+  const int r0 = blockIdx.y * ROWS_PER_BLOCK, r1 = min(M, r0 + ROWS_PER_BLOCK);
+  if (c < C)
+    for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+      float4 v = mmd_ld4(a + (size_t)row * C + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  float s = block_chan_sum(acc, sRed, tid);
+  if (tid < 64 && blockIdx.x * 64 + tid < C) atomicAdd(&out[blockIdx.x * 64 + tid], s);
+}
+extern "C" int mmd_colsum(const float* a, float* out, int M, int C, hipStream_t stream) {
+  if (!a || !out || M <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, a, out, M, C);
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- stem im2col: NCHW image -> [B*OH*OW, Kp] rows
+// (3x3 stride-2 TF-SAME conv as a GEMM; k index = ci*9 + i*3 + j matches the [Cout,Cin,3,3] weight layout)
+__global__ void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int Cin, int H, int W, int OH,
+                                   int OW, int pad_t, int pad_l, int Kp) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)B * OH * OW * Kp;
+  if (idx >= total) return;
+  int k = (int)(idx % Kp); size_t m = idx / Kp;
+  int ow = (int)(m % OW); m /= OW;
+  int oh = (int)(m % OH); int b = (int)(m / OH);
+  float v = 0.f;
+  if (k < Cin * 9) {
+    int ci = k / 9, t = k % 9, i = t / 3, j = t % 3;
+    int ih = oh * 2 + i - pad_t, iw = ow * 2 + j - pad_l;
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((size_t)b * Cin + ci) * H + ih) * W + iw];
+  }
+  col[idx] = v;
+}
+extern "C" int mmd_stem_im2col(const float* x, float* col, int B, int Cin, int H, int W, int Kp, hipStream_t stream) {
+  if (!x || !col || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Kp < Cin * 9 || (Kp & 3)) return MMD_EINVAL;
+  int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  int eh = (OH - 1) * 2 - H + 3, ew = (OW - 1) * 2 - W + 3;
+  if (eh < 0) eh = 0; if (ew < 0) ew = 0;
+  size_t total = (size_t)B * OH * OW * Kp;
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, col, B, Cin, H, W, OH, OW,
+                     eh / 2, ew / 2, Kp);
+  return mmd_check_launch();
+}
+
+// ---------------------------------------------------------------- misc
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p, float* __restrict__ dl, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { float q = p[i]; dl[i] = dp[i] * q * (1.f - q); }
+}
+// dlogit = dprob * p * (1-p)
+extern "C" int mmd_sigmoid_bwd(const float* dprob, const float* prob, float* dlogit, long long n, hipStream_t stream) {
+  if (!dprob || !prob || !dlogit || n <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, dprob, prob, dlogit, (size_t)n);
+  return mmd_check_launch();
+}
+
+// gather [B, A_total, C] head-gradient rows of one pyramid level into a dense [B*HW*?, C'] matrix and back is
+// avoided: the header GEMMs read/write the concatenated buffer through (batch_stride, offset) directly.
+// This helper copies a level slice out of the concatenated tensor: dst[b*rows + r, :] = src[b*bs + off + r*N ...]
+__global__ void slice_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int rows, int N,
+                                  long long bstride, long long off) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t per = (size_t)rows * N;
+  if (i >= per * B) return;
+  int b = (int)(i / per); size_t r = i % per;
+  dst[i] = src[(size_t)b * bstride + off + r];
+}
+extern "C" int mmd_slice_rows(const float* src, float* dst, int B, int rows, int N, long long batch_stride,
+                              long long offset, hipStream_t stream) {
+  if (!src || !dst || B <= 0 || rows <= 0 || N <= 0) return MMD_EINVAL;
+  size_t n = (size_t)B * rows * N;
+  hipLaunchKernelGGL(slice_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, dst, B, rows, N, batch_stride, offset);
+  return mmd_check_launch();
+}

@@ -1,0 +1,303 @@
+// Distillation and detection losses, forward + gradient in the same pass — CDNA4 / gfx950.
+//   MTA attention transfer ...... src/loss/MTALoss.py:15-77   (quirk kept: kl_div is fed probabilities)
+//   focal + smooth-L1 ........... src/loss/YetAnotherFocalLoss.py:6-190
+// Both are HBM-streaming reductions: the MTA channel reduction uses one wave per pixel row with a
+// shuffle tree; the per-image softmax/KL rows and the anchor assignment use block reductions.
+#include "common.h"
+
+// ------------------------------------------------------------------ MTA: a[b,j] = mean_c f[b,j,c]^p
+__global__ __launch_bounds__(256) void mta_attention_kernel(const float* __restrict__ f, float* __restrict__ a, int rows, int C,
+                                                            float p) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= rows) return;
+  const float* fr = f + (size_t)wave * C;
+  float acc = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 v = mmd_ld4(fr + c);
+    if (p == 2.f) acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    else acc += powf(v.x, p) + powf(v.y, p) + powf(v.z, p) + powf(v.w, p);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) a[wave] = acc / (float)C;
+}
+extern "C" int mmd_mta_attention(const float* f, float* a, int rows, int C, float p, hipStream_t stream) {
+  if (!f || !a || rows <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  hipLaunchKernelGGL(mta_attention_kernel, dim3(cdiv((long long)rows * 64, 256)), dim3(256), 0, stream, f, a, rows, C, p);
+  return mmd_check_launch();
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sm, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sm, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  float r = -INFINITY;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, sm[i]);
+  return r;
+}
+
+// One block per image. a_s [B,HW]; a_t0..2 [B,HW] raw attention means of nt teachers (nt==1: pairwise;
+// nt>1: list mode = L1-normalised product of the L2-normalised maps).  loss[0] += sum_j v*(log v - u) / B.
+// If da_s != null: da_s[b,j] (+)= dL/d a_s[b,j] * gscale   (student side only; teachers are constants).
+__global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a_s, const float* __restrict__ t0,
+                                                     const float* __restrict__ t1, const float* __restrict__ t2, int nt,
+                                                     int HW, int B, float T, float* loss, float* da_s, float gscale,
+                                                     int accumulate) {
+  __shared__ float sm[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* as = a_s + (size_t)b * HW;
+  const float* tp[3] = {t0 + (size_t)b * HW, t1 ? t1 + (size_t)b * HW : nullptr, t2 ? t2 + (size_t)b * HW : nullptr};
+  // L2 norms
+  float acc = 0.f;
+  for (int j = tid; j < HW; j += 256) acc += as[j] * as[j];
+  const float ns = fmaxf(sqrtf(block_sum(acc, sm, tid)), 1e-12f);
+  float nk[3] = {1.f, 1.f, 1.f};
+  for (int k = 0; k < nt; ++k) {
+    acc = 0.f;
+    for (int j = tid; j < HW; j += 256) acc += tp[k][j] * tp[k][j];
+    nk[k] = fmaxf(sqrtf(block_sum(acc, sm, tid)), 1e-12f);
+  }
+  float l1 = 1.f;
+  if (nt > 1) {
+    acc = 0.f;
+    for (int j = tid; j < HW; j += 256) {
+      float q = 1.f;
+      for (int k = 0; k < nt; ++k) q *= tp[k][j] / nk[k];
+      acc += fabsf(q);
+    }
+    l1 = fmaxf(block_sum(acc, sm, tid), 1e-12f);
+  }
+  auto that = [&](int j) {
+    float q = 1.f;
+    for (int k = 0; k < nt; ++k) q *= tp[k][j] / nk[k];
+    return nt > 1 ? q / l1 : q;
+  };
+  // softmax(x/T) over j for student and teacher
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int j = tid; j < HW; j += 256) { ms = fmaxf(ms, as[j] / ns / T); mt = fmaxf(mt, that(j) / T); }
+  ms = block_max(ms, sm, tid); mt = block_max(mt, sm, tid);
+  float es = 0.f, et = 0.f;
+  for (int j = tid; j < HW; j += 256) { es += __expf(as[j] / ns / T - ms); et += __expf(that(j) / T - mt); }
+  es = block_sum(es, sm, tid); et = block_sum(et, sm, tid);
+  // KL (as the reference calls it) and the two dot products the backward needs
+  float kl = 0.f, dot_gu = 0.f;
+  for (int j = tid; j < HW; j += 256) {
+    float u = __expf(as[j] / ns / T - ms) / es;
+    float v = __expf(that(j) / T - mt) / et;
+    kl += (v > 0.f ? v * __logf(v) : 0.f) - v * u;
+    dot_gu += (-v) * u;            // g_j = -v_j (scaled later)
+  }
+  kl = block_sum(kl, sm, tid); dot_gu = block_sum(dot_gu, sm, tid);
+  if (tid == 0) atomicAdd(loss, kl / (float)B);
+  if (!da_s) return;
+  // d ahat_j = u_j (g_j - <g,u>) / T ;  da_j = (d ahat_j - ahat_j <ahat, d ahat>) / ns
+  float dot_ad = 0.f;
+  for (int j = tid; j < HW; j += 256) {
+    float ah = as[j] / ns;
+    float u = __expf(ah / T - ms) / es;
+    float v = __expf(that(j) / T - mt) / et;
+    float dah = u * (-v - dot_gu) / T;
+    dot_ad += ah * dah;
+  }
+  dot_ad = block_sum(dot_ad, sm, tid);
+  const float sc = gscale / (float)B;
+  for (int j = tid; j < HW; j += 256) {
+    float ah = as[j] / ns;
+    float u = __expf(ah / T - ms) / es;
+    float v = __expf(that(j) / T - mt) / et;
+    float dah = u * (-v - dot_gu) / T;
+    float d = (dah - ah * dot_ad) / ns * sc;
+    size_t o = (size_t)b * HW + j;
+    da_s[o] = accumulate ? da_s[o] + d : d;
+  }
+}
+extern "C" int mmd_mta_kl(const float* a_s, const float* a_t0, const float* a_t1, const float* a_t2, int nteachers,
+                          int B, int HW, float T, float* loss, float* da_s, float gscale, int accumulate,
+                          hipStream_t stream) {
+  if (!a_s || !a_t0 || !loss || B <= 0 || HW <= 0 || nteachers < 1 || nteachers > 3 || !(T > 0.f)) return MMD_EINVAL;
+  if ((nteachers > 1 && !a_t1) || (nteachers > 2 && !a_t2)) return MMD_EINVAL;
+  hipLaunchKernelGGL(mta_kl_kernel, dim3(B), dim3(256), 0, stream, a_s, a_t0, a_t1, a_t2, nteachers, HW, B, T, loss, da_s,
+                     gscale, accumulate);
+  return mmd_check_launch();
+}
+
+// df[b,j,c] (+)= da[b,j] * p * f^(p-1) / C
+__global__ __launch_bounds__(256) void mta_attention_bwd_kernel(const float* __restrict__ f, const float* __restrict__ da,
+                                                                float* __restrict__ df, int rows, int C, float p, int accumulate) {
+  const int c4n = C >> 2;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)rows * c4n) return;
+  int row = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
+  float k = da[row] * p / (float)C;
+  size_t off = (size_t)row * C + c;
+  float4 v = mmd_ld4(f + off), o;
+  if (p == 2.f) { o.x = k * v.x; o.y = k * v.y; o.z = k * v.z; o.w = k * v.w; }
+  else { o.x = k * powf(v.x, p - 1.f); o.y = k * powf(v.y, p - 1.f); o.z = k * powf(v.z, p - 1.f); o.w = k * powf(v.w, p - 1.f); }
+  if (accumulate) { float4 q = mmd_ld4(df + off); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+  mmd_st4(df + off, o);
+}
+extern "C" int mmd_mta_attention_bwd(const float* f, const float* da, float* df, int rows, int C, float p, int accumulate,
+                                     hipStream_t stream) {
+  if (!f || !da || !df || rows <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  hipLaunchKernelGGL(mta_attention_bwd_kernel, dim3(cdiv((long long)rows * (C >> 2), 256)), dim3(256), 0, stream, f, da, df,
+                     rows, C, p, accumulate);
+  return mmd_check_launch();
+}
+
+// ------------------------------------------------------------------ focal loss
+// boxes [B, maxg, 5] (x1,y1,x2,y2,label), nbox [B].  assign[b,a]: >=0 positive (box index), -1 ignore, -2 negative.
+__global__ __launch_bounds__(256) void focal_assign_kernel(const float* __restrict__ anchors, const float* __restrict__ boxes,
+                                                           const int* __restrict__ nbox, int maxg, int A, int* __restrict__ assign,
+                                                           int* npos) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int G = min(nbox[b], maxg);
+  int cnt = 0;
+  if (a < A && G > 0) {
+    float4 an = mmd_ld4(anchors + (size_t)a * 4);     // y1,x1,y2,x2
+    float aarea = (an.z - an.x) * (an.w - an.y);
+    float best = -INFINITY; int bi = 0;
+    const float* bx = boxes + (size_t)b * maxg * 5;
+    for (int g = 0; g < G; ++g) {
+      float x1 = bx[g * 5], y1 = bx[g * 5 + 1], x2 = bx[g * 5 + 2], y2 = bx[g * 5 + 3];
+      float area = (x2 - x1) * (y2 - y1);
+      float iw = fmaxf(fminf(an.w, x2) - fmaxf(an.y, x1), 0.f);
+      float ih = fmaxf(fminf(an.z, y2) - fmaxf(an.x, y1), 0.f);
+      float ua = fmaxf(aarea + area - iw * ih, 1e-8f);
+      float iou = iw * ih / ua;
+      if (iou > best) { best = iou; bi = g; }      // first maximum wins, like torch.max on CPU
+    }
+    int v = best >= 0.5f ? bi : (best < 0.4f ? -2 : -1);
+    assign[(size_t)b * A + a] = v;
+    cnt = v >= 0;
+  }
+  unsigned long long m = __ballot(cnt);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&npos[b], __popcll(m));
+}
+
+// loss sums: acc[b*2+0] += cls-sum, acc[b*2+1] += reg-sum (double).  Gradients written for every element.
+__global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                                         const float* __restrict__ anchors, const float* __restrict__ boxes,
+                                                         const int* __restrict__ nbox, const int* __restrict__ assign,
+                                                         const int* __restrict__ npos, int maxg, int A, int NC, int B,
+                                                         double* acc, float* __restrict__ dcls, float* __restrict__ dreg,
+                                                         float gscale, int to_logit) {
+  __shared__ double sd[8];
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  int total = 0;
+  for (int i = 0; i < B; ++i) total += min(nbox[i], maxg);
+  const int G = min(nbox[b], maxg);
+  const float alpha = 0.25f;
+  double lc = 0.0, lr = 0.0;
+  if (a < A) {
+    const float* p = cls + ((size_t)b * A + a) * NC;
+    float* dp = dcls ? dcls + ((size_t)b * A + a) * NC : nullptr;
+    float* dr = dreg ? dreg + ((size_t)b * A + a) * 4 : nullptr;
+    if (total == 0) {                       // whole batch without boxes: zero loss, no gradient
+      if (dp) for (int c = 0; c < NC; ++c) dp[c] = 0.f;
+      if (dr) { dr[0] = dr[1] = dr[2] = dr[3] = 0.f; }
+    } else {
+      const int as = G > 0 ? assign[(size_t)b * A + a] : -2;
+      const int np = G > 0 ? npos[b] : 0;
+      const float norm = G > 0 ? fmaxf((float)np, 1.f) : 1.f;     // image w/o boxes: un-normalised (reference quirk)
+      const float gs = gscale / (float)B / norm;
+      int lab = -1;
+      const float* bx = boxes + ((size_t)b * maxg + (as >= 0 ? as : 0)) * 5;
+      if (as >= 0) lab = (int)bx[4];
+      for (int c = 0; c < NC; ++c) {
+        float raw = p[c];
+        float q = fminf(fmaxf(raw, 1e-4f), 1.f - 1e-4f);
+        bool inside = raw >= 1e-4f && raw <= 1.f - 1e-4f;
+        float l = 0.f, d = 0.f;
+        if (as != -1) {
+          if (c == lab) {
+            float om = 1.f - q, lg = __logf(q);
+            l = -alpha * om * om * lg;
+            d = alpha * (2.f * om * lg - om * om / q);
+          } else {
+            float om = 1.f - q, lg = __logf(om);
+            l = -(1.f - alpha) * q * q * lg;
+            d = (1.f - alpha) * (-2.f * q * lg + q * q / om);
+          }
+        }
+        lc += (double)l;
+        if (dp) {
+          float gv = inside ? d * gs : 0.f;
+          if (to_logit) gv *= raw * (1.f - raw);
+          dp[c] = gv;
+        }
+      }
+      lc /= (double)norm;
+      float g4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (as >= 0) {
+        float4 an = mmd_ld4(anchors + (size_t)a * 4);
+        float aw = an.w - an.y, ah = an.z - an.x;
+        float acx = an.y + 0.5f * aw, acy = an.x + 0.5f * ah;
+        float gw = bx[2] - bx[0], gh = bx[3] - bx[1];
+        float gcx = bx[0] + 0.5f * gw, gcy = bx[1] + 0.5f * gh;
+        gw = fmaxf(gw, 1.f); gh = fmaxf(gh, 1.f);
+        float t[4] = {(gcy - acy) / ah, (gcx - acx) / aw, __logf(gh / ah), __logf(gw / aw)};
+        const float* r = reg + ((size_t)b * A + a) * 4;
+        const float gr = gscale / (float)B / (4.f * (float)np);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float diff = r[k] - t[k];
+          float ad = fabsf(diff);
+          float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+          if (ad <= 1.f / 9.f) { lr += 4.5 * (double)ad * ad; g4[k] = 9.f * ad * sgn * gr; }
+          else { lr += (double)ad - 0.5 / 9.0; g4[k] = sgn * gr; }
+        }
+        lr /= (4.0 * (double)np);
+      }
+      if (dr) { dr[0] = g4[0]; dr[1] = g4[1]; dr[2] = g4[2]; dr[3] = g4[3]; }
+    }
+  }
+  lc = wave_sum_d(lc); lr = wave_sum_d(lr);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sd[wave * 2] = lc; sd[wave * 2 + 1] = lr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[b * 2], sd[0] + sd[2] + sd[4] + sd[6]);
+    atomicAdd(&acc[b * 2 + 1], sd[1] + sd[3] + sd[5] + sd[7]);
+  }
+}
+
+// out[0] = regression loss, out[1] = classification loss (means over images; zeros if the batch has no box)
+__global__ void focal_finalize_kernel(const double* acc, const int* nbox, int maxg, int B, float* out, int* any_boxes) {
+  if (threadIdx.x != 0) return;
+  int total = 0;
+  for (int i = 0; i < B; ++i) total += min(nbox[i], maxg);
+  double c = 0, r = 0;
+  for (int i = 0; i < B; ++i) { c += acc[i * 2]; r += acc[i * 2 + 1]; }
+  out[0] = total ? (float)(r / B) : 0.f;
+  out[1] = total ? (float)(c / B) : 0.f;
+  if (any_boxes && total) *any_boxes = 1;     // sticky: head parameters have received a gradient
+}
+
+// cls [B,A,NC] post-sigmoid probabilities, reg [B,A,4], anchors [A,4] (y1,x1,y2,x2).
+// workspace: assign int[B*A], npos int[B] (zeroed here), acc double[2B] (zeroed here).
+extern "C" int mmd_focal_loss(const float* cls, const float* reg, const float* anchors, const float* boxes,
+                              const int* nbox, int maxg, int B, int A, int NC, int* assign_ws, int* npos_ws,
+                              double* acc_ws, float* loss_out, float* dcls, float* dreg, float grad_scale,
+                              int to_logit, int* any_boxes, hipStream_t stream) {
+  if (!cls || !reg || !anchors || !boxes || !nbox || !assign_ws || !npos_ws || !acc_ws || !loss_out) return MMD_EINVAL;
+  if (B <= 0 || A <= 0 || NC <= 0 || maxg <= 0) return MMD_EINVAL;
+  hipMemsetAsync(npos_ws, 0, sizeof(int) * B, stream);
+  hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * B, stream);
+  dim3 grid(cdiv(A, 256), B);
+  hipLaunchKernelGGL(focal_assign_kernel, grid, dim3(256), 0, stream, anchors, boxes, nbox, maxg, A, assign_ws, npos_ws);
+  hipLaunchKernelGGL(focal_loss_kernel, grid, dim3(256), 0, stream, cls, reg, anchors, boxes, nbox, assign_ws, npos_ws, maxg,
+                     A, NC, B, acc_ws, dcls, dreg, grad_scale, to_logit);
+  hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, stream, acc_ws, nbox, maxg, B, loss_out, any_boxes);
+  return mmd_check_launch();
+}

@@ -1,0 +1,82 @@
+// Flat-buffer optimizer and utilities — CDNA4 / gfx950.
+// All student parameters, gradients and Adam moments live in single flat fp32 buffers (one 32 MB
+// stream each), so the optimizer is ONE coalesced float4 pass and the gradient all-reduce works on
+// contiguous buckets.  Reference: torch.optim.Adam as configured in
+// src/optimization/train_methods.py:825-833 (no weight decay passed, no amsgrad), stepped at
+// src/optimization/traditional.py:190.
+#include "common.h"
+
+// state[0] = step (as float, exact up to 2^24), state[1] = lr/bc1, state[2] = 1/sqrt(bc2)
+// hyper: device floats [lr, beta1, beta2, eps] so a captured graph sees scheduler updates.
+__global__ void adam_prep_kernel(float* state, const float* hyper, const int* active) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (active && *active == 0) return;
+  float step = state[0] + 1.f;
+  state[0] = step;
+  double b1 = hyper[1], b2 = hyper[2];
+  double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  state[1] = (float)((double)hyper[0] / bc1);
+  state[2] = (float)(1.0 / sqrt(bc2));
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* state, const float* hyper,
+                                                   const int* active, float gscale, size_t n4) {
+  if (active && *active == 0) return;
+  const float step_size = state[1], inv_sqrt_bc2 = state[2];
+  const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pp = mmd_ld4(p + i * 4), gg = mmd_ld4(g + i * 4), mm = mmd_ld4(m + i * 4), vv = mmd_ld4(v + i * 4);
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = G[k] * gscale;
+      M[k] = b1 * M[k] + (1.f - b1) * gk;
+      V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+      float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
+      P[k] -= step_size * (M[k] / denom);
+    }
+    mmd_st4(p + i * 4, pp); mmd_st4(m + i * 4, mm); mmd_st4(v + i * 4, vv);
+  }
+}
+// One Adam step over a contiguous segment of the flat buffers (n % 4 == 0, 16-byte aligned).
+// `active` (nullable): device int; the segment is skipped while it is 0 (parameters that have never
+// received a gradient are skipped by torch.optim.Adam as well: p.grad is None).
+extern "C" int mmd_adam_step(float* p, const float* g, float* m, float* v, float* state, const float* hyper,
+                             const int* active, float grad_scale, long long n, hipStream_t stream) {
+  if (!p || !g || !m || !v || !state || !hyper || n <= 0 || (n & 3)) return MMD_EINVAL;
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, stream, state, hyper, active);
+  size_t n4 = (size_t)n / 4;
+  int blocks = cdiv(n4, 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, state, hyper, active, grad_scale, n4);
+  return mmd_check_launch();
+}
+
+extern "C" int mmd_memset_async(void* p, int value, long long bytes, hipStream_t stream) {
+  if (!p || bytes <= 0) return MMD_EINVAL;
+  return hipMemsetAsync(p, value, (size_t)bytes, stream) == hipSuccess ? MMD_OK : MMD_ELAUNCH;
+}
+
+// sum of squares of a flat buffer into out[0] (double), for clip_grad_norm_ (traditional.py:184-188)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, double* out) {
+  __shared__ double sd[4];
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += (double)x[i] * x[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sd[0] + sd[1] + sd[2] + sd[3]);
+}
+__global__ void clip_scale_kernel(float* __restrict__ x, size_t n, const double* sumsq, float max_norm) {
+  float norm = (float)sqrt(*sumsq);
+  float coef = max_norm / (norm + 1e-6f);
+  if (coef >= 1.f) return;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= coef;
+}
+extern "C" int mmd_clip_grad_norm(float* g, long long n, float max_norm, double* sumsq_ws, hipStream_t stream) {
+  if (!g || n <= 0 || !sumsq_ws || !(max_norm > 0.f)) return MMD_EINVAL;
+  hipMemsetAsync(sumsq_ws, 0, sizeof(double), stream);
+  int blocks = cdiv(n, 1024); if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, g, (size_t)n, sumsq_ws);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, stream, g, (size_t)n, sumsq_ws, max_norm);
+  return mmd_check_launch();
+}

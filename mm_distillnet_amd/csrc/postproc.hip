@@ -1,0 +1,251 @@
+// Device-side pseudo-label generation (no per-image host sync) — CDNA4 / gfx950.
+//   decode + clip + threshold + class filter ... src/YetAnotherEfficientDet.py:574-602, src/utils/utils.py:123-231
+//   class-aware NMS per teacher, int() truncation . src/utils/utils.py:205-231,285-323 (torchvision batched_nms semantics)
+//   cross-teacher merge + class-agnostic NMS ..... src/optimization/train_methods.py:361-411
+// Integer / index results are meant to be bit-identical to the CPU path, so the box arithmetic uses
+// explicitly rounded fp32 ops (no FMA contraction) in the reference's operation order, candidates are
+// compacted in ANCHOR ORDER (block prefix sums, not atomics) and the NMS sort is (score desc, index asc).
+// Reference quirk kept: the score emitted for a kept box is the score of the idx-th OVER-THRESHOLD
+// candidate, idx being the box's index in the class-filtered list (src/utils/utils.py:193-213).
+#include "common.h"
+
+#define PP_CAP 1024          // candidates per image handled by one NMS block
+
+// ---- pass 1: per anchor best class/score and flags
+__global__ __launch_bounds__(256) void pp_score_kernel(const float* __restrict__ cls, int A, int NC, float thr,
+                                                       unsigned long long valid_mask, float* __restrict__ score,
+                                                       unsigned char* __restrict__ clsid, unsigned char* __restrict__ flags) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= A) return;
+  const float* p = cls + ((size_t)b * A + a) * NC;
+  float best = p[0]; int bi = 0;
+  for (int c = 1; c < NC; ++c) { float v = p[c]; if (v > best) { best = v; bi = c; } }
+  size_t o = (size_t)b * A + a;
+  score[o] = best; clsid[o] = (unsigned char)bi;
+  unsigned char f = 0;
+  if (best > thr) { f = 1; if ((valid_mask >> bi) & 1ull) f |= 2; }
+  flags[o] = f;
+}
+
+// ---- pass 2: ordered compaction (one 1024-thread block per image)
+// over_scores[b, i]      : score of the i-th over-threshold anchor (anchor order)
+// cand[b, i, 0..5]       : (x1,y1,x2,y2,score,class) of the i-th over-threshold AND valid-class anchor
+__global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restrict__ reg, const float* __restrict__ anchors,
+                                                          const float* __restrict__ score, const unsigned char* __restrict__ clsid,
+                                                          const unsigned char* __restrict__ flags, int A, float image_size,
+                                                          float* __restrict__ over_scores, float* __restrict__ cand,
+                                                          int* __restrict__ n_over, int* __restrict__ n_keep, int* overflow) {
+  __shared__ int s_o[16], s_k[16];
+  __shared__ int base_o, base_k;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) { base_o = 0; base_k = 0; }
+  __syncthreads();
+  for (int a0 = 0; a0 < A; a0 += 1024) {
+    const int a = a0 + tid;
+    unsigned char f = (a < A) ? flags[(size_t)b * A + a] : 0;
+    unsigned long long mo = __ballot(f & 1), mk = __ballot((f >> 1) & 1);
+    unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int po = __popcll(mo & lt), pk = __popcll(mk & lt);
+    if (lane == 0) { s_o[wave] = __popcll(mo); s_k[wave] = __popcll(mk); }
+    __syncthreads();
+    int wo = 0, wk = 0, to = 0, tk = 0;
+    for (int i = 0; i < 16; ++i) { if (i < wave) { wo += s_o[i]; wk += s_k[i]; } to += s_o[i]; tk += s_k[i]; }
+    const int bo = base_o, bk = base_k;
+    if (f & 1) {
+      int pos = bo + wo + po;
+      float sc = score[(size_t)b * A + a];
+      if (pos < PP_CAP) over_scores[(size_t)b * PP_CAP + pos] = sc; else *overflow = 1;
+      if (f & 2) {
+        int kp = bk + wk + pk;
+        if (kp < PP_CAP) {
+          float4 an = mmd_ld4(anchors + (size_t)a * 4);                 // y1,x1,y2,x2
+          float4 r = mmd_ld4(reg + ((size_t)b * A + a) * 4);            // dy,dx,dh,dw
+          float yca = __fdiv_rn(__fadd_rn(an.x, an.z), 2.f), xca = __fdiv_rn(__fadd_rn(an.y, an.w), 2.f);
+          float ha = __fsub_rn(an.z, an.x), wa = __fsub_rn(an.w, an.y);
+          float w = __fmul_rn(expf(r.w), wa), h = __fmul_rn(expf(r.z), ha);
+          float yc = __fadd_rn(__fmul_rn(r.x, ha), yca), xc = __fadd_rn(__fmul_rn(r.y, wa), xca);
+          float x1 = __fsub_rn(xc, __fdiv_rn(w, 2.f)), y1 = __fsub_rn(yc, __fdiv_rn(h, 2.f));
+          float x2 = __fadd_rn(xc, __fdiv_rn(w, 2.f)), y2 = __fadd_rn(yc, __fdiv_rn(h, 2.f));
+          x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, image_size); y2 = fminf(y2, image_size);
+          float* o = cand + ((size_t)b * PP_CAP + kp) * 6;
+          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)clsid[(size_t)b * A + a];
+        } else *overflow = 1;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { base_o = bo + to; base_k = bk + tk; }
+    __syncthreads();
+  }
+  if (tid == 0) { n_over[b] = min(base_o, PP_CAP); n_keep[b] = min(base_k, PP_CAP); }
+}
+
+extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, int B, int A, int NC,
+                                 float conf_threshold, unsigned long long valid_class_mask, float image_size,
+                                 float* score_ws, unsigned char* clsid_ws, unsigned char* flags_ws,
+                                 float* over_scores, float* cand, int* n_over, int* n_keep, int* overflow,
+                                 hipStream_t stream) {
+  if (!cls || !reg || !anchors || !score_ws || !clsid_ws || !flags_ws || !over_scores || !cand || !n_over || !n_keep || !overflow)
+    return MMD_EINVAL;
+  if (B <= 0 || A <= 0 || NC <= 0 || NC > 64) return MMD_EINVAL;
+  hipLaunchKernelGGL(pp_score_kernel, dim3(cdiv(A, 256), B), dim3(256), 0, stream, cls, A, NC, conf_threshold,
+                     valid_class_mask, score_ws, clsid_ws, flags_ws);
+  hipLaunchKernelGGL(pp_compact_kernel, dim3(B), dim3(1024), 0, stream, reg, anchors, score_ws, clsid_ws, flags_ws, A,
+                     image_size, over_scores, cand, n_over, n_keep, overflow);
+  return mmd_check_launch();
+}
+
+// ---- greedy NMS over rows [x1,y1,x2,y2,score,label] (one 1024-thread block per image)
+// mode 0 (per-teacher): class-aware (boxes offset by label*(max_coord+1) like torchvision.batched_nms);
+//         out row = (int(x1),int(y1),int(min(x2,S)),int(min(y2,S)), over_scores[orig idx], label_map[label])
+// mode 1 (cross-teacher merge): rows gathered from up to 3 sources in order, class-agnostic;
+//         out row = (x1,y1,x2,y2,label)  [5 columns]
+struct NmsArgs {
+  const float* src[3]; const int* cnt[3]; int nsrc;
+  int mode; float thr; int inclusive;
+  const float* over_scores; const int* label_map; float image_size;
+  float* out; int* out_cnt; int out_cols; int out_cap;
+  unsigned long long* mask_ws; int* overflow;
+};
+
+__global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
+  __shared__ float skey[PP_CAP];
+  __shared__ int sidx[PP_CAP];
+  __shared__ float sbox[PP_CAP * 4];
+  __shared__ float sarea[PP_CAP];
+  __shared__ unsigned long long smask[3584];      // 28 KB: used when n * words <= 3584
+  __shared__ int skeep[PP_CAP];
+  __shared__ float sred[16];
+  __shared__ int s_n, s_nk;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // gather source rows (concatenation order = source order)
+  int cnts[3] = {0, 0, 0}, n = 0;
+  for (int s = 0; s < a.nsrc; ++s) { cnts[s] = min(a.cnt[s][b], PP_CAP); n += cnts[s]; }
+  if (n > PP_CAP) { if (tid == 0) *a.overflow = 1; n = PP_CAP; }
+  auto row_ptr = [&](int i) -> const float* {
+    int s = 0;
+    while (s < a.nsrc - 1 && i >= cnts[s]) { i -= cnts[s]; ++s; }
+    return a.src[s] + ((size_t)b * PP_CAP + i) * 6;
+  };
+  if (n == 0) { if (tid == 0) a.out_cnt[b] = 0; return; }
+  // sort keys
+  float myscore = -INFINITY;
+  if (tid < n) myscore = row_ptr(tid)[4];
+  skey[tid] = myscore; sidx[tid] = tid;
+  __syncthreads();
+  // bitonic sort, descending score, ascending index on ties (1024 slots)
+  for (int k = 2; k <= PP_CAP; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      int ixj = tid ^ j;
+      if (ixj > tid) {
+        float k0 = skey[tid], k1 = skey[ixj]; int i0 = sidx[tid], i1 = sidx[ixj];
+        bool first_before = (k0 > k1) || (k0 == k1 && i0 < i1);     // "tid element sorts before ixj element"
+        bool up = ((tid & k) == 0);
+        if (up ? !first_before : first_before) { skey[tid] = k1; skey[ixj] = k0; sidx[tid] = i1; sidx[ixj] = i0; }
+      }
+      __syncthreads();
+    }
+  // max coordinate for the class offset
+  float maxc = -INFINITY;
+  if (a.mode == 0) {
+    if (tid < n) { const float* r = row_ptr(tid); maxc = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])); }
+    maxc = wave_max(maxc);
+    if ((tid & 63) == 0) sred[tid >> 6] = maxc;
+    __syncthreads();
+    maxc = sred[0];
+    for (int i = 1; i < 16; ++i) maxc = fmaxf(maxc, sred[i]);
+  }
+  if (tid < n) {
+    const float* r = row_ptr(sidx[tid]);
+    float off = 0.f;
+    if (a.mode == 0) off = __fmul_rn(r[5], __fadd_rn(maxc, 1.f));
+    float x1 = __fadd_rn(r[0], off), y1 = __fadd_rn(r[1], off), x2 = __fadd_rn(r[2], off), y2 = __fadd_rn(r[3], off);
+    sbox[tid * 4] = x1; sbox[tid * 4 + 1] = y1; sbox[tid * 4 + 2] = x2; sbox[tid * 4 + 3] = y2;
+    sarea[tid] = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+  }
+  __syncthreads();
+  const int words = (n + 63) >> 6;
+  const bool in_lds = n * words <= 3584;
+  unsigned long long* mask = in_lds ? smask : a.mask_ws + (size_t)b * PP_CAP * (PP_CAP / 64);
+  for (int e = tid; e < n * words; e += 1024) {
+    int i = e / words, w = e % words;
+    unsigned long long bits = 0ull;
+    float ix1 = sbox[i * 4], iy1 = sbox[i * 4 + 1], ix2 = sbox[i * 4 + 2], iy2 = sbox[i * 4 + 3], ia = sarea[i];
+    int j0 = w * 64;
+    for (int q = 0; q < 64; ++q) {
+      int j = j0 + q;
+      if (j <= i || j >= n) continue;
+      float xx1 = fmaxf(ix1, sbox[j * 4]), yy1 = fmaxf(iy1, sbox[j * 4 + 1]);
+      float xx2 = fminf(ix2, sbox[j * 4 + 2]), yy2 = fminf(iy2, sbox[j * 4 + 3]);
+      float ww = fmaxf(0.f, __fsub_rn(xx2, xx1)), hh = fmaxf(0.f, __fsub_rn(yy2, yy1));
+      float inter = __fmul_rn(ww, hh);
+      float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ia, sarea[j]), inter));
+      bool hit = a.inclusive ? (ovr >= a.thr) : (ovr > a.thr);
+      if (hit) bits |= 1ull << q;
+    }
+    mask[(size_t)i * words + w] = bits;
+  }
+  __syncthreads();
+  if (!in_lds) __threadfence();
+  __syncthreads();
+  if (tid < 64) {
+    unsigned long long removed = 0ull;     // lane w owns word w (w < words <= 16)
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+      unsigned long long rw = __shfl(removed, i >> 6, 64);
+      if (!((rw >> (i & 63)) & 1ull)) {
+        if (tid == 0) skeep[nk] = i;
+        ++nk;
+        if (tid < words) removed |= mask[(size_t)i * words + tid];
+      }
+    }
+    if (tid == 0) { s_nk = nk; s_n = n; }
+  }
+  __syncthreads();
+  int nk = s_nk;
+  if (nk > a.out_cap) { if (tid == 0) *a.overflow = 1; nk = a.out_cap; }
+  if (tid == 0) a.out_cnt[b] = nk;
+  for (int k = tid; k < nk; k += 1024) {
+    int oi = sidx[skeep[k]];
+    const float* r = row_ptr(oi);
+    float* o = a.out + ((size_t)b * a.out_cap + k) * a.out_cols;
+    if (a.mode == 0) {
+      o[0] = (float)(int)fmaxf(r[0], 0.f); o[1] = (float)(int)fmaxf(r[1], 0.f);
+      o[2] = (float)(int)fminf(r[2], a.image_size); o[3] = (float)(int)fminf(r[3], a.image_size);
+      o[4] = a.over_scores[(size_t)b * PP_CAP + oi];            // reference quirk, see header
+      o[5] = (float)a.label_map[(int)r[5]];
+    } else {
+      o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[5];
+    }
+  }
+}
+
+// per-teacher NMS: cand [B,PP_CAP,6] + n_keep -> out [B,PP_CAP,6] (truncated coords, quirk score, mapped label), out_cnt [B]
+extern "C" int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scores, const int* label_map,
+                               float nms_threshold, int inclusive, float image_size, int B, float* out, int* out_cnt,
+                               unsigned long long* mask_ws, int* overflow, hipStream_t stream) {
+  if (!cand || !n_keep || !over_scores || !label_map || !out || !out_cnt || !mask_ws || !overflow || B <= 0) return MMD_EINVAL;
+  NmsArgs a{};
+  a.src[0] = cand; a.cnt[0] = n_keep; a.nsrc = 1; a.mode = 0; a.thr = nms_threshold; a.inclusive = inclusive;
+  a.over_scores = over_scores; a.label_map = label_map; a.image_size = image_size;
+  a.out = out; a.out_cnt = out_cnt; a.out_cols = 6; a.out_cap = PP_CAP; a.mask_ws = mask_ws; a.overflow = overflow;
+  hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
+  return mmd_check_launch();
+}
+
+// cross-teacher merge: up to 3 per-teacher outputs ([B,PP_CAP,6] + counts, in teacher order) ->
+// boxes [B,maxg,5] (x1,y1,x2,y2,label) in NMS keep order, nbox [B]
+extern "C" int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2,
+                             const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes,
+                             int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, hipStream_t stream) {
+  if (!t0 || !c0 || !boxes || !nbox || !mask_ws || !overflow || B <= 0 || nteachers < 1 || nteachers > 3 || maxg <= 0) return MMD_EINVAL;
+  if ((nteachers > 1 && (!t1 || !c1)) || (nteachers > 2 && (!t2 || !c2))) return MMD_EINVAL;
+  NmsArgs a{};
+  a.src[0] = t0; a.cnt[0] = c0; a.src[1] = t1; a.cnt[1] = c1; a.src[2] = t2; a.cnt[2] = c2; a.nsrc = nteachers;
+  a.mode = 1; a.thr = iou_threshold; a.inclusive = inclusive;
+  a.out = boxes; a.out_cnt = nbox; a.out_cols = 5; a.out_cap = maxg; a.mask_ws = mask_ws; a.overflow = overflow;
+  hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
+  return mmd_check_launch();
+}
+
+extern "C" int mmd_pp_cap(void) { return PP_CAP; }

@@ -1,0 +1,333 @@
+// Pointwise (1x1) convolution as an fp32 MFMA GEMM on NHWC rows — CDNA4 / gfx950.
+//
+//   forward / input-gradient:  Y[M,N] = pro(X)[M,K] * W[N,K]^T   (+ epilogue)        -> pw_gemm_kernel
+//   weight-gradient:           dW[N,K] += dY[M,N]^T * pro(X)[M,K]                     -> pw_wgrad_kernel
+//
+// pro(X) = act(X*in_scale[k] + in_shift[k]) * gate[image(row), k]  is applied while the A tile is staged
+// through registers into LDS, so a producer's BatchNorm+swish (and the MBConv squeeze-excite gate)
+// never round-trip through HBM as a separate tensor.
+// Reference op: nn.Conv2d(k=1) inside Conv2dStaticSamePadding (src/YetAnotherEfficientNet.py:27-65,
+// call sites :427,446 and src/YetAnotherEfficientDet.py:171,238-265); BN/swish fused here replace
+// src/YetAnotherEfficientNet.py:428,447,126-143.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A and B tiles sit in LDS as
+// [row][k] with k contiguous and a 4-float row pad (stride 36 floats -> conflict-free ds_read_b128);
+// each lane reads 4 consecutive k for its row, lanes 32..63 take the next 4 k, which feeds 4 MFMAs.
+#include "common.h"
+
+struct PwArgs {
+  const float* x; const float* w; float* y;
+  int M, K, N;
+  const float* in_scale; const float* in_shift; int in_act;
+  const float* gate; int rows_per_image;
+  const float* bias; const float* out_scale; const float* out_shift; int out_act;
+  const float* residual; double* stats;
+  long long y_batch_stride; long long y_offset;
+  int ntn; int nblk;
+};
+
+#define PW_BM 128
+#define PW_BK 32
+#define PW_LD 36
+
+template <int BN_T>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
+  constexpr int NS = BN_T / 32;          // 32-col slabs per wave
+  constexpr int NB = BN_T / 32;          // B float4 loads per thread (BN_T*8/256)
+  __shared__ float sA[PW_BM * PW_LD];
+  __shared__ float sB[BN_T * PW_LD];
+  __shared__ float sRed[2 * 4 * BN_T];
+
+  const int tid = threadIdx.x;
+  const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
+  const int tn = t % a.ntn, tm = t / a.ntn;
+  const int m0 = tm * PW_BM, n0 = tn * BN_T;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int kq = (tid & 7) * 4;          // this thread's k offset inside a K tile
+  const int lrow = tid >> 3;             // 0..31
+
+  // per-thread row bookkeeping for the 4 A loads
+  const float* xrow[4]; const float* grow[4]; bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = m0 + lrow + i * 32;
+    rok[i] = row < a.M;
+    int rr = rok[i] ? row : 0;
+    xrow[i] = a.x + (size_t)rr * a.K;
+    grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
+  }
+  const float* wrow[NB]; bool wok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int col = n0 + lrow + i * 32;
+    wok[i] = col < a.N;
+    wrow[i] = a.w + (size_t)(wok[i] ? col : 0) * a.K;
+  }
+
+  f32x16 acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+  float4 ra[4], rg[4], rb[NB], rsc, rsh;
+  bool kok;
+  auto gload = [&](int k0) {
+    int k = k0 + kq;
+    kok = k < a.K;
+    if (a.in_scale) {
+      rsc = kok ? mmd_ld4(a.in_scale + k) : make_float4(0, 0, 0, 0);
+      rsh = kok ? mmd_ld4(a.in_shift + k) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = kok && rok[i];
+      ra[i] = ok ? mmd_ld4(xrow[i] + k) : make_float4(0, 0, 0, 0);
+      if (a.gate) rg[i] = ok ? mmd_ld4(grow[i] + k) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = (kok && wok[i]) ? mmd_ld4(wrow[i] + k) : make_float4(0, 0, 0, 0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if (a.in_scale) {
+        v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
+      }
+      if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+      if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(&sA[(lrow + i * 32) * PW_LD + kq]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = rb[i];
+  };
+
+  const int nk = (a.K + PW_BK - 1) / PW_BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * PW_BK);
+    const float* pa = &sA[(wave * 32 + r) * PW_LD + h * 4];
+    const float* pb = &sB[r * PW_LD + h * 4];
+#pragma unroll
+    for (int kk = 0; kk < PW_BK / 8; ++kk) {
+      float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * PW_LD + kk * 8);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int col = n0 + j * 32 + r;
+    const bool cok = col < a.N;
+    const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
+    const float osc = (a.out_scale && cok) ? a.out_scale[col] : 1.f;
+    const float osh = (a.out_scale && cok) ? a.out_shift[col] : 0.f;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (cok && row < a.M) {
+        float v = acc[j][q] + bias;
+        s += v; ss += v * v;
+        if (a.out_scale) v = v * osc + osh;
+        v = mmd_act(v, a.out_act);
+        size_t off;
+        if (a.y_batch_stride) {
+          int img = row / a.rows_per_image;
+          off = (size_t)img * a.y_batch_stride + a.y_offset + (size_t)(row - img * a.rows_per_image) * a.N + col;
+        } else {
+          off = (size_t)row * a.N + col;
+        }
+        if (a.residual) v += a.residual[off];
+        a.y[off] = v;
+      }
+    }
+    if (a.stats) {
+      s += __shfl_xor(s, 32, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) { sRed[wave * BN_T + j * 32 + r] = s; sRed[4 * BN_T + wave * BN_T + j * 32 + r] = ss; }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    if (tid < BN_T) {
+      int col = n0 + tid;
+      if (col < a.N) {
+        float s = sRed[tid] + sRed[BN_T + tid] + sRed[2 * BN_T + tid] + sRed[3 * BN_T + tid];
+        float ss = sRed[4 * BN_T + tid] + sRed[5 * BN_T + tid] + sRed[6 * BN_T + tid] + sRed[7 * BN_T + tid];
+        atomicAdd(&a.stats[col], (double)s);
+        atomicAdd(&a.stats[a.N + col], (double)ss);
+      }
+    }
+  }
+}
+
+extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N,
+                              const float* in_scale, const float* in_shift, int in_act,
+                              const float* gate, int rows_per_image,
+                              const float* bias, const float* out_scale, const float* out_shift, int out_act,
+                              const float* residual, double* stats,
+                              long long y_batch_stride, long long y_offset, hipStream_t stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || !x || !w || !y) return MMD_EINVAL;
+  if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
+  if ((out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
+  PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1,
+           bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, 0, 0};
+  int ntm = cdiv(M, PW_BM);
+  mmd_prof_begin(MMD_FAM_PW, stream);
+  if (N <= 32) {
+    a.ntn = cdiv(N, 32); a.nblk = ntm * a.ntn;
+    hipLaunchKernelGGL(pw_gemm_kernel<32>, dim3(a.nblk), dim3(256), 0, stream, a);
+  } else {
+    a.ntn = cdiv(N, 64); a.nblk = ntm * a.ntn;
+    hipLaunchKernelGGL(pw_gemm_kernel<64>, dim3(a.nblk), dim3(256), 0, stream, a);
+  }
+  mmd_prof_end(MMD_FAM_PW, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
+  return mmd_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: dW[N,K] += sum_m dY[m,n] * pro(X)[m,k]; output tile 64(n) x 64(k) per block,
+// each of the 4 waves owns a 32x32 sub-tile; the reduction over M is split across blocks
+// (mchunk rows each) and combined with fp32 atomics (256-B contiguous per wave-instruction).
+struct WgArgs {
+  const float* dy; const float* x; float* dw;
+  int M, K, N;
+  const float* in_scale; const float* in_shift; int in_act;
+  const float* gate; int rows_per_image;
+  int mchunk; int ntn; int ntk;
+};
+#define WG_LD 68
+
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
+  __shared__ float sD[32 * WG_LD];
+  __shared__ float sX[32 * WG_LD];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tk = b % a.ntk; b /= a.ntk;
+  const int tn = b % a.ntn; b /= a.ntn;
+  const int mbeg = b * a.mchunk;
+  const int mend = min(a.M, mbeg + a.mchunk);
+  const int n0 = tn * 64, k0 = tk * 64;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int c4 = (tid & 15) * 4;         // column offset inside the 64-wide tile
+  const int lrow = tid >> 4;             // 0..15
+  const bool nok = (n0 + c4) < a.N, kok = (k0 + c4) < a.K;
+  float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
+  if (a.in_scale && kok) { xsc = mmd_ld4(a.in_scale + k0 + c4); xsh = mmd_ld4(a.in_shift + k0 + c4); }
+
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+
+  float4 rd[2], rx[2], rg[2];
+  bool rok[2];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = mb + lrow + i * 16;
+      rok[i] = row < mend;
+      rd[i] = (rok[i] && nok) ? mmd_ld4(a.dy + (size_t)row * a.N + n0 + c4) : make_float4(0, 0, 0, 0);
+      rx[i] = (rok[i] && kok) ? mmd_ld4(a.x + (size_t)row * a.K + k0 + c4) : make_float4(0, 0, 0, 0);
+      if (a.gate)
+        rg[i] = (rok[i] && kok) ? mmd_ld4(a.gate + (size_t)(row / a.rows_per_image) * a.K + k0 + c4)
+                                : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = rx[i];
+      if (a.in_scale) {
+        v.x = v.x * xsc.x + xsh.x; v.y = v.y * xsc.y + xsh.y; v.z = v.z * xsc.z + xsh.z; v.w = v.w * xsc.w + xsh.w;
+      }
+      if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+      if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      if (!(rok[i] && kok)) v = make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(&sX[(lrow + i * 16) * WG_LD + c4]) = v;
+      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = rd[i];
+    }
+  };
+
+  if (mbeg < mend) gload(mbeg);
+  for (int mb = mbeg; mb < mend; mb += 32) {
+    lstore();
+    __syncthreads();
+    if (mb + 32 < mend) gload(mb + 32);
+    const float* pd = &sD[h * WG_LD + wn * 32 + r];
+    const float* px = &sX[h * WG_LD + wk * 32 + r];
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[tt * 2 * WG_LD], px[tt * 2 * WG_LD], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int kcol = k0 + wk * 32 + r;
+  if (kcol < a.K) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      int n = n0 + wn * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (n < a.N) atomicAdd(&a.dw[(size_t)n * a.K + kcol], acc[q]);
+    }
+  }
+}
+
+extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N,
+                                     const float* in_scale, const float* in_shift, int in_act,
+                                     const float* gate, int rows_per_image, hipStream_t stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !dy || !x || !dw) return MMD_EINVAL;
+  if (gate && rows_per_image <= 0) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
+  WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0};
+  a.ntn = cdiv(N, 64); a.ntk = cdiv(K, 64);
+  int tiles = a.ntn * a.ntk;
+  int splits = 2048 / tiles; if (splits < 1) splits = 1;
+  int maxs = cdiv(M, 64); if (splits > maxs) splits = maxs;
+  a.mchunk = cdiv(cdiv(M, splits), 32) * 32;
+  splits = cdiv(M, a.mchunk);
+  mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
+  hipLaunchKernelGGL(pw_wgrad_kernel, dim3(tiles * splits), dim3(256), 0, stream, a);
+  mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
+  return mmd_check_launch();
+}
+
+// dX[M,K] = dY[M,N] * W[N,K]: same MFMA kernel with the transposed weight copy Wt[K,N]
+// (kept per layer by the engine and refreshed after each optimizer step, see mmd_transpose2d).
+extern "C" int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N,
+                                   int accumulate, hipStream_t stream) {
+  // Y'=dx [M,K], X'=dy [M,N], W'=wt [K,N] -> reduction dim is N
+  return mmd_pwconv_fwd(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, 0,
+                        nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, stream);
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+  __shared__ float tile[32][33];
+  int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8)
+    if (r0 + i < R && c < C) tile[i][threadIdx.x] = src[(size_t)(r0 + i) * C + c];
+  __syncthreads();
+  int rr = r0 + threadIdx.x, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += 8)
+    if (c0 + i < C && rr < R) dst[(size_t)(c0 + i) * R + rr] = tile[threadIdx.x][i];
+}
+
+// dst[C,R] = src[R,C]^T
+extern "C" int mmd_transpose2d(const float* src, float* dst, int R, int C, hipStream_t stream) {
+  if (R <= 0 || C <= 0 || !src || !dst) return MMD_EINVAL;
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, src, dst, R, C);
+  return mmd_check_launch();
+}

@@ -1,0 +1,542 @@
+"""Explicit forward / backward schedule of one EfficientDet on the HIP kernels (no autograd, no tracing).
+
+The network is static, so the host simply issues the kernel sequence; the whole step is captured in a
+hipGraph by step.py.  Activations are NHWC fp32 "rows" [B*H*W, C].  A conv's BatchNorm+swish is not
+materialised: the conv writes its raw output z plus per-channel sums, `bn_finalize` turns the sums
+into (scale, shift), and every CONSUMER applies act(z*scale+shift) while staging its input
+(kernel prologue).  Only narrow tensors (MBConv block outputs, BiFPN node outputs) are materialised.
+
+Reference schedule being restated: YetAnotherEfficientDet.forward (src/YetAnotherEfficientDet.py:662-685),
+EfficientNet tap wrapper (:550-572), MBConvBlock.forward (src/YetAnotherEfficientNet.py:450-485),
+BiFPN._forward_fast_attention (:320-392), Regressor/Classifier.forward (:463-532); the backward is
+what autograd derives for them.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .arch import NetSpec, BN_EPS, BN_MOMENTUM, pyramid_sizes
+from .store import ParamStore, Arena
+
+NONE, SWISH, SIGMOID = 0, 1, 2
+call = _lib.call
+
+
+@dataclass
+class Feat:
+    """rows [B*H*W, C] plus the pending per-channel transform consumers must apply."""
+    z: torch.Tensor
+    B: int
+    H: int
+    W: int
+    C: int
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    act: int = NONE
+
+    @property
+    def M(self) -> int:
+        return self.B * self.H * self.W
+
+
+class GradSlot:
+    def __init__(self):
+        self.t: Optional[torch.Tensor] = None
+
+
+class Net:
+    def __init__(self, spec: NetSpec, device, trainable: bool, arena: Optional[Arena] = None,
+                 zarena: Optional[Arena] = None):
+        self.spec = spec
+        self.device = device
+        self.trainable = trainable
+        self.ps = ParamStore(spec, device, with_grads=trainable)
+        self.arena = arena or Arena(device)
+        self.zarena = zarena or Arena(device, 64 << 20)       # per-step accumulators, zeroed in one memset
+        self.bn_momentum = BN_MOMENTUM
+        n = self.ps.bn_total
+        if trainable:
+            self.t_scale = torch.zeros(n, device=device)
+            self.t_shift = torch.zeros(n, device=device)
+            self.t_mean = torch.zeros(n, device=device)
+            self.t_invstd = torch.zeros(n, device=device)
+        self.tape: Dict[str, object] = {}
+        self._anchors: Dict[int, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def load_state(self, state):
+        self.ps.load_state(state)
+        self.refresh()
+
+    def refresh(self):
+        """Recompute derived buffers after parameters changed: eval-BN fold and transposed 1x1 weights."""
+        ps = self.ps
+        call("mmd_bn_fold", ps.flat[ps.gamma_off:ps.gamma_off + ps.bn_total], ps.flat[ps.beta_off:ps.beta_off + ps.bn_total],
+             ps.rmean, ps.rvar, BN_EPS, ps.fold_scale, ps.fold_shift, ps.bn_total)
+        if self.trainable:
+            self.refresh_wt()
+
+    def refresh_wt(self):
+        ps = self.ps
+        for key in ps.wt_off:
+            e = ps.entries[key]
+            call("mmd_transpose2d", ps.w(key), ps.w_t(key), e.native[0], e.native[1])
+
+    # ------------------------------------------------------------------ small helpers
+    def _alloc(self, *shape):
+        return self.arena.alloc(shape)
+
+    def _zalloc(self, shape, dtype=torch.float32):
+        return self.zarena.alloc(shape, dtype)
+
+    def begin_step(self):
+        """Reset the bump arenas and zero the accumulator arena (one memset for all per-step sums)."""
+        self.arena.reset()
+        used = self.zarena.used_bytes()
+        self.zarena.reset()
+        for c in self.zarena.chunks:
+            call("mmd_memset_async", c, 0, c.numel())
+        self.tape = {}
+
+    def _bn_aff(self, name: str, train: bool, stats, count: int):
+        """-> (scale, shift[, mean, invstd]) for BN `name`; train: finalize batch stats + update running."""
+        b = self.ps.bn(name)
+        if not train:
+            return b["fscale"], b["fshift"], None, None
+        o, c = b["off"], b["C"]
+        sc, sh = self.t_scale[o:o + c], self.t_shift[o:o + c]
+        mu, istd = self.t_mean[o:o + c], self.t_invstd[o:o + c]
+        call("mmd_bn_finalize", stats, count, b["gamma"], b["beta"], b["rmean"], b["rvar"], float(self.bn_momentum),
+             BN_EPS, sc, sh, mu, istd, c)
+        return sc, sh, mu, istd
+
+    def _stats(self, C: int):
+        return self._zalloc((2 * C,), torch.float64)
+
+    def _pw(self, x: Feat, wkey: str, N: int, bias=None, stats=None, out_aff=None, out_act=NONE, residual=None,
+            gate=None, y=None, ybs=0, yoff=0, plain_in=False):
+        M, K = x.M, x.C
+        if y is None:
+            y = self._alloc(M, N)
+        call("mmd_pwconv_fwd", x.z, self.ps.w(wkey), y, M, K, N,
+             None if plain_in else x.scale, None if plain_in else x.shift, NONE if plain_in else x.act,
+             gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
+             residual, stats, ybs, yoff)
+        return y
+
+    def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None):
+        OH, OW = -(-x.H // s), -(-x.W // s)
+        y = self._alloc(x.B * OH * OW, x.C)
+        call("mmd_dwconv_fwd", x.z, self.ps.w(wkey), y, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act,
+             out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act, stats, pool)
+        return y, OH, OW
+
+    def anchors(self, image_size: int) -> torch.Tensor:
+        """[A,4] (y1,x1,y2,x2) fp32, float64 math then cast (src/YetAnotherEfficientDet.py:116-147)."""
+        if image_size not in self._anchors:
+            import itertools
+            import numpy as np
+            scales = np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)])
+            ratios = [(1.0, 1.0), (1.4, 0.7), (0.7, 1.4)]
+            allb = []
+            for stride in [8, 16, 32, 64, 128]:
+                lv = []
+                for scale, ratio in itertools.product(scales, ratios):
+                    base = self.spec.anchor_scale * stride * scale
+                    ax, ay = base * ratio[0] / 2.0, base * ratio[1] / 2.0
+                    x = np.arange(stride / 2, image_size, stride)
+                    xv, yv = np.meshgrid(x, x)
+                    xv, yv = xv.reshape(-1), yv.reshape(-1)
+                    b = np.vstack((yv - ay, xv - ax, yv + ay, xv + ax)).swapaxes(0, 1)
+                    lv.append(np.expand_dims(b, 1))
+                allb.append(np.concatenate(lv, axis=1).reshape(-1, 4))
+            self._anchors[image_size] = torch.from_numpy(np.vstack(allb).astype(np.float32)).to(self.device)
+        return self._anchors[image_size]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, train: bool = False, drop_scale: Optional[torch.Tensor] = None):
+        """x: [B,Cin,S,S] NCHW fp32 on device.  drop_scale: [n_skip_blocks, B] = mask/keep (train only).
+        Returns cls [B,A,NC] (probabilities), reg [B,A,4], features: list of 5 Feat (NHWC rows)."""
+        if train and not self.trainable:
+            raise RuntimeError("train-mode forward on a frozen (teacher) net")
+        spec, ps = self.spec, self.ps
+        B, Cin, S, _ = x.shape
+        tape = self.tape if train else {}
+        P = "backbone_net.model"
+        # ---- stem: im2col + GEMM
+        OH = (S + 1) // 2
+        col = self._alloc(B * OH * OH, ps.stem_kp)
+        call("mmd_stem_im2col", x, col, B, Cin, S, S, ps.stem_kp)
+        colf = Feat(col, B, OH, OH, ps.stem_kp)
+        st = self._stats(spec.stem_out) if train else None
+        z = self._pw(colf, f"{P}._conv_stem.conv.weight", spec.stem_out, stats=st)
+        sc, sh, mu, istd = self._bn_aff(f"{P}._bn0", train, st, B * OH * OH)
+        cur = Feat(z, B, OH, OH, spec.stem_out, sc, sh, SWISH)
+        if train:
+            tape["stem"] = (colf, cur, mu, istd)
+        taps: List[Feat] = []
+        skip_i = 0
+        for blk in spec.blocks:
+            q = f"{P}._blocks.{blk.idx}"
+            inp = cur
+            rec = {"inp": inp}
+            if blk.expand != 1:
+                st0 = self._stats(blk.cmid) if train else None
+                z0 = self._pw(inp, f"{q}._expand_conv.conv.weight", blk.cmid, stats=st0)
+                a0 = self._bn_aff(f"{q}._bn0", train, st0, inp.M)
+                f0 = Feat(z0, B, inp.H, inp.W, blk.cmid, a0[0], a0[1], SWISH)
+                rec["f0"], rec["bn0"] = f0, a0
+            else:
+                f0 = inp
+            st1 = self._stats(blk.cmid) if train else None
+            z1, H1, W1 = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, stats=st1)
+            M1 = B * H1 * W1
+            a1 = self._bn_aff(f"{q}._bn1", train, st1, M1)
+            f1 = Feat(z1, B, H1, W1, blk.cmid, a1[0], a1[1], SWISH)
+            pooled = self._zalloc((B, blk.cmid))
+            call("mmd_chan_pool", z1, a1[0], a1[1], SWISH, None, pooled, 1.0 / (H1 * W1), B, H1 * W1, blk.cmid)
+            hpre = self._alloc(B, blk.se)
+            gate = self._alloc(B, blk.cmid)
+            call("mmd_se_fc_fwd", pooled, ps.w(f"{q}._se_reduce.conv.weight"), ps.w(f"{q}._se_reduce.conv.bias"),
+                 ps.w(f"{q}._se_expand.conv.weight"), ps.w(f"{q}._se_expand.conv.bias"), hpre, gate, B, blk.cmid, blk.se)
+            res = inp.z if blk.skip else None
+            if train:
+                st2 = self._stats(blk.cout)
+                z2 = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, stats=st2, gate=gate)
+                a2 = self._bn_aff(f"{q}._bn2", True, st2, M1)
+                y = self._alloc(M1, blk.cout)
+                rs = None
+                if blk.skip and blk.drop_rate and drop_scale is not None:
+                    rs = drop_scale[skip_i]
+                call("mmd_affine_act", z2, a2[0], a2[1], NONE, rs, H1 * W1, res, y, M1, blk.cout)
+                rec.update(f1=f1, bn1=a1, pooled=pooled, hpre=hpre, gate=gate, z2=z2, bn2=a2, rs=rs)
+            else:
+                b2 = ps.bn(f"{q}._bn2")
+                y = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, gate=gate,
+                             out_aff=(b2["fscale"], b2["fshift"]), residual=res)
+            if blk.skip:
+                skip_i += 1
+            cur = Feat(y, B, H1, W1, blk.cout)
+            rec["out"] = cur
+            if train:
+                tape[f"blk{blk.idx}"] = rec
+            if blk.idx in spec.taps:
+                taps.append(cur)
+        # ---- BiFPN
+        feats = self._bifpn(taps, train, tape)
+        # ---- heads
+        A = sum(f.H * f.W for f in feats) * spec.num_anchors
+        reg = self._alloc(B, A, 4)
+        cls = self._alloc(B, A, spec.num_classes)
+        self._head("regressor", feats, 4, reg, A, NONE, train, tape)
+        self._head("classifier", feats, spec.num_classes, cls, A, SIGMOID, train, tape)
+        if train:
+            tape["feats"] = feats
+            tape["A"] = A
+            tape["cls"] = cls
+            # num_batches_tracked += 1 for every BN (one tiny torch op on the contiguous counter vector)
+            ps.nbt.add_(1)
+        return cls, reg, feats
+
+    def _sep_bn(self, name: str, x: Feat, train: bool, rec: dict, bn_name: Optional[str] = None) -> Feat:
+        """SeparableConvBlock(norm=True, activation=False) on a materialised input -> materialised output."""
+        ps = self.ps
+        W = x.C
+        zd, _, _ = self._dw(x, f"{name}.depthwise_conv.conv.weight", 3, 1)
+        zdf = Feat(zd, x.B, x.H, x.W, W)
+        bn_name = bn_name or f"{name}.bn"
+        bias = ps.w(f"{name}.pointwise_conv.conv.bias")
+        if train:
+            st = self._stats(W)
+            z = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, stats=st)
+            a = self._bn_aff(bn_name, True, st, x.M)
+            y = self._alloc(x.M, W)
+            call("mmd_affine_act", z, a[0], a[1], NONE, None, 0, None, y, x.M, W)
+            rec.update(zd=zdf, z=z, bn=a)
+        else:
+            b = ps.bn(bn_name)
+            y = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]))
+        return Feat(y, x.B, x.H, x.W, W)
+
+    def _down_channel(self, name: str, x: Feat, train: bool, tape: dict) -> Feat:
+        ps = self.ps
+        W = self.spec.fpn_w
+        bias = ps.w(f"{name}.0.conv.bias")
+        rec = {"x": x}
+        if train:
+            st = self._stats(W)
+            z = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, stats=st)
+            a = self._bn_aff(f"{name}.1", True, st, x.M)
+            y = self._alloc(x.M, W)
+            call("mmd_affine_act", z, a[0], a[1], NONE, None, 0, None, y, x.M, W)
+            rec.update(z=z, bn=a)
+            tape[name] = rec
+        else:
+            b = ps.bn(f"{name}.1")
+            y = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]))
+        out = Feat(y, x.B, x.H, x.W, W)
+        rec["out"] = out
+        return out
+
+    def _pool(self, x: Feat) -> Feat:
+        OH, OW = (x.H + 1) // 2, (x.W + 1) // 2
+        y = self._alloc(x.B * OH * OW, x.C)
+        call("mmd_maxpool_same_fwd", x.z, y, x.B, x.H, x.W, x.C)
+        return Feat(y, x.B, OH, OW, x.C)
+
+    def _node(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
+              pl: Optional[Feat], train: bool, tape: dict) -> Feat:
+        f = self._alloc(in0.M, in0.C)
+        th = self.ps.w(f"{cell}.{theta}")
+        call("mmd_bifpn_fuse_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th, f,
+             in0.B, in0.H, in0.W, in0.C)
+        ff = Feat(f, in0.B, in0.H, in0.W, in0.C)
+        rec = {"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": ff, "conv": conv}
+        out = self._sep_bn(f"{cell}.{conv}", ff, train, rec)
+        rec["out"] = out
+        if train:
+            tape.setdefault(cell + ".nodes", []).append(rec)
+        return out
+
+    def _bifpn(self, taps: List[Feat], train: bool, tape: dict) -> List[Feat]:
+        feats: List[Feat] = list(taps)
+        for c in range(self.spec.fpn_cells):
+            cell = f"bifpn.{c}"
+            if c == 0:
+                p3, p4, p5 = feats
+                c6 = self._down_channel(f"{cell}.p5_to_p6", p5, train, tape)
+                p6_in = self._pool(c6)
+                p7_in = self._pool(p6_in)
+                p3_in = self._down_channel(f"{cell}.p3_down_channel", p3, train, tape)
+                p4_in = self._down_channel(f"{cell}.p4_down_channel", p4, train, tape)
+                p5_in = self._down_channel(f"{cell}.p5_down_channel", p5, train, tape)
+                if train:
+                    tape[cell + ".first"] = {"c6": c6, "p6_in": p6_in, "p7_in": p7_in}
+            else:
+                p3_in, p4_in, p5_in, p6_in, p7_in = feats
+            p6_up = self._node(cell, "conv6_up", "p6_w1", p6_in, None, p7_in, None, train, tape)
+            p5_up = self._node(cell, "conv5_up", "p5_w1", p5_in, None, p6_up, None, train, tape)
+            p4_up = self._node(cell, "conv4_up", "p4_w1", p4_in, None, p5_up, None, train, tape)
+            p3_out = self._node(cell, "conv3_up", "p3_w1", p3_in, None, p4_up, None, train, tape)
+            if c == 0:
+                p4_in = self._down_channel(f"{cell}.p4_down_channel_2", taps[1], train, tape)
+                p5_in = self._down_channel(f"{cell}.p5_down_channel_2", taps[2], train, tape)
+            p4_out = self._node(cell, "conv4_down", "p4_w2", p4_in, p4_up, None, p3_out, train, tape)
+            p5_out = self._node(cell, "conv5_down", "p5_w2", p5_in, p5_up, None, p4_out, train, tape)
+            p6_out = self._node(cell, "conv6_down", "p6_w2", p6_in, p6_up, None, p5_out, train, tape)
+            p7_out = self._node(cell, "conv7_down", "p7_w2", p7_in, None, None, p6_out, train, tape)
+            feats = [p3_out, p4_out, p5_out, p6_out, p7_out]
+        return feats
+
+    def _head(self, hname: str, feats: List[Feat], per_anchor: int, out: torch.Tensor, A: int, out_act: int,
+              train: bool, tape: dict):
+        ps, spec = self.ps, self.spec
+        nout = spec.num_anchors * per_anchor
+        aoff = 0
+        recs = []
+        for lvl, f in enumerate(feats):
+            cur = f
+            layers = []
+            for i in range(spec.head_layers):
+                cname = f"{hname}.conv_list.{i}"
+                zd, _, _ = self._dw(cur, f"{cname}.depthwise_conv.conv.weight", 3, 1)
+                zdf = Feat(zd, f.B, f.H, f.W, f.C)
+                st = self._stats(f.C) if train else None
+                z = self._pw(zdf, f"{cname}.pointwise_conv.conv.weight", f.C, bias=ps.w(f"{cname}.pointwise_conv.conv.bias"),
+                             stats=st)
+                a = self._bn_aff(f"{hname}.bn_list.{lvl}.{i}", train, st, f.M)
+                nxt = Feat(z, f.B, f.H, f.W, f.C, a[0], a[1], SWISH)
+                layers.append({"x": cur, "zd": zdf, "out": nxt, "bn": a})
+                cur = nxt
+            zd, _, _ = self._dw(cur, f"{hname}.header.depthwise_conv.conv.weight", 3, 1)
+            zdf = Feat(zd, f.B, f.H, f.W, f.C)
+            self._pw(zdf, f"{hname}.header.pointwise_conv.conv.weight", nout, bias=ps.w(f"{hname}.header.pointwise_conv.conv.bias"),
+                     out_act=out_act, y=out, ybs=A * per_anchor, yoff=aoff * per_anchor)
+            recs.append({"layers": layers, "hx": cur, "hzd": zdf, "aoff": aoff})
+            aoff += f.H * f.W * spec.num_anchors
+        if train:
+            tape[hname] = recs
+
+    # ------------------------------------------------------------------ backward (student)
+    def _acc(self, slot: GradSlot, src: torch.Tensor):
+        """slot (+)= src ; first writer just adopts the tensor."""
+        if slot.t is None:
+            slot.t = src
+        else:
+            call("mmd_scale_acc", src, slot.t, None, 0, 0, 1, src.numel())
+
+    def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
+                mul_bc=None, mul_b=None, add_bc=None) -> torch.Tensor:
+        """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated."""
+        b = self.ps.bn(bn_name)
+        sums = self._zalloc((2 * C,), torch.float64)
+        g = self._alloc(M, C)
+        call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, g, sums, M, C)
+        dz = self._alloc(M, C)
+        call("mmd_bn_bwd_apply", g, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C)
+        return dz
+
+    def _pw_bwd(self, dz: torch.Tensor, x: Feat, wkey: str, N: int, bias_key: Optional[str], want_dx: bool,
+                gate=None, plain_in=False) -> Optional[torch.Tensor]:
+        ps = self.ps
+        M, K = x.M, x.C
+        if bias_key:
+            call("mmd_colsum", dz, ps.g(bias_key), M, N)
+        call("mmd_pwconv_bwd_weight", dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
+             None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W)
+        if not want_dx:
+            return None
+        dx = self._alloc(M, K)
+        call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dx, M, K, N, 0)
+        return dx
+
+    def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True):
+        ps = self.ps
+        call("mmd_dwconv_bwd_weight", x.z, dzd, ps.g(wkey), x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act)
+        if not want_dx:
+            return None
+        dx = self._alloc(x.M, x.C)
+        call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s)
+        return dx
+
+    def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]]):
+        """Accumulates parameter gradients into ps.grad.  dcls_logit [B,A,NC] is the gradient w.r.t. the
+        classifier header's PRE-sigmoid output, dreg [B,A,4], dfeats[l] (nullable) w.r.t. the BiFPN outputs."""
+        spec, ps, tape = self.spec, self.ps, self.tape
+        feats: List[Feat] = tape["feats"]
+        A = tape["A"]
+        slots: Dict[int, GradSlot] = {}
+
+        def slot(f: Feat) -> GradSlot:
+            return slots.setdefault(f.z.data_ptr(), GradSlot())
+
+        for f, d in zip(feats, dfeats):
+            if d is not None:
+                slot(f).t = d
+        # ---- heads
+        for hname, per_anchor, dout in (("classifier", spec.num_classes, dcls_logit), ("regressor", 4, dreg)):
+            nout = spec.num_anchors * per_anchor
+            for lvl, rec in enumerate(tape[hname]):
+                f = feats[lvl]
+                dy = self._alloc(f.M, nout)
+                call("mmd_slice_rows", dout, dy, f.B, f.H * f.W, nout, A * per_anchor, rec["aoff"] * per_anchor)
+                dzd = self._pw_bwd(dy, rec["hzd"], f"{hname}.header.pointwise_conv.conv.weight", nout,
+                                   f"{hname}.header.pointwise_conv.conv.bias", True)
+                g = self._dw_bwd(dzd, rec["hx"], f"{hname}.header.depthwise_conv.conv.weight", 3, 1)
+                for i in reversed(range(spec.head_layers)):
+                    L = rec["layers"][i]
+                    cname = f"{hname}.conv_list.{i}"
+                    dz = self._bn_bwd(g, L["out"].z, L["bn"], f"{hname}.bn_list.{lvl}.{i}", SWISH, f.M, f.C)
+                    dzd = self._pw_bwd(dz, L["zd"], f"{cname}.pointwise_conv.conv.weight", f.C,
+                                       f"{cname}.pointwise_conv.conv.bias", True)
+                    g = self._dw_bwd(dzd, L["x"], f"{cname}.depthwise_conv.conv.weight", 3, 1)
+                self._acc(slot(f), g)
+        # ---- BiFPN (cells and nodes in reverse)
+        for c in reversed(range(spec.fpn_cells)):
+            cell = f"bifpn.{c}"
+            for rec in reversed(tape[cell + ".nodes"]):
+                out: Feat = rec["out"]
+                s = slot(out)
+                if s.t is None:
+                    continue          # node output unused downstream (cannot happen in this topology)
+                name = f"{cell}.{rec['conv']}"
+                W = out.C
+                dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W)
+                dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W,
+                                   f"{name}.pointwise_conv.conv.bias", True)
+                df = self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1)
+                in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
+                th = ps.w(f"{cell}.{rec['theta']}")
+                nth = th.numel()
+                dx = self._alloc(out.M, W)
+                wdot = self._zalloc((4,))
+                call("mmd_bifpn_fuse_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                     df, dx, wdot, in0.B, in0.H, in0.W, W)
+                call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
+                wi = 0
+                for operand, kind in ((in0, "same"), (in1, "same"), (up, "up"), (pl, "pool")):
+                    if operand is None:
+                        continue
+                    sl = slot(operand)
+                    accumulate = 0 if sl.t is None else 1
+                    if sl.t is None:
+                        sl.t = self._alloc(operand.M, W)
+                    if kind == "same":
+                        call("mmd_scale_acc", dx, sl.t, th, nth, wi, accumulate, dx.numel())
+                    elif kind == "up":
+                        call("mmd_upsample2_bwd_acc", dx, sl.t, th, nth, wi, accumulate, in0.B, in0.H, in0.W, W)
+                    else:
+                        call("mmd_maxpool_same_bwd_acc", operand.z, dx, sl.t, th, nth, wi, accumulate, operand.B, operand.H,
+                             operand.W, W)
+                    wi += 1
+            if c == 0:
+                first = tape[cell + ".first"]
+                c6, p6_in, p7_in = first["c6"], first["p6_in"], first["p7_in"]
+                s7, s6 = slot(p7_in), slot(p6_in)
+                if s7.t is not None:
+                    acc = 0 if s6.t is None else 1
+                    if s6.t is None:
+                        s6.t = self._alloc(p6_in.M, p6_in.C)
+                    call("mmd_maxpool_same_bwd_acc", p6_in.z, s7.t, s6.t, None, 0, 0, acc, p6_in.B, p6_in.H, p6_in.W, p6_in.C)
+                if s6.t is not None:
+                    sc6 = slot(c6)
+                    sc6.t = self._alloc(c6.M, c6.C)
+                    call("mmd_maxpool_same_bwd_acc", c6.z, s6.t, sc6.t, None, 0, 0, 0, c6.B, c6.H, c6.W, c6.C)
+                for nm in ("p5_down_channel_2", "p4_down_channel_2", "p5_down_channel", "p4_down_channel",
+                           "p3_down_channel", "p5_to_p6"):
+                    name = f"{cell}.{nm}"
+                    rec = tape[name]
+                    out = rec["out"]
+                    s = slot(out)
+                    if s.t is None:
+                        continue
+                    x: Feat = rec["x"]
+                    dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C)
+                    dx = self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, f"{name}.0.conv.bias", True)
+                    self._acc(slot(x), dx)
+        # ---- backbone (blocks in reverse)
+        P = "backbone_net.model"
+        for blk in reversed(spec.blocks):
+            q = f"{P}._blocks.{blk.idx}"
+            rec = tape[f"blk{blk.idx}"]
+            out: Feat = rec["out"]
+            inp: Feat = rec["inp"]
+            s = slot(out)
+            if s.t is None:
+                continue              # blocks after the last tap do not exist; defensive
+            dy = s.t
+            f1: Feat = rec["f1"]
+            M1, HW1 = f1.M, f1.H * f1.W
+            dz2 = self._bn_bwd(dy, rec["z2"], rec["bn2"], f"{q}._bn2", NONE, M1, blk.cout, rpi=HW1, mul_b=rec["rs"])
+            if blk.skip:
+                self._acc(slot(inp), dy)
+            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
+            # squeeze-excite backward
+            dgate = self._zalloc((f1.B, blk.cmid))
+            call("mmd_chan_pool", f1.z, f1.scale, f1.shift, SWISH, g1, dgate, 1.0, f1.B, HW1, blk.cmid)
+            dpe = self._alloc(f1.B, blk.cmid)
+            dpr = self._alloc(f1.B, blk.se)
+            dpooled = self._alloc(f1.B, blk.cmid)
+            call("mmd_se_fc_bwd", dgate, rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
+                 ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dpooled, 1.0 / HW1, ps.g(f"{q}._se_reduce.conv.weight"),
+                 ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"), ps.g(f"{q}._se_expand.conv.bias"),
+                 f1.B, blk.cmid, blk.se)
+            dz1 = self._bn_bwd(g1, f1.z, rec["bn1"], f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
+                               add_bc=dpooled)
+            f0: Feat = rec.get("f0", inp)
+            g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
+            if blk.expand != 1:
+                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid)
+                dx = self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True)
+                self._acc(slot(inp), dx)
+            else:
+                self._acc(slot(inp), g0)
+        # ---- stem
+        colf, stem, mu, istd = tape["stem"]
+        s = slot(stem)
+        dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C)
+        self._pw_bwd(dz, colf, f"{P}._conv_stem.conv.weight", stem.C, None, False)

@@ -1,0 +1,353 @@
+"""GPU parity: every HIP entry point (through the C ABI) against a plain PyTorch-CPU fp32 reference of the
+same op (autograd supplies the backward references).  Tolerances are fp32: rtol 1e-4..1e-3 as stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mm_distillnet_amd import _lib
+
+call = _lib.call
+DEV = "cuda"
+
+
+def g(t):
+    return t.detach().contiguous().to(DEV)
+
+
+def nhwc(t):   # [B,C,H,W] -> rows [B*H*W, C]
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    scale = max(b.abs().max().item(), 1e-30)
+    err = (a - b).abs().max().item()
+    assert err <= atol * scale + rtol * scale, f"{msg} max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def same_pad(x, k, s):
+    h, w = x.shape[-2:]
+    eh = (math.ceil(w / s) - 1) * s - w + k
+    ev = (math.ceil(h / s) - 1) * s - h + k
+    return F.pad(x, [eh // 2, eh - eh // 2, ev // 2, ev - ev // 2])
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 24, 40), (128, 16, 16), (1000, 88, 528), (77, 208, 36), (513, 352, 112)])
+def test_pwconv_fwd_full(M, K, N):
+    torch.manual_seed(M + K + N)
+    B = 4 if M % 4 == 0 else 1
+    rpi = M // B
+    x = torch.randn(M, K); w = torch.randn(N, K) / math.sqrt(K)
+    isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+    gate = torch.rand(B, K)
+    bias = torch.randn(N) * 0.1
+    osc, osh = torch.rand(N) + 0.5, torch.randn(N) * 0.1
+    res = torch.randn(M, N)
+    a = swish(x * isc + ish) * gate.repeat_interleave(rpi, 0)
+    raw = a @ w.t() + bias
+    ref = swish(raw * osc + osh) + res
+    y = torch.empty(M, N, device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, g(isc), g(ish), 1, g(gate), rpi, g(bias), g(osc), g(osh), 1, g(res),
+         stats, 0, 0)
+    close(y, ref, 2e-4, 1e-5, "pw fwd")
+    close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
+    close(stats[N:], (raw.double() ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
+    # plain path
+    y2 = torch.empty(M, N, device=DEV)
+    call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    close(y2, x @ w.t(), 2e-4, 1e-5, "pw plain")
+
+
+def test_pwconv_fwd_remap():
+    torch.manual_seed(1)
+    B, HW, K, N, A_total_rows = 2, 48, 112, 36, 200
+    x = torch.randn(B * HW, K); w = torch.randn(N, K) / 10; bias = torch.randn(N)
+    out = torch.zeros(B, A_total_rows * 4, device=DEV)
+    off = 17 * 4
+    call("mmd_pwconv_fwd", g(x), g(w), out, B * HW, K, N, None, None, 0, None, HW, g(bias), None, None, 2, None, None,
+         A_total_rows * 4, off)
+    ref = torch.sigmoid(x @ w.t() + bias).view(B, HW * N)
+    close(out[:, off:off + HW * N], ref, 2e-4, 1e-5)
+    assert out[:, :off].abs().max().item() == 0 and out[:, off + HW * N:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 24, 40), (4096, 16, 96), (1000, 528, 88), (130, 112, 180)])
+def test_pwconv_bwd(M, K, N):
+    torch.manual_seed(M)
+    B = 2
+    rpi = M // B
+    x = torch.randn(M, K, requires_grad=True); w = (torch.randn(N, K) / math.sqrt(K)).requires_grad_(True)
+    isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+    gate = torch.rand(B, K)
+    a = swish(x * isc + ish) * gate.repeat_interleave(rpi, 0)
+    a.retain_grad()
+    y = a @ w.t()
+    dy = torch.randn(M, N)
+    y.backward(dy)
+    dw = torch.zeros(N, K, device=DEV)
+    call("mmd_pwconv_bwd_weight", g(dy), g(x), dw, M, K, N, g(isc), g(ish), 1, g(gate), rpi)
+    close(dw, w.grad, 3e-4, 1e-5, "dW")
+    wt = torch.empty(K, N, device=DEV)
+    call("mmd_transpose2d", g(w), wt, N, K)
+    close(wt, w.detach().t())
+    dx = torch.full((M, K), 0.5, device=DEV)
+    call("mmd_pwconv_bwd_data", g(dy), wt, dx, M, K, N, 1)
+    close(dx, a.grad + 0.5, 3e-4, 1e-5, "dX acc")
+    call("mmd_pwconv_bwd_data", g(dy), wt, dx, M, K, N, 0)
+    close(dx, a.grad, 3e-4, 1e-5, "dX")
+
+
+@pytest.mark.parametrize("k,s,H,W,C", [(3, 1, 13, 9, 20), (5, 1, 16, 16, 144), (3, 2, 16, 16, 96), (5, 2, 17, 12, 48),
+                                        (3, 1, 4, 4, 112), (5, 2, 32, 32, 240), (3, 2, 9, 7, 16)])
+def test_dwconv(k, s, H, W, C):
+    torch.manual_seed(k * 100 + s * 10 + C)
+    B = 2
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    w = (torch.randn(C, 1, k, k) / k).requires_grad_(True)
+    isc, ish = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    a = swish(x * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1))
+    a.retain_grad()
+    y = F.conv2d(same_pad(a, k, s), w, stride=s, groups=C)
+    OH, OW = y.shape[-2:]
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    wn = g(w.detach().reshape(C, k * k).t())
+    yo = torch.empty(B * OH * OW, C, device=DEV)
+    stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, 0, stats, None)
+    close(yo.view(B, OH, OW, C), nhwc(y), 2e-4, 1e-5, "dw fwd")
+    close(stats[:C], y.double().sum((0, 2, 3)), 1e-4, 1e-4)
+    close(stats[C:], (y.double() ** 2).sum((0, 2, 3)), 1e-4, 1e-5)
+    # eval epilogue + pool
+    osc, osh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    pool = torch.zeros(B, C, device=DEV)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, g(osc), g(osh), 1, None, pool)
+    ye = swish(y * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
+    close(yo.view(B, OH, OW, C), nhwc(ye), 2e-4, 1e-5, "dw eval")
+    close(pool, ye.mean((2, 3)), 2e-4, 1e-5, "pool")
+    # backward
+    dxo = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dxo, B, H, W, C, k, s)
+    close(dxo.view(B, H, W, C), nhwc(a.grad), 2e-4, 1e-5, "dw bwd data")
+    dwo = torch.zeros(k * k, C, device=DEV)
+    call("mmd_dwconv_bwd_weight", g(nhwc(x)), g(nhwc(dy)), dwo, B, H, W, C, k, s, g(isc), g(ish), 1)
+    close(dwo, w.grad.reshape(C, k * k).t(), 3e-4, 1e-5, "dw bwd weight")
+
+
+@pytest.mark.parametrize("M,C,act", [(500, 48, 1), (64, 112, 0), (2048, 528, 1)])
+def test_bn_train_fwd_bwd(M, C, act):
+    torch.manual_seed(C)
+    B = 2
+    rpi = M // B
+    z = (torch.randn(M, C) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C) + 0.5).requires_grad_(True); beta = (torch.randn(C) * 0.1).requires_grad_(True)
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    rm2, rv2 = rm.clone(), rv.clone()
+    y = F.batch_norm(z, rm2, rv2, gamma, beta, True, 0.01, 1e-3)
+    a = swish(y) if act else y
+    mul_bc, add_bc, mul_b = torch.rand(B, C), torch.randn(B, C) * 0.1, torch.rand(B)
+    gin = torch.randn(M, C)
+    geff = gin * mul_bc.repeat_interleave(rpi, 0) * mul_b.repeat_interleave(rpi).view(-1, 1) + add_bc.repeat_interleave(rpi, 0)
+    a.backward(geff)
+    stats = torch.stack([z.detach().double().sum(0), (z.detach().double() ** 2).sum(0)]).reshape(-1).to(DEV)
+    sc, sh, mu, istd = (torch.empty(C, device=DEV) for _ in range(4))
+    drm, drv = g(rm), g(rv)
+    call("mmd_bn_finalize", stats, M, g(gamma), g(beta), drm, drv, 0.01, 1e-3, sc, sh, mu, istd, C)
+    close(drm, rm2, 1e-5, 1e-6); close(drv, rv2, 1e-5, 1e-6)
+    yy = torch.empty(M, C, device=DEV)
+    call("mmd_affine_act", g(z), sc, sh, act, None, 0, None, yy, M, C)
+    close(yy, a, 1e-4, 1e-5, "bn apply")
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    gy = torch.empty(M, C, device=DEV)
+    call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, gy, sums, M, C)
+    dz = torch.empty(M, C, device=DEV)
+    dga, dbe = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    call("mmd_bn_bwd_apply", gy, g(z), mu, istd, g(gamma), sums, M, dz, dga, dbe, M, C)
+    close(dz, z.grad, 5e-4, 1e-5, "bn dz")
+    close(dga, gamma.grad, 5e-4, 1e-5, "dgamma"); close(dbe, beta.grad, 5e-4, 1e-5, "dbeta")
+
+
+def test_affine_act_residual_and_fold():
+    torch.manual_seed(0)
+    B, HW, C = 3, 50, 24
+    M = B * HW
+    z, res = torch.randn(M, C), torch.randn(M, C)
+    gam, bet, rm, rv = torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.3
+    sc, sh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("mmd_bn_fold", g(gam), g(bet), g(rm), g(rv), 1e-3, sc, sh, C)
+    rs = torch.tensor([0.0, 1.25, 1.25])
+    y = torch.empty(M, C, device=DEV)
+    call("mmd_affine_act", g(z), sc, sh, 0, g(rs), HW, g(res), y, M, C)
+    ref = F.batch_norm(z, rm, rv, gam, bet, False, 0.0, 1e-3) * rs.repeat_interleave(HW).view(-1, 1) + res
+    close(y, ref, 1e-4, 1e-5)
+
+
+def test_se_path():
+    torch.manual_seed(2)
+    B, HW, C, S = 3, 64, 144, 6
+    z = torch.randn(B * HW, C, requires_grad=True)
+    sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    wr = (torch.randn(S, C) / 12).requires_grad_(True); br = torch.randn(S, requires_grad=True)
+    we = (torch.randn(C, S) / 3).requires_grad_(True); be = torch.randn(C, requires_grad=True)
+    a = swish(z * sc + sh).view(B, HW, C)
+    pooled = a.mean(1)
+    hpre = pooled @ wr.t() + br
+    gate = torch.sigmoid(swish(hpre) @ we.t() + be)
+    out = a * gate.unsqueeze(1)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    dpool = torch.zeros(B, C, device=DEV)
+    call("mmd_chan_pool", g(z), g(sc), g(sh), 1, None, dpool, 1.0 / HW, B, HW, C)
+    close(dpool, pooled, 1e-4, 1e-5, "pool")
+    dh, dg = torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
+    call("mmd_se_fc_fwd", dpool, g(wr), g(br), g(we), g(be), dh, dg, B, C, S)
+    close(dh, hpre, 1e-4, 1e-5); close(dg, gate, 1e-4, 1e-5, "gate")
+    # backward: dgate = sum_hw gout*a
+    dgate = torch.zeros(B, C, device=DEV)
+    call("mmd_chan_pool", g(z), g(sc), g(sh), 1, g(gout.reshape(B * HW, C)), dgate, 1.0, B, HW, C)
+    close(dgate, (gout * a.detach()).sum(1), 2e-4, 1e-5, "dgate")
+    dpe, dpr, dpooled = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
+    gwr, gbr, gwe, gbe = (torch.zeros_like(t, device=DEV) for t in (wr, br, we, be))
+    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), g(we), dpe, dpr, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S)
+    close(gwr, wr.grad, 3e-4, 1e-5, "dwr"); close(gbr, br.grad, 3e-4, 1e-5); close(gwe, we.grad, 3e-4, 1e-5, "dwe")
+    close(gbe, be.grad, 3e-4, 1e-5)
+    # full dz through bn_bwd_reduce with mul_bc = gate, add_bc = dpooled (identity "BN": mean 0, invstd 1)
+    gy = torch.empty(B * HW, C, device=DEV)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", g(gout.reshape(B * HW, C)), g(z), g(sc), g(sh), torch.zeros(C, device=DEV),
+         torch.ones(C, device=DEV), 1, dg, None, dpooled, HW, gy, sums, B * HW, C)
+    close(gy * g(sc), z.grad, 3e-4, 1e-5, "dz through SE")
+
+
+def test_colsum_slice_sigmoid():
+    torch.manual_seed(3)
+    a = torch.randn(700, 36)
+    out = torch.ones(36, device=DEV)
+    call("mmd_colsum", g(a), out, 700, 36)
+    close(out, a.sum(0) + 1, 1e-4, 1e-5)
+    B, rows, N, At = 2, 10, 36, 100
+    src = torch.randn(B, At * 4)
+    dst = torch.empty(B * rows, N, device=DEV)
+    call("mmd_slice_rows", g(src), dst, B, rows, N, At * 4, 20)
+    close(dst.view(B, rows * N), src[:, 20:20 + rows * N])
+    p, dp = torch.rand(1000), torch.randn(1000)
+    dl = torch.empty(1000, device=DEV)
+    call("mmd_sigmoid_bwd", g(dp), g(p), dl, 1000)
+    close(dl, dp * p * (1 - p))
+
+
+@pytest.mark.parametrize("cin,S", [(3, 32), (1, 18), (8, 16)])
+def test_stem_im2col(cin, S):
+    torch.manual_seed(cin)
+    B = 2
+    x = torch.randn(B, cin, S, S); w = torch.randn(32, cin, 3, 3)
+    ref = F.conv2d(same_pad(x, 3, 2), w, stride=2)
+    OH = ref.shape[-1]
+    Kp = (cin * 9 + 3) // 4 * 4
+    col = torch.empty(B * OH * OH, Kp, device=DEV)
+    call("mmd_stem_im2col", g(x), col, B, cin, S, S, Kp)
+    wp = torch.zeros(32, Kp); wp[:, :cin * 9] = w.reshape(32, -1)
+    y = torch.empty(B * OH * OH, 32, device=DEV)
+    call("mmd_pwconv_fwd", col, g(wp), y, B * OH * OH, Kp, 32, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    close(y.view(B, OH, OH, 32), nhwc(ref), 2e-4, 1e-5)
+
+
+def _maxpool_ref(x):
+    return F.max_pool2d(same_pad(x, 3, 2), 3, 2)
+
+
+@pytest.mark.parametrize("mode", ["td", "bu", "p7"])
+def test_bifpn_fuse(mode):
+    torch.manual_seed(7)
+    B, H, W, C = 2, 8, 8, 16
+    in0 = torch.randn(B, C, H, W, requires_grad=True)
+    in1 = torch.randn(B, C, H, W, requires_grad=True) if mode == "bu" else None
+    up = torch.randn(B, C, H // 2, W // 2, requires_grad=True) if mode == "td" else None
+    pl = (torch.randn(B, C, 2 * H, 2 * W) - 1.5).requires_grad_(True) if mode in ("bu", "p7") else None  # mostly negative: border windows hit the zero pad
+    n = 2 if mode != "bu" else 3
+    theta = torch.tensor([0.7, 1.3, -0.2][:n] if mode != "bu" else [0.7, -0.2, 1.3], requires_grad=True)
+    r = F.relu(theta); wts = r / (r.sum() + 1e-4)
+    ops = [in0] + ([in1] if in1 is not None else []) + ([F.interpolate(up, scale_factor=2, mode="nearest")] if up is not None else []) + ([_maxpool_ref(pl)] if pl is not None else [])
+    xs = sum(wi * o for wi, o in zip(wts, ops))
+    f = swish(xs)
+    df = torch.randn_like(f)
+    f.backward(df)
+    gp = lambda t: g(nhwc(t)) if t is not None else None
+    out = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_bifpn_fuse_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), out, B, H, W, C)
+    close(out.view(B, H, W, C), nhwc(f), 2e-4, 1e-5, "fuse fwd")
+    dx = torch.empty(B * H * W, C, device=DEV)
+    wdot = torch.zeros(4, device=DEV)
+    call("mmd_bifpn_fuse_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), gp(df), dx, wdot, B, H, W, C)
+    dth = torch.zeros(n, device=DEV)
+    call("mmd_bifpn_theta_bwd", g(theta), wdot, dth, n)
+    close(dth, theta.grad, 5e-4, 1e-5, "dtheta")
+    d0 = torch.full((B * H * W, C), 0.25, device=DEV)
+    call("mmd_scale_acc", dx, d0, g(theta), n, 0, 1, dx.numel())
+    close(d0.view(B, H, W, C), nhwc(in0.grad) + 0.25, 3e-4, 1e-5, "din0")
+    wi = 1
+    if in1 is not None:
+        d1 = torch.empty(B * H * W, C, device=DEV)
+        call("mmd_scale_acc", dx, d1, g(theta), n, wi, 0, dx.numel())
+        close(d1.view(B, H, W, C), nhwc(in1.grad), 3e-4, 1e-5, "din1"); wi += 1
+    if up is not None:
+        du = torch.empty(B * (H // 2) * (W // 2), C, device=DEV)
+        call("mmd_upsample2_bwd_acc", dx, du, g(theta), n, wi, 0, B, H, W, C)
+        close(du.view(B, H // 2, W // 2, C), nhwc(up.grad), 3e-4, 1e-5, "dup"); wi += 1
+    if pl is not None:
+        dp = torch.empty(B * 4 * H * W, C, device=DEV)
+        call("mmd_maxpool_same_bwd_acc", gp(pl), dx, dp, g(theta), n, wi, 0, B, 2 * H, 2 * W, C)
+        close(dp.view(B, 2 * H, 2 * W, C), nhwc(pl.grad), 3e-4, 1e-5, "dpool")
+
+
+@pytest.mark.parametrize("H,W", [(8, 8), (7, 5), (2, 2)])
+def test_maxpool(H, W):
+    torch.manual_seed(H)
+    B, C = 2, 8
+    x = (torch.randn(B, C, H, W) - 1.0).requires_grad_(True)
+    y = _maxpool_ref(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    OH, OW = y.shape[-2:]
+    out = torch.empty(B * OH * OW, C, device=DEV)
+    call("mmd_maxpool_same_fwd", g(nhwc(x)), out, B, H, W, C)
+    close(out.view(B, OH, OW, C), nhwc(y))
+    dx = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_maxpool_same_bwd_acc", g(nhwc(x)), g(nhwc(dy)), dx, None, 0, 0, 0, B, H, W, C)
+    close(dx.view(B, H, W, C), nhwc(x.grad))
+
+
+def test_adam_and_clip():
+    torch.manual_seed(5)
+    n = 4096 + 8
+    p = torch.randn(n); gr = torch.randn(n) * 0.01
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4, betas=(0.9, 0.999))
+    dp, dm, dv = g(p), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.zeros(4, device=DEV)
+    hyper = torch.tensor([1e-4, 0.9, 0.999, 1e-8], device=DEV)
+    for it in range(3):
+        gg = gr * (it + 1)
+        ref.grad = gg.clone(); opt.step()
+        call("mmd_adam_step", dp, g(gg), dm, dv, state, hyper, None, 1.0, n)
+    close(dp, ref.detach(), 1e-6, 1e-7, "adam")
+    inactive = torch.zeros(1, dtype=torch.int32, device=DEV)
+    before = dp.clone()
+    call("mmd_adam_step", dp, g(gr), dm, dv, state, hyper, inactive, 1.0, n)
+    assert torch.equal(before, dp) and state[0].item() == 3.0
+    gbuf = g(gr * 100)
+    ws = torch.zeros(1, dtype=torch.float64, device=DEV)
+    call("mmd_clip_grad_norm", gbuf, n, 1.0, ws)
+    refg = (gr * 100).clone(); tot = refg.norm(); refg *= 1.0 / (tot + 1e-6)
+    close(gbuf, refg, 1e-5, 1e-7)
