@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: distillation-step images/sec (3 frozen EfficientDet-D2 teachers + trainable audio
+student, MTA + focal losses, backward, gradient all-reduce, Adam), D2 @ 512x512, per-GPU batch 8, fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (per-GPU batch fixed); student gradients all-reduced with RCCL.
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant kernel
+family (hipEvents on the launch stream, see csrc/prof.hip) and `cpu_baseline` (the oracle/ port of the same
+step on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mm_distillnet_amd import _lib  # noqa: E402
+from mm_distillnet_amd.arch import make_spec  # noqa: E402
+from mm_distillnet_amd.engine import Net  # noqa: E402
+from mm_distillnet_amd.step import DistillEngine, StepConfig  # noqa: E402
+from mm_distillnet_amd.synth import synth_state, synth_inputs, calibrate_bn_  # noqa: E402
+
+FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
+            1: ("pw_wgrad_kernel (1x1 conv weight-grad MFMA GEMM)", "mfma"),
+            2: ("dw_fwd_kernel (depthwise conv forward)", "hbm"),
+            3: ("dw_bwd kernels (depthwise conv backward)", "hbm"),
+            4: ("row-streaming kernels (BN backward / affine / pools)", "hbm")}
+PEAK = {"mfma": 157.3, "hbm": 8000.0}      # TFLOP/s fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
+
+
+def calibrated_state(spec, seed, x, device, cls_bias=-4.0):
+    """hash weights + BN running stats calibrated with one train-mode pass of the HIP engine."""
+    st = synth_state(spec, seed=seed, cls_bias=cls_bias)
+    net = Net(spec, device, trainable=True)
+
+    def tf(state, xin, mom):
+        net.load_state(state)
+        net.bn_momentum = mom
+        net.begin_step()
+        net.forward(xin.to(device), train=True, drop_scale=None)
+        torch.cuda.synchronize()
+        ex = net.ps.export_state()
+        for k in state:
+            if "running_" in k:
+                state[k].copy_(ex[k])
+
+    calibrate_bn_(st, tf, x, seed=seed)
+    del net
+    torch.cuda.empty_cache()
+    return st
+
+
+def cpu_baseline(sstate, tstates, S, sample_b):
+    from oracle import step_ref as ST
+    from mm_distillnet_amd.arch import make_spec as ms
+    torch.set_num_threads(os.cpu_count() or 1)
+    batch = synth_inputs(sample_b, S, seed=77)
+    spec = ms(2, 8)
+    ones = {b.idx: torch.ones(sample_b) for b in spec.blocks if b.skip}
+
+    def one():
+        st = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sstate.items()}
+        t0 = time.time()
+        out = ST.distill_forward(st, tstates, batch, S, 2, ones)
+        loss = ST.total_loss(out)
+        if loss.requires_grad:
+            loss.backward()
+        params = {k: v for k, v in st.items() if v.requires_grad}
+        grads = {k: v.grad for k, v in params.items() if v.grad is not None}
+        with torch.no_grad():
+            ST.adam_step(params, grads, {})
+        return time.time() - t0
+
+    one()                       # warm-up (thread pools, allocator)
+    ts = sorted(one() for _ in range(2))
+    return {"value": round(sample_b / ts[0], 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_b} images @ {S}x{S}: full step (3 teacher fwd + student fwd/bwd + losses + Adam) of the "
+                      f"oracle/ PyTorch-CPU port, best of 2 after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    S, B = args.size, args.batch
+    mods = {"rgb": (3, 1), "depth": (3, 2), "thermal": (1, 3)}
+    specs = {k: make_spec(2, c) for k, (c, _) in mods.items()}
+    calib = synth_inputs(4, 256, seed=1234)
+    tstates = {k: calibrated_state(specs[k], seed, calib[k], dev) for k, (_, seed) in mods.items()}
+    sspec = make_spec(2, 8)
+    sstate = calibrated_state(sspec, 4, calib["audio"], dev)
+    eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S), world_size=world, process_group=pg)
+    eng.load(sstate, tstates)
+    if world > 1:   # identical initial student on every rank (DDP broadcasts parameters at construction)
+        import torch.distributed as dist
+        dist.broadcast(eng.student.ps.flat, 0)
+        eng.student.refresh()
+    batch = {k: v.to(dev) for k, v in synth_inputs(B, S, seed=24 + rank).items()}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = not args.no_graph
+    if use_graph:
+        eng.capture(batch)
+        run = lambda: eng.replay()
+    else:
+        run = lambda: eng.step(batch)
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.check_overflow()
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    nbox = eng.out["nbox"].cpu().tolist()
+
+    # ---- roofline of the dominant kernel family: one eager step bracketed with hipEvents on the launch stream
+    roof = None
+    cpu = None
+    if rank == 0:
+        dll = _lib.LIB.load()
+        for fam in FAMILIES:
+            dll.mmd_prof_enable(fam, 1)
+        torch.cuda.synchronize()
+        eng.step_body(batch if not use_graph else eng.static, eng.static["drop_scale"] if use_graph else eng.make_drop_scale(B))
+        torch.cuda.synchronize()
+        import ctypes
+        res = {}
+        for fam in FAMILIES:
+            buf = (ctypes.c_double * 4)()
+            dll.mmd_prof_collect(fam, buf)
+            dll.mmd_prof_enable(fam, 0)
+            res[fam] = list(buf)
+        fam = max(res, key=lambda f: res[f][1])
+        n, tms, fl, by = res[fam]
+        name, bound = FAMILIES[fam]
+        if bound == "mfma":
+            achieved = fl / (tms * 1e-3) / 1e12
+            unit = "TFLOP/s"
+        else:
+            achieved = by / (tms * 1e-3) / 1e9
+            unit = "GB/s"
+        roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": PEAK[bound], "unit": unit,
+                "frac": round(achieved / PEAK[bound], 4), "traffic": None, "launches_per_step": int(n),
+                "avg_launch_us": round(tms * 1e3 / max(n, 1), 2), "family_ms_per_step": round(tms, 3),
+                "algorithmic_bytes_per_step": by, "algorithmic_flops_per_step": fl,
+                "all_families_ms": {FAMILIES[f][0].split(" ")[0]: round(res[f][1], 3) for f in res}}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sstate, tstates, S, args.cpu_sample)
+        line = {"metric": "distillation-step images/sec (3 teachers + audio student, D2, bs=8)", "value": round(value, 2),
+                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[2]: full 3-teacher (RGB+thermal+depth) -> audio student distillation "
+                                       "step, EfficientDet-D2, 512x512, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % B,
+                           "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
+                           "graph": use_graph, "pseudo_label_boxes_per_image": nbox},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

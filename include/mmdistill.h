@@ -104,6 +104,9 @@ int mmd_focal_loss(const float* cls, const float* reg, const float* anchors, con
 // torch.optim.Adam step on a flat segment (src/optimization/train_methods.py:825-833, traditional.py:190).
 int mmd_adam_step(float* p, const float* g, float* m, float* v, float* state, const float* hyper, const int* active, float grad_scale, long long n, hipStream_t stream);
 
+// Adam over the whole flat buffer with the head (regressor/classifier) ranges skipped until they first receive a gradient.
+int mmd_adam_step_gated(float* p, const float* g, float* m, float* v, float* state_main, float* state_head, const float* hyper, const int* head_active, long long b0, long long e0, long long b1, long long e1, long long b2, long long e2, float grad_scale, long long n, hipStream_t stream);
+
 // hipMemsetAsync wrapper (graph-capturable zeroing of stats / gradient buffers).
 int mmd_memset_async(void* p, int value, long long bytes, hipStream_t stream);
 

@@ -80,3 +80,62 @@ extern "C" int mmd_clip_grad_norm(float* g, long long n, float max_norm, double*
   hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, stream, g, (size_t)n, sumsq_ws, max_norm);
   return mmd_check_launch();
 }
+
+// Whole-buffer Adam with the "head" parameter ranges gated by a device flag.  torch.optim.Adam skips
+// parameters whose .grad is None and keeps a per-parameter step count; in the reference the
+// regressor/classifier parameters have no gradient until the first batch with pseudo-labels
+// (src/loss/YetAnotherFocalLoss.py:179-187 returns constants), after which zero_grad() keeps zero
+// tensors around.  ranges: 3 x [begin,end) in floats (conv weights, BN gammas, BN betas of the heads).
+struct AdamRanges { long long b[3]; long long e[3]; };
+__global__ void adam_prep2_kernel(float* st_main, float* st_head, const float* hyper, const int* head_active) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int s = 0; s < 2; ++s) {
+    float* state = s ? st_head : st_main;
+    if (s && *head_active == 0) continue;
+    float step = state[0] + 1.f;
+    state[0] = step;
+    double b1 = hyper[1], b2 = hyper[2];
+    double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    state[1] = (float)((double)hyper[0] / bc1);
+    state[2] = (float)(1.0 / sqrt(bc2));
+  }
+}
+__global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, const float* st_main, const float* st_head,
+                                                    const float* hyper, const int* head_active, AdamRanges r, float gscale,
+                                                    size_t n4) {
+  const int hact = *head_active;
+  const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    long long e0 = (long long)i * 4;
+    bool head = (e0 >= r.b[0] && e0 < r.e[0]) || (e0 >= r.b[1] && e0 < r.e[1]) || (e0 >= r.b[2] && e0 < r.e[2]);
+    if (head && !hact) continue;
+    const float* st = head ? st_head : st_main;
+    const float step_size = st[1], inv_sqrt_bc2 = st[2];
+    float4 pp = mmd_ld4(p + i * 4), gg = mmd_ld4(g + i * 4), mm = mmd_ld4(m + i * 4), vv = mmd_ld4(v + i * 4);
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = G[k] * gscale;
+      M[k] = b1 * M[k] + (1.f - b1) * gk;
+      V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+      float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
+      P[k] -= step_size * (M[k] / denom);
+    }
+    mmd_st4(p + i * 4, pp); mmd_st4(m + i * 4, mm); mmd_st4(v + i * 4, vv);
+  }
+}
+extern "C" int mmd_adam_step_gated(float* p, const float* g, float* m, float* v, float* state_main, float* state_head,
+                                   const float* hyper, const int* head_active, long long b0, long long e0, long long b1,
+                                   long long e1, long long b2, long long e2, float grad_scale, long long n,
+                                   hipStream_t stream) {
+  if (!p || !g || !m || !v || !state_main || !state_head || !hyper || !head_active || n <= 0 || (n & 3)) return MMD_EINVAL;
+  if ((b0 | e0 | b1 | e1 | b2 | e2) & 3) return MMD_EINVAL;
+  AdamRanges r{{b0, b1, b2}, {e0, e1, e2}};
+  hipLaunchKernelGGL(adam_prep2_kernel, dim3(1), dim3(64), 0, stream, state_main, state_head, hyper, head_active);
+  size_t n4 = (size_t)n / 4;
+  int blocks = cdiv(n4, 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam2_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, state_main, state_head, hyper,
+                     head_active, r, grad_scale, n4);
+  return mmd_check_launch();
+}

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
     if (f & 1) {
       int pos = bo + wo + po;
       float sc = score[(size_t)b * A + a];
-      if (pos < PP_CAP) over_scores[(size_t)b * PP_CAP + pos] = sc; else *overflow = 1;
+      // only the first PP_CAP entries can ever be indexed (index < n_keep <= PP_CAP), so a longer list is not an error
+      if (pos < PP_CAP) over_scores[(size_t)b * PP_CAP + pos] = sc;
       if (f & 2) {
         int kp = bk + wk + pk;
         if (kp < PP_CAP) {

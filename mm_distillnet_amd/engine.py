@@ -56,7 +56,7 @@ class Net:
         self.trainable = trainable
         self.ps = ParamStore(spec, device, with_grads=trainable)
         self.arena = arena or Arena(device)
-        self.zarena = zarena or Arena(device, 64 << 20)       # per-step accumulators, zeroed in one memset
+        self.zarena = zarena or Arena(device, 64 << 20, zero_new=True)       # per-step accumulators, zeroed in one memset
         self.bn_momentum = BN_MOMENTUM
         n = self.ps.bn_total
         if trainable:

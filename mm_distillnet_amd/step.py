@@ -1,0 +1,277 @@
+"""One distillation step of MM-DistillNet on the HIP engine, capturable as a single hipGraph.
+
+Mirrors the reference's per-step path:
+  ModelWithNMSLoss(.Augmented).forward  src/optimization/train_methods.py:310-422 / 436-517
+  (ModelWithNMSKDListLoss for kd_mode="list": :84-162)
+  loss mixing + backward + step         src/optimization/traditional.py:171-190
+with every per-image host loop and `.cpu()` sync replaced by device kernels: teachers' pseudo-labels
+(decode, class filter, NMS), the cross-teacher merge + NMS, the focal/smooth-L1 and MTA losses with
+their gradients, the student backward, gradient all-reduce (RCCL, student gradients only) and Adam.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .arch import NetSpec, make_spec
+from .engine import Net, Feat, NONE, SWISH
+from .store import Arena
+
+call = _lib.call
+TEACHER_ORDER = ("rgb", "depth", "thermal")     # ModuleDict insertion order in train.py:123-135
+
+
+@dataclass
+class StepConfig:
+    image_size: int = 512
+    conf_threshold: float = 0.3
+    nms_threshold: float = 0.5
+    merge_iou: float = 0.5
+    T: float = 9.0
+    p: float = 2.0
+    w_main: float = 1.0
+    w_kd: float = 0.005
+    lr: float = 1e-4
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+    grad_clip: float = -1.0
+    kd_mode: str = "pairwise"          # "pairwise" = ModelWithNMSLoss(.Augmented); "list" = ModelWithNMSKDListLoss
+    valid_prediction_ids: tuple = (6,)  # VOC id of "car" (src/datasets/BaseDataset.py:141-165)
+    label_map: Optional[List[int]] = None
+    inclusive_nms: bool = False
+    max_boxes: int = 512
+
+
+class DistillEngine:
+    def __init__(self, student_spec: NetSpec, teacher_specs: Dict[str, NetSpec], device, cfg: StepConfig,
+                 world_size: int = 1, process_group=None):
+        self.cfg = cfg
+        self.device = device
+        self.world_size = world_size
+        self.pg = process_group
+        self.student = Net(student_spec, device, trainable=True)
+        self.teachers: Dict[str, Net] = {m: Net(teacher_specs[m], device, trainable=False)
+                                         for m in TEACHER_ORDER if m in teacher_specs}
+        ps = self.student.ps
+        n = ps.n_params
+        self.exp_avg = torch.zeros(n, device=device)
+        self.exp_avg_sq = torch.zeros(n, device=device)
+        self.adam_main = torch.zeros(4, device=device)
+        self.adam_head = torch.zeros(4, device=device)
+        self.hyper = torch.tensor([cfg.lr, cfg.b1, cfg.b2, cfg.eps], device=device)
+        self.head_active = torch.zeros(1, dtype=torch.int32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.ws = Arena(device, 256 << 20)        # loss / pseudo-label workspaces (bump, reset per step)
+        self.head_ranges = self._head_ranges()
+        nc = student_spec.num_classes
+        lm = cfg.label_map if cfg.label_map is not None else list(range(nc))
+        self.label_map = torch.tensor(lm, dtype=torch.int32, device=device)
+        self.valid_mask = 0
+        for i in cfg.valid_prediction_ids:
+            self.valid_mask |= 1 << int(i)
+        self.cap = int(_lib.LIB.load().mmd_pp_cap())
+        self.graph = None
+        self.static: Dict[str, torch.Tensor] = {}
+        self.out: Dict[str, torch.Tensor] = {}
+        self.n_skip = sum(1 for b in student_spec.blocks if b.skip)
+        self.keep = torch.tensor([1.0 - b.drop_rate for b in student_spec.blocks if b.skip], device=device).view(-1, 1)
+
+    # ------------------------------------------------------------------
+    def _head_ranges(self):
+        """[begin,end) float ranges of the regressor/classifier parameters in the flat buffer."""
+        ps = self.student.ps
+        conv = [e for e in ps.entries.values() if e.key.startswith(("regressor", "classifier"))]
+        b0 = min(e.off for e in conv)
+        e0 = ps.n_conv
+        bn = [n for n in ps.bn_names if n.startswith(("regressor", "classifier"))]
+        lo = min(ps.bn_off[n] for n in bn)
+        hi = max(ps.bn_off[n] + ((ps.bn_c[n] + 3) // 4 * 4) for n in bn)
+        # heads' conv weights must be the tail of the conv region and their BN channels contiguous
+        assert all(e.off >= b0 for e in conv) and all(
+            (not k.startswith(("regressor", "classifier"))) or ps.entries[k].off >= b0 for k in ps.order)
+        return (b0, e0, ps.gamma_off + lo, ps.gamma_off + hi, ps.beta_off + lo, ps.beta_off + hi)
+
+    def load(self, student_state, teacher_states: Dict[str, dict]):
+        self.student.load_state(student_state)
+        for m, net in self.teachers.items():
+            net.load_state(teacher_states[m])
+
+    def set_lr(self, lr: float):
+        self.hyper[0] = lr
+
+    def make_drop_scale(self, batch: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """mask/keep per skip block and sample: floor(keep + U[0,1)) / keep (src/YetAnotherEfficientNet.py:173-182)."""
+        u = torch.rand(self.n_skip, batch, device=self.device, generator=generator)
+        return torch.floor(self.keep + u) / self.keep
+
+    # ------------------------------------------------------------------
+    def _pseudo_labels(self, net: Net, cls, reg, B: int, A: int, S: int):
+        ws, cap = self.ws, self.cap
+        nc = net.spec.num_classes
+        score = ws.alloc((B * A,)); clsid = ws.alloc((B * A,), torch.uint8); flags = ws.alloc((B * A,), torch.uint8)
+        over = ws.alloc((B, cap)); cand = ws.alloc((B, cap, 6))
+        n_over = ws.alloc((B,), torch.int32); n_keep = ws.alloc((B,), torch.int32)
+        call("mmd_decode_filter", cls, reg, net.anchors(S), B, A, nc, float(self.cfg.conf_threshold), self.valid_mask, float(S),
+             score, clsid, flags, over, cand, n_over, n_keep, self.overflow)
+        rows = ws.alloc((B, cap, 6)); cnt = ws.alloc((B,), torch.int32)
+        call("mmd_nms_teacher", cand, n_keep, over, self.label_map, float(self.cfg.nms_threshold),
+             1 if self.cfg.inclusive_nms else 0, float(S), B, rows, cnt, self.mask_ws, self.overflow)
+        return rows, cnt
+
+    def _attention(self, f: Feat) -> torch.Tensor:
+        a = self.ws.alloc((f.M,))
+        call("mmd_mta_attention", f.z, a, f.M, f.C, float(self.cfg.p))
+        return a
+
+    def step_body(self, batch: Dict[str, torch.Tensor], drop_scale: torch.Tensor):
+        """Issues the whole step on the current stream.  batch tensors are NCHW fp32 on device."""
+        cfg = self.cfg
+        st = self.student
+        S = cfg.image_size
+        B = batch["audio"].shape[0]
+        self.ws.reset()
+        self.mask_ws = self.ws.alloc((B * self.cap * (self.cap // 64),), torch.int64)
+        st.begin_step()
+        cls_s, reg_s, feats_s = st.forward(batch["audio"], train=True, drop_scale=drop_scale)
+        A = cls_s.shape[1]
+        nlv = len(feats_s)
+        a_s = [self._attention(f) for f in feats_s]
+        da = [self.ws.alloc((f.M,)) for f in feats_s]
+        nt = len(self.teachers)
+        kd = self.ws.alloc((nt if cfg.kd_mode == "pairwise" else 1, nlv))
+        call("mmd_memset_async", kd, 0, kd.numel() * 4)
+        rows_t, cnt_t, att_t = [], [], []
+        for ti, (mod, net) in enumerate(self.teachers.items()):
+            net.begin_step()
+            cls_t, reg_t, feats_t = net.forward(batch[mod], train=False)
+            r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
+            rows_t.append(r); cnt_t.append(c)
+            at = [self._attention(f) for f in feats_t]
+            att_t.append(at)
+            if cfg.kd_mode == "pairwise":
+                for l, f in enumerate(feats_s):
+                    call("mmd_mta_kl", a_s[l], at[l], None, None, 1, B, f.H * f.W, float(cfg.T), kd[ti, l:l + 1], da[l],
+                         float(cfg.w_kd), 1 if ti > 0 else 0)
+        if cfg.kd_mode != "pairwise":
+            for l, f in enumerate(feats_s):
+                call("mmd_mta_kl", a_s[l], att_t[0][l], att_t[1][l] if nt > 1 else None, att_t[2][l] if nt > 2 else None,
+                     nt, B, f.H * f.W, float(cfg.T), kd[0, l:l + 1], da[l], float(cfg.w_kd), 0)
+        dfe = []
+        for l, f in enumerate(feats_s):
+            d = st._alloc(f.M, f.C)
+            call("mmd_mta_attention_bwd", f.z, da[l], d, f.M, f.C, float(cfg.p), 0)
+            dfe.append(d)
+        # cross-teacher merge -> annotations
+        G = cfg.max_boxes
+        boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
+        call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
+             rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(cfg.merge_iou),
+             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow)
+        # focal + smooth-L1 with gradients w.r.t. (pre-sigmoid) classifier logits and regression
+        nc = st.spec.num_classes
+        assign = self.ws.alloc((B * A,), torch.int32); npos = self.ws.alloc((B,), torch.int32)
+        acc = self.ws.alloc((2 * B,), torch.float64); main = self.ws.alloc((2,))
+        dcls = st._alloc(B, A, nc); dreg = st._alloc(B, A, 4)
+        call("mmd_focal_loss", cls_s, reg_s, st.anchors(S), boxes, nbox, G, B, A, nc, assign, npos, acc, main, dcls, dreg,
+             float(cfg.w_main), 1, self.head_active)
+        # backward + optimizer
+        call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
+        st.backward(dcls, dreg, dfe)
+        self.out = {"reg": main[0:1], "cls": main[1:2], "kd": kd, "boxes": boxes, "nbox": nbox,
+                    "cls_s": cls_s, "reg_s": reg_s, "feats_s": feats_s, "rows_t": rows_t, "cnt_t": cnt_t}
+        return self.out
+
+    def allreduce_grads(self):
+        """RCCL all-reduce(sum) of the flat student gradient buffer (teachers are frozen: nothing else is
+        exchanged).  The 1/world average is folded into the optimizer's grad_scale.  head_active is reduced
+        with max so that every rank gates the same parameter ranges (ranks may disagree on whether their
+        batch had pseudo-labels)."""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        g = self.student.ps.grad
+        nb = 4
+        per = (g.numel() // nb + 3) // 4 * 4
+        for i in range(nb):
+            seg = g[i * per:min(g.numel(), (i + 1) * per)]
+            if seg.numel():
+                dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.pg)
+        dist.all_reduce(self.head_active, op=dist.ReduceOp.MAX, group=self.pg)
+
+    def optimizer_body(self):
+        cfg, ps = self.cfg, self.student.ps
+        gs = 1.0 / self.world_size
+        if cfg.grad_clip > 0:
+            if self.world_size > 1:
+                ps.grad.mul_(gs)
+                gs = 1.0
+            ws = self.ws.alloc((1,), torch.float64)
+            call("mmd_clip_grad_norm", ps.grad, ps.grad.numel(), float(cfg.grad_clip), ws)
+        r = self.head_ranges
+        call("mmd_adam_step_gated", ps.flat, ps.grad, self.exp_avg, self.exp_avg_sq, self.adam_main, self.adam_head,
+             self.hyper, self.head_active, r[0], r[1], r[2], r[3], r[4], r[5], float(gs), ps.n_params)
+        self.student.refresh_wt()
+
+    # ------------------------------------------------------------------ eager / graph drivers
+    def step(self, batch: Dict[str, torch.Tensor], drop_scale: Optional[torch.Tensor] = None):
+        """Eager step (no graph): forward, losses, backward, all-reduce, Adam."""
+        B = batch["audio"].shape[0]
+        if drop_scale is None:
+            drop_scale = self.make_drop_scale(B)
+        out = self.step_body(batch, drop_scale)
+        self.allreduce_grads()
+        self.optimizer_body()
+        return out
+
+    def capture(self, batch: Dict[str, torch.Tensor]):
+        """Warm up eagerly (sizes the arenas), then capture forward+loss+backward and the optimizer as two
+        hipGraphs; the gradient all-reduce runs between them (RCCL is launched eagerly, not captured)."""
+        B = batch["audio"].shape[0]
+        self.static = {k: v.clone() for k, v in batch.items()}
+        self.static["drop_scale"] = self.make_drop_scale(B)
+        torch.cuda.synchronize()
+        # snapshot so the warm-up steps do not change the training trajectory
+        ps = self.student.ps
+        snap = [t.clone() for t in (ps.flat, ps.rmean, ps.rvar, ps.nbt, self.exp_avg, self.exp_avg_sq, self.adam_main,
+                                    self.adam_head, self.head_active)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.step_body(self.static, self.static["drop_scale"])
+                self.optimizer_body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for arena in [self.ws, self.student.arena, self.student.zarena] + [a for n in self.teachers.values() for a in (n.arena, n.zarena)]:
+            arena.frozen = True
+        self.g_main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_main):
+            self.step_body(self.static, self.static["drop_scale"])
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self.optimizer_body()
+        for dst, src in zip((ps.flat, ps.rmean, ps.rvar, ps.nbt, self.exp_avg, self.exp_avg_sq, self.adam_main,
+                             self.adam_head, self.head_active), snap):
+            dst.copy_(src)
+        self.student.refresh()
+        torch.cuda.synchronize()
+        self.graph = True
+
+    def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, drop_scale: Optional[torch.Tensor] = None):
+        if batch is not None:
+            for k, v in batch.items():
+                self.static[k].copy_(v, non_blocking=True)
+        B = self.static["audio"].shape[0]
+        self.static["drop_scale"].copy_(drop_scale if drop_scale is not None else self.make_drop_scale(B))
+        self.g_main.replay()
+        self.allreduce_grads()
+        self.g_opt.replay()
+        return self.out
+
+    def check_overflow(self):
+        if int(self.overflow.item()):
+            raise RuntimeError("pseudo-label candidate capacity exceeded (more than %d candidates per image)" % self.cap)

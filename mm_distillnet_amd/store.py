@@ -208,8 +208,9 @@ class Arena:
     """Bump allocator over a few big device chunks; reset() every step gives identical addresses each
     step (what a captured hipGraph needs) and avoids allocator traffic for ~10^3 activations."""
 
-    def __init__(self, device, chunk_bytes: int = 1 << 30):
+    def __init__(self, device, chunk_bytes: int = 1 << 30, zero_new: bool = False):
         self.device = device
+        self.zero_new = zero_new        # accumulator arenas must start from zeros (atomics add into them)
         self.chunk_bytes = chunk_bytes
         self.chunks: List[torch.Tensor] = []
         self.ci = 0
@@ -233,7 +234,8 @@ class Arena:
             if self.ci == len(self.chunks):
                 if self.frozen:
                     raise RuntimeError("arena would grow while frozen (a graph was captured on it)")
-                self.chunks.append(torch.empty(max(self.chunk_bytes, nbytes), dtype=torch.uint8, device=self.device))
+                mk = torch.zeros if self.zero_new else torch.empty
+                self.chunks.append(mk(max(self.chunk_bytes, nbytes), dtype=torch.uint8, device=self.device))
             c = self.chunks[self.ci]
             if self.off + nbytes <= c.numel():
                 t = c[self.off:self.off + n * isz].view(dtype).view(shape)

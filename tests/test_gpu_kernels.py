@@ -71,7 +71,7 @@ def test_pwconv_fwd_full(M, K, N):
 
 def test_pwconv_fwd_remap():
     torch.manual_seed(1)
-    B, HW, K, N, A_total_rows = 2, 48, 112, 36, 200
+    B, HW, K, N, A_total_rows = 2, 48, 112, 36, 600
     x = torch.randn(B * HW, K); w = torch.randn(N, K) / 10; bias = torch.randn(N)
     out = torch.zeros(B, A_total_rows * 4, device=DEV)
     off = 17 * 4
