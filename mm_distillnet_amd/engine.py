@@ -154,7 +154,8 @@ class Net:
                     b = np.vstack((yv - ay, xv - ax, yv + ay, xv + ax)).swapaxes(0, 1)
                     lv.append(np.expand_dims(b, 1))
                 allb.append(np.concatenate(lv, axis=1).reshape(-1, 4))
-            self._anchors[image_size] = torch.from_numpy(np.vstack(allb).astype(np.float32)).to(self.device)
+            self._anchors[image_size] = torch.from_numpy(
+                np.ascontiguousarray(np.vstack(allb).astype(np.float32))).contiguous().to(self.device)
         return self._anchors[image_size]
 
     # ------------------------------------------------------------------ forward

@@ -91,8 +91,12 @@ def test_graph_replay_matches_eager():
         out = eng_b.replay(batch, ds)
     torch.cuda.synchronize()
     pa, pb = eng_a.student.ps.flat, eng_b.student.ps.flat
-    # identical kernels and order; only fp32 atomics may reorder sums
-    assert (pa - pb).abs().max().item() <= 2e-5 * pa.abs().max().item() + 1e-7
+    # identical kernels and order; only fp32 atomics reorder sums.  Adam turns a gradient that is pure rounding noise
+    # (e.g. conv biases in front of a train-mode BN, true gradient 0) into +-lr steps, so a small set of parameters
+    # may differ by up to steps*lr; everything else must agree tightly.
+    diff = (pa - pb).abs()
+    assert diff.max().item() <= 3 * 1e-4 * 2.1
+    assert (diff > 2e-5).float().mean().item() < 5e-3
     assert eng_a.adam_main[0].item() == eng_b.adam_main[0].item() == 3.0
     assert torch.equal(eng_a.student.ps.nbt, eng_b.student.ps.nbt)
     np.testing.assert_allclose(eng_a.out["kd"].cpu().numpy(), out["kd"].cpu().numpy(), rtol=1e-4)
