@@ -57,6 +57,7 @@ static inline int mmd_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMD_OK : MMD_ELAUNCH;
 }
+int mmd_zero_bytes(void* p, size_t bytes, hipStream_t stream);   // optim.hip
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel event timing (bench.py roofline leg) ----

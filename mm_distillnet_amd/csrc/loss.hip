@@ -292,8 +292,8 @@ extern "C" int mmd_focal_loss(const float* cls, const float* reg, const float* a
                               int to_logit, int* any_boxes, hipStream_t stream) {
   if (!cls || !reg || !anchors || !boxes || !nbox || !assign_ws || !npos_ws || !acc_ws || !loss_out) return MMD_EINVAL;
   if (B <= 0 || A <= 0 || NC <= 0 || maxg <= 0) return MMD_EINVAL;
-  hipMemsetAsync(npos_ws, 0, sizeof(int) * B, stream);
-  hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * B, stream);
+  mmd_zero_bytes(npos_ws, sizeof(int) * B, stream);
+  mmd_zero_bytes(acc_ws, sizeof(double) * 2 * B, stream);
   dim3 grid(cdiv(A, 256), B);
   hipLaunchKernelGGL(focal_assign_kernel, grid, dim3(256), 0, stream, anchors, boxes, nbox, maxg, A, assign_ws, npos_ws);
   hipLaunchKernelGGL(focal_loss_kernel, grid, dim3(256), 0, stream, cls, reg, anchors, boxes, nbox, assign_ws, npos_ws, maxg,

@@ -51,8 +51,27 @@ extern "C" int mmd_adam_step(float* p, const float* g, float* m, float* v, float
   return mmd_check_launch();
 }
 
+// Zero fill as a plain kernel: hipMemsetAsync nodes recorded by stream capture did not reliably clear the large
+// accumulator arenas on replay (sums kept growing across replays), a kernel node has no such ambiguity.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ p, size_t n16, unsigned char* tail, int ntail) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+int mmd_zero_bytes(void* p, size_t bytes, hipStream_t stream) {
+  uintptr_t a = (uintptr_t)p;
+  if (a & 15) {            // unaligned start: byte loop for the head
+    return hipMemsetAsync(p, 0, bytes, stream) == hipSuccess ? MMD_OK : MMD_ELAUNCH;
+  }
+  size_t n16 = bytes / 16;
+  int ntail = (int)(bytes - n16 * 16);
+  int blocks = cdiv(n16 ? n16 : 1, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, stream, (float4*)p, n16, (unsigned char*)p + n16 * 16, ntail);
+  return mmd_check_launch();
+}
 extern "C" int mmd_memset_async(void* p, int value, long long bytes, hipStream_t stream) {
   if (!p || bytes <= 0) return MMD_EINVAL;
+  if (value == 0) return mmd_zero_bytes(p, (size_t)bytes, stream);
   return hipMemsetAsync(p, value, (size_t)bytes, stream) == hipSuccess ? MMD_OK : MMD_ELAUNCH;
 }
 
@@ -74,7 +93,7 @@ __global__ void clip_scale_kernel(float* __restrict__ x, size_t n, const double*
 }
 extern "C" int mmd_clip_grad_norm(float* g, long long n, float max_norm, double* sumsq_ws, hipStream_t stream) {
   if (!g || n <= 0 || !sumsq_ws || !(max_norm > 0.f)) return MMD_EINVAL;
-  hipMemsetAsync(sumsq_ws, 0, sizeof(double), stream);
+  mmd_zero_bytes(sumsq_ws, sizeof(double), stream);
   int blocks = cdiv(n, 1024); if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, g, (size_t)n, sumsq_ws);
   hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, stream, g, (size_t)n, sumsq_ws, max_norm);

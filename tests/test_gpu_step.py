@@ -85,25 +85,34 @@ def test_step_golden(golden_dir, variant):
 
 
 def test_graph_replay_matches_eager():
+    """The captured hipGraphs must reproduce the eager step: same pseudo-labels and losses, gradients equal up to the
+    run-to-run noise of fp32 atomics (measured eager-vs-eager: ~2e-4 of the largest gradient at this tiny size), and
+    every replay must start from cleared accumulators (labels of a frozen teacher cannot change between replays)."""
     S, B = 128, 2
     batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
     eng_a, spec = build("pairwise", S)
     eng_b, _ = build("pairwise", S)
     g = torch.Generator(device=DEV).manual_seed(1)
-    scales = [eng_a.make_drop_scale(B, g) for _ in range(3)]
-    for ds in scales:
-        eng_a.step(batch, ds)
+    ds = eng_a.make_drop_scale(B, g)
     eng_b.capture(batch)
-    for ds in scales:
-        out = eng_b.replay(batch, ds)
+    oa = eng_a.step_body(batch, ds)
+    eng_b.static["drop_scale"].copy_(ds)
+    eng_b.g_main.replay()
     torch.cuda.synchronize()
-    pa, pb = eng_a.student.ps.flat, eng_b.student.ps.flat
-    # identical kernels and order; only fp32 atomics reorder sums.  Adam turns a gradient that is pure rounding noise
-    # (e.g. conv biases in front of a train-mode BN, true gradient 0) into +-lr steps, so a small set of parameters
-    # may differ by up to steps*lr; everything else must agree tightly.
-    diff = (pa - pb).abs()
-    assert diff.max().item() <= 3 * 1e-4 * 2.1
-    assert (diff > 2e-5).float().mean().item() < 5e-3
-    assert eng_a.adam_main[0].item() == eng_b.adam_main[0].item() == 3.0
+    ob = eng_b.out
+    assert oa["nbox"].tolist() == ob["nbox"].tolist()
+    for k in ("reg", "cls", "kd"):
+        np.testing.assert_allclose(oa[k].cpu().numpy(), ob[k].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    ga, gb = eng_a.student.ps.grad, eng_b.student.ps.grad
+    assert torch.isfinite(gb).all()
+    assert (ga - gb).abs().max().item() <= 2e-3 * ga.abs().max().item()
+    eng_a.optimizer_body(); eng_b.g_opt.replay()
+    torch.cuda.synchronize()
+    assert eng_a.adam_main[0].item() == eng_b.adam_main[0].item() == 1.0
     assert torch.equal(eng_a.student.ps.nbt, eng_b.student.ps.nbt)
-    np.testing.assert_allclose(eng_a.out["kd"].cpu().numpy(), out["kd"].cpu().numpy(), rtol=1e-4)
+    # replays 2 and 3: frozen teachers + same inputs -> identical labels every time
+    for _ in range(2):
+        eng_b.replay(batch, ds)
+    torch.cuda.synchronize()
+    assert eng_b.out["nbox"].tolist() == oa["nbox"].tolist()
+    assert torch.isfinite(eng_b.student.ps.flat).all() and eng_b.adam_main[0].item() == 3.0
