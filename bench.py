@@ -63,19 +63,21 @@ def tune_teacher_bias(spec, state, x, device, target_per_image=40):
     random-weight teachers otherwise emit either nothing or thousands of boxes, which is not the workload."""
     import math
     net = Net(spec, device, trainable=False)
-    net.load_state(state)
-    net.begin_step()
-    cls, _, _ = net.forward(x.to(device), train=False)
-    p = cls.clamp(1e-7, 1 - 1e-7)
-    logit = torch.log(p / (1 - p))
-    best, arg = logit.max(2)
-    car = best[arg == 6]
-    k = min(car.numel() - 1, target_per_image * cls.shape[0])
-    if k <= 0:
-        return
-    v = torch.sort(car, descending=True)[0][k].item()
-    delta = math.log(0.3 / 0.7) - v
-    state["classifier.header.pointwise_conv.conv.bias"] += delta
+    xd = x.to(device)
+    for _ in range(4):          # sigmoid saturates: iterate until the count is in range
+        net.load_state(state)
+        net.begin_step()
+        cls, _, _ = net.forward(xd, train=False)
+        p = cls.double().clamp(1e-12, 1 - 1e-12)
+        logit = torch.log(p / (1 - p))
+        best, arg = logit.max(2)
+        car = best[arg == 6]
+        n_now = int((car > math.log(0.3 / 0.7)).sum().item())
+        tgt = target_per_image * cls.shape[0]
+        if 0.5 * tgt <= n_now <= 1.5 * tgt or car.numel() <= tgt:
+            break
+        v = torch.sort(car, descending=True)[0][tgt].item()
+        state["classifier.header.pointwise_conv.conv.bias"] += float(math.log(0.3 / 0.7) - v)
     del net
     torch.cuda.empty_cache()
 
