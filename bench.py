@@ -85,7 +85,9 @@ def tune_teacher_bias(spec, state, x, device, target_per_image=40):
 def cpu_baseline(sstate, tstates, S, sample_b):
     from oracle import step_ref as ST
     from mm_distillnet_amd.arch import make_spec as ms
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, 64)))
+    log("cpu baseline on %d threads" % torch.get_num_threads())
     batch = synth_inputs(sample_b, S, seed=77)
     spec = ms(2, 8)
     ones = {b.idx: torch.ones(sample_b) for b in spec.blocks if b.skip}
@@ -104,11 +106,19 @@ def cpu_baseline(sstate, tstates, S, sample_b):
             ST.adam_step(params, grads, {})
         return time.time() - t0
 
-    one()                       # warm-up (thread pools, allocator)
-    ts = sorted(one() for _ in range(2))
+    t_w = one()                 # warm-up (thread pools, allocator)
+    log("cpu baseline warm-up step %.1fs" % t_w)
+    ts = sorted(one() for _ in range(1 if t_w > 20 else 2))
     return {"value": round(sample_b / ts[0], 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{sample_b} images @ {S}x{S}: full step (3 teacher fwd + student fwd/bwd + losses + Adam) of the "
-                      f"oracle/ PyTorch-CPU port, best of 2 after 1 warm-up"}
+                      f"oracle/ PyTorch-CPU port, best of <=2 after 1 warm-up"}
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    print("[bench %6.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -137,12 +147,14 @@ def main():
     mods = {"rgb": (3, 1), "depth": (3, 2), "thermal": (1, 3)}
     specs = {k: make_spec(2, c) for k, (c, _) in mods.items()}
     calib = synth_inputs(4, 256, seed=1234)
+    log("building states")
     tstates = {k: calibrated_state(specs[k], seed, calib[k], dev) for k, (_, seed) in mods.items()}
     sspec = make_spec(2, 8)
     sstate = calibrated_state(sspec, 4, calib["audio"], dev)
     batch_cpu = synth_inputs(B, S, seed=24 + rank)
     for k in tstates:
         tune_teacher_bias(specs[k], tstates[k], batch_cpu[k], dev)
+    log("teacher biases tuned")
     eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S), world_size=world, process_group=pg)
     eng.load(sstate, tstates)
     if world > 1:   # identical initial student on every rank (DDP broadcasts parameters at construction)
@@ -159,8 +171,10 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph
+    log("engine loaded")
     if use_graph:
         eng.capture(batch)
+        log("graphs captured")
         run = lambda: eng.replay()
     else:
         run = lambda: eng.step(batch)
@@ -178,6 +192,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
+    log("timed %d steps: %.2f ms/step" % (args.steps, ms))
     if int(eng.overflow.item()):
         print("per-teacher candidate counts:", [c.cpu().tolist() for c in eng.out["cnt_t"]], file=sys.stderr)
     eng.check_overflow()
@@ -201,6 +216,7 @@ def main():
             dll.mmd_prof_collect(fam, buf)
             dll.mmd_prof_enable(fam, 0)
             res[fam] = list(buf)
+        log("family times ms: %s" % {f: round(res[f][1], 3) for f in res})
         fam = max(res, key=lambda f: res[f][1])
         n, tms, fl, by = res[fam]
         name, bound = FAMILIES[fam]
