@@ -204,6 +204,8 @@ def main():
     cpu = None
     if rank == 0:
         dll = _lib.LIB.load()
+        if os.environ.get("MMD_PROF_DUMP"):
+            dll.mmd_prof_dump_to(os.environ["MMD_PROF_DUMP"].encode())
         for fam in FAMILIES:
             dll.mmd_prof_enable(fam, 1)
         torch.cuda.synchronize()
@@ -217,6 +219,7 @@ def main():
             dll.mmd_prof_enable(fam, 0)
             res[fam] = list(buf)
         log("family times ms: %s" % {f: round(res[f][1], 3) for f in res})
+        dll.mmd_prof_dump_to(None)
         fam = max(res, key=lambda f: res[f][1])
         n, tms, fl, by = res[fam]
         name, bound = FAMILIES[fam]

@@ -69,7 +69,7 @@ int mmd_chan_pool(const float* z, const float* scale, const float* shift, int ac
 int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
 
 // Backward of the squeeze-excite FCs (weight grads +=, dpooled scaled by dpool_scale = 1/HW).
-int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
+int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
 
 // BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat).
 int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, hipStream_t stream);
@@ -128,6 +128,8 @@ int mmd_pp_cap(void);
 
 // Profiling hooks for bench.py (hipEvents on the launch stream).
 int mmd_prof_is_on(int family);
+
+int mmd_prof_dump_to(const char* path);
 
 int mmd_prof_enable(int family, int on);
 

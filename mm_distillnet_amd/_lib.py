@@ -32,7 +32,9 @@ def parse_header(path: str = HEADER) -> Dict[str, list]:
         if args and args != "void":
             for a in args.split(","):
                 a = a.strip()
-                if "*" in a:
+                if a.startswith("const char"):
+                    types.append(ctypes.c_char_p)
+                elif "*" in a:
                     types.append(ctypes.c_void_p)
                 else:
                     t = " ".join(a.split()[:-1])

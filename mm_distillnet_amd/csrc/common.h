@@ -66,6 +66,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 extern "C" int mmd_prof_is_on(int family);
 void mmd_prof_begin(int family, hipStream_t s);
 void mmd_prof_end(int family, hipStream_t s, double flops, double bytes);
+void mmd_prof_tag(int family, const char* fmt, long long a, long long b, long long c, long long d);
 #define MMD_FAM_PW 0
 #define MMD_FAM_PW_WGRAD 1
 #define MMD_FAM_DW 2

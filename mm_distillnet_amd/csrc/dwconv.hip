@@ -184,6 +184,7 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   a.flip = 0; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
   a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
+  mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW, stream);
   int rc;
   if (k == 3 && stride == 1) rc = dw_fwd_launch<3, 1>(a, stream);

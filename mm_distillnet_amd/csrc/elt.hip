@@ -147,70 +147,89 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
   return mmd_check_launch();
 }
 
-// ---------------------------------------------------------------- squeeze-excite FCs (one block per image)
+// ---------------------------------------------------------------- squeeze-excite FCs
 // reference: src/YetAnotherEfficientNet.py:469-474.  wr [S,C], br [S], we [C,S], be [C].
-__global__ __launch_bounds__(256) void se_fc_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
-                                                        const float* __restrict__ br, const float* __restrict__ we,
-                                                        const float* __restrict__ be, float* __restrict__ hpre,
-                                                        float* __restrict__ gate, int C, int S) {
-  extern __shared__ float sm[];  // [C] pooled + [S] hidden
-  float* sp = sm; float* shid = sm + C;
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int c = tid; c < C; c += 256) sp[c] = pooled[(size_t)b * C + c];
-  __syncthreads();
-  for (int j = wave; j < S; j += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc += wr[(size_t)j * C + c] * sp[c];
-    acc = wave_sum(acc);
-    if (lane == 0) { float h = acc + br[j]; hpre[(size_t)b * S + j] = h; shid[j] = mmd_swish(h); }
+// Two small launches with enough blocks to fill the chip (one block per image was 50 us per call):
+//   hidden: one wave per (image, j): hpre[b,j] = wr[j,:].pooled[b,:] + br[j]        (coalesced over C)
+//   gate  : one wave per 16 channels: gate[b,c] = sigmoid(we[c,:].swish(hpre[b,:]) + be[c])   (coalesced over S)
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
+                                                        const float* __restrict__ br, float* __restrict__ hpre, int C, int S) {
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.y * 4 + wave;
+  if (j >= S) return;
+  const float* p = pooled + (size_t)b * C;
+  const float* w = wr + (size_t)j * C;
+  float acc = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 a = mmd_ld4(p + c), q = mmd_ld4(w + c);
+    acc += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
   }
+  acc = wave_sum(acc);
+  if (lane == 0) hpre[(size_t)b * S + j] = acc + br[j];
+}
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hpre, const float* __restrict__ we,
+                                                      const float* __restrict__ be, float* __restrict__ gate, int C, int S) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = threadIdx.x; j < S; j += 256) sh[j] = mmd_swish(hpre[(size_t)b * S + j]);
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float acc = be[c];
-    for (int j = 0; j < S; ++j) acc += we[(size_t)c * S + j] * shid[j];
-    gate[(size_t)b * C + c] = mmd_sigmoid(acc);
+  for (int i = 0; i < 16; ++i) {
+    int c = blockIdx.y * 64 + wave * 16 + i;
+    if (c >= C) break;
+    float acc = 0.f;
+    for (int j = lane; j < S; j += 64) acc += we[(size_t)c * S + j] * sh[j];
+    acc = wave_sum(acc);
+    if (lane == 0) gate[(size_t)b * C + c] = mmd_sigmoid(acc + be[c]);
   }
 }
 extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
                              float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
-  if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || S <= 0) return MMD_EINVAL;
-  hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(B), dim3(256), (C + S) * sizeof(float), stream, pooled, wr, br, we, be, hpre, gate, C, S);
+  if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_hidden_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, stream, hpre, we, be, gate, C, S);
   return mmd_check_launch();
 }
 
-// backward, step 1 (one block per image): dgate[b,c] = dL/d gate ->
-//   dpe[b,c] = dgate*gate*(1-gate), dpr[b,j] = (We^T dpe)_j * swish'(hpre), dpooled[b,c] = dpool_scale * (Wr^T dpr)_c
-__global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                        const float* __restrict__ hpre, const float* __restrict__ wr,
-                                                        const float* __restrict__ we, float* __restrict__ dpe,
-                                                        float* __restrict__ dpr, float* __restrict__ dpooled,
-                                                        float dpool_scale, int C, int S) {
-  extern __shared__ float sm[];  // [C] dpe, [S] dpr
-  float* sdpe = sm; float* sdpr = sm + C;
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int c = tid; c < C; c += 256) {
-    float g = gate[(size_t)b * C + c];
-    float d = dgate[(size_t)b * C + c] * g * (1.f - g);
-    sdpe[c] = d;
-    dpe[(size_t)b * C + c] = d;
+// backward, step 1a: per (image, 64-channel chunk): dpe[b,c] = dgate*gate*(1-gate); dh[b,j] += sum_c we[c,j]*dpe[b,c]
+// (we rows staged through LDS so the global reads stay coalesced; dh is a zeroed accumulator)
+__global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                       const float* __restrict__ we, float* __restrict__ dpe, float* dh,
+                                                       int C, int S) {
+  extern __shared__ float sm[];      // [64*S] we rows + [64] dpe
+  float* swe = sm; float* sd = sm + 64 * S;
+  const int b = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int nc = min(64, C - c0);
+  for (int i = tid; i < nc * S; i += 256) swe[i] = we[(size_t)c0 * S + i];
+  if (tid < nc) {
+    float g = gate[(size_t)b * C + c0 + tid];
+    float d = dgate[(size_t)b * C + c0 + tid] * g * (1.f - g);
+    sd[tid] = d;
+    dpe[(size_t)b * C + c0 + tid] = d;
   }
   __syncthreads();
-  for (int j = wave; j < S; j += 4) {
+  for (int j = tid; j < S; j += 256) {
     float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc += we[(size_t)c * S + j] * sdpe[c];
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float d = acc * mmd_swish_grad(hpre[(size_t)b * S + j]);
-      sdpr[j] = d;
-      dpr[(size_t)b * S + j] = d;
-    }
+    for (int c = 0; c < nc; ++c) acc += swe[c * S + j] * sd[c];
+    atomicAdd(&dh[(size_t)b * S + j], acc);
+  }
+}
+// step 1b: dpr[b,j] = dh[b,j]*swish'(hpre[b,j]); dpooled[b,c] = dpool_scale * sum_j wr[j,c]*dpr[b,j]
+__global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* __restrict__ dh, const float* __restrict__ hpre,
+                                                       const float* __restrict__ wr, float* __restrict__ dpr,
+                                                       float* __restrict__ dpooled, float dpool_scale, int C, int S) {
+  __shared__ float sd[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < S; j += 256) {
+    float d = dh[(size_t)b * S + j] * mmd_swish_grad(hpre[(size_t)b * S + j]);
+    sd[j] = d;
+    if (blockIdx.y == 0) dpr[(size_t)b * S + j] = d;
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sdpr[j];
-    dpooled[(size_t)b * C + c] = acc * dpool_scale;
-  }
+  const int c = blockIdx.y * 256 + tid;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sd[j];
+  dpooled[(size_t)b * C + c] = acc * dpool_scale;
 }
 // step 2 (grid over weights, sums over the batch, no atomics):
 //   dwe[c,j] += sum_b dpe[b,c]*swish(hpre[b,j]); dbe[c] += sum_b dpe[b,c]
@@ -244,14 +263,17 @@ __global__ void se_fc_wgrad_kernel(const float* __restrict__ dpe, const float* _
   }
 }
 extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled,
-                             const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dpooled,
-                             float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S,
-                             hipStream_t stream) {
-  if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dpooled || !dwr || !dbr || !dwe || !dbe)
+                             const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed,
+                             float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B,
+                             int C, int S, hipStream_t stream) {
+  if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dh_zeroed || !dpooled || !dwr || !dbr ||
+      !dwe || !dbe)
     return MMD_EINVAL;
-  if (B <= 0 || C <= 0 || S <= 0) return MMD_EINVAL;
-  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(B), dim3(256), (C + S) * sizeof(float), stream, dgate, gate, hpre, wr, we,
-                     dpe_ws, dpr_ws, dpooled, dpool_scale, C, S);
+  if (B <= 0 || C <= 0 || S <= 0 || S > 256) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(C, 64)), dim3(256), (64 * S + 64) * sizeof(float), stream, dgate, gate, we,
+                     dpe_ws, dh_zeroed, C, S);
+  hipLaunchKernelGGL(se_bwd_b_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dh_zeroed, hpre, wr, dpr_ws, dpooled,
+                     dpool_scale, C, S);
   hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,
                      pooled, dwr, dbr, dwe, dbe, B, C, S);
   return mmd_check_launch();

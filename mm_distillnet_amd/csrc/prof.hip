@@ -4,8 +4,10 @@
 #include "common.h"
 #include <vector>
 #include <mutex>
+#include <cstdio>
+#include <cstring>
 
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; char tag[48]; };
 static int g_on[MMD_FAM_COUNT] = {0};
 static std::vector<ProfRec> g_recs[MMD_FAM_COUNT];
 static hipEvent_t g_cur[MMD_FAM_COUNT];
@@ -24,11 +26,25 @@ void mmd_prof_begin(int family, hipStream_t s) {
   hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
   g_cur[family] = e;
 }
+static char g_tag[MMD_FAM_COUNT][48];
+void mmd_prof_tag(int family, const char* fmt, long long a, long long b, long long c, long long d) {
+  if (!g_on[family]) return;
+  snprintf(g_tag[family], sizeof(g_tag[family]), fmt, a, b, c, d);
+}
+static FILE* g_dump = nullptr;
+extern "C" int mmd_prof_dump_to(const char* path) {
+  if (g_dump) { fclose(g_dump); g_dump = nullptr; }
+  if (path) g_dump = fopen(path, "w");
+  return MMD_OK;
+}
 void mmd_prof_end(int family, hipStream_t s, double flops, double bytes) {
   if (!g_on[family]) return;
   hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
   std::lock_guard<std::mutex> lk(g_mu);
-  g_recs[family].push_back({g_cur[family], e, flops, bytes});
+  ProfRec r{g_cur[family], e, flops, bytes, {0}};
+  memcpy(r.tag, g_tag[family], sizeof(r.tag));
+  g_tag[family][0] = 0;
+  g_recs[family].push_back(r);
 }
 
 // Synchronises the recorded events and returns totals; clears the records.
@@ -41,6 +57,7 @@ extern "C" int mmd_prof_collect(int family, double* out) {
     hipEventSynchronize(r.e1);
     float t = 0; hipEventElapsedTime(&t, r.e0, r.e1);
     ms += t; fl += r.flops; by += r.bytes; ++n;
+    if (g_dump) fprintf(g_dump, "%d,%s,%.3f,%.0f,%.0f\n", family, r.tag, t * 1e3, r.flops, r.bytes);
     hipEventDestroy(r.e0); hipEventDestroy(r.e1);
   }
   g_recs[family].clear();

@@ -188,6 +188,7 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1,
            bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, 0, 0};
   int ntm = cdiv(M, PW_BM);
+  mmd_prof_tag(MMD_FAM_PW, "pw M%lld K%lld N%lld f%lld", M, K, N, (in_act ? 1 : 0) | (gate ? 2 : 0) | (stats ? 4 : 0) | (residual ? 8 : 0) | (out_scale ? 16 : 0));
   mmd_prof_begin(MMD_FAM_PW, stream);
   if (N <= 32) {
     a.ntn = cdiv(N, 32); a.nblk = ntm * a.ntn;
@@ -299,6 +300,7 @@ extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw,
   int maxs = cdiv(M, 64); if (splits > maxs) splits = maxs;
   a.mchunk = cdiv(cdiv(M, splits), 32) * 32;
   splits = cdiv(M, a.mchunk);
+  mmd_prof_tag(MMD_FAM_PW_WGRAD, "wg M%lld K%lld N%lld s%lld", M, K, N, splits);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
   hipLaunchKernelGGL(pw_wgrad_kernel, dim3(tiles * splits), dim3(256), 0, stream, a);
   mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));

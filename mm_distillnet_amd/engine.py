@@ -522,8 +522,9 @@ class Net:
             dpe = self._alloc(f1.B, blk.cmid)
             dpr = self._alloc(f1.B, blk.se)
             dpooled = self._alloc(f1.B, blk.cmid)
+            dh = self._zalloc((f1.B, blk.se))
             call("mmd_se_fc_bwd", dgate, rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
-                 ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dpooled, 1.0 / HW1, ps.g(f"{q}._se_reduce.conv.weight"),
+                 ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, ps.g(f"{q}._se_reduce.conv.weight"),
                  ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"), ps.g(f"{q}._se_expand.conv.bias"),
                  f1.B, blk.cmid, blk.se)
             dz1 = self._bn_bwd(g1, f1.z, rec["bn1"], f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],

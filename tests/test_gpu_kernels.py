@@ -219,7 +219,8 @@ def test_se_path():
     close(dgate, (gout * a.detach()).sum(1), 2e-4, 1e-5, "dgate")
     dpe, dpr, dpooled = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
     gwr, gbr, gwe, gbe = (torch.zeros_like(t, device=DEV) for t in (wr, br, we, be))
-    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), g(we), dpe, dpr, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S)
+    dhz = torch.zeros(B, S, device=DEV)
+    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), g(we), dpe, dpr, dhz, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S)
     close(gwr, wr.grad, 3e-4, 1e-5, "dwr"); close(gbr, br.grad, 3e-4, 1e-5); close(gwe, we.grad, 3e-4, 1e-5, "dwe")
     close(gbe, be.grad, 3e-4, 1e-5)
     # full dz through bn_bwd_reduce with mul_bc = gate, add_bc = dpooled (identity "BN": mean 0, invstd 1)
