@@ -75,6 +75,9 @@ class DistillEngine:
             self.valid_mask |= 1 << int(i)
         self.cap = int(_lib.LIB.load().mmd_pp_cap())
         self.graph = None
+        self.concurrent_teachers = True
+        self.side_streams: List = []
+        self.fork_stream = True if torch.cuda.is_available() and str(device).startswith("cuda") else None
         self.static: Dict[str, torch.Tensor] = {}
         self.out: Dict[str, torch.Tensor] = {}
         self.n_skip = sum(1 for b in student_spec.blocks if b.skip)
@@ -118,8 +121,9 @@ class DistillEngine:
         call("mmd_decode_filter", cls, reg, net.anchors(S), B, A, nc, float(self.cfg.conf_threshold), self.valid_mask, float(S),
              score, clsid, flags, over, cand, n_over, n_keep, self.overflow)
         rows = ws.alloc((B, cap, 6)); cnt = ws.alloc((B,), torch.int32)
+        mask_ws = ws.alloc((B * cap * (cap // 64),), torch.int64)      # per teacher: teachers run concurrently
         call("mmd_nms_teacher", cand, n_keep, over, self.label_map, float(self.cfg.nms_threshold),
-             1 if self.cfg.inclusive_nms else 0, float(S), B, rows, cnt, self.mask_ws, self.overflow)
+             1 if self.cfg.inclusive_nms else 0, float(S), B, rows, cnt, mask_ws, self.overflow)
         return rows, cnt
 
     def _attention(self, f: Feat) -> torch.Tensor:
@@ -135,6 +139,12 @@ class DistillEngine:
         B = batch["audio"].shape[0]
         self.ws.reset()
         self.mask_ws = self.ws.alloc((B * self.cap * (self.cap // 64),), torch.int64)
+        if self.fork_stream is None:
+            self.concurrent_teachers = False
+        fork_event = None
+        if self.concurrent_teachers:
+            # teachers fork from here, before the student forward is enqueued
+            fork_event = torch.cuda.current_stream().record_event()
         st.begin_step()
         cls_s, reg_s, feats_s = st.forward(batch["audio"], train=True, drop_scale=drop_scale)
         A = cls_s.shape[1]
@@ -144,15 +154,28 @@ class DistillEngine:
         nt = len(self.teachers)
         kd = self.ws.alloc((nt if cfg.kd_mode == "pairwise" else 1, nlv))
         call("mmd_memset_async", kd, 0, kd.numel() * 4)
+        # the three frozen teachers are independent of each other and of the student forward: issue them on
+        # side streams (parallel branches of the captured graph) so their many small kernels fill the chip together
         rows_t, cnt_t, att_t = [], [], []
+        main_stream = torch.cuda.current_stream()
+        concurrent = self.concurrent_teachers and torch.cuda.is_available()
+        if concurrent and not self.side_streams:
+            self.side_streams = [torch.cuda.Stream() for _ in self.teachers]
         for ti, (mod, net) in enumerate(self.teachers.items()):
-            net.begin_step()
-            cls_t, reg_t, feats_t = net.forward(batch[mod], train=False)
-            r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
-            rows_t.append(r); cnt_t.append(c)
-            at = [self._attention(f) for f in feats_t]
-            att_t.append(at)
-            if cfg.kd_mode == "pairwise":
+            side = self.side_streams[ti] if concurrent else main_stream
+            if concurrent:
+                side.wait_event(fork_event)
+            with torch.cuda.stream(side):
+                net.begin_step()
+                cls_t, reg_t, feats_t = net.forward(batch[mod], train=False)
+                r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
+                at = [self._attention(f) for f in feats_t]
+            rows_t.append(r); cnt_t.append(c); att_t.append(at)
+        if concurrent:
+            for side in self.side_streams:
+                main_stream.wait_stream(side)
+        if cfg.kd_mode == "pairwise":
+            for ti, at in enumerate(att_t):
                 for l, f in enumerate(feats_s):
                     call("mmd_mta_kl", a_s[l], at[l], None, None, 1, B, f.H * f.W, float(cfg.T), kd[ti, l:l + 1], da[l],
                          float(cfg.w_kd), 1 if ti > 0 else 0)
