@@ -175,6 +175,155 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// "Skinny" variant for layers whose 128x64 tiling gives too few blocks (deep 16x16 / 32x32 stages, BiFPN and
+// head layers): block tile 32(M) x 64(N); the four waves split K (wave w owns k in [32w,32w+32) of every
+// 128-wide K step), partial accumulators are summed through LDS and the epilogue is done row-major by all
+// 256 threads (coalesced 256-B row segments).  4x more blocks and a 4x shorter serial MFMA chain per block.
+#define SK_BM 32
+#define SK_BN 64
+#define SK_BK 128
+#define SK_LD 132
+
+__global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
+  __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
+  __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
+  __shared__ float sRed[2 * 4 * SK_BN];
+  const int tid = threadIdx.x;
+  const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
+  const int tn = t % a.ntn, tm = t / a.ntn;
+  const int m0 = tm * SK_BM, n0 = tn * SK_BN;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int kq = (tid & 31) * 4;          // k offset inside the 128-wide step
+  const int lrow = tid >> 5;              // 0..7
+
+  const float* xrow[4]; const float* grow[4]; bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = m0 + lrow + i * 8;
+    rok[i] = row < a.M;
+    int rr = rok[i] ? row : 0;
+    xrow[i] = a.x + (size_t)rr * a.K;
+    grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
+  }
+  const float* wrow[8]; bool wok[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int col = n0 + lrow + i * 8;
+    wok[i] = col < a.N;
+    wrow[i] = a.w + (size_t)(wok[i] ? col : 0) * a.K;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+  float4 ra[4], rg[4], rb[8], rsc, rsh;
+  bool kok;
+  auto gload = [&](int k0) {
+    int k = k0 + kq;
+    kok = k < a.K;
+    if (a.in_scale) {
+      rsc = kok ? mmd_ld4(a.in_scale + k) : make_float4(0, 0, 0, 0);
+      rsh = kok ? mmd_ld4(a.in_shift + k) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = kok && rok[i];
+      ra[i] = ok ? mmd_ld4(xrow[i] + k) : make_float4(0, 0, 0, 0);
+      if (a.gate) rg[i] = ok ? mmd_ld4(grow[i] + k) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = (kok && wok[i]) ? mmd_ld4(wrow[i] + k) : make_float4(0, 0, 0, 0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if (a.in_scale) {
+        v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
+      }
+      if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+      if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = rb[i];
+  };
+
+  const int nk = (a.K + SK_BK - 1) / SK_BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * SK_BK);
+    const float* pa = &sA[r * SK_LD + wave * 32 + h * 4];
+    const float* pb = &sB[r * SK_LD + wave * 32 + h * 4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * SK_LD + kk * 8);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- cross-wave K reduction through LDS: part[wave][row][col], row-major 32 x 64
+  float* part = sB;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+      part[(wave * SK_BM + row) * SK_BN + j * 32 + r] = acc[j][q];
+    }
+  __syncthreads();
+  // ---- epilogue, thread -> (col = tid & 63, rows (tid >> 6) + 4 i)
+  const int cl = tid & 63, col = n0 + cl;
+  const bool cok = col < a.N;
+  const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
+  const float osc = (a.out_scale && cok) ? a.out_scale[col] : 1.f;
+  const float osh = (a.out_scale && cok) ? a.out_shift[col] : 0.f;
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int rl = (tid >> 6) + 4 * i, row = m0 + rl;
+    float v = part[rl * SK_BN + cl] + part[(SK_BM + rl) * SK_BN + cl] + part[(2 * SK_BM + rl) * SK_BN + cl] +
+              part[(3 * SK_BM + rl) * SK_BN + cl] + bias;
+    if (cok && row < a.M) {
+      s += v; ss += v * v;
+      if (a.out_scale) v = v * osc + osh;
+      v = mmd_act(v, a.out_act);
+      size_t off;
+      if (a.y_batch_stride) {
+        int img = row / a.rows_per_image;
+        off = (size_t)img * a.y_batch_stride + a.y_offset + (size_t)(row - img * a.rows_per_image) * a.N + col;
+      } else {
+        off = (size_t)row * a.N + col;
+      }
+      if (a.residual) v += a.residual[off];
+      a.y[off] = v;
+    }
+  }
+  if (a.stats) {
+    sRed[(tid >> 6) * SK_BN + cl] = s; sRed[4 * SK_BN + (tid >> 6) * SK_BN + cl] = ss;
+    __syncthreads();
+    if (tid < SK_BN && n0 + tid < a.N) {
+      float s2 = sRed[tid] + sRed[SK_BN + tid] + sRed[2 * SK_BN + tid] + sRed[3 * SK_BN + tid];
+      float q2 = sRed[4 * SK_BN + tid] + sRed[5 * SK_BN + tid] + sRed[6 * SK_BN + tid] + sRed[7 * SK_BN + tid];
+      atomicAdd(&a.stats[n0 + tid], (double)s2);
+      atomicAdd(&a.stats[a.N + n0 + tid], (double)q2);
+    }
+  }
+}
+
 extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N,
                               const float* in_scale, const float* in_shift, int in_act,
                               const float* gate, int rows_per_image,
@@ -190,7 +339,11 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   int ntm = cdiv(M, PW_BM);
   mmd_prof_tag(MMD_FAM_PW, "pw M%lld K%lld N%lld f%lld", M, K, N, (in_act ? 1 : 0) | (gate ? 2 : 0) | (stats ? 4 : 0) | (residual ? 8 : 0) | (out_scale ? 16 : 0));
   mmd_prof_begin(MMD_FAM_PW, stream);
-  if (N <= 32) {
+  const long long big_tiles = (long long)ntm * cdiv(N, 64);
+  if (big_tiles < 160 && N > 16) {
+    a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
+    hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
+  } else if (N <= 32) {
     a.ntn = cdiv(N, 32); a.nblk = ntm * a.ntn;
     hipLaunchKernelGGL(pw_gemm_kernel<32>, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {

@@ -42,7 +42,8 @@ def same_pad(x, k, s):
     return F.pad(x, [eh // 2, eh - eh // 2, ev // 2, ev - ev // 2])
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 24, 40), (128, 16, 16), (1000, 88, 528), (77, 208, 36), (513, 352, 112)])
+@pytest.mark.parametrize("M,K,N", [(300, 24, 40), (128, 16, 16), (1000, 88, 528), (77, 208, 36), (513, 352, 112),
+                                   (33000, 16, 96), (20480, 48, 288), (2048, 1248, 208), (40960, 32, 16)])
 def test_pwconv_fwd_full(M, K, N):
     torch.manual_seed(M + K + N)
     B = 4 if M % 4 == 0 else 1
