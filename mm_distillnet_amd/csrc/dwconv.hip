@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   float4 acc[Cf::R];
 #pragma unroll
   for (int o = 0; o < Cf::R; ++o) acc[o] = make_float4(0, 0, 0, 0);
-#pragma unroll
+  // the tap-row loop is NOT unrolled for k=5: a fully unrolled body keeps all 25 weight float4s live
+  // (256 VGPRs, one wave per SIMD); rolled it needs ~100 and four waves hide the LDS latency
+#pragma unroll(K == 3 ? 3 : 1)
   for (int i = 0; i < K; ++i) {
     float4 in[Cf::SEG];
     const float* prow = &sIn[((orow * S + i) * Cf::IW + ocol0 * S) * 64 + c4];
