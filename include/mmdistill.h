@@ -43,7 +43,7 @@ int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, co
 
 // Depthwise kxk TF-SAME conv, NHWC, fused producer BN+swish prologue, stats / eval-BN+swish / SE-pool epilogue.
 // Replaces Conv2dStaticSamePadding(groups=C) (src/YetAnotherEfficientNet.py:433-435, src/YetAnotherEfficientDet.py:169-170) incl. F.pad (:51-65).
-int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, hipStream_t stream);
+int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, hipStream_t stream);
 
 // Input gradient of the depthwise conv.
 int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, hipStream_t stream);
@@ -55,15 +55,19 @@ int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int
 // Replaces nn.BatchNorm2d forward in training (call sites SURVEY 2.1).
 int mmd_bn_finalize(const double* stats, long long count, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int C, hipStream_t stream);
 
+// All train-mode BN layers of a net finalized in one launch (running stats + saved mean/invstd for the backward);
+// forward consumers derive (scale, shift) on the fly from the raw sums (in_stats/in_gamma/in_beta/in_count arguments).
+int mmd_bn_finalize_all(const double* stats_flat, const float* count, const int* layer_off, const int* layer_C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int total, hipStream_t stream);
+
 // Eval-mode BatchNorm2d folded to per-channel (scale, shift).
 int mmd_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift, int C, hipStream_t stream);
 
 // y = act(z*scale+shift) * rowscale[image] + res : BN apply, drop-connect scaling and identity skip
 // (src/YetAnotherEfficientNet.py:173-182,479-485).
-int mmd_affine_act(const float* z, const float* scale, const float* shift, int act, const float* rowscale, int rows_per_image, const float* res, float* y, int M, int C, hipStream_t stream);
+int mmd_affine_act(const float* z, const float* scale, const float* shift, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, int act, const float* rowscale, int rows_per_image, const float* res, float* y, int M, int C, hipStream_t stream);
 
 // out[b,c] += s * sum_hw (g? g*a : a), a = act(z*scale+shift): SE global average pool (src/YetAnotherEfficientNet.py:470) and d(gate).
-int mmd_chan_pool(const float* z, const float* scale, const float* shift, int act, const float* g, float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream);
+int mmd_chan_pool(const float* z, const float* scale, const float* shift, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g, float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream);
 
 // Squeeze-excite FCs: gate = sigmoid(We*swish(Wr*pooled+br)+be) (src/YetAnotherEfficientNet.py:471-474).
 int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
@@ -138,13 +142,16 @@ int mmd_prof_collect(int family, double* out);
 // 1x1 conv as fp32 MFMA GEMM with fused producer-BN/swish/SE-gate prologue and bias/BN/act/residual/stats epilogue.
 // Replaces nn.Conv2d(k=1) in Conv2dStaticSamePadding (src/YetAnotherEfficientNet.py:27-65; call sites :427,446,
 // src/YetAnotherEfficientDet.py:171,238-265) + BatchNorm2d/swish that follow (:428,447,126-143).
-int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, hipStream_t stream);
+int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, hipStream_t stream);
 
 // dW[N,K] += dY^T * pro(X) (autograd of the 1x1 conv weight; reference: loss.backward(), src/optimization/traditional.py:182).
 int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);
 
 // dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
 int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);
+
+// Every 1x1 weight of the student transposed in one launch (desc rows: src_off, dst_off, R, C, first_tile).
+int mmd_transpose_batched(const float* src_base, float* dst_base, const long long* desc, int n, int total_tiles, hipStream_t stream);
 
 // dst[C,R] = src[R,C]^T (refreshes the Wt copies after an optimizer step).
 int mmd_transpose2d(const float* src, float* dst, int R, int C, hipStream_t stream);

@@ -44,6 +44,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// "Live" BatchNorm: per-channel (scale, shift) derived on the fly from the raw batch sums a producer kernel accumulated
+// (train-mode forward), so no per-layer finalize launch sits between producer and consumer.  Same arithmetic as
+// bn_finalize_kernel (double mean/var, float invstd), hence bit-identical coefficients in every block.
+struct BnLive { const double* stats; const float* gamma; const float* beta; double inv_count; int C; float eps; };
+__device__ __forceinline__ void bn_live_coef(const BnLive& b, int c, float& sc, float& sh) {
+  double mean = b.stats[c] * b.inv_count;
+  double var = b.stats[b.C + c] * b.inv_count - mean * mean;
+  if (var < 0) var = 0;
+  float invstd = (float)(1.0 / sqrt(var + (double)b.eps));
+  sc = b.gamma[c] * invstd;
+  sh = b.beta[c] - (float)mean * sc;
+}
+__device__ __forceinline__ void bn_live_coef4(const BnLive& b, int c, float4& sc, float4& sh) {
+  bn_live_coef(b, c, sc.x, sh.x); bn_live_coef(b, c + 1, sc.y, sh.y);
+  bn_live_coef(b, c + 2, sc.z, sh.z); bn_live_coef(b, c + 3, sc.w, sh.w);
+}
+static inline BnLive mmd_make_bn(const double* stats, const float* gamma, const float* beta, long long count, int C) {
+  BnLive b; b.stats = stats; b.gamma = gamma; b.beta = beta; b.inv_count = count > 0 ? 1.0 / (double)count : 0.0; b.C = C;
+  b.eps = 1e-3f; return b;
+}
+
 // XCD-aware 1-D block remap (8 XCDs, blocks dealt round-robin): gives each XCD a contiguous
 // chunk of the logical tile order so neighbouring tiles share one L2. Bijective only when
 // nblk % 8 == 0; otherwise identity.

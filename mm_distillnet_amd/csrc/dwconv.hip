@@ -18,7 +18,7 @@ struct DwArgs {
   int B, H, W, C, OH, OW;
   int pad_t, pad_l;
   int flip;
-  const float* in_scale; const float* in_shift; int in_act;
+  const float* in_scale; const float* in_shift; int in_act; BnLive in_bn;
   const float* out_scale; const float* out_shift; int out_act;
   double* stats; float* pool; float pool_scale;
   int tiles_h, tiles_w, cchunks;
@@ -40,13 +40,17 @@ __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float* sIn, int 
   const int c = c0 + c4;
   const bool cok = c < a.C;
   float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-  if (a.in_scale && cok) { sc = mmd_ld4(a.in_scale + c); sh = mmd_ld4(a.in_shift + c); }
+  const bool xf = a.in_scale || a.in_bn.stats;
+  if (cok) {
+    if (a.in_bn.stats) bn_live_coef4(a.in_bn, c, sc, sh);
+    else if (a.in_scale) { sc = mmd_ld4(a.in_scale + c); sh = mmd_ld4(a.in_shift + c); }
+  }
   for (int p = tid >> 4; p < Cf::IH * Cf::IW; p += 16) {
     int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
     float4 v = make_float4(0, 0, 0, 0);
     if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
       v = mmd_ld4(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
-      if (a.in_scale) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
+      if (xf) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
     }
     *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
@@ -175,6 +179,7 @@ static int same_pad_lo(int n, int k, int s, int* out) {
 // y[B,OH,OW,C] = dwconv_same(pro(x)[B,H,W,C], w[k*k,C]); OH = ceil(H/stride).
 extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
                               const float* in_scale, const float* in_shift, int in_act,
+                              const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                               const float* out_scale, const float* out_shift, int out_act,
                               double* stats, float* pool, hipStream_t stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
@@ -183,7 +188,9 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   DwArgs a{};
   a.x = x; a.w = w; a.y = y; a.B = B; a.H = H; a.W = W; a.C = C;
   a.pad_t = same_pad_lo(H, k, stride, &a.OH); a.pad_l = same_pad_lo(W, k, stride, &a.OW);
+  if (in_stats && (in_scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   a.flip = 0; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  a.in_bn = mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C);
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
   a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
   mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);

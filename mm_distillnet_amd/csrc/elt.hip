@@ -56,6 +56,42 @@ extern "C" int mmd_bn_finalize(const double* stats, long long count, const float
   return mmd_check_launch();
 }
 
+// All BN layers of a net in ONE launch (end of the train-mode forward): stats_flat [2 x C_l per layer at 2*off_l],
+// count[c] = rows that produced channel c's sums, layer_off[c] = channel offset of c's layer, layer_C[c] = its width.
+__global__ void bn_finalize_all_kernel(const double* __restrict__ stats, const float* __restrict__ count,
+                                       const int* __restrict__ layer_off, const int* __restrict__ layer_C,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* rmean,
+                                       float* rvar, float momentum, float eps, float* scale, float* shift, float* mean_out,
+                                       float* invstd_out, int total) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= total) return;
+  double n = (double)count[c];
+  if (n <= 0.0) return;                     // padding channel or a layer that did not run this step
+  int lo = layer_off[c], lc = layer_C[c], ci = c - lo;
+  double mean = stats[2 * (size_t)lo + ci] / n;
+  double var = stats[2 * (size_t)lo + lc + ci] / n - mean * mean;
+  if (var < 0) var = 0;
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean; invstd_out[c] = invstd;
+  double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+}
+extern "C" int mmd_bn_finalize_all(const double* stats_flat, const float* count, const int* layer_off, const int* layer_C,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* scale, float* shift, float* mean_out,
+                                   float* invstd_out, int total, hipStream_t stream) {
+  if (!stats_flat || !count || !layer_off || !layer_C || !gamma || !beta || !running_mean || !running_var || !scale ||
+      !shift || !mean_out || !invstd_out || total <= 0)
+    return MMD_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_all_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, stats_flat, count, layer_off,
+                     layer_C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, total);
+  return mmd_check_launch();
+}
+
 // eval-mode BN folded to scale/shift: scale = g/sqrt(rv+eps), shift = b - rm*scale
 __global__ void bn_fold_kernel(const float* g, const float* b, const float* rm, const float* rv, float eps, float* scale,
                                float* shift, int C) {
@@ -74,14 +110,15 @@ extern "C" int mmd_bn_fold(const float* gamma, const float* beta, const float* r
 
 // ---------------------------------------------------------------- y = act(z*scale+shift)*rowscale[img] + res
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int act,
+                                                         const float* __restrict__ shift, BnLive bn, int act,
                                                          const float* __restrict__ rowscale, int rows_per_image,
                                                          const float* __restrict__ res, float* __restrict__ y, int M, int C) {
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   if (c >= C) return;
   float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-  if (scale) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
+  if (bn.stats) bn_live_coef4(bn, c, sc, sh);
+  else if (scale) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
   const int r0 = blockIdx.y * ROWS_PER_BLOCK;
   const int r1 = min(M, r0 + ROWS_PER_BLOCK);
   for (int row = r0 + (tid >> 4); row < r1; row += 16) {
@@ -95,13 +132,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     mmd_st4(y + off, v);
   }
 }
-extern "C" int mmd_affine_act(const float* z, const float* scale, const float* shift, int act, const float* rowscale,
-                              int rows_per_image, const float* res, float* y, int M, int C, hipStream_t stream) {
+extern "C" int mmd_affine_act(const float* z, const float* scale, const float* shift, const double* in_stats,
+                              const float* in_gamma, const float* in_beta, long long in_count, int act,
+                              const float* rowscale, int rows_per_image, const float* res, float* y, int M, int C,
+                              hipStream_t stream) {
   if (!z || !y || M <= 0 || C <= 0 || (C & 3) || (rowscale && rows_per_image <= 0)) return MMD_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
+  if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(affine_act_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, z, scale, shift,
-                     act, rowscale, rows_per_image, res, y, M, C);
+                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, rowscale, rows_per_image, res, y, M, C);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * (res ? 3 : 2));
   return mmd_check_launch();
 }
@@ -110,7 +150,7 @@ extern "C" int mmd_affine_act(const float* z, const float* scale, const float* s
 // out[b,c] += out_scale * sum_{rows of image b} (g ? g*a : a),  a = act(z*scale+shift)
 // (squeeze-excite average pool forward; d(gate) in the backward)
 __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, int act,
+                                                        const float* __restrict__ shift, BnLive bn, int act,
                                                         const float* __restrict__ g, float* __restrict__ out,
                                                         float out_scale, int rows_per_image, int C, int nsplit) {
   __shared__ float sRed[256];
@@ -119,7 +159,10 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
   const int b = blockIdx.y;
   const bool cok = c < C;
   float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-  if (scale && cok) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
+  if (cok) {
+    if (bn.stats) bn_live_coef4(bn, c, sc, sh);
+    else if (scale) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
+  }
   float4 acc = make_float4(0, 0, 0, 0);
   if (cok) {
     for (int r = blockIdx.z * 16 + (tid >> 4); r < rows_per_image; r += 16 * nsplit) {
@@ -134,15 +177,17 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
   float s = block_chan_sum(acc, sRed, tid);
   if (tid < 64 && blockIdx.x * 64 + tid < C) atomicAdd(&out[(size_t)b * C + blockIdx.x * 64 + tid], s * out_scale);
 }
-extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* shift, int act, const float* g, float* out,
-                             float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
+extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* shift, const double* in_stats,
+                             const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
+                             float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
   if (!z || !out || B <= 0 || rows_per_image <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
+  if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   int base = cdiv(C, 64) * B;
   int ns = cdiv(1024, base); int mx = cdiv(rows_per_image, 64); if (ns > mx) ns = mx; if (ns < 1) ns = 1;
   mmd_prof_begin(MMD_FAM_ELT, stream);
-  hipLaunchKernelGGL(chan_pool_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift, act, g, out,
-                     out_scale, rows_per_image, C, ns);
+  hipLaunchKernelGGL(chan_pool_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift,
+                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, g, out, out_scale, rows_per_image, C, ns);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * B * (double)rows_per_image * C * (g ? 2 : 1));
   return mmd_check_launch();
 }

@@ -18,7 +18,7 @@
 struct PwArgs {
   const float* x; const float* w; float* y;
   int M, K, N;
-  const float* in_scale; const float* in_shift; int in_act;
+  const float* in_scale; const float* in_shift; int in_act; BnLive in_bn;
   const float* gate; int rows_per_image;
   const float* bias; const float* out_scale; const float* out_shift; int out_act;
   const float* residual; double* stats;
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   auto gload = [&](int k0) {
     int k = k0 + kq;
     kok = k < a.K;
-    if (a.in_scale) {
+    if (a.in_bn.stats) {
+      rsc = make_float4(0, 0, 0, 0); rsh = rsc;
+      if (kok) bn_live_coef4(a.in_bn, k, rsc, rsh);
+    } else if (a.in_scale) {
       rsc = kok ? mmd_ld4(a.in_scale + k) : make_float4(0, 0, 0, 0);
       rsh = kok ? mmd_ld4(a.in_shift + k) : make_float4(0, 0, 0, 0);
     }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
-      if (a.in_scale) {
+      if (a.in_scale || a.in_bn.stats) {
         v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
       }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
@@ -224,7 +227,10 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   auto gload = [&](int k0) {
     int k = k0 + kq;
     kok = k < a.K;
-    if (a.in_scale) {
+    if (a.in_bn.stats) {
+      rsc = make_float4(0, 0, 0, 0); rsh = rsc;
+      if (kok) bn_live_coef4(a.in_bn, k, rsc, rsh);
+    } else if (a.in_scale) {
       rsc = kok ? mmd_ld4(a.in_scale + k) : make_float4(0, 0, 0, 0);
       rsh = kok ? mmd_ld4(a.in_shift + k) : make_float4(0, 0, 0, 0);
     }
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
-      if (a.in_scale) {
+      if (a.in_scale || a.in_bn.stats) {
         v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
       }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
 
 extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N,
                               const float* in_scale, const float* in_shift, int in_act,
+                              const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                               const float* gate, int rows_per_image,
                               const float* bias, const float* out_scale, const float* out_shift, int out_act,
                               const float* residual, double* stats,
@@ -334,7 +341,9 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
   if ((out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
-  PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1,
+  if (in_stats && (in_scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
+  PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, mmd_make_bn(in_stats, in_gamma, in_beta, in_count, K), gate,
+           rows_per_image > 0 ? rows_per_image : 1,
            bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, 0, 0};
   int ntm = cdiv(M, PW_BM);
   mmd_prof_tag(MMD_FAM_PW, "pw M%lld K%lld N%lld f%lld", M, K, N, (in_act ? 1 : 0) | (gate ? 2 : 0) | (stats ? 4 : 0) | (residual ? 8 : 0) | (out_scale ? 16 : 0));
@@ -465,7 +474,7 @@ extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw,
 extern "C" int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N,
                                    int accumulate, hipStream_t stream) {
   // Y'=dx [M,K], X'=dy [M,N], W'=wt [K,N] -> reduction dim is N
-  return mmd_pwconv_fwd(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, 0,
+  return mmd_pwconv_fwd(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, stream);
 }
 
@@ -484,5 +493,33 @@ __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restr
 extern "C" int mmd_transpose2d(const float* src, float* dst, int R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0 || !src || !dst) return MMD_EINVAL;
   hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, src, dst, R, C);
+  return mmd_check_launch();
+}
+
+// All student 1x1 weights transposed in ONE launch: desc[l] = {src_off, dst_off, R, C, first_tile} (floats / 32x32 tiles)
+__global__ void transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst, const long long* __restrict__ desc,
+                                         int n) {
+  __shared__ float tile[32][33];
+  const int tb = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (desc[mid * 5 + 4] <= tb) lo = mid; else hi = mid - 1; }
+  const long long* d = desc + lo * 5;
+  const int R = (int)d[2], C = (int)d[3];
+  const int tl = tb - (int)d[4], tcx = (C + 31) / 32;
+  const int bx = tl % tcx, by = tl / tcx;
+  const float* s = src + d[0];
+  float* o = dst + d[1];
+  int c = bx * 32 + threadIdx.x, r0 = by * 32;
+  for (int i = threadIdx.y; i < 32; i += 8)
+    if (r0 + i < R && c < C) tile[i][threadIdx.x] = s[(size_t)(r0 + i) * C + c];
+  __syncthreads();
+  int rr = r0 + threadIdx.x, c0 = bx * 32;
+  for (int i = threadIdx.y; i < 32; i += 8)
+    if (c0 + i < C && rr < R) o[(size_t)(c0 + i) * R + rr] = tile[threadIdx.x][i];
+}
+extern "C" int mmd_transpose_batched(const float* src_base, float* dst_base, const long long* desc, int n, int total_tiles,
+                                     hipStream_t stream) {
+  if (!src_base || !dst_base || !desc || n <= 0 || total_tiles <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(32, 8), 0, stream, src_base, dst_base, desc, n);
   return mmd_check_launch();
 }

@@ -37,6 +37,7 @@ class Feat:
     scale: Optional[torch.Tensor] = None
     shift: Optional[torch.Tensor] = None
     act: int = NONE
+    bn: Optional[tuple] = None     # train-mode forward: (stats[2C] double, gamma, beta, count) -> coefficients derived on the fly
 
     @property
     def M(self) -> int:
@@ -64,6 +65,26 @@ class Net:
             self.t_shift = torch.zeros(n, device=device)
             self.t_mean = torch.zeros(n, device=device)
             self.t_invstd = torch.zeros(n, device=device)
+            self.stats_flat = torch.zeros(2 * n, dtype=torch.float64, device=device)
+            lo = torch.zeros(n, dtype=torch.int32)
+            lc = torch.zeros(n, dtype=torch.int32)
+            for name in self.ps.bn_names:
+                o, c = self.ps.bn_off[name], self.ps.bn_c[name]
+                lo[o:o + c] = o
+                lc[o:o + c] = c
+            self.bn_layer_off = lo.to(device)
+            self.bn_layer_c = lc.to(device)
+            self.bn_count_host = torch.zeros(n, dtype=torch.float32)
+            self.bn_count = torch.zeros(n, dtype=torch.float32, device=device)
+            self._bn_count_key = None
+            descs, tiles = [], 0
+            for key in self.ps.wt_off:
+                e = self.ps.entries[key]
+                R, C = e.native
+                descs.append([e.off, self.ps.wt_off[key], R, C, tiles])
+                tiles += ((R + 31) // 32) * ((C + 31) // 32)
+            self.wt_desc = torch.tensor(descs, dtype=torch.int64, device=device)
+            self.wt_tiles = tiles
         self.tape: Dict[str, object] = {}
         self._anchors: Dict[int, torch.Tensor] = {}
 
@@ -82,9 +103,7 @@ class Net:
 
     def refresh_wt(self):
         ps = self.ps
-        for key in ps.wt_off:
-            e = ps.entries[key]
-            call("mmd_transpose2d", ps.w(key), ps.w_t(key), e.native[0], e.native[1])
+        call("mmd_transpose_batched", ps.flat, ps.wt, self.wt_desc, self.wt_desc.shape[0], self.wt_tiles)
 
     # ------------------------------------------------------------------ small helpers
     def _alloc(self, *shape):
@@ -100,38 +119,50 @@ class Net:
         self.zarena.reset()
         for c in self.zarena.chunks:
             call("mmd_memset_async", c, 0, c.numel())
+        if self.trainable:
+            call("mmd_memset_async", self.stats_flat, 0, self.stats_flat.numel() * 8)
         self.tape = {}
 
+    def _bn_stats(self, name: str, train: bool):
+        """Raw-sum accumulator [2C] (double) of BN `name` for this step (train) or None (eval)."""
+        if not train:
+            return None
+        b = self.ps.bn(name)
+        o, c = b["off"], b["C"]
+        return self.stats_flat[2 * o:2 * o + 2 * c]
+
     def _bn_aff(self, name: str, train: bool, stats, count: int):
-        """-> (scale, shift[, mean, invstd]) for BN `name`; train: finalize batch stats + update running."""
+        """-> (scale, shift, mean, invstd, live).  eval: folded running stats.  train: views that the batched finalize
+        at the end of the forward fills (the backward reads them) + the `live` tuple forward consumers use."""
         b = self.ps.bn(name)
         if not train:
-            return b["fscale"], b["fshift"], None, None
+            return b["fscale"], b["fshift"], None, None, None
         o, c = b["off"], b["C"]
-        sc, sh = self.t_scale[o:o + c], self.t_shift[o:o + c]
-        mu, istd = self.t_mean[o:o + c], self.t_invstd[o:o + c]
-        call("mmd_bn_finalize", stats, count, b["gamma"], b["beta"], b["rmean"], b["rvar"], float(self.bn_momentum),
-             BN_EPS, sc, sh, mu, istd, c)
-        return sc, sh, mu, istd
+        self.bn_count_host[o:o + c] = float(count)
+        return (self.t_scale[o:o + c], self.t_shift[o:o + c], self.t_mean[o:o + c], self.t_invstd[o:o + c],
+                (stats, b["gamma"], b["beta"], int(count)))
 
-    def _stats(self, C: int):
-        return self._zalloc((2 * C,), torch.float64)
+    @staticmethod
+    def _xf(x: Feat):
+        """prologue arguments (scale, shift, act, stats, gamma, beta, count) of a forward consumer of x"""
+        if x.bn is not None:
+            return (None, None, x.act, x.bn[0], x.bn[1], x.bn[2], x.bn[3])
+        return (x.scale, x.shift, x.act, None, None, None, 0)
 
     def _pw(self, x: Feat, wkey: str, N: int, bias=None, stats=None, out_aff=None, out_act=NONE, residual=None,
             gate=None, y=None, ybs=0, yoff=0, plain_in=False):
         M, K = x.M, x.C
         if y is None:
             y = self._alloc(M, N)
-        call("mmd_pwconv_fwd", x.z, self.ps.w(wkey), y, M, K, N,
-             None if plain_in else x.scale, None if plain_in else x.shift, NONE if plain_in else x.act,
-             gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
+        xf = (None, None, NONE, None, None, None, 0) if plain_in else self._xf(x)
+        call("mmd_pwconv_fwd", x.z, self.ps.w(wkey), y, M, K, N, *xf, gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
              residual, stats, ybs, yoff)
         return y
 
     def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None):
         OH, OW = -(-x.H // s), -(-x.W // s)
         y = self._alloc(x.B * OH * OW, x.C)
-        call("mmd_dwconv_fwd", x.z, self.ps.w(wkey), y, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act,
+        call("mmd_dwconv_fwd", x.z, self.ps.w(wkey), y, x.B, x.H, x.W, x.C, k, s, *self._xf(x),
              out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act, stats, pool)
         return y, OH, OW
 
@@ -173,10 +204,10 @@ class Net:
         col = self._alloc(B * OH * OH, ps.stem_kp)
         call("mmd_stem_im2col", x, col, B, Cin, S, S, ps.stem_kp)
         colf = Feat(col, B, OH, OH, ps.stem_kp)
-        st = self._stats(spec.stem_out) if train else None
+        st = self._bn_stats(f"{P}._bn0", train)
         z = self._pw(colf, f"{P}._conv_stem.conv.weight", spec.stem_out, stats=st)
-        sc, sh, mu, istd = self._bn_aff(f"{P}._bn0", train, st, B * OH * OH)
-        cur = Feat(z, B, OH, OH, spec.stem_out, sc, sh, SWISH)
+        sc, sh, mu, istd, live = self._bn_aff(f"{P}._bn0", train, st, B * OH * OH)
+        cur = Feat(z, B, OH, OH, spec.stem_out, sc, sh, SWISH, live)
         if train:
             tape["stem"] = (colf, cur, mu, istd)
         taps: List[Feat] = []
@@ -186,36 +217,46 @@ class Net:
             inp = cur
             rec = {"inp": inp}
             if blk.expand != 1:
-                st0 = self._stats(blk.cmid) if train else None
+                st0 = self._bn_stats(f"{q}._bn0", train)
                 z0 = self._pw(inp, f"{q}._expand_conv.conv.weight", blk.cmid, stats=st0)
                 a0 = self._bn_aff(f"{q}._bn0", train, st0, inp.M)
-                f0 = Feat(z0, B, inp.H, inp.W, blk.cmid, a0[0], a0[1], SWISH)
+                f0 = Feat(z0, B, inp.H, inp.W, blk.cmid, a0[0], a0[1], SWISH, a0[4])
                 rec["f0"], rec["bn0"] = f0, a0
             else:
                 f0 = inp
-            st1 = self._stats(blk.cmid) if train else None
-            z1, H1, W1 = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, stats=st1)
+            res = inp.z if blk.skip else None
+            H1, W1 = -(-f0.H // blk.stride), -(-f0.W // blk.stride)
             M1 = B * H1 * W1
-            a1 = self._bn_aff(f"{q}._bn1", train, st1, M1)
-            f1 = Feat(z1, B, H1, W1, blk.cmid, a1[0], a1[1], SWISH)
             pooled = self._zalloc((B, blk.cmid))
-            call("mmd_chan_pool", z1, a1[0], a1[1], SWISH, None, pooled, 1.0 / (H1 * W1), B, H1 * W1, blk.cmid)
             hpre = self._alloc(B, blk.se)
             gate = self._alloc(B, blk.cmid)
-            call("mmd_se_fc_fwd", pooled, ps.w(f"{q}._se_reduce.conv.weight"), ps.w(f"{q}._se_reduce.conv.bias"),
-                 ps.w(f"{q}._se_expand.conv.weight"), ps.w(f"{q}._se_expand.conv.bias"), hpre, gate, B, blk.cmid, blk.se)
-            res = inp.z if blk.skip else None
+            se_w = (ps.w(f"{q}._se_reduce.conv.weight"), ps.w(f"{q}._se_reduce.conv.bias"),
+                    ps.w(f"{q}._se_expand.conv.weight"), ps.w(f"{q}._se_expand.conv.bias"))
             if train:
-                st2 = self._stats(blk.cout)
+                st1 = self._bn_stats(f"{q}._bn1", True)
+                z1, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, stats=st1)
+                a1 = self._bn_aff(f"{q}._bn1", True, st1, M1)
+                f1 = Feat(z1, B, H1, W1, blk.cmid, a1[0], a1[1], SWISH, a1[4])
+                call("mmd_chan_pool", z1, *self._xf(f1)[:2], *self._xf(f1)[3:], SWISH, None, pooled, 1.0 / (H1 * W1), B,
+                     H1 * W1, blk.cmid)
+                call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
+                st2 = self._bn_stats(f"{q}._bn2", True)
                 z2 = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, stats=st2, gate=gate)
                 a2 = self._bn_aff(f"{q}._bn2", True, st2, M1)
                 y = self._alloc(M1, blk.cout)
                 rs = None
                 if blk.skip and blk.drop_rate and drop_scale is not None:
                     rs = drop_scale[skip_i]
-                call("mmd_affine_act", z2, a2[0], a2[1], NONE, rs, H1 * W1, res, y, M1, blk.cout)
+                call("mmd_affine_act", z2, None, None, a2[4][0], a2[4][1], a2[4][2], a2[4][3], NONE, rs, H1 * W1, res, y, M1,
+                     blk.cout)
                 rec.update(f1=f1, bn1=a1, pooled=pooled, hpre=hpre, gate=gate, z2=z2, bn2=a2, rs=rs)
             else:
+                # frozen net: BN1+swish and the SE average pool ride in the depthwise epilogue (no separate pool pass)
+                b1 = ps.bn(f"{q}._bn1")
+                a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
+                                     out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled)
+                f1 = Feat(a1v, B, H1, W1, blk.cmid)
+                call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 b2 = ps.bn(f"{q}._bn2")
                 y = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, gate=gate,
                              out_aff=(b2["fscale"], b2["fshift"]), residual=res)
@@ -239,6 +280,15 @@ class Net:
             tape["feats"] = feats
             tape["A"] = A
             tape["cls"] = cls
+            # every BN layer finalized in one launch: running stats + (scale, shift, mean, invstd) for the backward
+            key = (B, S)
+            if self._bn_count_key != key:
+                self.bn_count.copy_(self.bn_count_host)
+                self._bn_count_key = key
+            call("mmd_bn_finalize_all", self.stats_flat, self.bn_count, self.bn_layer_off, self.bn_layer_c,
+                 ps.flat[ps.gamma_off:ps.gamma_off + ps.bn_total], ps.flat[ps.beta_off:ps.beta_off + ps.bn_total],
+                 ps.rmean, ps.rvar, float(self.bn_momentum), BN_EPS, self.t_scale, self.t_shift, self.t_mean,
+                 self.t_invstd, ps.bn_total)
             # num_batches_tracked += 1 for every BN (one tiny torch op on the contiguous counter vector)
             ps.nbt.add_(1)
         return cls, reg, feats
@@ -252,11 +302,11 @@ class Net:
         bn_name = bn_name or f"{name}.bn"
         bias = ps.w(f"{name}.pointwise_conv.conv.bias")
         if train:
-            st = self._stats(W)
+            st = self._bn_stats(bn_name, True)
             z = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, stats=st)
             a = self._bn_aff(bn_name, True, st, x.M)
             y = self._alloc(x.M, W)
-            call("mmd_affine_act", z, a[0], a[1], NONE, None, 0, None, y, x.M, W)
+            call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, x.M, W)
             rec.update(zd=zdf, z=z, bn=a)
         else:
             b = ps.bn(bn_name)
@@ -269,11 +319,11 @@ class Net:
         bias = ps.w(f"{name}.0.conv.bias")
         rec = {"x": x}
         if train:
-            st = self._stats(W)
+            st = self._bn_stats(f"{name}.1", True)
             z = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, stats=st)
             a = self._bn_aff(f"{name}.1", True, st, x.M)
             y = self._alloc(x.M, W)
-            call("mmd_affine_act", z, a[0], a[1], NONE, None, 0, None, y, x.M, W)
+            call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, x.M, W)
             rec.update(z=z, bn=a)
             tape[name] = rec
         else:
@@ -346,11 +396,11 @@ class Net:
                 cname = f"{hname}.conv_list.{i}"
                 zd, _, _ = self._dw(cur, f"{cname}.depthwise_conv.conv.weight", 3, 1)
                 zdf = Feat(zd, f.B, f.H, f.W, f.C)
-                st = self._stats(f.C) if train else None
+                st = self._bn_stats(f"{hname}.bn_list.{lvl}.{i}", train)
                 z = self._pw(zdf, f"{cname}.pointwise_conv.conv.weight", f.C, bias=ps.w(f"{cname}.pointwise_conv.conv.bias"),
                              stats=st)
                 a = self._bn_aff(f"{hname}.bn_list.{lvl}.{i}", train, st, f.M)
-                nxt = Feat(z, f.B, f.H, f.W, f.C, a[0], a[1], SWISH)
+                nxt = Feat(z, f.B, f.H, f.W, f.C, a[0], a[1], SWISH, a[4])
                 layers.append({"x": cur, "zd": zdf, "out": nxt, "bn": a})
                 cur = nxt
             zd, _, _ = self._dw(cur, f"{hname}.header.depthwise_conv.conv.weight", 3, 1)
@@ -432,8 +482,8 @@ class Net:
                     L = rec["layers"][i]
                     cname = f"{hname}.conv_list.{i}"
                     dz = self._bn_bwd(g, L["out"].z, L["bn"], f"{hname}.bn_list.{lvl}.{i}", SWISH, f.M, f.C)
-                    dzd = self._pw_bwd(dz, L["zd"], f"{cname}.pointwise_conv.conv.weight", f.C,
-                                       f"{cname}.pointwise_conv.conv.bias", True)
+                    # a bias in front of a train-mode BN has an exactly-zero gradient (sum_m dz = 0): no colsum launch
+                    dzd = self._pw_bwd(dz, L["zd"], f"{cname}.pointwise_conv.conv.weight", f.C, None, True)
                     g = self._dw_bwd(dzd, L["x"], f"{cname}.depthwise_conv.conv.weight", 3, 1)
                 self._acc(slot(f), g)
         # ---- BiFPN (cells and nodes in reverse)
@@ -447,8 +497,7 @@ class Net:
                 name = f"{cell}.{rec['conv']}"
                 W = out.C
                 dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W)
-                dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W,
-                                   f"{name}.pointwise_conv.conv.bias", True)
+                dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
                 df = self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1)
                 in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
                 th = ps.w(f"{cell}.{rec['theta']}")
@@ -497,7 +546,7 @@ class Net:
                         continue
                     x: Feat = rec["x"]
                     dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C)
-                    dx = self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, f"{name}.0.conv.bias", True)
+                    dx = self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, None, True)
                     self._acc(slot(x), dx)
         # ---- backbone (blocks in reverse)
         P = "backbone_net.model"
@@ -518,7 +567,7 @@ class Net:
             g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
             # squeeze-excite backward
             dgate = self._zalloc((f1.B, blk.cmid))
-            call("mmd_chan_pool", f1.z, f1.scale, f1.shift, SWISH, g1, dgate, 1.0, f1.B, HW1, blk.cmid)
+            call("mmd_chan_pool", f1.z, f1.scale, f1.shift, None, None, None, 0, SWISH, g1, dgate, 1.0, f1.B, HW1, blk.cmid)
             dpe = self._alloc(f1.B, blk.cmid)
             dpr = self._alloc(f1.B, blk.se)
             dpooled = self._alloc(f1.B, blk.cmid)

@@ -59,14 +59,14 @@ def test_pwconv_fwd_full(M, K, N):
     ref = swish(raw * osc + osh) + res
     y = torch.empty(M, N, device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, g(isc), g(ish), 1, g(gate), rpi, g(bias), g(osc), g(osh), 1, g(res),
+    call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, g(isc), g(ish), 1, None, None, None, 0, g(gate), rpi, g(bias), g(osc), g(osh), 1, g(res),
          stats, 0, 0)
     close(y, ref, 2e-4, 1e-5, "pw fwd")
     close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
     close(stats[N:], (raw.double() ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
     # plain path
     y2 = torch.empty(M, N, device=DEV)
-    call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
     close(y2, x @ w.t(), 2e-4, 1e-5, "pw plain")
 
 
@@ -76,7 +76,7 @@ def test_pwconv_fwd_remap():
     x = torch.randn(B * HW, K); w = torch.randn(N, K) / 10; bias = torch.randn(N)
     out = torch.zeros(B, A_total_rows * 4, device=DEV)
     off = 17 * 4
-    call("mmd_pwconv_fwd", g(x), g(w), out, B * HW, K, N, None, None, 0, None, HW, g(bias), None, None, 2, None, None,
+    call("mmd_pwconv_fwd", g(x), g(w), out, B * HW, K, N, None, None, 0, None, None, None, 0, None, HW, g(bias), None, None, 2, None, None,
          A_total_rows * 4, off)
     ref = torch.sigmoid(x @ w.t() + bias).view(B, HW * N)
     close(out[:, off:off + HW * N], ref, 2e-4, 1e-5)
@@ -126,14 +126,14 @@ def test_dwconv(k, s, H, W, C):
     wn = g(w.detach().reshape(C, k * k).t())
     yo = torch.empty(B * OH * OW, C, device=DEV)
     stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
-    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, 0, stats, None)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, None, None, 0, stats, None)
     close(yo.view(B, OH, OW, C), nhwc(y), 2e-4, 1e-5, "dw fwd")
     close(stats[:C], y.double().sum((0, 2, 3)), 1e-4, 1e-4)
     close(stats[C:], (y.double() ** 2).sum((0, 2, 3)), 1e-4, 1e-5)
     # eval epilogue + pool
     osc, osh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
     pool = torch.zeros(B, C, device=DEV)
-    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, g(osc), g(osh), 1, None, pool)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, g(osc), g(osh), 1, None, pool)
     ye = swish(y * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
     close(yo.view(B, OH, OW, C), nhwc(ye), 2e-4, 1e-5, "dw eval")
     close(pool, ye.mean((2, 3)), 2e-4, 1e-5, "pool")
@@ -167,7 +167,7 @@ def test_bn_train_fwd_bwd(M, C, act):
     call("mmd_bn_finalize", stats, M, g(gamma), g(beta), drm, drv, 0.01, 1e-3, sc, sh, mu, istd, C)
     close(drm, rm2, 1e-5, 1e-6); close(drv, rv2, 1e-5, 1e-6)
     yy = torch.empty(M, C, device=DEV)
-    call("mmd_affine_act", g(z), sc, sh, act, None, 0, None, yy, M, C)
+    call("mmd_affine_act", g(z), sc, sh, None, None, None, 0, act, None, 0, None, yy, M, C)
     close(yy, a, 1e-4, 1e-5, "bn apply")
     sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     gy = torch.empty(M, C, device=DEV)
@@ -189,7 +189,7 @@ def test_affine_act_residual_and_fold():
     call("mmd_bn_fold", g(gam), g(bet), g(rm), g(rv), 1e-3, sc, sh, C)
     rs = torch.tensor([0.0, 1.25, 1.25])
     y = torch.empty(M, C, device=DEV)
-    call("mmd_affine_act", g(z), sc, sh, 0, g(rs), HW, g(res), y, M, C)
+    call("mmd_affine_act", g(z), sc, sh, None, None, None, 0, 0, g(rs), HW, g(res), y, M, C)
     ref = F.batch_norm(z, rm, rv, gam, bet, False, 0.0, 1e-3) * rs.repeat_interleave(HW).view(-1, 1) + res
     close(y, ref, 1e-4, 1e-5)
 
@@ -209,14 +209,14 @@ def test_se_path():
     gout = torch.randn_like(out)
     out.backward(gout)
     dpool = torch.zeros(B, C, device=DEV)
-    call("mmd_chan_pool", g(z), g(sc), g(sh), 1, None, dpool, 1.0 / HW, B, HW, C)
+    call("mmd_chan_pool", g(z), g(sc), g(sh), None, None, None, 0, 1, None, dpool, 1.0 / HW, B, HW, C)
     close(dpool, pooled, 1e-4, 1e-5, "pool")
     dh, dg = torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
     call("mmd_se_fc_fwd", dpool, g(wr), g(br), g(we), g(be), dh, dg, B, C, S)
     close(dh, hpre, 1e-4, 1e-5); close(dg, gate, 1e-4, 1e-5, "gate")
     # backward: dgate = sum_hw gout*a
     dgate = torch.zeros(B, C, device=DEV)
-    call("mmd_chan_pool", g(z), g(sc), g(sh), 1, g(gout.reshape(B * HW, C)), dgate, 1.0, B, HW, C)
+    call("mmd_chan_pool", g(z), g(sc), g(sh), None, None, None, 0, 1, g(gout.reshape(B * HW, C)), dgate, 1.0, B, HW, C)
     close(dgate, (gout * a.detach()).sum(1), 2e-4, 1e-5, "dgate")
     dpe, dpr, dpooled = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
     gwr, gbr, gwe, gbe = (torch.zeros_like(t, device=DEV) for t in (wr, br, we, be))
@@ -261,7 +261,7 @@ def test_stem_im2col(cin, S):
     call("mmd_stem_im2col", g(x), col, B, cin, S, S, Kp)
     wp = torch.zeros(32, Kp); wp[:, :cin * 9] = w.reshape(32, -1)
     y = torch.empty(B * OH * OH, 32, device=DEV)
-    call("mmd_pwconv_fwd", col, g(wp), y, B * OH * OH, Kp, 32, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    call("mmd_pwconv_fwd", col, g(wp), y, B * OH * OH, Kp, 32, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
     close(y.view(B, OH, OH, 32), nhwc(ref), 2e-4, 1e-5)
 
 
@@ -353,3 +353,61 @@ def test_adam_and_clip():
     call("mmd_clip_grad_norm", gbuf, n, 1.0, ws)
     refg = (gr * 100).clone(); tot = refg.norm(); refg *= 1.0 / (tot + 1e-6)
     close(gbuf, refg, 1e-5, 1e-7)
+
+
+def test_live_bn_matches_finalized():
+    """Forward consumers that derive (scale, shift) on the fly from raw batch sums must agree bit for bit with the
+    finalize kernel's coefficients (same arithmetic), for every consumer kind; plus the batched finalize."""
+    torch.manual_seed(11)
+    B, H, W, C, N = 2, 12, 12, 48, 40
+    M = B * H * W
+    z = torch.randn(M, C) * 1.7 + 0.3
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    stats = torch.cat([z.double().sum(0), (z.double() ** 2).sum(0)]).to(DEV)
+    sc, sh, mu, istd = (torch.empty(C, device=DEV) for _ in range(4))
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    call("mmd_bn_finalize", stats, M, g(gamma), g(beta), rm, rv, 0.01, 1e-3, sc, sh, mu, istd, C)
+    # batched finalize over a 2-layer table (this layer + an idle one)
+    tot = 2 * C
+    lo = torch.cat([torch.zeros(C), torch.full((C,), C)]).int().to(DEV)
+    lc = torch.full((tot,), C).int().to(DEV)
+    cnt = torch.cat([torch.full((C,), float(M)), torch.zeros(C)]).to(DEV)
+    sflat = torch.cat([stats, torch.zeros(2 * C, dtype=torch.float64, device=DEV)])
+    o = [torch.zeros(tot, device=DEV) for _ in range(4)]
+    rm2, rv2 = torch.zeros(tot, device=DEV), torch.ones(tot, device=DEV)
+    call("mmd_bn_finalize_all", sflat, cnt, lo, lc, g(torch.cat([gamma, gamma])), g(torch.cat([beta, beta])), rm2, rv2, 0.01, 1e-3,
+         o[0], o[1], o[2], o[3], tot)
+    assert torch.equal(o[0][:C], sc) and torch.equal(o[1][:C], sh) and torch.equal(o[2][:C], mu) and torch.equal(o[3][:C], istd)
+    assert torch.equal(rm2[:C], rm) and torch.equal(rv2[:C], rv) and o[0][C:].abs().max().item() == 0
+    live = (stats, g(gamma), g(beta), M)
+    w = torch.randn(N, C) / 7
+    y1, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    call("mmd_pwconv_fwd", g(z), g(w), y1, M, C, N, sc, sh, 1, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    call("mmd_pwconv_fwd", g(z), g(w), y2, M, C, N, None, None, 1, *live, None, 0, None, None, None, 0, None, None, 0, 0)
+    assert torch.equal(y1, y2)
+    wd = g(torch.randn(9, C) / 3)
+    d1, d2 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    call("mmd_dwconv_fwd", g(z), wd, d1, B, H, W, C, 3, 1, sc, sh, 1, None, None, None, 0, None, None, 0, None, None)
+    call("mmd_dwconv_fwd", g(z), wd, d2, B, H, W, C, 3, 1, None, None, 1, *live, None, None, 0, None, None)
+    assert torch.equal(d1, d2)
+    a1, a2 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    call("mmd_affine_act", g(z), sc, sh, None, None, None, 0, 1, None, 0, None, a1, M, C)
+    call("mmd_affine_act", g(z), None, None, *live, 1, None, 0, None, a2, M, C)
+    assert torch.equal(a1, a2)
+    p1, p2 = torch.zeros(B, C, device=DEV), torch.zeros(B, C, device=DEV)
+    call("mmd_chan_pool", g(z), sc, sh, None, None, None, 0, 1, None, p1, 1.0, B, H * W, C)
+    call("mmd_chan_pool", g(z), None, None, *live, 1, None, p2, 1.0, B, H * W, C)
+    close(p1, p2, 1e-6, 1e-7)
+
+
+def test_transpose_batched():
+    torch.manual_seed(2)
+    shapes = [(40, 24), (33, 65), (112, 112)]
+    src = torch.randn(sum(r * c for r, c in shapes) + 8)
+    desc, so, do, tiles = [], 4, 0, 0
+    for r, c in shapes:
+        desc.append([so, do, r, c, tiles]); tiles += ((r + 31) // 32) * ((c + 31) // 32); so += r * c; do += r * c
+    dst = torch.zeros(do, device=DEV)
+    call("mmd_transpose_batched", g(src), dst, torch.tensor(desc, dtype=torch.int64, device=DEV), len(shapes), tiles)
+    for (so, do, r, c, _) in desc:
+        close(dst[do:do + r * c].view(c, r), src[so:so + r * c].view(r, c).t())
