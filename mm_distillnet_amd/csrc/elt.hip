@@ -193,7 +193,8 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
 }
 
 // ---------------------------------------------------------------- squeeze-excite FCs
-// reference: src/YetAnotherEfficientNet.py:469-474.  wr [S,C], br [S], we [C,S], be [C].
+// reference: src/YetAnotherEfficientNet.py:469-474.  wr [S,C], br [S], be [C]; the expand weight is kept TRANSPOSED,
+// wet [S,C] (native layout of the engine), so every access below is coalesced over channels.
 // Two small launches with enough blocks to fill the chip (one block per image was 50 us per call):
 //   hidden: one wave per (image, j): hpre[b,j] = wr[j,:].pooled[b,:] + br[j]        (coalesced over C)
 //   gate  : one wave per 16 channels: gate[b,c] = sigmoid(we[c,:].swish(hpre[b,:]) + be[c])   (coalesced over S)
@@ -212,51 +213,42 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict_
   acc = wave_sum(acc);
   if (lane == 0) hpre[(size_t)b * S + j] = acc + br[j];
 }
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hpre, const float* __restrict__ we,
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hpre, const float* __restrict__ wet,
                                                       const float* __restrict__ be, float* __restrict__ gate, int C, int S) {
   __shared__ float sh[256];
-  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
   for (int j = threadIdx.x; j < S; j += 256) sh[j] = mmd_swish(hpre[(size_t)b * S + j]);
   __syncthreads();
-  for (int i = 0; i < 16; ++i) {
-    int c = blockIdx.y * 64 + wave * 16 + i;
-    if (c >= C) break;
-    float acc = 0.f;
-    for (int j = lane; j < S; j += 64) acc += we[(size_t)c * S + j] * sh[j];
-    acc = wave_sum(acc);
-    if (lane == 0) gate[(size_t)b * C + c] = mmd_sigmoid(acc + be[c]);
-  }
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  float acc = be[c];
+  for (int j = 0; j < S; ++j) acc += wet[(size_t)j * C + c] * sh[j];      // wet [S][C]: coalesced over c
+  gate[(size_t)b * C + c] = mmd_sigmoid(acc);
 }
 extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
                              float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
   if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256) return MMD_EINVAL;
   hipLaunchKernelGGL(se_hidden_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, stream, hpre, we, be, gate, C, S);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, hpre, we, be, gate, C, S);
   return mmd_check_launch();
 }
 
-// backward, step 1a: per (image, 64-channel chunk): dpe[b,c] = dgate*gate*(1-gate); dh[b,j] += sum_c we[c,j]*dpe[b,c]
-// (we rows staged through LDS so the global reads stay coalesced; dh is a zeroed accumulator)
+// backward, step 1a: dpe[b,c] = dgate*gate*(1-gate) (recomputed per wave); dh[b,j] = sum_c wet[j,c]*dpe[b,c], one wave per (b,j)
 __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                       const float* __restrict__ we, float* __restrict__ dpe, float* dh,
+                                                       const float* __restrict__ wet, float* __restrict__ dpe, float* dh,
                                                        int C, int S) {
-  extern __shared__ float sm[];      // [64*S] we rows + [64] dpe
-  float* swe = sm; float* sd = sm + 64 * S;
-  const int b = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
-  const int nc = min(64, C - c0);
-  for (int i = tid; i < nc * S; i += 256) swe[i] = we[(size_t)c0 * S + i];
-  if (tid < nc) {
-    float g = gate[(size_t)b * C + c0 + tid];
-    float d = dgate[(size_t)b * C + c0 + tid] * g * (1.f - g);
-    sd[tid] = d;
-    dpe[(size_t)b * C + c0 + tid] = d;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.y * 4 + wave;
+  if (j >= S) return;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float g = gate[(size_t)b * C + c];
+    float d = dgate[(size_t)b * C + c] * g * (1.f - g);
+    if (j == 0) dpe[(size_t)b * C + c] = d;
+    acc += wet[(size_t)j * C + c] * d;
   }
-  __syncthreads();
-  for (int j = tid; j < S; j += 256) {
-    float acc = 0.f;
-    for (int c = 0; c < nc; ++c) acc += swe[c * S + j] * sd[c];
-    atomicAdd(&dh[(size_t)b * S + j], acc);
-  }
+  acc = wave_sum(acc);
+  if (lane == 0) dh[(size_t)b * S + j] = acc;
 }
 // step 1b: dpr[b,j] = dh[b,j]*swish'(hpre[b,j]); dpooled[b,c] = dpool_scale * sum_j wr[j,c]*dpr[b,j]
 __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* __restrict__ dh, const float* __restrict__ hpre,
@@ -284,8 +276,8 @@ __global__ void se_fc_wgrad_kernel(const float* __restrict__ dpe, const float* _
                                    float* dwe, float* dbe, int B, int C, int S) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * S) return;
-  {  // dwe laid out [C][S]
-    int c = i / S, j = i % S;
+  {  // dwe laid out [S][C] (transposed native layout)
+    int j = i / C, c = i % C;
     float acc = 0.f, accb = 0.f;
     for (int b = 0; b < B; ++b) {
       float d = dpe[(size_t)b * C + c];
@@ -315,8 +307,7 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
       !dwe || !dbe)
     return MMD_EINVAL;
   if (B <= 0 || C <= 0 || S <= 0 || S > 256) return MMD_EINVAL;
-  hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(C, 64)), dim3(256), (64 * S + 64) * sizeof(float), stream, dgate, gate, we,
-                     dpe_ws, dh_zeroed, C, S);
+  hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, dgate, gate, we, dpe_ws, dh_zeroed, C, S);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dh_zeroed, hpre, wr, dpr_ws, dpooled,
                      dpool_scale, C, S);
   hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,

@@ -458,8 +458,10 @@ extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw,
   WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0};
   a.ntn = cdiv(N, 64); a.ntk = cdiv(K, 64);
   int tiles = a.ntn * a.ntk;
-  int splits = 2048 / tiles; if (splits < 1) splits = 1;
-  int maxs = cdiv(M, 64); if (splits > maxs) splits = maxs;
+  // enough blocks to fill 256 CUs a few times over, but every split ends in N*K fp32 atomics (1.3 TB/s chip-wide):
+  // keep at least 256 rows per split so the atomic traffic stays well below the streamed bytes
+  int splits = 1024 / tiles; if (splits < 1) splits = 1;
+  int maxs = cdiv(M, 256); if (splits > maxs) splits = maxs;
   a.mchunk = cdiv(cdiv(M, splits), 32) * 32;
   splits = cdiv(M, a.mchunk);
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wg M%lld K%lld N%lld s%lld", M, K, N, splits);

@@ -48,7 +48,9 @@ class ParamStore:
         ordered = sorted([r for r in rows if r[2] in conv_kinds], key=lambda r: exec_rank(r[0]))
         self.stem_kp = _r4(spec.in_channels * 9)
         for key, shape, kind in ordered:
-            if kind == "pw" or kind == "se_w":
+            if kind == "se_w" and key.endswith("_se_expand.conv.weight"):
+                native = (shape[1], shape[0])          # [S][C]: the gate kernel reads it coalesced over channels
+            elif kind == "pw" or kind == "se_w":
                 native = (shape[0], shape[1])
             elif kind == "dw":
                 native = (shape[2] * shape[3], shape[0])
@@ -132,7 +134,7 @@ class ParamStore:
             t = state[key].detach().to("cpu", torch.float32)
             if tuple(t.shape) != e.shape:
                 raise ValueError(f"shape mismatch for {key}: {tuple(t.shape)} vs {e.shape}")
-            if e.kind == "dw":
+            if e.kind == "dw" or (e.kind == "se_w" and e.native[0] != e.shape[0]):
                 nat = t.reshape(e.shape[0], -1).t().contiguous()
             elif e.kind == "stem":
                 nat = torch.zeros(e.native, dtype=torch.float32)
@@ -163,7 +165,7 @@ class ParamStore:
             if key in self.entries:
                 e = self.entries[key]
                 nat = host[e.off:e.off + e.n].view(e.native)
-                if e.kind == "dw":
+                if e.kind == "dw" or (e.kind == "se_w" and e.native[0] != e.shape[0]):
                     t = nat.t().contiguous().view(e.shape)
                 elif e.kind == "stem":
                     t = nat[:, :e.shape[1] * 9].contiguous().view(e.shape)
@@ -191,7 +193,7 @@ class ParamStore:
         out: Dict[str, torch.Tensor] = {}
         for key, e in self.entries.items():
             nat = host[e.off:e.off + e.n].view(e.native)
-            if e.kind == "dw":
+            if e.kind == "dw" or (e.kind == "se_w" and e.native[0] != e.shape[0]):
                 out[key] = nat.t().contiguous().view(e.shape)
             elif e.kind == "stem":
                 out[key] = nat[:, :e.shape[1] * 9].contiguous().view(e.shape)

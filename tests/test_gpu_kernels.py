@@ -212,17 +212,18 @@ def test_se_path():
     call("mmd_chan_pool", g(z), g(sc), g(sh), None, None, None, 0, 1, None, dpool, 1.0 / HW, B, HW, C)
     close(dpool, pooled, 1e-4, 1e-5, "pool")
     dh, dg = torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
-    call("mmd_se_fc_fwd", dpool, g(wr), g(br), g(we), g(be), dh, dg, B, C, S)
+    wet = g(we.detach().t())       # engine-native [S][C]
+    call("mmd_se_fc_fwd", dpool, g(wr), g(br), wet, g(be), dh, dg, B, C, S)
     close(dh, hpre, 1e-4, 1e-5); close(dg, gate, 1e-4, 1e-5, "gate")
     # backward: dgate = sum_hw gout*a
     dgate = torch.zeros(B, C, device=DEV)
     call("mmd_chan_pool", g(z), g(sc), g(sh), None, None, None, 0, 1, g(gout.reshape(B * HW, C)), dgate, 1.0, B, HW, C)
     close(dgate, (gout * a.detach()).sum(1), 2e-4, 1e-5, "dgate")
     dpe, dpr, dpooled = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
-    gwr, gbr, gwe, gbe = (torch.zeros_like(t, device=DEV) for t in (wr, br, we, be))
+    gwr, gbr, gwe, gbe = (torch.zeros_like(t, device=DEV) for t in (wr, br, we.t().contiguous(), be))
     dhz = torch.zeros(B, S, device=DEV)
-    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), g(we), dpe, dpr, dhz, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S)
-    close(gwr, wr.grad, 3e-4, 1e-5, "dwr"); close(gbr, br.grad, 3e-4, 1e-5); close(gwe, we.grad, 3e-4, 1e-5, "dwe")
+    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), wet, dpe, dpr, dhz, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S)
+    close(gwr, wr.grad, 3e-4, 1e-5, "dwr"); close(gbr, br.grad, 3e-4, 1e-5); close(gwe, we.grad.t(), 3e-4, 1e-5, "dwe")
     close(gbe, be.grad, 3e-4, 1e-5)
     # full dz through bn_bwd_reduce with mul_bc = gate, add_bc = dpooled (identity "BN": mean 0, invstd 1)
     gy = torch.empty(B * HW, C, device=DEV)
