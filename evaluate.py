@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Evaluation entry point with the reference's CLI (evaluate.py:51-170 upstream):
+
+    python evaluate.py --config_file F --checkpoint P [--overwrite JSON]
+
+The student's detections (score > conf_threshold, class filter, NMS — the same device kernels that make the
+teachers' pseudo-labels) are scored against the merged multi-teacher pseudo ground truth with the reference's
+AP@0.5 / AP@0.75 / AP@Ave definitions (mm_distillnet_amd/metrics.py) and written to <exp>/results.<rank>.csv.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import train as T  # noqa: E402
+from mm_distillnet_amd.data import SyntheticMultimodalDetection, collate  # noqa: E402
+from mm_distillnet_amd.metrics import ap_table  # noqa: E402
+from mm_distillnet_amd.step import DistillEngine  # noqa: E402
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config_file", required=True)
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--overwrite", type=str, default=None)
+    ap.add_argument("--just_plot", action="store_true")
+    a = ap.parse_args(argv)
+    cfg, _ = T.parse_config(["--config_file", a.config_file] + (["--overwrite", a.overwrite] if a.overwrite else []))
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    sspec, sstate, tspecs, tstates = T.load_states(cfg, int(cfg.get("compound_coef", 2)))
+    if a.checkpoint:
+        c = torch.load(a.checkpoint, map_location="cpu", weights_only=False)
+        sstate = c["state_dict"] if "state_dict" in c else c
+    eng = DistillEngine(sspec, tspecs, dev, T.step_config(cfg))
+    eng.load(sstate, tstates)
+    test_set = SyntheticMultimodalDetection(cfg, "test")
+    loader = torch.utils.data.DataLoader(test_set, batch_size=cfg.getint("batch_size"), shuffle=False, collate_fn=collate)
+    preds, labels = [], []
+    for rgb, thermal, depth, audio, _, ids in loader:
+        batch = {"rgb": rgb.to(dev), "thermal": thermal.to(dev), "depth": depth.to(dev), "audio": audio.to(dev)}
+        p, l = eng.predict(batch)
+        preds += p; labels += l
+    eng.check_overflow()
+    table = ap_table(preds, labels)
+    print({k: round(v, 3) for k, v in table.items()})
+    if os.path.exists(cfg["exp_name"]):
+        import pandas as pd
+        pd.DataFrame([dict(exp_name=cfg["exp_name"], modality="ALL", **table)]).to_csv(
+            f"{cfg['exp_name']}/results.{cfg['rank']}.csv", index=False)
+    return table
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,8 @@ class Net:
     def refresh(self):
         """Recompute derived buffers after parameters changed: eval-BN fold and transposed 1x1 weights."""
         ps = self.ps
+        if not ps.flat.is_cuda:
+            return            # host-side construction (state-dict plumbing, CPU tests): nothing to derive yet
         call("mmd_bn_fold", ps.flat[ps.gamma_off:ps.gamma_off + ps.bn_total], ps.flat[ps.beta_off:ps.beta_off + ps.bn_total],
              ps.rmean, ps.rvar, BN_EPS, ps.fold_scale, ps.fold_shift, ps.bn_total)
         if self.trainable:

@@ -295,6 +295,38 @@ class DistillEngine:
         self.g_opt.replay()
         return self.out
 
+    @torch.no_grad()
+    def predict(self, batch: Dict[str, torch.Tensor]):
+        """Evaluation path (get_predictions_multiteacher): student detections [n,6] per image from an
+        eval-mode forward, and the merged multi-teacher pseudo ground truth [m,5] per image, as numpy lists."""
+        cfg, S = self.cfg, self.cfg.image_size
+        B = batch["audio"].shape[0]
+        self.ws.reset()
+        self.mask_ws = self.ws.alloc((B * self.cap * (self.cap // 64),), torch.int64)
+        st = self.student
+        st.refresh()
+        st.begin_step()
+        cls_s, reg_s, _ = st.forward(batch["audio"], train=False)
+        A = cls_s.shape[1]
+        rows_s, cnt_s = self._pseudo_labels(st, cls_s, reg_s, B, A, S)
+        rows_t, cnt_t = [], []
+        for mod, net in self.teachers.items():
+            net.begin_step()
+            cls_t, reg_t, _ = net.forward(batch[mod], train=False)
+            r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
+            rows_t.append(r); cnt_t.append(c)
+        nt = len(rows_t)
+        G = cfg.max_boxes
+        boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
+        call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
+             rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(cfg.merge_iou),
+             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow)
+        torch.cuda.synchronize()
+        cs, nb = cnt_s.cpu().tolist(), nbox.cpu().tolist()
+        preds = [rows_s[i, :cs[i]].cpu().numpy() for i in range(B)]
+        labels = [boxes[i, :nb[i]].cpu().numpy() for i in range(B)]
+        return preds, labels
+
     def check_overflow(self):
         if int(self.overflow.item()):
             raise RuntimeError("pseudo-label candidate capacity exceeded (more than %d candidates per image)" % self.cap)

@@ -187,6 +187,42 @@ class ParamStore:
                 out[key] = nbt[bn_index[name]].clone()
         return out
 
+    def export_flat(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Any parameter-shaped flat buffer (Adam moments ...) as reference-layout tensors keyed by parameter name."""
+        host = flat.detach().cpu()
+        out: Dict[str, torch.Tensor] = {}
+        for key, e in self.entries.items():
+            nat = host[e.off:e.off + e.n].view(e.native)
+            if e.kind == "dw" or (e.kind == "se_w" and e.native[0] != e.shape[0]):
+                out[key] = nat.t().contiguous().view(e.shape)
+            elif e.kind == "stem":
+                out[key] = nat[:, :e.shape[1] * 9].contiguous().view(e.shape)
+            else:
+                out[key] = nat.reshape(e.shape).clone()
+        for name in self.bn_names:
+            o, c = self.bn_off[name], self.bn_c[name]
+            out[name + ".weight"] = host[self.gamma_off + o:self.gamma_off + o + c].clone()
+            out[name + ".bias"] = host[self.beta_off + o:self.beta_off + o + c].clone()
+        return out
+
+    def import_flat(self, flat: torch.Tensor, tensors: Dict[str, torch.Tensor]) -> None:
+        host = torch.zeros(self.n_params, dtype=torch.float32)
+        for key, e in self.entries.items():
+            t = tensors[key].detach().float().cpu()
+            if e.kind == "dw" or (e.kind == "se_w" and e.native[0] != e.shape[0]):
+                nat = t.reshape(e.shape[0], -1).t().contiguous()
+            elif e.kind == "stem":
+                nat = torch.zeros(e.native, dtype=torch.float32)
+                nat[:, :e.shape[1] * 9] = t.reshape(e.shape[0], -1)
+            else:
+                nat = t.reshape(e.native)
+            host[e.off:e.off + e.n] = nat.reshape(-1)
+        for name in self.bn_names:
+            o, c = self.bn_off[name], self.bn_c[name]
+            host[self.gamma_off + o:self.gamma_off + o + c] = tensors[name + ".weight"].float().cpu()
+            host[self.beta_off + o:self.beta_off + o + c] = tensors[name + ".bias"].float().cpu()
+        flat.copy_(host)
+
     def export_grads(self) -> Dict[str, torch.Tensor]:
         """Gradients in reference layout keyed like named_parameters() (tests / autograd facade)."""
         host = self.grad.detach().cpu()

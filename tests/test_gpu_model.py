@@ -1,0 +1,103 @@
+"""GPU: the reference-shaped Python surface (nn.Module facade, loss modules, train.py / evaluate.py) on the HIP engine."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mm_distillnet_amd.model import YetAnotherEfficientDet, MTALoss, YetAnotherFocalLoss
+from mm_distillnet_amd.synth import synth_inputs
+from oracle import effdet_ref as O
+from oracle import losses_ref as L
+from helpers import make_state, grad_state
+
+DEV = "cuda"
+
+
+def test_facade_forward_backward_and_optimizer():
+    spec, st = make_state(2, 8, 13, "audio")
+    m = YetAnotherEfficientDet(compound_coef=2, in_channels=8, device=DEV)
+    m.load_state_dict(st)
+    x = synth_inputs(2, 128, seed=25)["audio"]
+    # eval forward
+    m.eval()
+    with torch.no_grad():
+        (c, r, a), f = m(x.to(DEV))
+        (co, ro, ao), fo = O.forward({k: v.clone() for k, v in st.items()}, x, 2, False)
+    assert (c.cpu() - co).abs().max() < 1e-3 * co.abs().max() and (r.cpu() - ro).abs().max() < 1e-3 * ro.abs().max()
+    assert torch.equal(a.cpu(), ao) and all(tuple(u.shape) == tuple(v.shape) for u, v in zip(f, fo))
+    # train forward/backward with the reference-style loss modules; compare against the oracle on the same masks
+    m.train()
+    torch.manual_seed(3)
+    (c, r, a), f = m(x.to(DEV))
+    ann = [np.array([[10, 12, 60, 70, 6], [64, 30, 120, 100, 6]], np.float32), np.zeros((0,), np.float32)]
+    ft = [torch.randn_like(u) for u in f]
+    reg_l, cls_l = YetAnotherFocalLoss()([c, r, a], ann)
+    kd = MTALoss(T=9, p=2)(f, ft)
+    loss = reg_l.sum() + cls_l.sum() + 0.005 * kd.sum()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt.zero_grad()
+    loss.backward()
+    g = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    assert all(torch.isfinite(v).all() for v in g.values())
+    # oracle with the masks the facade drew: re-run deterministically (all masks = keep) is not possible, so check
+    # loss-module parity on the facade's own outputs and gradient flow consistency instead
+    rl, cl = L.focal_loss(c.detach().cpu(), r.detach().cpu(), a.cpu(), ann)
+    assert abs(rl.item() - reg_l.item()) < 2e-4 * abs(rl.item()) + 1e-7 and abs(cl.item() - cls_l.item()) < 2e-4 * abs(cl.item())
+    kdo = L.mta_loss([u.detach().cpu() for u in f], [t.cpu() for t in ft], 9.0, 2.0)
+    assert torch.allclose(kd.cpu(), kdo, rtol=1e-4, atol=1e-5)
+    before = {k: p.detach().cpu().clone() for k, p in m.named_parameters()}
+    opt.step()
+    moved = sum(int((p.detach().cpu() != before[k]).any()) for k, p in m.named_parameters())
+    assert moved > 600                               # every tensor with a gradient moved; views share the flat buffer
+    ex = m._net.ps.export_state()
+    k = "classifier.header.pointwise_conv.conv.weight"
+    assert torch.equal(ex[k], dict(m.named_parameters())[k].detach().cpu())
+
+
+def test_facade_gradients_match_oracle_without_drop_connect():
+    """Exact gradient parity of the autograd node: eval-free path with drop-connect disabled (keep = 1)."""
+    spec, st = make_state(2, 8, 13, "audio")
+    m = YetAnotherEfficientDet(compound_coef=2, in_channels=8, device=DEV)
+    m.load_state_dict(st)
+    m.train()
+    object.__setattr__(m, "_keep", torch.full_like(m._keep, 1.0) + 0.0)      # floor(1 + U)/1 = 1 for every sample
+    x = synth_inputs(2, 128, seed=25)["audio"]
+    (c, r, a), f = m(x.to(DEV))
+    loss = c.sum() * 0.01 + (r ** 2).mean() + sum((u ** 2).mean() for u in f)
+    loss.backward()
+    so = grad_state(st)
+    ones = {b.idx: torch.ones(2) * (1.0 - b.drop_rate) for b in spec.blocks if b.skip}   # x/keep*mask with mask=keep -> x
+    (co, ro, ao), fo = O.forward(so, x, 2, True, ones)
+    lo = co.sum() * 0.01 + (ro ** 2).mean() + sum((u ** 2).mean() for u in fo)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-3 * abs(lo.item())
+    worst = 0.0
+    gmax = max(v.grad.abs().max().item() for v in so.values() if v.requires_grad)
+    for k, p in m.named_parameters():
+        ref = so[k].grad
+        s = ref.abs().max().item()
+        if s > 1e-6 * gmax:
+            worst = max(worst, (p.grad.cpu() - ref).abs().max().item() / s)
+    assert worst < 2e-2, worst
+
+
+def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, root)
+    import train, evaluate
+    ov = '{"image_size": 128, "batch_size": 2, "synthetic_length": 8, "num_epoches": 1, "exp_name": "exp", "resume": "False"}'
+    cfgf = os.path.join(root, "configs", "mm-distillnet.cfg")
+    loss = train.main(["--config_file", cfgf, "--overwrite", ov, "--max_steps", "3"])
+    assert np.isfinite(loss)
+    ck = tmp_path / "exp" / "checkpoint.0.pth.tar"
+    assert ck.exists()
+    c = torch.load(ck, map_location="cpu", weights_only=False)
+    assert set(c) >= {"epoch", "state_dict", "best_loss", "best_epoch", "optimizer", "scheduler"}
+    table = evaluate.main(["--config_file", cfgf, "--checkpoint", str(ck), "--overwrite", ov])
+    assert set(table) == {"AP@0.5", "AP@0.75", "AP@Ave"}
+    assert (tmp_path / "exp" / "results.0.csv").exists()
