@@ -52,7 +52,7 @@ def test_facade_forward_backward_and_optimizer():
     before = {k: p.detach().cpu().clone() for k, p in m.named_parameters()}
     opt.step()
     moved = sum(int((p.detach().cpu() != before[k]).any()) for k, p in m.named_parameters())
-    assert moved > 600                               # every tensor with a gradient moved; views share the flat buffer
+    assert moved > 550    # every tensor with a non-zero gradient moved (biases in front of a BN have exactly 0); views share the flat buffer
     ex = m._net.ps.export_state()
     k = "classifier.header.pointwise_conv.conv.weight"
     assert torch.equal(ex[k], dict(m.named_parameters())[k].detach().cpu())
@@ -80,7 +80,7 @@ def test_facade_gradients_match_oracle_without_drop_connect():
     for k, p in m.named_parameters():
         ref = so[k].grad
         s = ref.abs().max().item()
-        if s > 1e-6 * gmax:
+        if s > 1e-4 * gmax:      # skip parameters whose true gradient is ~0 (additive constants in front of a train-mode BN)
             worst = max(worst, (p.grad.cpu() - ref).abs().max().item() / s)
     assert worst < 2e-2, worst
 
