@@ -14,6 +14,7 @@
 // [row][k] with k contiguous and a 4-float row pad (stride 36 floats -> conflict-free ds_read_b128);
 // each lane reads 4 consecutive k for its row, lanes 32..63 take the next 4 k, which feeds 4 MFMAs.
 #include "common.h"
+#include <cstdlib>
 
 struct PwArgs {
   const float* x; const float* w; float* y;
@@ -349,7 +350,8 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   mmd_prof_tag(MMD_FAM_PW, "pw M%lld K%lld N%lld f%lld", M, K, N, (in_act ? 1 : 0) | (gate ? 2 : 0) | (stats ? 4 : 0) | (residual ? 8 : 0) | (out_scale ? 16 : 0));
   mmd_prof_begin(MMD_FAM_PW, stream);
   const long long big_tiles = (long long)ntm * cdiv(N, 64);
-  if (big_tiles < 160 && N > 16) {
+  static const int k_small = getenv("MMD_SKINNY_K") ? atoi(getenv("MMD_SKINNY_K")) : 0;
+  if ((big_tiles < 160 || K <= k_small) && N > 16) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
     hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
   } else if (N <= 32) {
