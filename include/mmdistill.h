@@ -144,6 +144,20 @@ int mmd_prof_collect(int family, double* out);
 // src/YetAnotherEfficientDet.py:171,238-265) + BatchNorm2d/swish that follow (:428,447,126-143).
 int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, hipStream_t stream);
 
+// --- feature-pyramid ("pyr") launches: the 5 levels of a shared-weight head layer in ONE launch.  pyr_desc is a HOST
+// int array {n, B, H0, W0, H1, W1, ...}; level l occupies rows [row0_l, row0_l + B*H_l*W_l) of the row buffer and
+// every level starts at a multiple of 128 rows; per-level BatchNorm data sit lev_stride channels apart.
+// (Regressor/Classifier.forward, src/YetAnotherEfficientDet.py:463-532: conv_list shared across levels, bn_list per level.)
+int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
+
+int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long lev_stride, hipStream_t stream);
+
+int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const int* pyr_desc, int C, const float* in_scale, const float* in_shift, int in_act, long long lev_stride, hipStream_t stream);
+
+int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const int* pyr_desc, long long lev_stride, float* g_out, double* sums, int C, hipStream_t stream);
+
+int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, const int* pyr_desc, long long lev_stride, float* dz, float* dgamma, float* dbeta, int C, hipStream_t stream);
+
 // dW[N,K] += dY^T * pro(X) (autograd of the 1x1 conv weight; reference: loss.backward(), src/optimization/traditional.py:182).
 int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);
 

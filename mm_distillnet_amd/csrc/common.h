@@ -65,6 +65,42 @@ static inline BnLive mmd_make_bn(const double* stats, const float* gamma, const 
   b.eps = 1e-3f; return b;
 }
 
+// Feature pyramid stored as ONE row buffer: level l occupies rows [row0[l], row0[l] + B*H[l]*W[l]) and every level starts
+// at a multiple of 128 rows, so no GEMM / reduction tile straddles two levels.  Lets the shared-weight head layers run
+// all 5 levels in one launch (per-level BatchNorm parameters are lev_stride channels apart).
+#define MMD_MAX_LEV 5
+struct Pyr { int n; int B; int row0[MMD_MAX_LEV + 1]; int H[MMD_MAX_LEV]; int W[MMD_MAX_LEV]; int blk0[MMD_MAX_LEV + 1]; };
+__device__ __forceinline__ int pyr_level_of_row(const Pyr& p, int row) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MMD_MAX_LEV; ++i) if (i < p.n && row >= p.row0[i]) l = i;
+  return l;
+}
+__device__ __forceinline__ int pyr_level_of_block(const Pyr& p, int bid) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MMD_MAX_LEV; ++i) if (i < p.n && bid >= p.blk0[i]) l = i;
+  return l;
+}
+// host descriptor: {n, B, H0, W0, H1, W1, ...}
+static inline int mmd_make_pyr(Pyr& p, const int* desc) {
+  p.n = 0;
+  if (!desc) return 0;
+  int n = desc[0];
+  if (n < 1 || n > MMD_MAX_LEV || desc[1] < 1) return -1;
+  p.n = n; p.B = desc[1]; p.row0[0] = 0;
+  for (int l = 0; l < n; ++l) {
+    p.H[l] = desc[2 + 2 * l]; p.W[l] = desc[3 + 2 * l];
+    if (p.H[l] < 1 || p.W[l] < 1) return -1;
+    long long rows = (long long)p.B * p.H[l] * p.W[l];
+    p.row0[l + 1] = p.row0[l] + (int)((rows + 127) / 128 * 128);
+    p.blk0[l] = 0;
+  }
+  for (int l = n; l < MMD_MAX_LEV; ++l) { p.H[l] = p.W[l] = 1; p.row0[l + 1] = p.row0[n]; }
+  p.blk0[MMD_MAX_LEV] = 0;
+  return 0;
+}
+
 // XCD-aware 1-D block remap (8 XCDs, blocks dealt round-robin): gives each XCD a contiguous
 // chunk of the logical tile order so neighbouring tiles share one L2. Bijective only when
 // nblk % 8 == 0; otherwise identity.

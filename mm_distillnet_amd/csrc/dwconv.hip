@@ -22,6 +22,7 @@ struct DwArgs {
   const float* out_scale; const float* out_shift; int out_act;
   double* stats; float* pool; float pool_scale;
   int tiles_h, tiles_w, cchunks;
+  Pyr pyr; long long lev_stride;
 };
 
 template <int K, int S> struct DwCfg {
@@ -57,14 +58,32 @@ __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float* sIn, int 
   }
 }
 
+// pyramid launch (k=3, s=1 only): pick this block's level and rebase pointers / geometry / per-level BN parameters
+template <int TH, int TW>
+__device__ __forceinline__ int dw_enter_level(DwArgs& a, int bid) {
+  const int l = pyr_level_of_block(a.pyr, bid);
+  a.H = a.OH = a.pyr.H[l]; a.W = a.OW = a.pyr.W[l];
+  a.tiles_h = (a.H + TH - 1) / TH; a.tiles_w = (a.W + TW - 1) / TW;
+  const size_t ro = (size_t)a.pyr.row0[l] * a.C;
+  a.x += ro; a.y += ro;
+  if (a.in_scale) { a.in_scale += l * a.lev_stride; a.in_shift += l * a.lev_stride; }
+  if (a.in_bn.stats) {
+    a.in_bn.stats += 2 * l * a.lev_stride; a.in_bn.gamma += l * a.lev_stride; a.in_bn.beta += l * a.lev_stride;
+    a.in_bn.inv_count = 1.0 / ((double)a.B * a.H * a.W);
+  }
+  return bid - a.pyr.blk0[l];
+}
+
 template <int K, int S>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
+__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a_in) {
   using Cf = DwCfg<K, S>;
   __shared__ float sIn[Cf::IH * Cf::IW * 64];
   __shared__ float sW[K * K * 64];
   __shared__ float sRed[2 * 4 * 64];
   const int tid = threadIdx.x;
+  DwArgs a = a_in;
   int bid = blockIdx.x;
+  if (a.pyr.n) bid = dw_enter_level<Cf::TH, Cf::TW>(a, bid);
   const int cc = bid % a.cchunks; bid /= a.cchunks;
   const int tw = bid % a.tiles_w; bid /= a.tiles_w;
   const int th = bid % a.tiles_h; bid /= a.tiles_h;
@@ -205,6 +224,34 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   return rc;
 }
 
+// Depthwise 3x3/s1 over a whole feature pyramid in ONE launch (shared weights; per-level producer BN via lev_stride).
+// flip=1 gives the input gradient.  x, y: pyramid row buffers [row0[n], C].
+extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip,
+                               const float* in_scale, const float* in_shift, int in_act, const double* in_stats,
+                               const float* in_gamma, const float* in_beta, long long lev_stride, hipStream_t stream) {
+  if (!x || !w || !y || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
+  if (in_stats && (in_scale || !in_gamma || !in_beta)) return MMD_EINVAL;
+  DwArgs a{};
+  if (mmd_make_pyr(a.pyr, pyr_desc)) return MMD_EINVAL;
+  using Cf = DwCfg<3, 1>;
+  a.x = x; a.w = w; a.y = y; a.B = a.pyr.B; a.C = C; a.pad_t = 1; a.pad_l = 1; a.flip = flip;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_bn = mmd_make_bn(in_stats, in_gamma, in_beta, 1, C);
+  a.lev_stride = lev_stride; a.cchunks = cdiv(C, 64);
+  int nb = 0;
+  for (int l = 0; l < a.pyr.n; ++l) {
+    a.pyr.blk0[l] = nb;
+    nb += a.B * cdiv(a.pyr.H[l], Cf::TH) * cdiv(a.pyr.W[l], Cf::TW) * a.cchunks;
+  }
+  for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nb;
+  mmd_prof_tag(MMD_FAM_DW, "dwpyr n%lld C%lld f%lld b%lld", a.pyr.n, C, flip, nb);
+  mmd_prof_begin(MMD_FAM_DW, stream);
+  hipLaunchKernelGGL((dw_fwd_kernel<3, 1>), dim3(nb), dim3(256), 0, stream, a);
+  double rows = a.pyr.row0[a.pyr.n];
+  mmd_prof_end(MMD_FAM_DW, stream, 2.0 * rows * C * 9, 8.0 * rows * C);
+  return mmd_check_launch();
+}
+
 // ---- input gradient -------------------------------------------------------------------
 // stride 1: correlation with the flipped kernel and padding (k-1-pad) -> the forward kernel.
 // stride 2: gather form, <= ceil(k/2)^2 taps per input pixel.
@@ -274,16 +321,28 @@ struct DwWgArgs {
   int B, H, W, C, OH, OW, pad_t, pad_l;
   const float* in_scale; const float* in_shift; int in_act;
   int tiles_h, tiles_w, cchunks, nsplit;
+  Pyr pyr; long long lev_stride; int nsplit_lev[MMD_MAX_LEV];
 };
 
 template <int K, int S>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a_in) {
   using Cf = DwCfg<K, S>;
   static_assert(Cf::IH * Cf::IW >= 4 * K * K, "reduction scratch aliases the input tile");
   __shared__ float sIn[Cf::IH * Cf::IW * 64];
   float* sRed = sIn;                      // reused after the tile loop (behind a barrier)
   const int tid = threadIdx.x;
+  DwWgArgs a = a_in;
   int bid = blockIdx.x;
+  if (a.pyr.n) {
+    const int l = pyr_level_of_block(a.pyr, bid);
+    bid -= a.pyr.blk0[l];
+    a.H = a.OH = a.pyr.H[l]; a.W = a.OW = a.pyr.W[l];
+    a.tiles_h = (a.H + Cf::TH - 1) / Cf::TH; a.tiles_w = (a.W + Cf::TW - 1) / Cf::TW;
+    a.nsplit = a.nsplit_lev[l];
+    const size_t ro = (size_t)a.pyr.row0[l] * a.C;
+    a.x += ro; a.dy += ro;
+    if (a.in_scale) { a.in_scale += l * a.lev_stride; a.in_shift += l * a.lev_stride; }
+  }
   const int sp = bid % a.nsplit; bid /= a.nsplit;
   const int cc = bid % a.cchunks; bid /= a.cchunks;
   const int b = bid;
@@ -380,4 +439,31 @@ extern "C" int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw,
   mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
                4.0 * ((double)B * H * W * C + (double)B * a.OH * a.OW * C));
   return rc;
+}
+
+// Depthwise 3x3/s1 weight gradient over a whole pyramid (shared weights): dw[9,C] += sum over levels.
+extern "C" int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const int* pyr_desc, int C,
+                                          const float* in_scale, const float* in_shift, int in_act, long long lev_stride,
+                                          hipStream_t stream) {
+  if (!x || !dy || !dw || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
+  DwWgArgs a{};
+  if (mmd_make_pyr(a.pyr, pyr_desc)) return MMD_EINVAL;
+  using Cf = DwCfg<3, 1>;
+  a.x = x; a.dy = dy; a.dw = dw; a.B = a.pyr.B; a.C = C; a.pad_t = 1; a.pad_l = 1;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.lev_stride = lev_stride; a.cchunks = cdiv(C, 64);
+  int nb = 0;
+  for (int l = 0; l < a.pyr.n; ++l) {
+    int ntiles = cdiv(a.pyr.H[l], Cf::TH) * cdiv(a.pyr.W[l], Cf::TW);
+    int ns = ntiles / 8; if (ns < 1) ns = 1; if (ns > 16) ns = 16;
+    a.nsplit_lev[l] = ns;
+    a.pyr.blk0[l] = nb;
+    nb += a.B * a.cchunks * ns;
+  }
+  for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nb;
+  mmd_prof_begin(MMD_FAM_DW_BWD, stream);
+  hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(nb), dim3(256), 0, stream, a);
+  double rows = a.pyr.row0[a.pyr.n];
+  mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * rows * C * 9, 8.0 * rows * C);
+  return mmd_check_launch();
 }

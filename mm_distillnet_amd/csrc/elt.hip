@@ -324,15 +324,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int act, const float* __restrict__ mul_bc,
                                                             const float* __restrict__ mul_b, const float* __restrict__ add_bc,
                                                             int rows_per_image, float* __restrict__ g_out, double* sums,
-                                                            int M, int C) {
+                                                            int M, int C, Pyr pyr, long long lev_stride, int rpb) {
   __shared__ float sRed[256];
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   const bool cok = c < C;
+  const int r0 = blockIdx.y * rpb;
+  int r1 = min(M, r0 + rpb);
+  if (pyr.n) {                       // per-level BN parameters / sums; rows past the level's valid count are padding
+    const int lev = pyr_level_of_row(pyr, r0);
+    scale += lev * lev_stride; shift += lev * lev_stride; mean += lev * lev_stride; invstd += lev * lev_stride;
+    sums += 2 * lev * lev_stride;
+    r1 = min(r1, pyr.row0[lev] + pyr.B * pyr.H[lev] * pyr.W[lev]);
+  }
   float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
   if (cok) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); mu = mmd_ld4(mean + c); is = mmd_ld4(invstd + c); }
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-  const int r0 = blockIdx.y * ROWS_PER_BLOCK, r1 = min(M, r0 + ROWS_PER_BLOCK);
   if (cok) {
     for (int row = r0 + (tid >> 4); row < r1; row += 16) {
       size_t off = (size_t)row * C + c;
@@ -366,7 +373,7 @@ extern "C" int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float*
   if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g_in, z, scale,
-                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C);
+                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C, Pyr{}, 0, ROWS_PER_BLOCK);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }
@@ -376,19 +383,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            double count, float* __restrict__ dz, float* dgamma, float* dbeta,
-                                                           int M, int C) {
+                                                           int M, int C, Pyr pyr, long long lev_stride, int rpb) {
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   if (c >= C) return;
+  const int r0 = blockIdx.y * rpb;
+  int r1 = min(M, r0 + rpb);
+  bool first = blockIdx.y == 0;
+  if (pyr.n) {
+    const int lev = pyr_level_of_row(pyr, r0);
+    mean += lev * lev_stride; invstd += lev * lev_stride; gamma += lev * lev_stride; sums += 2 * lev * lev_stride;
+    if (dgamma) { dgamma += lev * lev_stride; dbeta += lev * lev_stride; }
+    count = (double)pyr.B * pyr.H[lev] * pyr.W[lev];
+    r1 = min(r1, pyr.row0[lev] + (int)count);
+    first = r0 == pyr.row0[lev];
+  }
   float4 mu = mmd_ld4(mean + c), is = mmd_ld4(invstd + c), ga = mmd_ld4(gamma + c);
   float m1[4], m2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { m1[i] = (float)(sums[c + i] / count); m2[i] = (float)(sums[C + c + i] / count); }
-  if (blockIdx.y == 0 && (tid >> 4) == 0 && dgamma) {
+  if (first && (tid >> 4) == 0 && dgamma) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dgamma[c + i] += (float)sums[C + c + i]; dbeta[c + i] += (float)sums[c + i]; }
   }
-  const int r0 = blockIdx.y * ROWS_PER_BLOCK, r1 = min(M, r0 + ROWS_PER_BLOCK);
   for (int row = r0 + (tid >> 4); row < r1; row += 16) {
     size_t off = (size_t)row * C + c;
     float4 gg = mmd_ld4(g + off), zz = mmd_ld4(z + off), o;
@@ -406,7 +423,7 @@ extern "C" int mmd_bn_bwd_apply(const float* g, const float* z, const float* mea
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g, z, mean,
-                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C);
+                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C, Pyr{}, 0, ROWS_PER_BLOCK);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }
@@ -489,5 +506,34 @@ extern "C" int mmd_slice_rows(const float* src, float* dst, int B, int rows, int
   if (!src || !dst || B <= 0 || rows <= 0 || N <= 0) return MMD_EINVAL;
   size_t n = (size_t)B * rows * N;
   hipLaunchKernelGGL(slice_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, dst, B, rows, N, batch_stride, offset);
+  return mmd_check_launch();
+}
+
+// BN(+swish) backward over a whole pyramid in one launch each (per-level BN parameters lev_stride channels apart)
+extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, int act, const int* pyr_desc,
+                                     long long lev_stride, float* g_out, double* sums, int C, hipStream_t stream) {
+  if (!g_in || !z || !scale || !shift || !mean || !invstd || !g_out || !sums || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  Pyr p;
+  if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
+  int M = p.row0[p.n];
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, g_in, z, scale, shift, mean,
+                     invstd, act, nullptr, nullptr, nullptr, 1, g_out, sums, M, C, p, lev_stride, 128);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
+  return mmd_check_launch();
+}
+extern "C" int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, const float* invstd,
+                                    const float* gamma, const double* sums, const int* pyr_desc, long long lev_stride,
+                                    float* dz, float* dgamma, float* dbeta, int C, hipStream_t stream) {
+  if (!g || !z || !mean || !invstd || !gamma || !sums || !dz || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  Pyr p;
+  if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
+  int M = p.row0[p.n];
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, g, z, mean, invstd, gamma, sums,
+                     1.0, dz, dgamma, dbeta, M, C, p, lev_stride, 128);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }

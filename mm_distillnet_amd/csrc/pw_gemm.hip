@@ -25,6 +25,7 @@ struct PwArgs {
   const float* residual; double* stats;
   long long y_batch_stride; long long y_offset;
   int ntn; int nblk;
+  Pyr pyr; long long yoff_lev[MMD_MAX_LEV]; long long lev_stride;
 };
 
 #define PW_BM 128
@@ -44,6 +45,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   const int tn = t % a.ntn, tm = t / a.ntn;
   const int m0 = tm * PW_BM, n0 = tn * BN_T;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  // pyramid launch: this tile lies inside one level; rows beyond the level's valid count are padding
+  int Mv = a.M, srow0 = 0, rpi = a.rows_per_image; long long yoff = a.y_offset; double* stats = a.stats;
+  if (a.pyr.n) {
+    const int lev = pyr_level_of_row(a.pyr, m0);
+    srow0 = a.pyr.row0[lev]; rpi = a.pyr.H[lev] * a.pyr.W[lev]; Mv = srow0 + a.pyr.B * rpi; yoff = a.yoff_lev[lev];
+    if (stats) stats += 2 * lev * a.lev_stride;
+  }
   const int kq = (tid & 7) * 4;          // this thread's k offset inside a K tile
   const int lrow = tid >> 3;             // 0..31
 
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int row = m0 + lrow + i * 32;
-    rok[i] = row < a.M;
+    rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
     xrow[i] = a.x + (size_t)rr * a.K;
     grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
@@ -143,15 +151,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (cok && row < a.M) {
+      if (cok && row < Mv) {
         float v = acc[j][q] + bias;
         s += v; ss += v * v;
         if (a.out_scale) v = v * osc + osh;
         v = mmd_act(v, a.out_act);
         size_t off;
         if (a.y_batch_stride) {
-          int img = row / a.rows_per_image;
-          off = (size_t)img * a.y_batch_stride + a.y_offset + (size_t)(row - img * a.rows_per_image) * a.N + col;
+          int img = (row - srow0) / rpi;
+          off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
         } else {
           off = (size_t)row * a.N + col;
         }
@@ -172,8 +180,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       if (col < a.N) {
         float s = sRed[tid] + sRed[BN_T + tid] + sRed[2 * BN_T + tid] + sRed[3 * BN_T + tid];
         float ss = sRed[4 * BN_T + tid] + sRed[5 * BN_T + tid] + sRed[6 * BN_T + tid] + sRed[7 * BN_T + tid];
-        atomicAdd(&a.stats[col], (double)s);
-        atomicAdd(&a.stats[a.N + col], (double)ss);
+        atomicAdd(&stats[col], (double)s);
+        atomicAdd(&stats[a.N + col], (double)ss);
       }
     }
   }
@@ -198,6 +206,12 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   const int tn = t % a.ntn, tm = t / a.ntn;
   const int m0 = tm * SK_BM, n0 = tn * SK_BN;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  int Mv = a.M, srow0 = 0, rpi = a.rows_per_image; long long yoff = a.y_offset; double* stats = a.stats;
+  if (a.pyr.n) {
+    const int lev = pyr_level_of_row(a.pyr, m0);
+    srow0 = a.pyr.row0[lev]; rpi = a.pyr.H[lev] * a.pyr.W[lev]; Mv = srow0 + a.pyr.B * rpi; yoff = a.yoff_lev[lev];
+    if (stats) stats += 2 * lev * a.lev_stride;
+  }
   const int kq = (tid & 31) * 4;          // k offset inside the 128-wide step
   const int lrow = tid >> 5;              // 0..7
 
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int row = m0 + lrow + i * 8;
-    rok[i] = row < a.M;
+    rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
     xrow[i] = a.x + (size_t)rr * a.K;
     grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
@@ -304,14 +318,14 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     const int rl = (tid >> 6) + 4 * i, row = m0 + rl;
     float v = part[rl * SK_BN + cl] + part[(SK_BM + rl) * SK_BN + cl] + part[(2 * SK_BM + rl) * SK_BN + cl] +
               part[(3 * SK_BM + rl) * SK_BN + cl] + bias;
-    if (cok && row < a.M) {
+    if (cok && row < Mv) {
       s += v; ss += v * v;
       if (a.out_scale) v = v * osc + osh;
       v = mmd_act(v, a.out_act);
       size_t off;
       if (a.y_batch_stride) {
-        int img = row / a.rows_per_image;
-        off = (size_t)img * a.y_batch_stride + a.y_offset + (size_t)(row - img * a.rows_per_image) * a.N + col;
+        int img = (row - srow0) / rpi;
+        off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
       } else {
         off = (size_t)row * a.N + col;
       }
@@ -325,11 +339,13 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     if (tid < SK_BN && n0 + tid < a.N) {
       float s2 = sRed[tid] + sRed[SK_BN + tid] + sRed[2 * SK_BN + tid] + sRed[3 * SK_BN + tid];
       float q2 = sRed[4 * SK_BN + tid] + sRed[5 * SK_BN + tid] + sRed[6 * SK_BN + tid] + sRed[7 * SK_BN + tid];
-      atomicAdd(&a.stats[n0 + tid], (double)s2);
-      atomicAdd(&a.stats[a.N + n0 + tid], (double)q2);
+      atomicAdd(&stats[n0 + tid], (double)s2);
+      atomicAdd(&stats[a.N + n0 + tid], (double)q2);
     }
   }
 }
+
+static int pw_dispatch(PwArgs& a, hipStream_t stream);
 
 extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N,
                               const float* in_scale, const float* in_shift, int in_act,
@@ -345,9 +361,14 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   if (in_stats && (in_scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, mmd_make_bn(in_stats, in_gamma, in_beta, in_count, K), gate,
            rows_per_image > 0 ? rows_per_image : 1,
-           bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, 0, 0};
+           bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, 0, 0, Pyr{}, {0, 0, 0, 0, 0}, 0};
+  return pw_dispatch(a, stream);
+}
+
+static int pw_dispatch(PwArgs& a, hipStream_t stream) {
+  const int M = a.M, K = a.K, N = a.N;
   int ntm = cdiv(M, PW_BM);
-  mmd_prof_tag(MMD_FAM_PW, "pw M%lld K%lld N%lld f%lld", M, K, N, (in_act ? 1 : 0) | (gate ? 2 : 0) | (stats ? 4 : 0) | (residual ? 8 : 0) | (out_scale ? 16 : 0));
+  mmd_prof_tag(MMD_FAM_PW, "pw M%lld K%lld N%lld f%lld", M, K, N, (a.in_act ? 1 : 0) | (a.gate ? 2 : 0) | (a.stats ? 4 : 0) | (a.residual ? 8 : 0) | (a.out_scale ? 16 : 0) | (a.pyr.n ? 32 : 0));
   mmd_prof_begin(MMD_FAM_PW, stream);
   const long long big_tiles = (long long)ntm * cdiv(N, 64);
   static const int k_small = getenv("MMD_SKINNY_K") ? atoi(getenv("MMD_SKINNY_K")) : 0;
@@ -363,6 +384,23 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   }
   mmd_prof_end(MMD_FAM_PW, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   return mmd_check_launch();
+}
+
+// Shared-weight head layer over a whole feature pyramid in one launch (see Pyr in common.h).  x, y: pyramid row
+// buffers [row0[n], K] / [row0[n], N] (or, with y_batch_stride != 0, the concatenated [B, A_total, c] head output with
+// per-level offsets y_off_lev).  stats (nullable): level l accumulates into stats + 2*l*lev_stride.
+extern "C" int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N,
+                                  const float* bias, int out_act, double* stats, long long lev_stride,
+                                  long long y_batch_stride, const long long* y_off_lev, hipStream_t stream) {
+  if (!x || !w || !y || !pyr_desc || K <= 0 || N <= 0 || (K & 3)) return MMD_EINVAL;
+  if (y_batch_stride && !y_off_lev) return MMD_EINVAL;
+  PwArgs a{};
+  if (mmd_make_pyr(a.pyr, pyr_desc)) return MMD_EINVAL;
+  a.x = x; a.w = w; a.y = y; a.M = a.pyr.row0[a.pyr.n]; a.K = K; a.N = N; a.rows_per_image = 1;
+  a.bias = bias; a.out_act = out_act; a.stats = stats; a.lev_stride = lev_stride; a.y_batch_stride = y_batch_stride;
+  a.in_bn = mmd_make_bn(nullptr, nullptr, nullptr, 0, K);
+  for (int l = 0; l < a.pyr.n; ++l) a.yoff_lev[l] = y_off_lev ? y_off_lev[l] : 0;
+  return pw_dispatch(a, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ what autograd derives for them.
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -295,7 +296,7 @@ class Net:
             ps.nbt.add_(1)
         return cls, reg, feats
 
-    def _sep_bn(self, name: str, x: Feat, train: bool, rec: dict, bn_name: Optional[str] = None) -> Feat:
+    def _sep_bn(self, name: str, x: Feat, train: bool, rec: dict, bn_name: Optional[str] = None, y=None) -> Feat:
         """SeparableConvBlock(norm=True, activation=False) on a materialised input -> materialised output."""
         ps = self.ps
         W = x.C
@@ -307,12 +308,13 @@ class Net:
             st = self._bn_stats(bn_name, True)
             z = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, stats=st)
             a = self._bn_aff(bn_name, True, st, x.M)
-            y = self._alloc(x.M, W)
+            if y is None:
+                y = self._alloc(x.M, W)
             call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, x.M, W)
             rec.update(zd=zdf, z=z, bn=a)
         else:
             b = ps.bn(bn_name)
-            y = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]))
+            y = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]), y=y)
         return Feat(y, x.B, x.H, x.W, W)
 
     def _down_channel(self, name: str, x: Feat, train: bool, tape: dict) -> Feat:
@@ -342,14 +344,14 @@ class Net:
         return Feat(y, x.B, OH, OW, x.C)
 
     def _node(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
-              pl: Optional[Feat], train: bool, tape: dict) -> Feat:
+              pl: Optional[Feat], train: bool, tape: dict, y=None) -> Feat:
         f = self._alloc(in0.M, in0.C)
         th = self.ps.w(f"{cell}.{theta}")
         call("mmd_bifpn_fuse_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th, f,
              in0.B, in0.H, in0.W, in0.C)
         ff = Feat(f, in0.B, in0.H, in0.W, in0.C)
         rec = {"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": ff, "conv": conv}
-        out = self._sep_bn(f"{cell}.{conv}", ff, train, rec)
+        out = self._sep_bn(f"{cell}.{conv}", ff, train, rec, y=y)
         rec["out"] = out
         if train:
             tape.setdefault(cell + ".nodes", []).append(rec)
@@ -371,48 +373,91 @@ class Net:
                     tape[cell + ".first"] = {"c6": c6, "p6_in": p6_in, "p7_in": p7_in}
             else:
                 p3_in, p4_in, p5_in, p6_in, p7_in = feats
+            last = c == self.spec.fpn_cells - 1
+            if last:    # final outputs land in ONE pyramid row buffer so the shared-weight heads run all levels per launch
+                sizes = [(p3_in.H, p3_in.W), (p4_in.H, p4_in.W), (p5_in.H, p5_in.W), (p6_in.H, p6_in.W), (p7_in.H, p7_in.W)]
+                pyr = self._make_pyr(p3_in.B, sizes)
+                fcat = self._alloc_pyr(pyr, p3_in.C)
+                ov = [fcat[pyr["row0"][l]:pyr["row0"][l] + pyr["rows"][l]] for l in range(5)]
+                self._pyr, self._fcat = pyr, fcat
+            else:
+                ov = [None] * 5
             p6_up = self._node(cell, "conv6_up", "p6_w1", p6_in, None, p7_in, None, train, tape)
             p5_up = self._node(cell, "conv5_up", "p5_w1", p5_in, None, p6_up, None, train, tape)
             p4_up = self._node(cell, "conv4_up", "p4_w1", p4_in, None, p5_up, None, train, tape)
-            p3_out = self._node(cell, "conv3_up", "p3_w1", p3_in, None, p4_up, None, train, tape)
+            p3_out = self._node(cell, "conv3_up", "p3_w1", p3_in, None, p4_up, None, train, tape, y=ov[0])
             if c == 0:
                 p4_in = self._down_channel(f"{cell}.p4_down_channel_2", taps[1], train, tape)
                 p5_in = self._down_channel(f"{cell}.p5_down_channel_2", taps[2], train, tape)
-            p4_out = self._node(cell, "conv4_down", "p4_w2", p4_in, p4_up, None, p3_out, train, tape)
-            p5_out = self._node(cell, "conv5_down", "p5_w2", p5_in, p5_up, None, p4_out, train, tape)
-            p6_out = self._node(cell, "conv6_down", "p6_w2", p6_in, p6_up, None, p5_out, train, tape)
-            p7_out = self._node(cell, "conv7_down", "p7_w2", p7_in, None, None, p6_out, train, tape)
+            p4_out = self._node(cell, "conv4_down", "p4_w2", p4_in, p4_up, None, p3_out, train, tape, y=ov[1])
+            p5_out = self._node(cell, "conv5_down", "p5_w2", p5_in, p5_up, None, p4_out, train, tape, y=ov[2])
+            p6_out = self._node(cell, "conv6_down", "p6_w2", p6_in, p6_up, None, p5_out, train, tape, y=ov[3])
+            p7_out = self._node(cell, "conv7_down", "p7_w2", p7_in, None, None, p6_out, train, tape, y=ov[4])
             feats = [p3_out, p4_out, p5_out, p6_out, p7_out]
         return feats
 
+    def _make_pyr(self, B: int, sizes):
+        rows = [B * h * w for h, w in sizes]
+        row0 = [0]
+        for r in rows:
+            row0.append(row0[-1] + (r + 127) // 128 * 128)
+        flat = [len(sizes), B]
+        for h, w in sizes:
+            flat += [h, w]
+        return {"desc": (ctypes.c_int * len(flat))(*flat), "row0": row0, "rows": rows, "sizes": sizes, "B": B,
+                "total": row0[-1], "padded": row0[-1] != sum(rows)}
+
+    def _alloc_pyr(self, pyr, C: int) -> torch.Tensor:
+        t = self._alloc(pyr["total"], C)
+        if pyr["padded"]:          # padding rows are multiplied in the weight-gradient GEMMs: they must be zeros, not stale bits
+            call("mmd_memset_async", t, 0, t.numel() * 4)
+        return t
+
     def _head(self, hname: str, feats: List[Feat], per_anchor: int, out: torch.Tensor, A: int, out_act: int,
               train: bool, tape: dict):
-        ps, spec = self.ps, self.spec
+        """Regressor / Classifier over all 5 pyramid levels per launch (conv weights shared across levels, BN per level:
+        bn_list.<lvl>.<i> sit head_layers*C channels apart in the contiguous BN arrays)."""
+        ps, spec, pyr = self.ps, self.spec, self._pyr
+        C, nl = feats[0].C, spec.head_layers
         nout = spec.num_anchors * per_anchor
-        aoff = 0
-        recs = []
-        for lvl, f in enumerate(feats):
-            cur = f
-            layers = []
-            for i in range(spec.head_layers):
-                cname = f"{hname}.conv_list.{i}"
-                zd, _, _ = self._dw(cur, f"{cname}.depthwise_conv.conv.weight", 3, 1)
-                zdf = Feat(zd, f.B, f.H, f.W, f.C)
-                st = self._bn_stats(f"{hname}.bn_list.{lvl}.{i}", train)
-                z = self._pw(zdf, f"{cname}.pointwise_conv.conv.weight", f.C, bias=ps.w(f"{cname}.pointwise_conv.conv.bias"),
-                             stats=st)
-                a = self._bn_aff(f"{hname}.bn_list.{lvl}.{i}", train, st, f.M)
-                nxt = Feat(z, f.B, f.H, f.W, f.C, a[0], a[1], SWISH, a[4])
-                layers.append({"x": cur, "zd": zdf, "out": nxt, "bn": a})
-                cur = nxt
-            zd, _, _ = self._dw(cur, f"{hname}.header.depthwise_conv.conv.weight", 3, 1)
-            zdf = Feat(zd, f.B, f.H, f.W, f.C)
-            self._pw(zdf, f"{hname}.header.pointwise_conv.conv.weight", nout, bias=ps.w(f"{hname}.header.pointwise_conv.conv.bias"),
-                     out_act=out_act, y=out, ybs=A * per_anchor, yoff=aoff * per_anchor)
-            recs.append({"layers": layers, "hx": cur, "hzd": zdf, "aoff": aoff})
-            aoff += f.H * f.W * spec.num_anchors
+        lev_stride = nl * C
+        off0 = ps.bn_off[f"{hname}.bn_list.0.0"]
+        for lvl in range(5):
+            for i in range(nl):
+                assert ps.bn_off[f"{hname}.bn_list.{lvl}.{i}"] == off0 + lvl * lev_stride + i * C
+        desc = pyr["desc"]
+        cur, cur_xf = self._fcat, (None, None, NONE, None, None, None)     # (scale, shift, act, stats, gamma, beta)
+        layers = []
+        for i in range(nl):
+            cname = f"{hname}.conv_list.{i}"
+            o = off0 + i * C
+            zd = self._alloc_pyr(pyr, C)
+            call("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride)
+            z = self._alloc_pyr(pyr, C)
+            st = self.stats_flat[2 * o:] if train else None
+            call("mmd_pwconv_fwd_pyr", zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
+                 ps.w(f"{cname}.pointwise_conv.conv.bias"), NONE, st, lev_stride, 0, None)
+            if train:
+                for lvl in range(5):
+                    ol = o + lvl * lev_stride
+                    self.bn_count_host[ol:ol + C] = float(pyr["rows"][lvl])
+                nxt_xf = (None, None, SWISH, st, ps.flat[ps.gamma_off + o:], ps.flat[ps.beta_off + o:])
+            else:
+                nxt_xf = (ps.fold_scale[o:], ps.fold_shift[o:], SWISH, None, None, None)
+            layers.append({"x": cur, "x_off": None if i == 0 else off0 + (i - 1) * C, "zd": zd, "z": z, "off": o})
+            cur, cur_xf = z, nxt_xf
+        zd = self._alloc_pyr(pyr, C)
+        call("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride)
+        aoff, yoff = 0, []
+        for (h, w) in pyr["sizes"]:
+            yoff.append(aoff * per_anchor)
+            aoff += h * w * spec.num_anchors
+        yoff_c = (ctypes.c_longlong * 5)(*yoff)
+        call("mmd_pwconv_fwd_pyr", zd, ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, desc, C, nout,
+             ps.w(f"{hname}.header.pointwise_conv.conv.bias"), out_act, None, 0, A * per_anchor, yoff_c)
         if train:
-            tape[hname] = recs
+            tape[hname] = {"layers": layers, "hx": cur, "hx_off": off0 + (nl - 1) * C, "hzd": zd, "yoff": yoff,
+                           "lev_stride": lev_stride}
 
     # ------------------------------------------------------------------ backward (student)
     def _acc(self, slot: GradSlot, src: torch.Tensor):
@@ -470,24 +515,59 @@ class Net:
         for f, d in zip(feats, dfeats):
             if d is not None:
                 slot(f).t = d
-        # ---- heads
+        # ---- heads: every layer handles the whole pyramid in one launch
+        pyr = self._pyr
+        desc, Mt = pyr["desc"], pyr["total"]
+        C = feats[0].C
+        gsum = None
         for hname, per_anchor, dout in (("classifier", spec.num_classes, dcls_logit), ("regressor", 4, dreg)):
+            rec = tape[hname]
             nout = spec.num_anchors * per_anchor
-            for lvl, rec in enumerate(tape[hname]):
-                f = feats[lvl]
-                dy = self._alloc(f.M, nout)
-                call("mmd_slice_rows", dout, dy, f.B, f.H * f.W, nout, A * per_anchor, rec["aoff"] * per_anchor)
-                dzd = self._pw_bwd(dy, rec["hzd"], f"{hname}.header.pointwise_conv.conv.weight", nout,
-                                   f"{hname}.header.pointwise_conv.conv.bias", True)
-                g = self._dw_bwd(dzd, rec["hx"], f"{hname}.header.depthwise_conv.conv.weight", 3, 1)
-                for i in reversed(range(spec.head_layers)):
-                    L = rec["layers"][i]
-                    cname = f"{hname}.conv_list.{i}"
-                    dz = self._bn_bwd(g, L["out"].z, L["bn"], f"{hname}.bn_list.{lvl}.{i}", SWISH, f.M, f.C)
-                    # a bias in front of a train-mode BN has an exactly-zero gradient (sum_m dz = 0): no colsum launch
-                    dzd = self._pw_bwd(dz, L["zd"], f"{cname}.pointwise_conv.conv.weight", f.C, None, True)
-                    g = self._dw_bwd(dzd, L["x"], f"{cname}.depthwise_conv.conv.weight", 3, 1)
-                self._acc(slot(f), g)
+            ls = rec["lev_stride"]
+            dy = self._alloc_pyr(pyr, nout)
+            for lvl, (h, w) in enumerate(pyr["sizes"]):
+                call("mmd_slice_rows", dout, dy[pyr["row0"][lvl]:], pyr["B"], h * w, nout, A * per_anchor, rec["yoff"][lvl])
+            hw_key = f"{hname}.header.pointwise_conv.conv.weight"
+            call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
+            call("mmd_pwconv_bwd_weight", dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
+            dzd = self._alloc_pyr(pyr, C)
+            call("mmd_pwconv_bwd_data", dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
+            xo = rec["hx_off"]
+            call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
+                 self.t_scale[xo:], self.t_shift[xo:], SWISH, ls)
+            g = self._alloc_pyr(pyr, C)
+            call("mmd_dwconv3_pyr", dzd, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
+                 None, None, None, 0)
+            bsums = self._zalloc((2 * 5 * ls,), torch.float64)
+            off0 = rec["layers"][0]["off"]
+            for i in reversed(range(spec.head_layers)):
+                L = rec["layers"][i]
+                cname = f"{hname}.conv_list.{i}"
+                o = L["off"]
+                sums = bsums[2 * (o - off0):]
+                gy = self._alloc_pyr(pyr, C)
+                call("mmd_bn_bwd_reduce_pyr", g, L["z"], self.t_scale[o:], self.t_shift[o:], self.t_mean[o:], self.t_invstd[o:],
+                     SWISH, desc, ls, gy, sums, C)
+                dz = self._alloc_pyr(pyr, C)
+                call("mmd_bn_bwd_apply_pyr", gy, L["z"], self.t_mean[o:], self.t_invstd[o:], ps.flat[ps.gamma_off + o:], sums,
+                     desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C)
+                wkey = f"{cname}.pointwise_conv.conv.weight"
+                call("mmd_pwconv_bwd_weight", dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
+                dzd = self._alloc_pyr(pyr, C)
+                call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
+                xo = L["x_off"]
+                call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,
+                     None if xo is None else self.t_scale[xo:], None if xo is None else self.t_shift[xo:],
+                     NONE if xo is None else SWISH, ls)
+                g = self._alloc_pyr(pyr, C)
+                call("mmd_dwconv3_pyr", dzd, ps.w(f"{cname}.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
+                     None, None, None, 0)
+            if gsum is None:
+                gsum = g
+            else:
+                call("mmd_scale_acc", g, gsum, None, 0, 0, 1, g.numel())
+        for lvl, f in enumerate(feats):
+            self._acc(slot(f), gsum[pyr["row0"][lvl]:pyr["row0"][lvl] + pyr["rows"][lvl]])
         # ---- BiFPN (cells and nodes in reverse)
         for c in reversed(range(spec.fpn_cells)):
             cell = f"bifpn.{c}"

@@ -412,3 +412,99 @@ def test_transpose_batched():
     call("mmd_transpose_batched", g(src), dst, torch.tensor(desc, dtype=torch.int64, device=DEV), len(shapes), tiles)
     for (so, do, r, c, _) in desc:
         close(dst[do:do + r * c].view(c, r), src[so:so + r * c].view(r, c).t())
+
+
+def _pyr(B, sizes):
+    import ctypes
+    rows = [B * h * w for h, w in sizes]
+    row0 = [0]
+    for r in rows:
+        row0.append(row0[-1] + (r + 127) // 128 * 128)
+    flat = [len(sizes), B] + [v for hw in sizes for v in hw]
+    return (ctypes.c_int * len(flat))(*flat), row0, rows
+
+
+def test_pyramid_launches_match_per_level():
+    """One-launch-per-pyramid kernels (heads) against the per-level kernels they replace, on a padded pyramid."""
+    import ctypes
+    torch.manual_seed(21)
+    B, C, N = 2, 112, 36
+    sizes = [(8, 8), (5, 3), (2, 2)]
+    desc, row0, rows = _pyr(B, sizes)
+    Mt, nl = row0[-1], len(sizes)
+    ls = 3 * C                                   # per-level BN stride (3 "layers" of C channels)
+    x = torch.zeros(Mt, C); dy = torch.zeros(Mt, C)
+    for l in range(nl):
+        x[row0[l]:row0[l] + rows[l]] = torch.randn(rows[l], C)
+        dy[row0[l]:row0[l] + rows[l]] = torch.randn(rows[l], C)
+    wd = torch.randn(9, C) / 3
+    sc = torch.rand(nl * ls) + 0.5; sh = torch.randn(nl * ls) * 0.1
+    o = C                                         # use "layer 1" of each level
+    # ---- depthwise forward with per-level prologue, and its flipped form
+    y = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls)
+    yf = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0)
+    dwp = torch.zeros(9, C, device=DEV)
+    call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dwp, desc, C, g(sc)[o:], g(sh)[o:], 1, ls)
+    dwr = torch.zeros(9, C, device=DEV)
+    for l, (h, w) in enumerate(sizes):
+        sl = slice(row0[l], row0[l] + rows[l])
+        ol = o + l * ls
+        yr = torch.empty(rows[l], C, device=DEV)
+        call("mmd_dwconv_fwd", g(x[sl]), g(wd), yr, B, h, w, C, 3, 1, g(sc[ol:ol + C]), g(sh[ol:ol + C]), 1, None, None, None, 0,
+             None, None, 0, None, None)
+        assert torch.equal(y[sl], yr), l
+        dxr = torch.empty(rows[l], C, device=DEV)
+        call("mmd_dwconv_bwd_data", g(dy[sl]), g(wd), dxr, B, h, w, C, 3, 1)
+        assert torch.equal(yf[sl], dxr), l
+        call("mmd_dwconv_bwd_weight", g(x[sl]), g(dy[sl]), dwr, B, h, w, C, 3, 1, g(sc[ol:ol + C]), g(sh[ol:ol + C]), 1)
+    close(dwp, dwr, 1e-4, 1e-5, "pyr dw wgrad")
+    # live-BN prologue per level
+    stats = torch.zeros(2 * nl * ls, dtype=torch.float64)
+    gam, bet = torch.rand(nl * ls) + 0.5, torch.randn(nl * ls) * 0.1
+    for l in range(nl):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        stats[2 * ol:2 * ol + C] = x[sl].double().sum(0); stats[2 * ol + C:2 * ol + 2 * C] = (x[sl].double() ** 2).sum(0)
+    yl = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls)
+    for l, (h, w) in enumerate(sizes):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        yr = torch.empty(rows[l], C, device=DEV)
+        call("mmd_dwconv_fwd", g(x[sl]), g(wd), yr, B, h, w, C, 3, 1, None, None, 1, g(stats[2 * ol:2 * ol + 2 * C]),
+             g(gam[ol:ol + C]), g(bet[ol:ol + C]), rows[l], None, None, 0, None, None)
+        assert torch.equal(yl[sl], yr), l
+    # ---- pointwise GEMM with per-level stats and the strided head output
+    wp = torch.randn(N, C) / 10; bias = torch.randn(N)
+    z = torch.zeros(Mt, N, device=DEV)
+    st = torch.zeros(2 * nl * ls, dtype=torch.float64, device=DEV)
+    call("mmd_pwconv_fwd_pyr", g(x), g(wp), z, desc, C, N, g(bias), 0, st[2 * o:], ls, 0, None)
+    A = sum(h * w for h, w in sizes) * 9
+    out = torch.zeros(B, A * 4, device=DEV)
+    yoff, a0 = [], 0
+    for h, w in sizes:
+        yoff.append(a0 * 4); a0 += h * w * 9
+    call("mmd_pwconv_fwd_pyr", g(x), g(wp), out, desc, C, N, g(bias), 2, None, 0, A * 4, (ctypes.c_longlong * 5)(*yoff, 0, 0))
+    for l, (h, w) in enumerate(sizes):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        ref = x[sl] @ wp.t() + bias
+        close(z[sl], ref, 2e-4, 1e-5, "pyr pw")
+        close(st[2 * ol:2 * ol + N], ref.double().sum(0), 1e-4, 1e-4)
+        close(st[2 * ol + ls * 0 + N:2 * ol + 2 * N], (ref.double() ** 2).sum(0), 1e-4, 1e-5)
+        close(out[:, yoff[l]:yoff[l] + h * w * N], torch.sigmoid(ref).view(B, h * w * N), 2e-4, 1e-5, "pyr head out")
+    # ---- segmented BN backward
+    mu, istd = torch.randn(nl * ls) * 0.1, torch.rand(nl * ls) + 0.5
+    gy = torch.zeros(Mt, C, device=DEV); dzp = torch.zeros(Mt, C, device=DEV)
+    sums = torch.zeros(2 * nl * ls, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce_pyr", g(dy), g(x), g(sc)[o:], g(sh)[o:], g(mu)[o:], g(istd)[o:], 1, desc, ls, gy, sums[2 * o:], C)
+    dga, dbe = torch.zeros(nl * ls, device=DEV), torch.zeros(nl * ls, device=DEV)
+    call("mmd_bn_bwd_apply_pyr", gy, g(x), g(mu)[o:], g(istd)[o:], g(gam)[o:], sums[2 * o:], desc, ls, dzp, dga[o:], dbe[o:], C)
+    for l in range(nl):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        cs = slice(ol, ol + C)
+        gr = torch.empty(rows[l], C, device=DEV); sr = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        call("mmd_bn_bwd_reduce", g(dy[sl]), g(x[sl]), g(sc[cs]), g(sh[cs]), g(mu[cs]), g(istd[cs]), 1, None, None, None, 0, gr, sr,
+             rows[l], C)
+        dr = torch.empty(rows[l], C, device=DEV); ga, be = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        call("mmd_bn_bwd_apply", gr, g(x[sl]), g(mu[cs]), g(istd[cs]), g(gam[cs]), sr, rows[l], dr, ga, be, rows[l], C)
+        close(dzp[sl], dr, 1e-5, 1e-6, "pyr bn dz"); close(dga[cs], ga, 1e-5, 1e-6); close(dbe[cs], be, 1e-5, 1e-6)
