@@ -34,71 +34,86 @@ template <int K, int S> struct DwCfg {
   static constexpr int SEG = (R - 1) * S + K;              // input columns one strip needs
 };
 
+// geometry + producer transform a block works with (kernel arguments, or one pyramid level of them) — kept in
+// registers: copying the whole argument struct and patching it put it in scratch memory (296 B/lane)
+struct DwView {
+  const float* x; int H, W, C;
+  float4 sc, sh; bool xf; int act;
+};
+
+__device__ __forceinline__ void dw_in_coef(const float* in_scale, const float* in_shift, const BnLive& bn, int c, bool cok,
+                                           DwView& v) {
+  v.sc = make_float4(1, 1, 1, 1); v.sh = make_float4(0, 0, 0, 0);
+  v.xf = in_scale || bn.stats;
+  if (cok) {
+    if (bn.stats) bn_live_coef4(bn, c, v.sc, v.sh);
+    else if (in_scale) { v.sc = mmd_ld4(in_scale + c); v.sh = mmd_ld4(in_shift + c); }
+  }
+}
+
 template <int K, int S>
-__device__ __forceinline__ void dw_stage_input(const DwArgs& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
+__device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
   using Cf = DwCfg<K, S>;
   const int c4 = (tid & 15) * 4;
   const int c = c0 + c4;
   const bool cok = c < a.C;
-  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-  const bool xf = a.in_scale || a.in_bn.stats;
-  if (cok) {
-    if (a.in_bn.stats) bn_live_coef4(a.in_bn, c, sc, sh);
-    else if (a.in_scale) { sc = mmd_ld4(a.in_scale + c); sh = mmd_ld4(a.in_shift + c); }
-  }
+  const float4 sc = a.sc, sh = a.sh;
   for (int p = tid >> 4; p < Cf::IH * Cf::IW; p += 16) {
     int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
     float4 v = make_float4(0, 0, 0, 0);
     if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
       v = mmd_ld4(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
-      if (xf) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
-      if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+      if (a.xf) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
+      if (a.act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
     }
     *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
   }
 }
 
-// pyramid launch (k=3, s=1 only): pick this block's level and rebase pointers / geometry / per-level BN parameters
-template <int TH, int TW>
-__device__ __forceinline__ int dw_enter_level(DwArgs& a, int bid) {
-  const int l = pyr_level_of_block(a.pyr, bid);
-  a.H = a.OH = a.pyr.H[l]; a.W = a.OW = a.pyr.W[l];
-  a.tiles_h = (a.H + TH - 1) / TH; a.tiles_w = (a.W + TW - 1) / TW;
-  const size_t ro = (size_t)a.pyr.row0[l] * a.C;
-  a.x += ro; a.y += ro;
-  if (a.in_scale) { a.in_scale += l * a.lev_stride; a.in_shift += l * a.lev_stride; }
-  if (a.in_bn.stats) {
-    a.in_bn.stats += 2 * l * a.lev_stride; a.in_bn.gamma += l * a.lev_stride; a.in_bn.beta += l * a.lev_stride;
-    a.in_bn.inv_count = 1.0 / ((double)a.B * a.H * a.W);
-  }
-  return bid - a.pyr.blk0[l];
-}
-
 template <int K, int S>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a_in) {
+__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   using Cf = DwCfg<K, S>;
   __shared__ float sIn[Cf::IH * Cf::IW * 64];
   __shared__ float sW[K * K * 64];
   __shared__ float sRed[2 * 4 * 64];
   const int tid = threadIdx.x;
-  DwArgs a = a_in;
   int bid = blockIdx.x;
-  if (a.pyr.n) bid = dw_enter_level<Cf::TH, Cf::TW>(a, bid);
+  // pyramid launch (k=3, s=1): pick this block's level (unrolled selects: no dynamic indexing of the argument arrays)
+  int H = a.H, W = a.W, OH = a.OH, OW = a.OW, tiles_h = a.tiles_h, tiles_w = a.tiles_w, lev = 0;
+  size_t ro = 0;
+  if (a.pyr.n) {
+    int blk = 0;
+    H = a.pyr.H[0]; W = a.pyr.W[0];
+#pragma unroll
+    for (int i = 1; i < MMD_MAX_LEV; ++i)
+      if (i < a.pyr.n && bid >= a.pyr.blk0[i]) { lev = i; H = a.pyr.H[i]; W = a.pyr.W[i]; ro = (size_t)a.pyr.row0[i]; blk = a.pyr.blk0[i]; }
+    bid -= blk; OH = H; OW = W; ro *= a.C;
+    tiles_h = (H + Cf::TH - 1) / Cf::TH; tiles_w = (W + Cf::TW - 1) / Cf::TW;
+  }
   const int cc = bid % a.cchunks; bid /= a.cchunks;
-  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
-  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
   const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
   const bool cok = c < a.C;
   const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
+  DwView v;
+  v.x = a.x + ro; v.H = H; v.W = W; v.C = a.C; v.act = a.in_act;
+  {
+    BnLive bn = a.in_bn;
+    const long long lo = (long long)lev * a.lev_stride;
+    if (bn.stats) { bn.stats += 2 * lo; bn.gamma += lo; bn.beta += lo; if (a.pyr.n) bn.inv_count = 1.0 / ((double)a.B * H * W); }
+    dw_in_coef(a.in_scale ? a.in_scale + lo : nullptr, a.in_scale ? a.in_shift + lo : nullptr, bn, c, cok, v);
+  }
+  float* const yout = a.y + ro;
 
   for (int i = tid; i < K * K * 16; i += 256) {
     int tap = i >> 4, q = (i & 15) * 4;
     int src = a.flip ? (K * K - 1 - tap) : tap;
-    float4 v = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
-    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = v;
+    float4 wv = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
+    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
   }
-  dw_stage_input<K, S>(a, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+  dw_stage_input<K, S>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
   __syncthreads();
 
   const int p = tid >> 4;
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a_in) {
 #pragma unroll
   for (int o = 0; o < Cf::R; ++o) {
     int ow = ow0 + ocol0 + o;
-    if (cok && oh < a.OH && ow < a.OW) {
+    if (cok && oh < OH && ow < OW) {
       float4 v = acc[o];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a_in) {
       if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
       if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
       pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
-      mmd_st4(a.y + (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + c, t);
+      mmd_st4(yout + (((size_t)b * OH + oh) * OW + ow) * a.C + c, t);
     }
   }
   if (a.stats || a.pool) {
@@ -325,25 +340,27 @@ struct DwWgArgs {
 };
 
 template <int K, int S>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a_in) {
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
   using Cf = DwCfg<K, S>;
   static_assert(Cf::IH * Cf::IW >= 4 * K * K, "reduction scratch aliases the input tile");
   __shared__ float sIn[Cf::IH * Cf::IW * 64];
   float* sRed = sIn;                      // reused after the tile loop (behind a barrier)
   const int tid = threadIdx.x;
-  DwWgArgs a = a_in;
   int bid = blockIdx.x;
+  int H = a.H, W = a.W, OH = a.OH, OW = a.OW, tiles_h = a.tiles_h, tiles_w = a.tiles_w, nsplit = a.nsplit, lev = 0;
+  size_t ro = 0;
   if (a.pyr.n) {
-    const int l = pyr_level_of_block(a.pyr, bid);
-    bid -= a.pyr.blk0[l];
-    a.H = a.OH = a.pyr.H[l]; a.W = a.OW = a.pyr.W[l];
-    a.tiles_h = (a.H + Cf::TH - 1) / Cf::TH; a.tiles_w = (a.W + Cf::TW - 1) / Cf::TW;
-    a.nsplit = a.nsplit_lev[l];
-    const size_t ro = (size_t)a.pyr.row0[l] * a.C;
-    a.x += ro; a.dy += ro;
-    if (a.in_scale) { a.in_scale += l * a.lev_stride; a.in_shift += l * a.lev_stride; }
+    int blk = 0;
+    H = a.pyr.H[0]; W = a.pyr.W[0]; nsplit = a.nsplit_lev[0];
+#pragma unroll
+    for (int i = 1; i < MMD_MAX_LEV; ++i)
+      if (i < a.pyr.n && bid >= a.pyr.blk0[i]) {
+        lev = i; H = a.pyr.H[i]; W = a.pyr.W[i]; ro = (size_t)a.pyr.row0[i]; blk = a.pyr.blk0[i]; nsplit = a.nsplit_lev[i];
+      }
+    bid -= blk; OH = H; OW = W; ro *= a.C;
+    tiles_h = (H + Cf::TH - 1) / Cf::TH; tiles_w = (W + Cf::TW - 1) / Cf::TW;
   }
-  const int sp = bid % a.nsplit; bid /= a.nsplit;
+  const int sp = bid % nsplit; bid /= nsplit;
   const int cc = bid % a.cchunks; bid /= a.cchunks;
   const int b = bid;
   const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
@@ -351,16 +368,22 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a_in) {
   const int p = tid >> 4;
   const int orow = p / (Cf::TW / Cf::R);
   const int ocol0 = (p % (Cf::TW / Cf::R)) * Cf::R;
-  DwArgs fa{};
-  fa.x = a.x; fa.H = a.H; fa.W = a.W; fa.C = a.C; fa.in_scale = a.in_scale; fa.in_shift = a.in_shift; fa.in_act = a.in_act;
+  DwView fa;
+  fa.x = a.x + ro; fa.H = H; fa.W = W; fa.C = a.C; fa.act = a.in_act;
+  {
+    BnLive none{};
+    const long long lo = (long long)lev * a.lev_stride;
+    dw_in_coef(a.in_scale ? a.in_scale + lo : nullptr, a.in_scale ? a.in_shift + lo : nullptr, none, c, cok, fa);
+  }
+  const float* const dyp = a.dy + ro;
 
   float4 acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0, 0, 0, 0);
 
-  const int ntiles = a.tiles_h * a.tiles_w;
-  for (int tile = sp; tile < ntiles; tile += a.nsplit) {
-    const int th = tile / a.tiles_w, tw = tile % a.tiles_w;
+  const int ntiles = tiles_h * tiles_w;
+  for (int tile = sp; tile < ntiles; tile += nsplit) {
+    const int th = tile / tiles_w, tw = tile % tiles_w;
     const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
     __syncthreads();
     dw_stage_input<K, S>(fa, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a_in) {
 #pragma unroll
     for (int o = 0; o < Cf::R; ++o) {
       int ow = ow0 + ocol0 + o;
-      g[o] = (cok && oh < a.OH && ow < a.OW) ? mmd_ld4(a.dy + (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + c)
+      g[o] = (cok && oh < OH && ow < OW) ? mmd_ld4(dyp + (((size_t)b * OH + oh) * OW + ow) * a.C + c)
                                               : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
