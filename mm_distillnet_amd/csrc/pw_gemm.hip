@@ -345,6 +345,215 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming variant for the HBM-bound layers (K <= 128, large M): a persistent block keeps its weight panel
+// B[BN, K] resident in LDS for its whole life and walks M tiles with the WHOLE K extent of the A tile double-buffered
+// (global loads of tile t+1 are in flight during the MFMAs and epilogue of tile t; one barrier per tile).  The A
+// stream is read once per 128-wide column panel; BN statistics are accumulated in registers across tiles and
+// leave as one atomic round per block.
+//   WM x WN waves: (2 x 2): BM = 64, wave tile 32 x (BN/2), BN in {64, 128};  (4 x 1): BM = 128, BN = 32.
+struct StArgs { PwArgs p; int KP; int LD; int mtiles; int gm; };   // KP = K rounded up to 8, LD = KP + 4, gm = blocks per column panel
+
+template <int WM, int NSW>
+__global__ __launch_bounds__(256) void pw_stream_kernel(StArgs sa) {
+  constexpr int WN = 4 / WM;
+  constexpr int BM = 32 * WM;
+  constexpr int BN = 32 * NSW * WN;
+  constexpr int NLD = 8;                         // max float4 A loads per thread: BM*KP/4/256 <= 128*128/4/256 = 16 for WM=4
+  constexpr int NLA = (WM == 4) ? 16 : 8;
+  extern __shared__ float smem[];
+  const PwArgs& a = sa.p;
+  const int KP = sa.KP, LD = sa.LD, f4row = KP >> 2;
+  float* sB = smem;
+  float* sA0 = sB + BN * LD;
+  float* sA1 = sA0 + BM * LD;
+  float* sSc = sA1 + BM * LD;                    // [KP] scale, [KP] shift
+  float* sRed = sSc + 2 * KP;                    // [2][WM][BN]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+  const int tn = blockIdx.x % a.ntn, bm = blockIdx.x / a.ntn;
+  const int n0 = tn * BN;
+  const bool xf = a.in_scale || a.in_bn.stats;
+
+  // ---- one-time: weight panel (zero-padded to [BN][KP]) and the prologue coefficients
+  for (int i = tid; i < BN * f4row; i += 256) {
+    int row = i / f4row, k = (i - row * f4row) * 4;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (n0 + row < a.N && k < a.K) v = mmd_ld4(a.w + (size_t)(n0 + row) * a.K + k);
+    *reinterpret_cast<float4*>(&sB[row * LD + k]) = v;
+  }
+  if (xf)
+    for (int k = tid; k < KP; k += 256) {
+      float sc = 0.f, sh = 0.f;
+      if (k < a.K) {
+        if (a.in_bn.stats) bn_live_coef(a.in_bn, k, sc, sh);
+        else { sc = a.in_scale[k]; sh = a.in_shift[k]; }
+      }
+      sSc[k] = sc; sSc[KP + k] = sh;
+    }
+  // per-thread load slots (same pattern every tile)
+  int lrow[NLA], lk[NLA];
+  const int nld = (BM * f4row + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    int idx = tid + i * 256;
+    lrow[i] = idx / f4row; lk[i] = (idx - lrow[i] * f4row) * 4;
+    if (i >= nld || lrow[i] >= BM) lrow[i] = -1;
+  }
+  float4 ra[NLA], rg[NLA];
+  auto gload = [&](int mt) {
+    const int m0 = mt * BM;
+    int Mv = a.M;
+    if (a.pyr.n) { const int lev = pyr_level_of_row(a.pyr, m0); Mv = a.pyr.row0[lev] + a.pyr.B * a.pyr.H[lev] * a.pyr.W[lev]; }
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      ra[i] = make_float4(0, 0, 0, 0);
+      if (lrow[i] >= 0) {
+        int row = m0 + lrow[i];
+        bool ok = row < Mv && lk[i] < a.K;
+        if (ok) ra[i] = mmd_ld4(a.x + (size_t)row * a.K + lk[i]);
+        if (a.gate) rg[i] = ok ? mmd_ld4(a.gate + (size_t)(row / a.rows_per_image) * a.K + lk[i]) : make_float4(0, 0, 0, 0);
+        if (!ok) lrow[i] = -2 - lrow[i];          // mark invalid for this tile (restored in lstore)
+      }
+    }
+  };
+  auto lstore = [&](float* sA) {
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      int lr = lrow[i];
+      if (lr == -1) continue;
+      bool ok = lr >= 0;
+      if (!ok) { lr = -2 - lr; lrow[i] = lr; }
+      float4 v = ra[i];
+      if (ok) {
+        if (xf) {
+          float4 sc = *reinterpret_cast<const float4*>(&sSc[lk[i]]), sh = *reinterpret_cast<const float4*>(&sSc[KP + lk[i]]);
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+        if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+        if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      } else v = make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(&sA[lr * LD + lk[i]]) = v;
+    }
+  };
+
+  float cs[NSW], css[NSW];
+#pragma unroll
+  for (int j = 0; j < NSW; ++j) { cs[j] = 0.f; css[j] = 0.f; }
+  double* stats0 = a.stats;          // level 0 base; per-level offset applied at flush time
+  int cur_lev = -1;
+
+  auto flush_stats = [&](int lev) {   // block-level reduce of the per-lane column sums and one atomic round
+    if (!a.stats) return;
+#pragma unroll
+    for (int j = 0; j < NSW; ++j) {
+      float s = cs[j] + __shfl_xor(cs[j], 32, 64), q = css[j] + __shfl_xor(css[j], 32, 64);
+      if (h == 0) { sRed[wm * BN + (wn * NSW + j) * 32 + r] = s; sRed[WM * BN + wm * BN + (wn * NSW + j) * 32 + r] = q; }
+      cs[j] = 0.f; css[j] = 0.f;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.N) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s += sRed[w * BN + tid]; q += sRed[WM * BN + w * BN + tid]; }
+      double* st = stats0 + (a.pyr.n ? 2 * (long long)lev * a.lev_stride : 0);
+      atomicAdd(&st[n0 + tid], (double)s);
+      atomicAdd(&st[a.N + n0 + tid], (double)q);
+    }
+    __syncthreads();
+  };
+
+  int mt = bm;
+  if (mt < sa.mtiles) gload(mt);
+  __syncthreads();                       // sB / sSc visible
+  if (mt < sa.mtiles) lstore(sA0);
+  __syncthreads();
+  int cur = 0;
+  for (; mt < sa.mtiles; mt += sa.gm) {
+    const int m0 = mt * BM;
+    const int nxt = mt + sa.gm;
+    if (nxt < sa.mtiles) gload(nxt);
+    int Mv = a.M, srow0 = 0, rpi = a.rows_per_image, lev = 0; long long yoff = a.y_offset;
+    if (a.pyr.n) {
+      lev = pyr_level_of_row(a.pyr, m0);
+      srow0 = a.pyr.row0[lev]; rpi = a.pyr.H[lev] * a.pyr.W[lev]; Mv = srow0 + a.pyr.B * rpi; yoff = a.yoff_lev[lev];
+      if (a.stats && cur_lev >= 0 && lev != cur_lev) flush_stats(cur_lev);      // wave-uniform, all threads take it together
+      cur_lev = lev;
+    }
+    const float* sA = cur ? sA1 : sA0;
+    f32x16 acc[NSW];
+#pragma unroll
+    for (int j = 0; j < NSW; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    const float* pa = &sA[(wm * 32 + r) * LD + h * 4];
+    const float* pb = &sB[(wn * NSW * 32 + r) * LD + h * 4];
+    for (int kk = 0; kk < KP; kk += 8) {
+      float4 av = *reinterpret_cast<const float4*>(pa + kk);
+#pragma unroll
+      for (int j = 0; j < NSW; ++j) {
+        float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * LD + kk);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NSW; ++j) {
+      const int col = n0 + (wn * NSW + j) * 32 + r;
+      const bool cok = col < a.N;
+      const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
+      const float osc = (a.out_scale && cok) ? a.out_scale[col] : 1.f;
+      const float osh = (a.out_scale && cok) ? a.out_shift[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (cok && row < Mv) {
+          float v = acc[j][q] + bias;
+          cs[j] += v; css[j] += v * v;
+          if (a.out_scale) v = v * osc + osh;
+          v = mmd_act(v, a.out_act);
+          size_t off;
+          if (a.y_batch_stride) {
+            int img = (row - srow0) / rpi;
+            off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
+          } else {
+            off = (size_t)row * a.N + col;
+          }
+          if (a.residual) v += a.residual[off];
+          a.y[off] = v;
+        }
+      }
+    }
+    if (nxt < sa.mtiles) lstore(cur ? sA0 : sA1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (a.stats && (cur_lev >= 0 || !a.pyr.n) && bm < sa.mtiles) flush_stats(cur_lev < 0 ? 0 : cur_lev);
+}
+
+template <int WM, int NSW>
+static int pw_stream_launch(PwArgs& a, hipStream_t stream) {
+  constexpr int WN = 4 / WM, BM = 32 * WM, BN = 32 * NSW * WN;
+  StArgs sa; sa.p = a;
+  sa.KP = (a.K + 7) / 8 * 8; sa.LD = sa.KP + 4;
+  sa.mtiles = cdiv(a.M, BM);
+  sa.p.ntn = cdiv(a.N, BN);
+  size_t lds = ((size_t)(BN + 2 * BM) * sa.LD + 2 * sa.KP + 2 * WM * BN) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)pw_stream_kernel<WM, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  int per_cu = (int)((160 * 1024) / lds); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
+  int gm = (256 * per_cu) / sa.p.ntn; if (gm < 1) gm = 1; if (gm > sa.mtiles) gm = sa.mtiles;
+  sa.gm = gm;
+  hipLaunchKernelGGL((pw_stream_kernel<WM, NSW>), dim3(gm * sa.p.ntn), dim3(256), lds, stream, sa);
+  return 0;
+}
+
 static int pw_dispatch(PwArgs& a, hipStream_t stream);
 
 extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N,
@@ -372,7 +581,12 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   mmd_prof_begin(MMD_FAM_PW, stream);
   const long long big_tiles = (long long)ntm * cdiv(N, 64);
   static const int k_small = getenv("MMD_SKINNY_K") ? atoi(getenv("MMD_SKINNY_K")) : 0;
-  if ((big_tiles < 160 || K <= k_small) && N > 16) {
+  static const int use_stream = getenv("MMD_NO_STREAM") ? 0 : 1;
+  if (use_stream && K <= 128 && big_tiles >= 160) {
+    if (N <= 32) pw_stream_launch<4, 1>(a, stream);
+    else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
+    else pw_stream_launch<2, 2>(a, stream);
+  } else if ((big_tiles < 160 || K <= k_small) && N > 16) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
     hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
   } else if (N <= 32) {

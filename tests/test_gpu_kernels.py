@@ -508,3 +508,37 @@ def test_pyramid_launches_match_per_level():
         dr = torch.empty(rows[l], C, device=DEV); ga, be = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
         call("mmd_bn_bwd_apply", gr, g(x[sl]), g(mu[cs]), g(istd[cs]), g(gam[cs]), sr, rows[l], dr, ga, be, rows[l], C)
         close(dzp[sl], dr, 1e-5, 1e-6, "pyr bn dz"); close(dga[cs], ga, 1e-5, 1e-6); close(dbe[cs], be, 1e-5, 1e-6)
+
+
+def test_pwconv_pyr_large_stream_path():
+    """Pyramid GEMM at head-like sizes (streaming kernel): per-level stats and the strided head output."""
+    import ctypes
+    torch.manual_seed(4)
+    B, C = 4, 112
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+    desc, row0, rows = _pyr(B, sizes)
+    Mt, ls, o = row0[-1], 3 * C, C
+    x = torch.randn(Mt, C)
+    for N, act in ((112, 0), (36, 2)):
+        w = torch.randn(N, C) / 10; bias = torch.randn(N)
+        if act == 0:
+            z = torch.zeros(Mt, N, device=DEV)
+            st = torch.zeros(2 * 5 * ls, dtype=torch.float64, device=DEV)
+            call("mmd_pwconv_fwd_pyr", g(x), g(w), z, desc, C, N, g(bias), 0, st[2 * o:], ls, 0, None)
+            for l in range(5):
+                sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+                ref = x[sl] @ w.t() + bias
+                close(z[sl], ref, 2e-4, 1e-5, f"pyr pw L{l}")
+                close(st[2 * ol:2 * ol + N], ref.double().sum(0), 1e-4, 1e-4)
+                close(st[2 * ol + N:2 * ol + 2 * N], (ref.double() ** 2).sum(0), 1e-4, 1e-5)
+        else:
+            A = sum(h * w_ for h, w_ in sizes) * 9
+            out = torch.zeros(B, A * 4, device=DEV)
+            yoff, a0 = [], 0
+            for h, w_ in sizes:
+                yoff.append(a0 * 4); a0 += h * w_ * 9
+            call("mmd_pwconv_fwd_pyr", g(x), g(w), out, desc, C, N, g(bias), 2, None, 0, A * 4, (ctypes.c_longlong * 5)(*yoff))
+            for l, (h, w_) in enumerate(sizes):
+                sl = slice(row0[l], row0[l] + rows[l])
+                ref = torch.sigmoid(x[sl] @ w.t() + bias).view(B, h * w_ * N)
+                close(out[:, yoff[l]:yoff[l] + h * w_ * N], ref, 2e-4, 1e-5, f"pyr head L{l}")
