@@ -581,7 +581,10 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   mmd_prof_begin(MMD_FAM_PW, stream);
   const long long big_tiles = (long long)ntm * cdiv(N, 64);
   static const int k_small = getenv("MMD_SKINNY_K") ? atoi(getenv("MMD_SKINNY_K")) : 0;
-  static const int use_stream = getenv("MMD_NO_STREAM") ? 0 : 1;
+  // measured r01: the streaming variant is ~2x SLOWER than the tiled kernel on every shape (1 block/CU, one wave per
+  // SIMD, nothing hides the LDS/epilogue latency) -> off unless MMD_STREAM=1; kept as the starting point for a
+  // software-pipelined version (profiles/r01_notes.md)
+  static const int use_stream = getenv("MMD_STREAM") ? 1 : 0;
   if (use_stream && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
