@@ -36,9 +36,12 @@ template <int BN_T>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   constexpr int NS = BN_T / 32;          // 32-col slabs per wave
   constexpr int NB = BN_T / 32;          // B float4 loads per thread (BN_T*8/256)
-  __shared__ float sA[PW_BM * PW_LD];
-  __shared__ float sB[BN_T * PW_LD];
+  constexpr int LDC = BN_T + 4;            // C staging row stride (floats)
+  constexpr int SM = (PW_BM * LDC > (PW_BM + BN_T) * PW_LD) ? PW_BM * LDC : (PW_BM + BN_T) * PW_LD;
+  __shared__ float smem[SM];              // A|B tiles in the K loop, then the C tile for the vectorised epilogue
   __shared__ float sRed[2 * 4 * BN_T];
+  float* const sA = smem;
+  float* const sB = smem + PW_BM * PW_LD;
 
   const int tid = threadIdx.x;
   const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
@@ -139,49 +142,66 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+  // ---- epilogue.  The accumulator (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) is staged through LDS so every
+  // thread then owns 4 consecutive columns: dwordx4 stores / residual loads (4x fewer store instructions than
+  // per-lane dword stores, which are issue-bound), per-row index math amortised over 4 values.
 #pragma unroll
-  for (int j = 0; j < NS; ++j) {
-    const int col = n0 + j * 32 + r;
-    const bool cok = col < a.N;
-    const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
-    const float osc = (a.out_scale && cok) ? a.out_scale[col] : 1.f;
-    const float osh = (a.out_scale && cok) ? a.out_shift[col] : 0.f;
-    float s = 0.f, ss = 0.f;
+  for (int j = 0; j < NS; ++j)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (cok && row < Mv) {
-        float v = acc[j][q] + bias;
-        s += v; ss += v * v;
-        if (a.out_scale) v = v * osc + osh;
-        v = mmd_act(v, a.out_act);
-        size_t off;
-        if (a.y_batch_stride) {
-          int img = (row - srow0) / rpi;
-          off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
-        } else {
-          off = (size_t)row * a.N + col;
-        }
-        if (a.residual) v += a.residual[off];
-        a.y[off] = v;
+    for (int q = 0; q < 16; ++q)
+      smem[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * LDC + j * 32 + r] = acc[j][q];
+  __syncthreads();
+  constexpr int CGN = BN_T / 4;            // column groups of 4
+  constexpr int RSTEP = 256 / CGN;         // row groups
+  const int cg = tid % CGN, rgrp = tid / CGN;
+  const int col = n0 + cg * 4;
+  const bool cok = col < a.N;              // N % 4 == 0: a column group is all-valid or all-out
+  float4 b4 = make_float4(0, 0, 0, 0), osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
+  if (cok) {
+    if (a.bias) b4 = mmd_ld4(a.bias + col);
+    if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
+  }
+  float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < PW_BM / RSTEP; ++i) {
+    const int rl = rgrp + RSTEP * i, row = m0 + rl;
+    if (cok && row < Mv) {
+      float4 v = *reinterpret_cast<const float4*>(&smem[rl * LDC + cg * 4]);
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+      q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+      if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
+      if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
+      size_t off;
+      if (a.y_batch_stride) {
+        int img = (row - srow0) / rpi;
+        off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
+      } else {
+        off = (size_t)row * a.N + col;
       }
-    }
-    if (a.stats) {
-      s += __shfl_xor(s, 32, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (h == 0) { sRed[wave * BN_T + j * 32 + r] = s; sRed[4 * BN_T + wave * BN_T + j * 32 + r] = ss; }
+      if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+      mmd_st4(a.y + off, v);
     }
   }
   if (a.stats) {
+    // lanes with equal (lane % CGN) share a column group: fold the row groups of a wave, then the 4 waves
+#pragma unroll
+    for (int o = CGN; o < 64; o <<= 1) {
+      s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
+      q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+    }
+    if (lane < CGN) {
+      *reinterpret_cast<float4*>(&sRed[wave * BN_T + lane * 4]) = s4;
+      *reinterpret_cast<float4*>(&sRed[4 * BN_T + wave * BN_T + lane * 4]) = q4;
+    }
     __syncthreads();
     if (tid < BN_T) {
-      int col = n0 + tid;
-      if (col < a.N) {
+      int c = n0 + tid;
+      if (c < a.N) {
         float s = sRed[tid] + sRed[BN_T + tid] + sRed[2 * BN_T + tid] + sRed[3 * BN_T + tid];
         float ss = sRed[4 * BN_T + tid] + sRed[5 * BN_T + tid] + sRed[6 * BN_T + tid] + sRed[7 * BN_T + tid];
-        atomicAdd(&stats[col], (double)s);
-        atomicAdd(&stats[a.N + col], (double)ss);
+        atomicAdd(&stats[c], (double)s);
+        atomicAdd(&stats[a.N + c], (double)ss);
       }
     }
   }
@@ -563,7 +583,7 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
                               const float* bias, const float* out_scale, const float* out_shift, int out_act,
                               const float* residual, double* stats,
                               long long y_batch_stride, long long y_offset, hipStream_t stream) {
-  if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || !x || !w || !y) return MMD_EINVAL;
+  if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !x || !w || !y) return MMD_EINVAL;
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
   if ((out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -609,7 +629,7 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
 extern "C" int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N,
                                   const float* bias, int out_act, double* stats, long long lev_stride,
                                   long long y_batch_stride, const long long* y_off_lev, hipStream_t stream) {
-  if (!x || !w || !y || !pyr_desc || K <= 0 || N <= 0 || (K & 3)) return MMD_EINVAL;
+  if (!x || !w || !y || !pyr_desc || K <= 0 || N <= 0 || (K & 3) || (N & 3)) return MMD_EINVAL;
   if (y_batch_stride && !y_off_lev) return MMD_EINVAL;
   PwArgs a{};
   if (mmd_make_pyr(a.pyr, pyr_desc)) return MMD_EINVAL;
