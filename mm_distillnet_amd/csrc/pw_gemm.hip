@@ -326,22 +326,30 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       part[(wave * SK_BM + row) * SK_BN + j * 32 + r] = acc[j][q];
     }
   __syncthreads();
-  // ---- epilogue, thread -> (col = tid & 63, rows (tid >> 6) + 4 i)
-  const int cl = tid & 63, col = n0 + cl;
+  // ---- epilogue: thread -> 4 consecutive columns (cg = tid & 15), rows (tid >> 4) + 16 i: dwordx4 stores
+  const int cg = tid & 15, rgrp = tid >> 4, col = n0 + cg * 4;
   const bool cok = col < a.N;
-  const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
-  const float osc = (a.out_scale && cok) ? a.out_scale[col] : 1.f;
-  const float osh = (a.out_scale && cok) ? a.out_shift[col] : 0.f;
-  float s = 0.f, ss = 0.f;
+  float4 b4 = make_float4(0, 0, 0, 0), osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
+  if (cok) {
+    if (a.bias) b4 = mmd_ld4(a.bias + col);
+    if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
+  }
+  float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int rl = (tid >> 6) + 4 * i, row = m0 + rl;
-    float v = part[rl * SK_BN + cl] + part[(SK_BM + rl) * SK_BN + cl] + part[(2 * SK_BM + rl) * SK_BN + cl] +
-              part[(3 * SK_BM + rl) * SK_BN + cl] + bias;
+  for (int i = 0; i < 2; ++i) {
+    const int rl = rgrp + 16 * i, row = m0 + rl;
+    float4 v = *reinterpret_cast<const float4*>(&part[rl * SK_BN + cg * 4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      float4 u = *reinterpret_cast<const float4*>(&part[(w * SK_BM + rl) * SK_BN + cg * 4]);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
     if (cok && row < Mv) {
-      s += v; ss += v * v;
-      if (a.out_scale) v = v * osc + osh;
-      v = mmd_act(v, a.out_act);
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+      q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+      if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
+      if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
       size_t off;
       if (a.y_batch_stride) {
         int img = (row - srow0) / rpi;
@@ -349,12 +357,20 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       } else {
         off = (size_t)row * a.N + col;
       }
-      if (a.residual) v += a.residual[off];
-      a.y[off] = v;
+      if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+      mmd_st4(a.y + off, v);
     }
   }
   if (a.stats) {
-    sRed[(tid >> 6) * SK_BN + cl] = s; sRed[4 * SK_BN + (tid >> 6) * SK_BN + cl] = ss;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
+      q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+    }
+    if (lane < 16) {
+      *reinterpret_cast<float4*>(&sRed[wave * SK_BN + lane * 4]) = s4;
+      *reinterpret_cast<float4*>(&sRed[4 * SK_BN + wave * SK_BN + lane * 4]) = q4;
+    }
     __syncthreads();
     if (tid < SK_BN && n0 + tid < a.N) {
       float s2 = sRed[tid] + sRed[SK_BN + tid] + sRed[2 * SK_BN + tid] + sRed[3 * SK_BN + tid];
