@@ -54,19 +54,32 @@ __device__ __forceinline__ void dw_in_coef(const float* in_scale, const float* i
 template <int K, int S>
 __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
   using Cf = DwCfg<K, S>;
+  constexpr int NPIX = Cf::IH * Cf::IW;
+  constexpr int NIT = (NPIX + 15) / 16;
   const int c4 = (tid & 15) * 4;
   const int c = c0 + c4;
   const bool cok = c < a.C;
   const float4 sc = a.sc, sh = a.sh;
-  for (int p = tid >> 4; p < Cf::IH * Cf::IW; p += 16) {
-    int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-      v = mmd_ld4(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
-      if (a.xf) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
-      if (a.act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+  // all global loads of the tile are issued before the first use (the transform + LDS write), so their latencies overlap
+  float4 v[NIT];
+  bool ok[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = (tid >> 4) + it * 16;
+    const int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
+    ok[it] = cok && p < NPIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+    v[it] = make_float4(0, 0, 0, 0);
+    if (ok[it]) v[it] = mmd_ld4(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = (tid >> 4) + it * 16;
+    float4 u = v[it];
+    if (ok[it]) {
+      if (a.xf) { u.x = u.x * sc.x + sh.x; u.y = u.y * sc.y + sh.y; u.z = u.z * sc.z + sh.z; u.w = u.w * sc.w + sh.w; }
+      if (a.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
     }
-    *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+    if (p < NPIX) *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = u;
   }
 }
 
