@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   else if (scale) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
   const int r0 = blockIdx.y * ROWS_PER_BLOCK;
   const int r1 = min(M, r0 + ROWS_PER_BLOCK);
+#pragma unroll 4
   for (int row = r0 + (tid >> 4); row < r1; row += 16) {
     size_t off = (size_t)row * C + c;
     float4 v = mmd_ld4(z + off);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
   }
   float4 acc = make_float4(0, 0, 0, 0);
   if (cok) {
+#pragma unroll 4
     for (int r = blockIdx.z * 16 + (tid >> 4); r < rows_per_image; r += 16 * nsplit) {
       size_t off = ((size_t)b * rows_per_image + r) * C + c;
       float4 v = mmd_ld4(z + off);
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (cok) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); mu = mmd_ld4(mean + c); is = mmd_ld4(invstd + c); }
   float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
   if (cok) {
-    for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+  #pragma unroll 4
+  for (int row = r0 + (tid >> 4); row < r1; row += 16) {
       size_t off = (size_t)row * C + c;
       float4 g = mmd_ld4(g_in + off), zz = mmd_ld4(z + off);
       int img = (mul_bc || mul_b || add_bc) ? row / rows_per_image : 0;
@@ -406,6 +409,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dgamma[c + i] += (float)sums[C + c + i]; dbeta[c + i] += (float)sums[c + i]; }
   }
+#pragma unroll 4
   for (int row = r0 + (tid >> 4); row < r1; row += 16) {
     size_t off = (size_t)row * C + c;
     float4 gg = mmd_ld4(g + off), zz = mmd_ld4(z + off), o;
@@ -436,7 +440,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
   float4 acc = make_float4(0, 0, 0, 0);
   const int r0 = blockIdx.y * ROWS_PER_BLOCK, r1 = min(M, r0 + ROWS_PER_BLOCK);
   if (c < C)
-    for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+  #pragma unroll 4
+  for (int row = r0 + (tid >> 4); row < r1; row += 16) {
       float4 v = mmd_ld4(a + (size_t)row * C + c);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
