@@ -23,6 +23,10 @@ extern "C" {
 // (src/YetAnotherEfficientDet.py:338-390).
 int mmd_bifpn_fuse_fwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, float* out, int B, int H, int W, int C, hipStream_t stream);
 
+// Fusion node + its depthwise 3x3 (SeparableConvBlock.depthwise_conv) in one launch; f_out (nullable) keeps the fused
+// activation for the backward.
+int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* f_out, float* zd, int B, int H, int W, int C, hipStream_t stream);
+
 // Backward of the fusion node, part 1: dx = df*swish'(x), wdot[i] += <dx, operand_i>.
 int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W, int C, hipStream_t stream);
 

@@ -74,6 +74,75 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(FuseArgs a, float* __rest
   mmd_st4(out + (((size_t)b * a.H + h) * a.W + x) * a.C + c, s);
 }
 
+// Fusion node + its depthwise 3x3 in ONE kernel: the fused activation f = swish(sum w_i * operand_i) is computed while
+// the 10x10x64 input tile (8x8 outputs + halo) is staged in LDS (halo pixels are recomputed by the neighbouring blocks),
+// optionally written out for the backward (interior pixels only), and the 3x3 taps run from LDS.
+// Replaces fuse_fwd_kernel + dw_fwd_kernel<3,1> (one launch and one read of f less per BiFPN node).
+__global__ __launch_bounds__(256) void fuse_dw_fwd_kernel(FuseArgs a, const float* __restrict__ wdw, float* __restrict__ f_out,
+                                                         float* __restrict__ zd, int tiles_h, int tiles_w, int cchunks) {
+  constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
+  __shared__ float sIn[IH * IW * 64];
+  __shared__ float sW[9 * 64];
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int cc = bid % cchunks; bid /= cchunks;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h; bid /= tiles_h;
+  const int b = bid;
+  const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  const bool cok = c < a.C;
+  const int oh0 = th * TH, ow0 = tw * TW;
+  for (int i = tid; i < 9 * 16; i += 256) {
+    int tap = i >> 4, q = (i & 15) * 4;
+    float4 wv = (c0 + q < a.C) ? mmd_ld4(wdw + (size_t)tap * a.C + c0 + q) : make_float4(0, 0, 0, 0);
+    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
+  }
+  for (int p = tid >> 4; p < IH * IW; p += 16) {
+    const int ih = oh0 - 1 + p / IW, iw = ow0 - 1 + p % IW;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+      float4 t0, t1, t2, t3;
+      v = fuse_presum(a, w, b, ih, iw, c, &t0, &t1, &t2, &t3);
+      v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w);
+      const int py = p / IW, px = p % IW;
+      if (f_out && py >= 1 && py <= TH && px >= 1 && px <= TW)
+        mmd_st4(f_out + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c, v);
+    }
+    *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+  }
+  __syncthreads();
+  const int p = tid >> 4;
+  const int orow = p / (TW / R);
+  const int ocol0 = (p % (TW / R)) * R;
+  float4 acc[R];
+#pragma unroll
+  for (int o = 0; o < R; ++o) acc[o] = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float4 in[SEG];
+    const float* prow = &sIn[((orow + i) * IW + ocol0) * 64 + c4];
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * 3 + j) * 64 + c4]);
+#pragma unroll
+      for (int o = 0; o < R; ++o) {
+        acc[o].x += in[o + j].x * wv.x; acc[o].y += in[o + j].y * wv.y;
+        acc[o].z += in[o + j].z * wv.z; acc[o].w += in[o + j].w * wv.w;
+      }
+    }
+  }
+  const int oh = oh0 + orow;
+#pragma unroll
+  for (int o = 0; o < R; ++o) {
+    int ow = ow0 + ocol0 + o;
+    if (cok && oh < a.H && ow < a.W) mmd_st4(zd + (((size_t)b * a.H + oh) * a.W + ow) * a.C + c, acc[o]);
+  }
+}
+
 static int fuse_fill(FuseArgs& a, const float* in0, const float* in1, const float* up, const float* pl,
                      const float* theta, int B, int H, int W, int C) {
   if (!in0 || !theta || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
@@ -94,6 +163,17 @@ extern "C" int mmd_bifpn_fuse_fwd(const float* in0, const float* in1, const floa
   if (rc || !out) return MMD_EINVAL;
   size_t total = (size_t)B * H * W * (C >> 2);
   hipLaunchKernelGGL(fuse_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, out);
+  return mmd_check_launch();
+}
+
+extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const float* up, const float* pool,
+                                     const float* theta, const float* w_dw, float* f_out, float* zd, int B, int H, int W,
+                                     int C, hipStream_t stream) {
+  FuseArgs a{};
+  int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (rc || !w_dw || !zd) return MMD_EINVAL;
+  int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
+  hipLaunchKernelGGL(fuse_dw_fwd_kernel, dim3((unsigned)(B * th * tw * cc)), dim3(256), 0, stream, a, w_dw, f_out, zd, th, tw, cc);
   return mmd_check_launch();
 }
 

@@ -296,11 +296,13 @@ class Net:
             ps.nbt.add_(1)
         return cls, reg, feats
 
-    def _sep_bn(self, name: str, x: Feat, train: bool, rec: dict, bn_name: Optional[str] = None, y=None) -> Feat:
-        """SeparableConvBlock(norm=True, activation=False) on a materialised input -> materialised output."""
+    def _sep_bn(self, name: str, x: Feat, train: bool, rec: dict, bn_name: Optional[str] = None, y=None, zd=None) -> Feat:
+        """SeparableConvBlock(norm=True, activation=False) on a materialised input -> materialised output.
+        zd: depthwise output already produced by the fused fusion+depthwise kernel."""
         ps = self.ps
         W = x.C
-        zd, _, _ = self._dw(x, f"{name}.depthwise_conv.conv.weight", 3, 1)
+        if zd is None:
+            zd, _, _ = self._dw(x, f"{name}.depthwise_conv.conv.weight", 3, 1)
         zdf = Feat(zd, x.B, x.H, x.W, W)
         bn_name = bn_name or f"{name}.bn"
         bias = ps.w(f"{name}.pointwise_conv.conv.bias")
@@ -345,13 +347,14 @@ class Net:
 
     def _node(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
               pl: Optional[Feat], train: bool, tape: dict, y=None) -> Feat:
-        f = self._alloc(in0.M, in0.C)
+        f = self._alloc(in0.M, in0.C) if train else None      # the fused activation is only kept for the backward
+        zd = self._alloc(in0.M, in0.C)
         th = self.ps.w(f"{cell}.{theta}")
-        call("mmd_bifpn_fuse_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th, f,
-             in0.B, in0.H, in0.W, in0.C)
-        ff = Feat(f, in0.B, in0.H, in0.W, in0.C)
+        call("mmd_bifpn_node_dw_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+             self.ps.w(f"{cell}.{conv}.depthwise_conv.conv.weight"), f, zd, in0.B, in0.H, in0.W, in0.C)
+        ff = Feat(f if f is not None else zd, in0.B, in0.H, in0.W, in0.C)
         rec = {"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": ff, "conv": conv}
-        out = self._sep_bn(f"{cell}.{conv}", ff, train, rec, y=y)
+        out = self._sep_bn(f"{cell}.{conv}", ff, train, rec, y=y, zd=zd)
         rec["out"] = out
         if train:
             tape.setdefault(cell + ".nodes", []).append(rec)

@@ -542,3 +542,28 @@ def test_pwconv_pyr_large_stream_path():
                 sl = slice(row0[l], row0[l] + rows[l])
                 ref = torch.sigmoid(x[sl] @ w.t() + bias).view(B, h * w_ * N)
                 close(out[:, yoff[l]:yoff[l] + h * w_ * N], ref, 2e-4, 1e-5, f"pyr head L{l}")
+
+
+@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 48), ("p7", 4, 4, 112)])
+def test_bifpn_node_dw_fused(mode, H, W, C):
+    """Fused fusion+depthwise kernel against the two kernels it replaces."""
+    torch.manual_seed(9)
+    B = 2
+    in0 = torch.randn(B * H * W, C)
+    in1 = torch.randn(B * H * W, C) if mode == "bu" else None
+    up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
+    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7") else None
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    wd = torch.randn(9, C) / 3
+    gp = lambda t: g(t) if t is not None else None
+    f_ref = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_bifpn_fuse_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), f_ref, B, H, W, C)
+    z_ref = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_dwconv_fwd", f_ref, g(wd), z_ref, B, H, W, C, 3, 1, None, None, 0, None, None, None, 0, None, None, 0, None, None)
+    f = torch.zeros(B * H * W, C, device=DEV); z = torch.zeros(B * H * W, C, device=DEV)
+    call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), f, z, B, H, W, C)
+    assert torch.equal(f, f_ref)
+    close(z, z_ref, 1e-6, 1e-7)
+    z2 = torch.zeros(B * H * W, C, device=DEV)
+    call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), None, z2, B, H, W, C)
+    assert torch.equal(z, z2)
