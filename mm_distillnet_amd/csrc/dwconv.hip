@@ -68,13 +68,13 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
     const int p = (tid >> 4) + it * 16;
     const int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
     ok[it] = cok && p < NPIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-    v[it] = make_float4(0, 0, 0, 0);
-    if (ok[it]) v[it] = mmd_ld4(a.x + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);     // unconditional load, masked below
+    v[it] = mmd_ld4(a.x + (((size_t)b * a.H + ihc) * a.W + iwc) * a.C + (cok ? c : 0));
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int p = (tid >> 4) + it * 16;
-    float4 u = v[it];
+    float4 u = ok[it] ? v[it] : make_float4(0, 0, 0, 0);
     if (ok[it]) {
       if (a.xf) { u.x = u.x * sc.x + sh.x; u.y = u.y * sc.y + sh.y; u.z = u.z * sc.z + sh.z; u.w = u.w * sc.w + sh.w; }
       if (a.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }

@@ -85,23 +85,20 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
   float4 ra[4], rg[4], rb[NB], rsc, rsh;
   bool kok;
   auto gload = [&](int k0) {
+    // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
+    // branch per load and a full vmcnt(0) drain, which serialises the prefetch
     int k = k0 + kq;
     kok = k < a.K;
-    if (a.in_bn.stats) {
-      rsc = make_float4(0, 0, 0, 0); rsh = rsc;
-      if (kok) bn_live_coef4(a.in_bn, k, rsc, rsh);
-    } else if (a.in_scale) {
-      rsc = kok ? mmd_ld4(a.in_scale + k) : make_float4(0, 0, 0, 0);
-      rsh = kok ? mmd_ld4(a.in_shift + k) : make_float4(0, 0, 0, 0);
-    }
+    const int kc = kok ? k : 0;
+    if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
+    else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bool ok = kok && rok[i];
-      ra[i] = ok ? mmd_ld4(xrow[i] + k) : make_float4(0, 0, 0, 0);
-      if (a.gate) rg[i] = ok ? mmd_ld4(grow[i] + k) : make_float4(0, 0, 0, 0);
+      ra[i] = mmd_ld4(xrow[i] + kc);
+      if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = (kok && wok[i]) ? mmd_ld4(wrow[i] + k) : make_float4(0, 0, 0, 0);
+    for (int i = 0; i < NB; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -116,7 +113,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
       *reinterpret_cast<float4*>(&sA[(lrow + i * 32) * PW_LD + kq]) = v;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = rb[i];
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
   };
 
   const int nk = (a.K + PW_BK - 1) / PW_BK;
@@ -260,23 +258,20 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   float4 ra[4], rg[4], rb[8], rsc, rsh;
   bool kok;
   auto gload = [&](int k0) {
+    // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
+    // branch per load and a full vmcnt(0) drain, which serialises the prefetch
     int k = k0 + kq;
     kok = k < a.K;
-    if (a.in_bn.stats) {
-      rsc = make_float4(0, 0, 0, 0); rsh = rsc;
-      if (kok) bn_live_coef4(a.in_bn, k, rsc, rsh);
-    } else if (a.in_scale) {
-      rsc = kok ? mmd_ld4(a.in_scale + k) : make_float4(0, 0, 0, 0);
-      rsh = kok ? mmd_ld4(a.in_shift + k) : make_float4(0, 0, 0, 0);
-    }
+    const int kc = kok ? k : 0;
+    if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
+    else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bool ok = kok && rok[i];
-      ra[i] = ok ? mmd_ld4(xrow[i] + k) : make_float4(0, 0, 0, 0);
-      if (a.gate) rg[i] = ok ? mmd_ld4(grow[i] + k) : make_float4(0, 0, 0, 0);
+      ra[i] = mmd_ld4(xrow[i] + kc);
+      if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = (kok && wok[i]) ? mmd_ld4(wrow[i] + k) : make_float4(0, 0, 0, 0);
+    for (int i = 0; i < 8; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -291,7 +286,8 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = rb[i];
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
   };
 
   const int nk = (a.K + SK_BK - 1) / SK_BK;
@@ -698,11 +694,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
     for (int i = 0; i < 2; ++i) {
       int row = mb + lrow + i * 16;
       rok[i] = row < mend;
-      rd[i] = (rok[i] && nok) ? mmd_ld4(a.dy + (size_t)row * a.N + n0 + c4) : make_float4(0, 0, 0, 0);
-      rx[i] = (rok[i] && kok) ? mmd_ld4(a.x + (size_t)row * a.K + k0 + c4) : make_float4(0, 0, 0, 0);
-      if (a.gate)
-        rg[i] = (rok[i] && kok) ? mmd_ld4(a.gate + (size_t)(row / a.rows_per_image) * a.K + k0 + c4)
-                                : make_float4(0, 0, 0, 0);
+      const int rc = rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
+      rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+      rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
+      if (a.gate) rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
     }
   };
   auto lstore = [&]() {
@@ -716,7 +711,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
       if (!(rok[i] && kok)) v = make_float4(0, 0, 0, 0);
       *reinterpret_cast<float4*>(&sX[(lrow + i * 16) * WG_LD + c4]) = v;
-      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = rd[i];
+      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = (rok[i] && nok) ? rd[i] : make_float4(0, 0, 0, 0);
     }
   };
 
