@@ -229,8 +229,16 @@ def main():
         else:
             achieved = by / (tms * 1e-3) / 1e9
             unit = "GB/s"
+        traffic = None
+        fam_key = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd"}[fam]
+        try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["families"][fam_key]
+            traffic = round(pm["hbm_bytes_per_step"] / max(n, 1), 1) if fam_key != "bn_bwd" else None
+        except Exception:
+            traffic = None
         roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": PEAK[bound], "unit": unit,
-                "frac": round(achieved / PEAK[bound], 4), "traffic": None, "launches_per_step": int(n),
+                "frac": round(achieved / PEAK[bound], 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(by / max(n, 1), 1), "launches_per_step": int(n),
                 "avg_launch_us": round(tms * 1e3 / max(n, 1), 2), "family_ms_per_step": round(tms, 3),
                 "algorithmic_bytes_per_step": by, "algorithmic_flops_per_step": fl,
                 "all_families_ms": {FAMILIES[f][0].split(" ")[0]: round(res[f][1], 3) for f in res}}

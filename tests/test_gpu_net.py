@@ -131,3 +131,20 @@ def test_net_eval_512_vs_oracle():
     assert relerr(cls, c) < 1e-3 and relerr(reg, r) < 1e-3
     for u, v in zip(feats, f):
         assert relerr(feat_nchw(u), v) < 1e-3
+
+
+def test_d4_eval_vs_oracle():
+    """BASELINE config-5 architecture (EfficientDet-D4: b4 backbone, 7 BiFPN cells of width 224, 4-layer heads) in fp32
+    on a 256x256 input against the oracle (the reference's load_model hard-codes D2; the classes support D4)."""
+    spec, st = make_state(4, 3, 31, "rgb")
+    net = Net(spec, DEV, trainable=False)
+    net.load_state(st)
+    x = synth_inputs(2, 256, seed=8)["rgb"]
+    net.begin_step()
+    cls, reg, feats = net.forward(x.to(DEV), train=False)
+    with torch.no_grad():
+        (c, r, a), f = O.forward(st, x, 4, False)
+    assert cls.shape == c.shape and reg.shape == r.shape
+    assert relerr(cls, c) < 2e-3 and relerr(reg, r) < 2e-3
+    for u, v in zip(feats, f):
+        assert relerr(feat_nchw(u), v) < 2e-3

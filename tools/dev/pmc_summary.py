@@ -1,0 +1,30 @@
+"""HBM traffic of ONE eager step (the dispatches after the last Adam launch of a `rocprofv3 --pmc X` run of bench.py),
+per kernel family, with the gfx950 FETCH_SIZE correction (x2 for wide coalesced reads; MI355X_MICROARCH.md HBM section).
+Usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv>"""
+import collections, csv, sys
+
+FAM = {"pw_gemm": ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel"), "pw_wgrad": ("pw_wgrad_kernel",),
+       "dw_fwd": ("dw_fwd_kernel", "fuse_dw_fwd_kernel"), "dw_bwd": ("dw_wgrad_kernel", "dw_bwd_data_s2_kernel"),
+       "bn_bwd": ("bn_bwd_reduce_kernel", "bn_bwd_apply_kernel")}
+
+
+def last_step(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ad = [i for i, r in enumerate(rows) if "adam2_kernel" in r["Kernel_Name"]]
+    seg = rows[ad[-1] + 1:]
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for r in seg:
+        name = r["Kernel_Name"]
+        for fam, keys in FAM.items():
+            if any(k in name for k in keys):
+                out[fam][0] += 1
+                out[fam][1] += float(r["Counter_Value"]) * 1024.0      # counters are in KiB
+    return out
+
+
+f, w = last_step(sys.argv[1]), last_step(sys.argv[2])
+print("family,launches,fetch_bytes_corrected(2x),write_bytes,total_hbm_bytes_per_step")
+for fam in FAM:
+    fb, wb = 2.0 * f[fam][1], w[fam][1]
+    print("%s,%d,%.4g,%.4g,%.4g" % (fam, f[fam][0], fb, wb, fb + wb))
