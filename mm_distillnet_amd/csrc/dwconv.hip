@@ -25,10 +25,14 @@ struct DwArgs {
   Pyr pyr; long long lev_stride;
 };
 
-template <int K, int S> struct DwCfg {
+// LANES = float4 lanes per pixel (16 -> 64-channel chunks; 8 / 4 -> 32- / 16-channel chunks for the thin early layers,
+// where a 64-wide chunk would leave 50-75 % of the threads idle)
+template <int K, int S, int LANES = 16> struct DwCfg {
   static constexpr int TH = (S == 1) ? 8 : 4;
   static constexpr int TW = 8;
-  static constexpr int R = TH * TW / 16;                   // outputs per pixel-group (along W)
+  static constexpr int CC = 4 * LANES;                      // channels per block
+  static constexpr int G = 256 / LANES;                     // pixel groups per block
+  static constexpr int R = TH * TW / G;                     // outputs per pixel-group (along W)
   static constexpr int IH = (TH - 1) * S + K;
   static constexpr int IW = (TW - 1) * S + K;
   static constexpr int SEG = (R - 1) * S + K;              // input columns one strip needs
@@ -51,12 +55,12 @@ __device__ __forceinline__ void dw_in_coef(const float* in_scale, const float* i
   }
 }
 
-template <int K, int S>
+template <int K, int S, int LANES = 16>
 __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
-  using Cf = DwCfg<K, S>;
+  using Cf = DwCfg<K, S, LANES>;
   constexpr int NPIX = Cf::IH * Cf::IW;
-  constexpr int NIT = (NPIX + 15) / 16;
-  const int c4 = (tid & 15) * 4;
+  constexpr int NIT = (NPIX + Cf::G - 1) / Cf::G;
+  const int c4 = (tid & (LANES - 1)) * 4;
   const int c = c0 + c4;
   const bool cok = c < a.C;
   const float4 sc = a.sc, sh = a.sh;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
   bool ok[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int p = (tid >> 4) + it * 16;
+    const int p = tid / LANES + it * Cf::G;
     const int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
     ok[it] = cok && p < NPIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
     const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);     // unconditional load, masked below
@@ -73,22 +77,23 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int p = (tid >> 4) + it * 16;
+    const int p = tid / LANES + it * Cf::G;
     float4 u = ok[it] ? v[it] : make_float4(0, 0, 0, 0);
     if (ok[it]) {
       if (a.xf) { u.x = u.x * sc.x + sh.x; u.y = u.y * sc.y + sh.y; u.z = u.z * sc.z + sh.z; u.w = u.w * sc.w + sh.w; }
       if (a.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
     }
-    if (p < NPIX) *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = u;
+    if (p < NPIX) *reinterpret_cast<float4*>(&sIn[p * Cf::CC + c4]) = u;
   }
 }
 
-template <int K, int S>
+template <int K, int S, int LANES = 16>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
-  using Cf = DwCfg<K, S>;
-  __shared__ float sIn[Cf::IH * Cf::IW * 64];
-  __shared__ float sW[K * K * 64];
-  __shared__ float sRed[2 * 4 * 64];
+  using Cf = DwCfg<K, S, LANES>;
+  constexpr int CC = Cf::CC;
+  __shared__ float sIn[Cf::IH * Cf::IW * CC];
+  __shared__ float sW[K * K * CC];
+  __shared__ float sRed[2 * 4 * CC];
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   // pyramid launch (k=3, s=1): pick this block's level (unrolled selects: no dynamic indexing of the argument arrays)
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
-  const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  const int c0 = cc * CC, c4 = (tid & (LANES - 1)) * 4, c = c0 + c4;
   const bool cok = c < a.C;
   const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
   DwView v;
@@ -120,16 +125,16 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   }
   float* const yout = a.y + ro;
 
-  for (int i = tid; i < K * K * 16; i += 256) {
-    int tap = i >> 4, q = (i & 15) * 4;
+  for (int i = tid; i < K * K * LANES; i += 256) {
+    int tap = i / LANES, q = (i % LANES) * 4;
     int src = a.flip ? (K * K - 1 - tap) : tap;
     float4 wv = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
-    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
+    *reinterpret_cast<float4*>(&sW[tap * CC + q]) = wv;
   }
-  dw_stage_input<K, S>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+  dw_stage_input<K, S, LANES>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
   __syncthreads();
 
-  const int p = tid >> 4;
+  const int p = tid / LANES;
   const int orow = p / (Cf::TW / Cf::R);
   const int ocol0 = (p % (Cf::TW / Cf::R)) * Cf::R;
   float4 acc[Cf::R];
@@ -140,12 +145,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
 #pragma unroll(K == 3 ? 3 : 1)
   for (int i = 0; i < K; ++i) {
     float4 in[Cf::SEG];
-    const float* prow = &sIn[((orow * S + i) * Cf::IW + ocol0 * S) * 64 + c4];
+    const float* prow = &sIn[((orow * S + i) * Cf::IW + ocol0 * S) * CC + c4];
 #pragma unroll
-    for (int q = 0; q < Cf::SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+    for (int q = 0; q < Cf::SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * CC);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * K + j) * 64 + c4]);
+      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * K + j) * CC + c4]);
 #pragma unroll
       for (int o = 0; o < Cf::R; ++o) {
         acc[o].x += in[o * S + j].x * wv.x; acc[o].y += in[o * S + j].y * wv.y;
@@ -173,22 +178,24 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   }
   if (a.stats || a.pool) {
     // reduce over the 4 pixel-groups of a wave (lanes l, l^16, l^32, l^48 share c4), then over 4 waves in LDS
-    auto red4 = [](float4 v) {
-      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
-      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+    auto red4 = [](float4 v) {       // lanes l, l^LANES, l^2LANES, ... of a wave share the channel group
+#pragma unroll
+      for (int o = LANES; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+      }
       return v;
     };
     const int wave = tid >> 6, lane = tid & 63;
     if (a.stats) {
       s = red4(s); ss = red4(ss);
-      if (lane < 16) {
-        *reinterpret_cast<float4*>(&sRed[wave * 64 + c4]) = s;
-        *reinterpret_cast<float4*>(&sRed[256 + wave * 64 + c4]) = ss;
+      if (lane < LANES) {
+        *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = s;
+        *reinterpret_cast<float4*>(&sRed[4 * CC + wave * CC + c4]) = ss;
       }
       __syncthreads();
-      if (tid < 64 && c0 + tid < a.C) {
-        float vs = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
-        float vq = sRed[256 + tid] + sRed[320 + tid] + sRed[384 + tid] + sRed[448 + tid];
+      if (tid < CC && c0 + tid < a.C) {
+        float vs = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
+        float vq = sRed[4 * CC + tid] + sRed[5 * CC + tid] + sRed[6 * CC + tid] + sRed[7 * CC + tid];
         atomicAdd(&a.stats[c0 + tid], (double)vs);
         atomicAdd(&a.stats[a.C + c0 + tid], (double)vq);
       }
@@ -196,23 +203,29 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
     if (a.pool) {
       pl = red4(pl);
-      if (lane < 16) *reinterpret_cast<float4*>(&sRed[wave * 64 + c4]) = pl;
+      if (lane < LANES) *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = pl;
       __syncthreads();
-      if (tid < 64 && c0 + tid < a.C) {
-        float v = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
+      if (tid < CC && c0 + tid < a.C) {
+        float v = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
         atomicAdd(&a.pool[(size_t)b * a.C + c0 + tid], v * a.pool_scale);
       }
     }
   }
 }
 
-template <int K, int S>
+template <int K, int S, int LANES = 16>
 static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
-  using Cf = DwCfg<K, S>;
-  a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = cdiv(a.C, 64);
+  using Cf = DwCfg<K, S, LANES>;
+  a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = cdiv(a.C, Cf::CC);
   long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
-  hipLaunchKernelGGL((dw_fwd_kernel<K, S>), dim3((unsigned)nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES>), dim3((unsigned)nb), dim3(256), 0, st, a);
   return mmd_check_launch();
+}
+// 3x3 / stride 1: narrow channel chunks when C is small (thin 256x256 layers of the backbone)
+static int dw_fwd_launch_31(DwArgs& a, hipStream_t st) {
+  if (a.C <= 16) return dw_fwd_launch<3, 1, 4>(a, st);
+  if (a.C <= 32) return dw_fwd_launch<3, 1, 8>(a, st);
+  return dw_fwd_launch<3, 1, 16>(a, st);
 }
 
 static int same_pad_lo(int n, int k, int s, int* out) {
@@ -243,7 +256,7 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW, stream);
   int rc;
-  if (k == 3 && stride == 1) rc = dw_fwd_launch<3, 1>(a, stream);
+  if (k == 3 && stride == 1) rc = dw_fwd_launch_31(a, stream);
   else if (k == 3) rc = dw_fwd_launch<3, 2>(a, stream);
   else if (stride == 1) rc = dw_fwd_launch<5, 1>(a, stream);
   else rc = dw_fwd_launch<5, 2>(a, stream);
@@ -330,7 +343,7 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
     DwArgs a{};
     a.x = dy; a.w = w; a.y = dx; a.B = B; a.H = H; a.W = W; a.C = C; a.OH = H; a.OW = W;
     a.pad_t = k - 1 - pt; a.pad_l = k - 1 - pl; a.flip = 1;
-    rc = (k == 3) ? dw_fwd_launch<3, 1>(a, stream) : dw_fwd_launch<5, 1>(a, stream);
+    rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch<5, 1>(a, stream);
   } else {
     size_t total = (size_t)B * H * W * (C >> 2);
     if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_kernel<3>, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, 0);

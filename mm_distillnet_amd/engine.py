@@ -88,6 +88,7 @@ class Net:
             self.wt_tiles = tiles
         self.tape: Dict[str, object] = {}
         self._anchors: Dict[int, torch.Tensor] = {}
+        self._side = None
 
     # ------------------------------------------------------------------ parameters
     def load_state(self, state):
@@ -504,6 +505,53 @@ class Net:
         call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s)
         return dx
 
+    def _head_bwd(self, hname: str, per_anchor: int, dout: torch.Tensor, tape: dict, pyr: dict, A: int, C: int):
+        """Backward of one head over the whole pyramid; returns the gradient w.r.t. the pyramid feature buffer."""
+        spec, ps = self.spec, self.ps
+        desc, Mt = pyr["desc"], pyr["total"]
+        rec = tape[hname]
+        nout = spec.num_anchors * per_anchor
+        ls = rec["lev_stride"]
+        dy = self._alloc_pyr(pyr, nout)
+        for lvl, (h, w) in enumerate(pyr["sizes"]):
+            call("mmd_slice_rows", dout, dy[pyr["row0"][lvl]:], pyr["B"], h * w, nout, A * per_anchor, rec["yoff"][lvl])
+        hw_key = f"{hname}.header.pointwise_conv.conv.weight"
+        call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
+        call("mmd_pwconv_bwd_weight", dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
+        dzd = self._alloc_pyr(pyr, C)
+        call("mmd_pwconv_bwd_data", dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
+        xo = rec["hx_off"]
+        call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
+             self.t_scale[xo:], self.t_shift[xo:], SWISH, ls)
+        g = self._alloc_pyr(pyr, C)
+        call("mmd_dwconv3_pyr", dzd, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
+             None, None, None, 0)
+        bsums = self._zalloc((2 * 5 * ls,), torch.float64)
+        off0 = rec["layers"][0]["off"]
+        for i in reversed(range(spec.head_layers)):
+            L = rec["layers"][i]
+            cname = f"{hname}.conv_list.{i}"
+            o = L["off"]
+            sums = bsums[2 * (o - off0):]
+            gy = self._alloc_pyr(pyr, C)
+            call("mmd_bn_bwd_reduce_pyr", g, L["z"], self.t_scale[o:], self.t_shift[o:], self.t_mean[o:], self.t_invstd[o:],
+                 SWISH, desc, ls, gy, sums, C)
+            dz = self._alloc_pyr(pyr, C)
+            call("mmd_bn_bwd_apply_pyr", gy, L["z"], self.t_mean[o:], self.t_invstd[o:], ps.flat[ps.gamma_off + o:], sums,
+                 desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C)
+            wkey = f"{cname}.pointwise_conv.conv.weight"
+            call("mmd_pwconv_bwd_weight", dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
+            dzd = self._alloc_pyr(pyr, C)
+            call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
+            xo = L["x_off"]
+            call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,
+                 None if xo is None else self.t_scale[xo:], None if xo is None else self.t_shift[xo:],
+                 NONE if xo is None else SWISH, ls)
+            g = self._alloc_pyr(pyr, C)
+            call("mmd_dwconv3_pyr", dzd, ps.w(f"{cname}.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
+                 None, None, None, 0)
+        return g
+
     def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]]):
         """Accumulates parameter gradients into ps.grad.  dcls_logit [B,A,NC] is the gradient w.r.t. the
         classifier header's PRE-sigmoid output, dreg [B,A,4], dfeats[l] (nullable) w.r.t. the BiFPN outputs."""
@@ -522,53 +570,23 @@ class Net:
         pyr = self._pyr
         desc, Mt = pyr["desc"], pyr["total"]
         C = feats[0].C
-        gsum = None
+        # the two heads are independent until their input gradients meet: the regressor runs on a side stream
+        # (a parallel branch of the captured graph); bsums / workspaces are allocated here on the host, in order
+        main_stream = torch.cuda.current_stream() if ps.flat.is_cuda else None
+        if main_stream is not None and self._side is None:
+            self._side = torch.cuda.Stream()
+        fork = main_stream.record_event() if main_stream is not None else None
+        gparts = []
         for hname, per_anchor, dout in (("classifier", spec.num_classes, dcls_logit), ("regressor", 4, dreg)):
-            rec = tape[hname]
-            nout = spec.num_anchors * per_anchor
-            ls = rec["lev_stride"]
-            dy = self._alloc_pyr(pyr, nout)
-            for lvl, (h, w) in enumerate(pyr["sizes"]):
-                call("mmd_slice_rows", dout, dy[pyr["row0"][lvl]:], pyr["B"], h * w, nout, A * per_anchor, rec["yoff"][lvl])
-            hw_key = f"{hname}.header.pointwise_conv.conv.weight"
-            call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
-            call("mmd_pwconv_bwd_weight", dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
-            dzd = self._alloc_pyr(pyr, C)
-            call("mmd_pwconv_bwd_data", dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
-            xo = rec["hx_off"]
-            call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
-                 self.t_scale[xo:], self.t_shift[xo:], SWISH, ls)
-            g = self._alloc_pyr(pyr, C)
-            call("mmd_dwconv3_pyr", dzd, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
-                 None, None, None, 0)
-            bsums = self._zalloc((2 * 5 * ls,), torch.float64)
-            off0 = rec["layers"][0]["off"]
-            for i in reversed(range(spec.head_layers)):
-                L = rec["layers"][i]
-                cname = f"{hname}.conv_list.{i}"
-                o = L["off"]
-                sums = bsums[2 * (o - off0):]
-                gy = self._alloc_pyr(pyr, C)
-                call("mmd_bn_bwd_reduce_pyr", g, L["z"], self.t_scale[o:], self.t_shift[o:], self.t_mean[o:], self.t_invstd[o:],
-                     SWISH, desc, ls, gy, sums, C)
-                dz = self._alloc_pyr(pyr, C)
-                call("mmd_bn_bwd_apply_pyr", gy, L["z"], self.t_mean[o:], self.t_invstd[o:], ps.flat[ps.gamma_off + o:], sums,
-                     desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C)
-                wkey = f"{cname}.pointwise_conv.conv.weight"
-                call("mmd_pwconv_bwd_weight", dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
-                dzd = self._alloc_pyr(pyr, C)
-                call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
-                xo = L["x_off"]
-                call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,
-                     None if xo is None else self.t_scale[xo:], None if xo is None else self.t_shift[xo:],
-                     NONE if xo is None else SWISH, ls)
-                g = self._alloc_pyr(pyr, C)
-                call("mmd_dwconv3_pyr", dzd, ps.w(f"{cname}.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
-                     None, None, None, 0)
-            if gsum is None:
-                gsum = g
-            else:
-                call("mmd_scale_acc", g, gsum, None, 0, 0, 1, g.numel())
+            use_side = main_stream is not None and hname == "regressor"
+            if use_side:
+                self._side.wait_event(fork)
+            with torch.cuda.stream(self._side if use_side else main_stream):
+                gparts.append(self._head_bwd(hname, per_anchor, dout, tape, pyr, A, C))
+        if main_stream is not None:
+            main_stream.wait_stream(self._side)
+        gsum = gparts[0]
+        call("mmd_scale_acc", gparts[1], gsum, None, 0, 0, 1, gsum.numel())
         for lvl, f in enumerate(feats):
             self._acc(slot(f), gsum[pyr["row0"][lvl]:pyr["row0"][lvl] + pyr["rows"][lvl]])
         # ---- BiFPN (cells and nodes in reverse)
