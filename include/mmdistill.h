@@ -79,11 +79,11 @@ int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const f
 // Backward of the squeeze-excite FCs (weight grads +=, dpooled scaled by dpool_scale = 1/HW).
 int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
 
-// BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat).
+// BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat). g_out may be NULL (g not stored).
 int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, hipStream_t stream);
 
-// BN backward pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dgamma/dbeta +=.
-int mmd_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, long long count, float* dz, float* dgamma, float* dbeta, int M, int C, hipStream_t stream);
+// BN backward pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dgamma/dbeta +=. With act/mul/add given, `g` is pass 1's g_in and g is recomputed.
+int mmd_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, long long count, float* dz, float* dgamma, float* dbeta, int M, int C, const float* scale, const float* shift, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, hipStream_t stream);
 
 // out[c] += sum_rows a[row,c] (bias gradients).
 int mmd_colsum(const float* a, float* out, int M, int C, hipStream_t stream);
@@ -160,7 +160,7 @@ int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const
 
 int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const int* pyr_desc, long long lev_stride, float* g_out, double* sums, int C, hipStream_t stream);
 
-int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, const int* pyr_desc, long long lev_stride, float* dz, float* dgamma, float* dbeta, int C, hipStream_t stream);
+int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, const int* pyr_desc, long long lev_stride, float* dz, float* dgamma, float* dbeta, int C, const float* scale, const float* shift, int act, hipStream_t stream);
 
 // dW[N,K] += dY^T * pro(X) (autograd of the 1x1 conv weight; reference: loss.backward(), src/optimization/traditional.py:182).
 int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);

@@ -318,8 +318,21 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
 }
 
 // ---------------------------------------------------------------- BN (+activation) backward
-// pass 1: g = (g_in * mul_bc[img,c] * mul_b[img] + add_bc[img,c]) * act'(z*scale+shift); g_out = g;
+// pass 1: g = (g_in * mul_bc[img,c] * mul_b[img] + add_bc[img,c]) * act'(z*scale+shift);
 //         sums[c] += g, sums[C+c] += g * xhat,  xhat = (z-mean)*invstd          
+//         g is written only when g_out != nullptr: pass 2 can recompute it from g_in (one HBM write less per layer)
+__device__ __forceinline__ float4 bn_bwd_g(float4 g, const float4& zz, const float4& sc, const float4& sh, int act,
+                                           const float* __restrict__ mul_bc, const float* __restrict__ mul_b,
+                                           const float* __restrict__ add_bc, int img, int C, int c) {
+  if (mul_bc) { float4 m = mmd_ld4(mul_bc + (size_t)img * C + c); g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w; }
+  if (mul_b) { float m = mul_b[img]; g.x *= m; g.y *= m; g.z *= m; g.w *= m; }
+  if (add_bc) { float4 m = mmd_ld4(add_bc + (size_t)img * C + c); g.x += m.x; g.y += m.y; g.z += m.z; g.w += m.w; }
+  if (act == MMD_ACT_SWISH) {
+    g.x *= mmd_swish_grad(zz.x * sc.x + sh.x); g.y *= mmd_swish_grad(zz.y * sc.y + sh.y);
+    g.z *= mmd_swish_grad(zz.z * sc.z + sh.z); g.w *= mmd_swish_grad(zz.w * sc.w + sh.w);
+  }
+  return g;
+}
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g_in, const float* __restrict__ z,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -348,14 +361,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       size_t off = (size_t)row * C + c;
       float4 g = mmd_ld4(g_in + off), zz = mmd_ld4(z + off);
       int img = (mul_bc || mul_b || add_bc) ? row / rows_per_image : 0;
-      if (mul_bc) { float4 m = mmd_ld4(mul_bc + (size_t)img * C + c); g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w; }
-      if (mul_b) { float m = mul_b[img]; g.x *= m; g.y *= m; g.z *= m; g.w *= m; }
-      if (add_bc) { float4 m = mmd_ld4(add_bc + (size_t)img * C + c); g.x += m.x; g.y += m.y; g.z += m.z; g.w += m.w; }
-      if (act == MMD_ACT_SWISH) {
-        g.x *= mmd_swish_grad(zz.x * sc.x + sh.x); g.y *= mmd_swish_grad(zz.y * sc.y + sh.y);
-        g.z *= mmd_swish_grad(zz.z * sc.z + sh.z); g.w *= mmd_swish_grad(zz.w * sc.w + sh.w);
-      }
-      mmd_st4(g_out + off, g);
+      g = bn_bwd_g(g, zz, sc, sh, act, mul_bc, mul_b, add_bc, img, C, c);
+      if (g_out) mmd_st4(g_out + off, g);
       s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
       s2.x += g.x * (zz.x - mu.x) * is.x; s2.y += g.y * (zz.y - mu.y) * is.y;
       s2.z += g.z * (zz.z - mu.z) * is.z; s2.w += g.w * (zz.w - mu.w) * is.w;
@@ -372,21 +379,24 @@ extern "C" int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float*
                                  const float* mean, const float* invstd, int act, const float* mul_bc,
                                  const float* mul_b, const float* add_bc, int rows_per_image, float* g_out,
                                  double* sums, int M, int C, hipStream_t stream) {
-  if (!g_in || !z || !scale || !shift || !mean || !invstd || !g_out || !sums || M <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if (!g_in || !z || !scale || !shift || !mean || !invstd || !sums || M <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g_in, z, scale,
                      shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C, Pyr{}, 0, ROWS_PER_BLOCK);
-  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * (g_out ? 3 : 2));
   return mmd_check_launch();
 }
 
 // pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); block row 0 also does dgamma += sum(g*xhat), dbeta += sum(g)
+//         g is either given (act NONE, no modifiers) or recomputed from g_in exactly as pass 1 did
+struct BnBwdMod { const float* scale; const float* shift; int act; const float* mul_bc; const float* mul_b; const float* add_bc;
+                  int rows_per_image; };
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            double count, float* __restrict__ dz, float* dgamma, float* dbeta,
-                                                           int M, int C, Pyr pyr, long long lev_stride, int rpb) {
+                                                           int M, int C, Pyr pyr, long long lev_stride, int rpb, BnBwdMod mod) {
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   if (c >= C) return;
@@ -396,12 +406,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   if (pyr.n) {
     const int lev = pyr_level_of_row(pyr, r0);
     mean += lev * lev_stride; invstd += lev * lev_stride; gamma += lev * lev_stride; sums += 2 * lev * lev_stride;
+    if (mod.scale) { mod.scale += lev * lev_stride; mod.shift += lev * lev_stride; }
     if (dgamma) { dgamma += lev * lev_stride; dbeta += lev * lev_stride; }
     count = (double)pyr.B * pyr.H[lev] * pyr.W[lev];
     r1 = min(r1, pyr.row0[lev] + (int)count);
     first = r0 == pyr.row0[lev];
   }
   float4 mu = mmd_ld4(mean + c), is = mmd_ld4(invstd + c), ga = mmd_ld4(gamma + c);
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+  if (mod.act != MMD_ACT_NONE) { sc = mmd_ld4(mod.scale + c); sh = mmd_ld4(mod.shift + c); }
+  const bool per_img = mod.mul_bc || mod.mul_b || mod.add_bc;
   float m1[4], m2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { m1[i] = (float)(sums[c + i] / count); m2[i] = (float)(sums[C + c + i] / count); }
@@ -413,6 +427,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (int row = r0 + (tid >> 4); row < r1; row += 16) {
     size_t off = (size_t)row * C + c;
     float4 gg = mmd_ld4(g + off), zz = mmd_ld4(z + off), o;
+    gg = bn_bwd_g(gg, zz, sc, sh, mod.act, mod.mul_bc, mod.mul_b, mod.add_bc, per_img ? row / mod.rows_per_image : 0, C, c);
     o.x = ga.x * is.x * (gg.x - m1[0] - (zz.x - mu.x) * is.x * m2[0]);
     o.y = ga.y * is.y * (gg.y - m1[1] - (zz.y - mu.y) * is.y * m2[1]);
     o.z = ga.z * is.z * (gg.z - m1[2] - (zz.z - mu.z) * is.z * m2[2]);
@@ -422,12 +437,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 extern "C" int mmd_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd,
                                 const float* gamma, const double* sums, long long count, float* dz, float* dgamma,
-                                float* dbeta, int M, int C, hipStream_t stream) {
+                                float* dbeta, int M, int C, const float* scale, const float* shift, int act,
+                                const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image,
+                                hipStream_t stream) {
   if (!g || !z || !mean || !invstd || !gamma || !sums || !dz || M <= 0 || C <= 0 || (C & 3) || count <= 0) return MMD_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  if (act != MMD_ACT_NONE && (act != MMD_ACT_SWISH || !scale || !shift)) return MMD_EINVAL;
+  if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g, z, mean,
-                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C, Pyr{}, 0, ROWS_PER_BLOCK);
+                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C, Pyr{}, 0, ROWS_PER_BLOCK,
+                     BnBwdMod{scale, shift, act, mul_bc, mul_b, add_bc, rows_per_image});
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }
@@ -518,7 +538,7 @@ extern "C" int mmd_slice_rows(const float* src, float* dst, int B, int rows, int
 extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale, const float* shift,
                                      const float* mean, const float* invstd, int act, const int* pyr_desc,
                                      long long lev_stride, float* g_out, double* sums, int C, hipStream_t stream) {
-  if (!g_in || !z || !scale || !shift || !mean || !invstd || !g_out || !sums || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if (!g_in || !z || !scale || !shift || !mean || !invstd || !sums || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
   Pyr p;
   if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
   int M = p.row0[p.n];
@@ -530,15 +550,17 @@ extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const fl
 }
 extern "C" int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, const float* invstd,
                                     const float* gamma, const double* sums, const int* pyr_desc, long long lev_stride,
-                                    float* dz, float* dgamma, float* dbeta, int C, hipStream_t stream) {
+                                    float* dz, float* dgamma, float* dbeta, int C, const float* scale, const float* shift,
+                                    int act, hipStream_t stream) {
   if (!g || !z || !mean || !invstd || !gamma || !sums || !dz || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  if (act != MMD_ACT_NONE && (act != MMD_ACT_SWISH || !scale || !shift)) return MMD_EINVAL;
   Pyr p;
   if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
   int M = p.row0[p.n];
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, g, z, mean, invstd, gamma, sums,
-                     1.0, dz, dgamma, dbeta, M, C, p, lev_stride, 128);
+                     1.0, dz, dgamma, dbeta, M, C, p, lev_stride, 128, BnBwdMod{scale, shift, act, nullptr, nullptr, nullptr, 1});
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }

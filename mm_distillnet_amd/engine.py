@@ -13,6 +13,7 @@ what autograd derives for them.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -89,6 +90,7 @@ class Net:
         self.tape: Dict[str, object] = {}
         self._anchors: Dict[int, torch.Tensor] = {}
         self._side = None
+        self._wg = None           # weight-gradient stream: nothing downstream of a wgrad until the optimizer
 
     # ------------------------------------------------------------------ parameters
     def load_state(self, state):
@@ -471,25 +473,41 @@ class Net:
         else:
             call("mmd_scale_acc", src, slot.t, None, 0, 0, 1, src.numel())
 
+    @contextlib.contextmanager
+    def _wgrad_stream(self):
+        """Weight-gradient kernels are leaves of the backward graph (only the optimizer reads them), so they are
+        issued on their own stream - a parallel branch of the captured graph - ordered after everything the
+        current stream has enqueued so far; backward() joins the stream at its end.  Arena buffers are never
+        reused within a step, so the only ordering needed is producer -> wgrad."""
+        if not self.ps.flat.is_cuda:
+            yield
+            return
+        if self._wg is None:
+            self._wg = torch.cuda.Stream()
+        self._wg.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(self._wg):
+            yield
+
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
                 mul_bc=None, mul_b=None, add_bc=None) -> torch.Tensor:
         """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated."""
         b = self.ps.bn(bn_name)
         sums = self._zalloc((2 * C,), torch.float64)
-        g = self._alloc(M, C)
-        call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, g, sums, M, C)
+        call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C)
         dz = self._alloc(M, C)
-        call("mmd_bn_bwd_apply", g, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C)
+        call("mmd_bn_bwd_apply", g_in, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C,
+             aff[0], aff[1], act, mul_bc, mul_b, add_bc, rpi)
         return dz
 
     def _pw_bwd(self, dz: torch.Tensor, x: Feat, wkey: str, N: int, bias_key: Optional[str], want_dx: bool,
                 gate=None, plain_in=False) -> Optional[torch.Tensor]:
         ps = self.ps
         M, K = x.M, x.C
-        if bias_key:
-            call("mmd_colsum", dz, ps.g(bias_key), M, N)
-        call("mmd_pwconv_bwd_weight", dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
-             None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W)
+        with self._wgrad_stream():
+            if bias_key:
+                call("mmd_colsum", dz, ps.g(bias_key), M, N)
+            call("mmd_pwconv_bwd_weight", dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
+                 None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W)
         if not want_dx:
             return None
         dx = self._alloc(M, K)
@@ -498,7 +516,8 @@ class Net:
 
     def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True):
         ps = self.ps
-        call("mmd_dwconv_bwd_weight", x.z, dzd, ps.g(wkey), x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act)
+        with self._wgrad_stream():
+            call("mmd_dwconv_bwd_weight", x.z, dzd, ps.g(wkey), x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act)
         if not want_dx:
             return None
         dx = self._alloc(x.M, x.C)
@@ -516,13 +535,15 @@ class Net:
         for lvl, (h, w) in enumerate(pyr["sizes"]):
             call("mmd_slice_rows", dout, dy[pyr["row0"][lvl]:], pyr["B"], h * w, nout, A * per_anchor, rec["yoff"][lvl])
         hw_key = f"{hname}.header.pointwise_conv.conv.weight"
-        call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
-        call("mmd_pwconv_bwd_weight", dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
+        with self._wgrad_stream():
+            call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
+            call("mmd_pwconv_bwd_weight", dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
         dzd = self._alloc_pyr(pyr, C)
         call("mmd_pwconv_bwd_data", dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
-        call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
-             self.t_scale[xo:], self.t_shift[xo:], SWISH, ls)
+        with self._wgrad_stream():
+            call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
+                 self.t_scale[xo:], self.t_shift[xo:], SWISH, ls)
         g = self._alloc_pyr(pyr, C)
         call("mmd_dwconv3_pyr", dzd, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
              None, None, None, 0)
@@ -533,20 +554,22 @@ class Net:
             cname = f"{hname}.conv_list.{i}"
             o = L["off"]
             sums = bsums[2 * (o - off0):]
-            gy = self._alloc_pyr(pyr, C)
             call("mmd_bn_bwd_reduce_pyr", g, L["z"], self.t_scale[o:], self.t_shift[o:], self.t_mean[o:], self.t_invstd[o:],
-                 SWISH, desc, ls, gy, sums, C)
+                 SWISH, desc, ls, None, sums, C)
             dz = self._alloc_pyr(pyr, C)
-            call("mmd_bn_bwd_apply_pyr", gy, L["z"], self.t_mean[o:], self.t_invstd[o:], ps.flat[ps.gamma_off + o:], sums,
-                 desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C)
+            call("mmd_bn_bwd_apply_pyr", g, L["z"], self.t_mean[o:], self.t_invstd[o:], ps.flat[ps.gamma_off + o:], sums,
+                 desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C, self.t_scale[o:], self.t_shift[o:],
+                 SWISH)
             wkey = f"{cname}.pointwise_conv.conv.weight"
-            call("mmd_pwconv_bwd_weight", dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
+            with self._wgrad_stream():
+                call("mmd_pwconv_bwd_weight", dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
             dzd = self._alloc_pyr(pyr, C)
             call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
-            call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,
-                 None if xo is None else self.t_scale[xo:], None if xo is None else self.t_shift[xo:],
-                 NONE if xo is None else SWISH, ls)
+            with self._wgrad_stream():
+                call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,
+                     None if xo is None else self.t_scale[xo:], None if xo is None else self.t_shift[xo:],
+                     NONE if xo is None else SWISH, ls)
             g = self._alloc_pyr(pyr, C)
             call("mmd_dwconv3_pyr", dzd, ps.w(f"{cname}.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
                  None, None, None, 0)
@@ -609,7 +632,8 @@ class Net:
                 wdot = self._zalloc((4,))
                 call("mmd_bifpn_fuse_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
                      df, dx, wdot, in0.B, in0.H, in0.W, W)
-                call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
+                with self._wgrad_stream():
+                    call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
                 wi = 0
                 for operand, kind in ((in0, "same"), (in1, "same"), (up, "up"), (pl, "pool")):
                     if operand is None:
@@ -694,3 +718,5 @@ class Net:
         s = slot(stem)
         dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C)
         self._pw_bwd(dz, colf, f"{P}._conv_stem.conv.weight", stem.C, None, False)
+        if self._wg is not None:
+            torch.cuda.current_stream().wait_stream(self._wg)

@@ -174,9 +174,19 @@ def test_bn_train_fwd_bwd(M, C, act):
     call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, gy, sums, M, C)
     dz = torch.empty(M, C, device=DEV)
     dga, dbe = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    call("mmd_bn_bwd_apply", gy, g(z), mu, istd, g(gamma), sums, M, dz, dga, dbe, M, C)
+    call("mmd_bn_bwd_apply", gy, g(z), mu, istd, g(gamma), sums, M, dz, dga, dbe, M, C, None, None, 0, None, None, None, 0)
     close(dz, z.grad, 5e-4, 1e-5, "bn dz")
     close(dga, gamma.grad, 5e-4, 1e-5, "dgamma"); close(dbe, beta.grad, 5e-4, 1e-5, "dbeta")
+    # the product path: pass 1 stores no g, pass 2 recomputes it from g_in with the same modifiers
+    sums2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, None, sums2, M, C)
+    close(sums2, sums, 1e-9, 1e-9, "bn sums (no g store)")
+    dz2 = torch.empty(M, C, device=DEV)
+    dga2, dbe2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    call("mmd_bn_bwd_apply", g(gin), g(z), mu, istd, g(gamma), sums2, M, dz2, dga2, dbe2, M, C, sc, sh, act, g(mul_bc), g(mul_b),
+         g(add_bc), rpi)
+    close(dz2, dz, 1e-6, 1e-7, "bn dz (recomputed g)")
+    close(dga2, dga, 1e-6, 1e-7); close(dbe2, dbe, 1e-6, 1e-7)
 
 
 def test_affine_act_residual_and_fold():
@@ -498,7 +508,16 @@ def test_pyramid_launches_match_per_level():
     sums = torch.zeros(2 * nl * ls, dtype=torch.float64, device=DEV)
     call("mmd_bn_bwd_reduce_pyr", g(dy), g(x), g(sc)[o:], g(sh)[o:], g(mu)[o:], g(istd)[o:], 1, desc, ls, gy, sums[2 * o:], C)
     dga, dbe = torch.zeros(nl * ls, device=DEV), torch.zeros(nl * ls, device=DEV)
-    call("mmd_bn_bwd_apply_pyr", gy, g(x), g(mu)[o:], g(istd)[o:], g(gam)[o:], sums[2 * o:], desc, ls, dzp, dga[o:], dbe[o:], C)
+    call("mmd_bn_bwd_apply_pyr", gy, g(x), g(mu)[o:], g(istd)[o:], g(gam)[o:], sums[2 * o:], desc, ls, dzp, dga[o:], dbe[o:], C,
+         None, None, 0)
+    # product path: no stored g, recomputed in pass 2
+    sums_b = torch.zeros(2 * nl * ls, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce_pyr", g(dy), g(x), g(sc)[o:], g(sh)[o:], g(mu)[o:], g(istd)[o:], 1, desc, ls, None, sums_b[2 * o:], C)
+    dzp2 = torch.zeros(Mt, C, device=DEV)
+    dga_b, dbe_b = torch.zeros(nl * ls, device=DEV), torch.zeros(nl * ls, device=DEV)
+    call("mmd_bn_bwd_apply_pyr", g(dy), g(x), g(mu)[o:], g(istd)[o:], g(gam)[o:], sums_b[2 * o:], desc, ls, dzp2, dga_b[o:],
+         dbe_b[o:], C, g(sc)[o:], g(sh)[o:], 1)
+    close(dzp2, dzp, 1e-6, 1e-7, "pyr bn dz (recomputed g)"); close(dga_b, dga, 1e-6, 1e-7); close(dbe_b, dbe, 1e-6, 1e-7)
     for l in range(nl):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         cs = slice(ol, ol + C)
@@ -506,7 +525,8 @@ def test_pyramid_launches_match_per_level():
         call("mmd_bn_bwd_reduce", g(dy[sl]), g(x[sl]), g(sc[cs]), g(sh[cs]), g(mu[cs]), g(istd[cs]), 1, None, None, None, 0, gr, sr,
              rows[l], C)
         dr = torch.empty(rows[l], C, device=DEV); ga, be = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-        call("mmd_bn_bwd_apply", gr, g(x[sl]), g(mu[cs]), g(istd[cs]), g(gam[cs]), sr, rows[l], dr, ga, be, rows[l], C)
+        call("mmd_bn_bwd_apply", gr, g(x[sl]), g(mu[cs]), g(istd[cs]), g(gam[cs]), sr, rows[l], dr, ga, be, rows[l], C,
+             None, None, 0, None, None, None, 0)
         close(dzp[sl], dr, 1e-5, 1e-6, "pyr bn dz"); close(dga[cs], ga, 1e-5, 1e-6); close(dbe[cs], be, 1e-5, 1e-6)
 
 

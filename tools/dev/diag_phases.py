@@ -1,0 +1,138 @@
+"""Phase timing on the GPU box: each phase of the distillation step captured as its own hipGraph and replayed.
+   usage: python tools/dev/diag_phases.py            (B=8, 512x512, D2)"""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench as BN
+from mm_distillnet_amd.arch import make_spec
+from mm_distillnet_amd.synth import synth_inputs
+from mm_distillnet_amd.step import DistillEngine, StepConfig
+
+dev = "cuda:0"; S, B = 512, 8
+mods = {"rgb": (3, 1), "depth": (3, 2), "thermal": (1, 3)}
+specs = {k: make_spec(2, c) for k, (c, _) in mods.items()}
+calib = synth_inputs(4, 256, seed=1234)
+tstates = {k: BN.calibrated_state(specs[k], seed, calib[k], dev) for k, (_, seed) in mods.items()}
+sspec = make_spec(2, 8)
+sstate = BN.calibrated_state(sspec, 4, calib["audio"], dev)
+batch_cpu = synth_inputs(B, S, seed=24)
+for k in tstates:
+    BN.tune_teacher_bias(specs[k], tstates[k], batch_cpu[k], dev)
+eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S))
+eng.load(sstate, tstates)
+batch = {k: v.to(dev) for k, v in batch_cpu.items()}
+eng.capture(batch)
+
+
+def timeit(name, g, n=10):
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"{name:<44} {(time.perf_counter() - t0) / n * 1e3:8.3f} ms", flush=True)
+
+
+def cap(fn):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+timeit("full step (g_main)", eng.g_main)
+timeit("optimizer (g_opt)", eng.g_opt)
+st = eng.student
+ds = eng.static["drop_scale"]
+
+
+def student_fwd():
+    st.begin_step()
+    st.forward(eng.static["audio"], train=True, drop_scale=ds)
+
+
+timeit("student forward (train)", cap(student_fwd))
+tn = list(eng.teachers.items())
+
+
+def one_teacher():
+    mod, net = tn[0]
+    net.begin_step()
+    c, r, f = net.forward(eng.static[mod], train=False)
+
+
+timeit("one teacher forward", cap(one_teacher))
+
+
+def one_teacher_pl():
+    mod, net = tn[0]
+    eng.ws.reset()
+    eng.mask_ws = eng.ws.alloc((B * eng.cap * (eng.cap // 64),), torch.int64)
+    net.begin_step()
+    c, r, f = net.forward(eng.static[mod], train=False)
+    eng._pseudo_labels(net, c, r, B, c.shape[1], S)
+
+
+timeit("one teacher forward + pseudo labels", cap(one_teacher_pl))
+
+
+def teachers_serial():
+    for mod, net in tn:
+        net.begin_step()
+        net.forward(eng.static[mod], train=False)
+
+
+timeit("3 teachers, one stream", cap(teachers_serial))
+
+
+def teachers_conc():
+    main = torch.cuda.current_stream()
+    ev = main.record_event()
+    for i, (mod, net) in enumerate(tn):
+        side = eng.side_streams[i]
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            net.begin_step()
+            net.forward(eng.static[mod], train=False)
+    for side in eng.side_streams:
+        main.wait_stream(side)
+
+
+timeit("3 teachers, side streams", cap(teachers_conc))
+
+
+def all_fwd():
+    main = torch.cuda.current_stream()
+    ev = main.record_event()
+    student_fwd()
+    for i, (mod, net) in enumerate(tn):
+        side = eng.side_streams[i]
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            net.begin_step()
+            net.forward(eng.static[mod], train=False)
+    for side in eng.side_streams:
+        main.wait_stream(side)
+
+
+timeit("student + 3 teachers forward, 4 streams", cap(all_fwd))
+
+# student-only step: teachers replaced by their cached outputs
+eng.step_body(eng.static, ds)
+torch.cuda.synchronize()
+cached = {}
+for mod, net in tn:
+    net.begin_step()
+    cached[mod] = net.forward(eng.static[mod], train=False)
+    net.begin_step = (lambda: None)
+    net.forward = (lambda x, train=False, _m=mod: cached[_m])
+torch.cuda.synchronize()
+timeit("step without teacher forwards", cap(lambda: eng.step_body(eng.static, ds)))
