@@ -193,6 +193,17 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     log("timed %d steps: %.2f ms/step" % (args.steps, ms))
+    if os.environ.get("MMD_BENCH_PERSTEP"):      # dev aid: per-step distribution (A/B comparisons need the median/min)
+        per = []
+        for _ in range(int(os.environ["MMD_BENCH_PERSTEP"])):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t1) * 1e3)
+        per.sort()
+        log("per-step ms: min %.3f  p25 %.3f  median %.3f  p75 %.3f  max %.3f" % (
+            per[0], per[len(per) // 4], per[len(per) // 2], per[3 * len(per) // 4], per[-1]))
     if int(eng.overflow.item()):
         print("per-teacher candidate counts:", [c.cpu().tolist() for c in eng.out["cnt_t"]], file=sys.stderr)
     eng.check_overflow()

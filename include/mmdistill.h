@@ -46,8 +46,10 @@ int mmd_maxpool_same_fwd(const float* src, float* out, int B, int PH, int PW, in
 int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream);
 
 // Depthwise kxk TF-SAME conv, NHWC, fused producer BN+swish prologue, stats / eval-BN+swish / SE-pool epilogue.
+// stats_ws/ws_slots (nullable/0): zeroed workspace of ws_slots*2C doubles; launches that would send > 128 blocks to one
+// BatchNorm-sum address spread their f64 atomics over the slots and fold them into `stats` (workspace left zero).
 // Replaces Conv2dStaticSamePadding(groups=C) (src/YetAnotherEfficientNet.py:433-435, src/YetAnotherEfficientDet.py:169-170) incl. F.pad (:51-65).
-int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, hipStream_t stream);
+int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream);
 
 // Input gradient of the depthwise conv.
 int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, hipStream_t stream);
@@ -80,7 +82,7 @@ int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const f
 int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
 
 // BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat). g_out may be NULL (g not stored).
-int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, hipStream_t stream);
+int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, double* stats_ws, int ws_slots, hipStream_t stream);
 
 // BN backward pass 2: dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dgamma/dbeta +=. With act/mul/add given, `g` is pass 1's g_in and g is recomputed.
 int mmd_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, long long count, float* dz, float* dgamma, float* dbeta, int M, int C, const float* scale, const float* shift, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, hipStream_t stream);
@@ -146,7 +148,7 @@ int mmd_prof_collect(int family, double* out);
 // 1x1 conv as fp32 MFMA GEMM with fused producer-BN/swish/SE-gate prologue and bias/BN/act/residual/stats epilogue.
 // Replaces nn.Conv2d(k=1) in Conv2dStaticSamePadding (src/YetAnotherEfficientNet.py:27-65; call sites :427,446,
 // src/YetAnotherEfficientDet.py:171,238-265) + BatchNorm2d/swish that follow (:428,447,126-143).
-int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, hipStream_t stream);
+int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, hipStream_t stream);
 
 // --- feature-pyramid ("pyr") launches: the 5 levels of a shared-weight head layer in ONE launch.  pyr_desc is a HOST
 // int array {n, B, H0, W0, H1, W1, ...}; level l occupies rows [row0_l, row0_l + B*H_l*W_l) of the row buffer and

@@ -115,6 +115,11 @@ static inline int mmd_check_launch() {
   return e == hipSuccess ? MMD_OK : MMD_ELAUNCH;
 }
 int mmd_zero_bytes(void* p, size_t bytes, hipStream_t stream);   // optim.hip
+// Same-address f64 atomics resolve memory-side (the XCD L2s are not coherent with each other) at ~17 ns apiece: a launch
+// that sends more than MMD_STATS_DEPTH (x 17 ns = 2 us) blocks to one BatchNorm-sum address spreads them over `slots` copies in a caller
+// workspace (zero on entry, left zero) and mmd_stats_fold adds the copies into the real sums.  (elt.hip)
+#define MMD_STATS_DEPTH 128
+int mmd_stats_fold(double* stats, double* ws, int slots, int n, hipStream_t stream);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel event timing (bench.py roofline leg) ----

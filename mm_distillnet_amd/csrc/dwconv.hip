@@ -21,6 +21,7 @@ struct DwArgs {
   const float* in_scale; const float* in_shift; int in_act; BnLive in_bn;
   const float* out_scale; const float* out_shift; int out_act;
   double* stats; float* pool; float pool_scale;
+  double* stats_ws; int ws_slots;            // slotted sums (common.h)
   int tiles_h, tiles_w, cchunks;
   Pyr pyr; long long lev_stride;
 };
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       if (tid < CC && c0 + tid < a.C) {
         float vs = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
         float vq = sRed[4 * CC + tid] + sRed[5 * CC + tid] + sRed[6 * CC + tid] + sRed[7 * CC + tid];
-        atomicAdd(&a.stats[c0 + tid], (double)vs);
-        atomicAdd(&a.stats[a.C + c0 + tid], (double)vq);
+        double* st = a.stats_ws ? a.stats_ws + (size_t)((blockIdx.x / a.cchunks) % a.ws_slots) * 2 * a.C : a.stats;
+        atomicAdd(&st[c0 + tid], (double)vs);
+        atomicAdd(&st[a.C + c0 + tid], (double)vq);
       }
       __syncthreads();
     }
@@ -218,7 +220,9 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   using Cf = DwCfg<K, S, LANES>;
   a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = cdiv(a.C, Cf::CC);
   long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
+  if (!a.stats || a.ws_slots < 2 || nb / a.cchunks <= MMD_STATS_DEPTH) a.stats_ws = nullptr;
   hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES>), dim3((unsigned)nb), dim3(256), 0, st, a);
+  if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * a.C, st);
   return mmd_check_launch();
 }
 // 3x3 / stride 1: narrow channel chunks when C is small (thin 256x256 layers of the backbone)
@@ -241,7 +245,7 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
                               const float* in_scale, const float* in_shift, int in_act,
                               const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                               const float* out_scale, const float* out_shift, int out_act,
-                              double* stats, float* pool, hipStream_t stream) {
+                              double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -253,6 +257,7 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   a.in_bn = mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C);
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
   a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
+  a.stats_ws = stats_ws; a.ws_slots = ws_slots;
   mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW, stream);
   int rc;

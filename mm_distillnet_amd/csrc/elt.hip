@@ -317,6 +317,19 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
   return mmd_check_launch();
 }
 
+// ---------------------------------------------------------------- slotted BatchNorm sums (see common.h)
+__global__ void stats_fold_kernel(double* stats, double* ws, int slots, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int k = 0; k < slots; ++k) { s += ws[(size_t)k * n + i]; ws[(size_t)k * n + i] = 0; }
+  stats[i] += s;
+}
+int mmd_stats_fold(double* stats, double* ws, int slots, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(stats_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, stats, ws, slots, n);
+  return mmd_check_launch();
+}
+
 // ---------------------------------------------------------------- BN (+activation) backward
 // pass 1: g = (g_in * mul_bc[img,c] * mul_b[img] + add_bc[img,c]) * act'(z*scale+shift);
 //         sums[c] += g, sums[C+c] += g * xhat,  xhat = (z-mean)*invstd          
@@ -339,8 +352,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             int act, const float* __restrict__ mul_bc,
                                                             const float* __restrict__ mul_b, const float* __restrict__ add_bc,
                                                             int rows_per_image, float* __restrict__ g_out, double* sums,
-                                                            int M, int C, Pyr pyr, long long lev_stride, int rpb) {
+                                                            int M, int C, Pyr pyr, long long lev_stride, int rpb,
+                                                            double* ws, int slots) {
   __shared__ float sRed[256];
+  if (ws) sums = ws + (size_t)(blockIdx.y % slots) * 2 * C;
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   const bool cok = c < C;
@@ -378,12 +393,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 extern "C" int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, int act, const float* mul_bc,
                                  const float* mul_b, const float* add_bc, int rows_per_image, float* g_out,
-                                 double* sums, int M, int C, hipStream_t stream) {
+                                 double* sums, int M, int C, double* stats_ws, int ws_slots, hipStream_t stream) {
   if (!g_in || !z || !scale || !shift || !mean || !invstd || !sums || M <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
   mmd_prof_begin(MMD_FAM_ELT, stream);
+  const bool slotted = stats_ws && ws_slots > 1 && cdiv(M, ROWS_PER_BLOCK) > MMD_STATS_DEPTH;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g_in, z, scale,
-                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C, Pyr{}, 0, ROWS_PER_BLOCK);
+                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C, Pyr{}, 0, ROWS_PER_BLOCK,
+                     slotted ? stats_ws : nullptr, ws_slots);
+  if (slotted) mmd_stats_fold(sums, stats_ws, ws_slots, 2 * C, stream);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * (g_out ? 3 : 2));
   return mmd_check_launch();
 }
@@ -544,7 +562,7 @@ extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const fl
   int M = p.row0[p.n];
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, g_in, z, scale, shift, mean,
-                     invstd, act, nullptr, nullptr, nullptr, 1, g_out, sums, M, C, p, lev_stride, 128);
+                     invstd, act, nullptr, nullptr, nullptr, 1, g_out, sums, M, C, p, lev_stride, 128, nullptr, 0);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }

@@ -23,6 +23,7 @@ struct PwArgs {
   const float* gate; int rows_per_image;
   const float* bias; const float* out_scale; const float* out_shift; int out_act;
   const float* residual; double* stats;
+  double* stats_ws; int ws_slots;            // slotted sums (common.h), tiled kernel only
   long long y_batch_stride; long long y_offset;
   int ntn; int nblk;
   Pyr pyr; long long yoff_lev[MMD_MAX_LEV]; long long lev_stride;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
     srow0 = a.pyr.row0[lev]; rpi = a.pyr.H[lev] * a.pyr.W[lev]; Mv = srow0 + a.pyr.B * rpi; yoff = a.yoff_lev[lev];
     if (stats) stats += 2 * lev * a.lev_stride;
   }
+  if (a.stats_ws) stats = a.stats_ws + (size_t)(tm % a.ws_slots) * 2 * a.N;
   const int kq = (tid & 7) * 4;          // this thread's k offset inside a K tile
   const int lrow = tid >> 3;             // 0..31
 
@@ -594,7 +596,8 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
                               const float* gate, int rows_per_image,
                               const float* bias, const float* out_scale, const float* out_shift, int out_act,
                               const float* residual, double* stats,
-                              long long y_batch_stride, long long y_offset, hipStream_t stream) {
+                              long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots,
+                              hipStream_t stream) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !x || !w || !y) return MMD_EINVAL;
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
@@ -602,7 +605,9 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   if (in_stats && (in_scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, mmd_make_bn(in_stats, in_gamma, in_beta, in_count, K), gate,
            rows_per_image > 0 ? rows_per_image : 1,
-           bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, 0, 0, Pyr{}, {0, 0, 0, 0, 0}, 0};
+           bias, out_scale, out_shift, out_act, residual, stats, nullptr, 0, y_batch_stride, y_offset, 0, 0, Pyr{},
+           {0, 0, 0, 0, 0}, 0};
+  if (stats && stats_ws && ws_slots > 1 && cdiv(M, PW_BM) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
   return pw_dispatch(a, stream);
 }
 
@@ -631,6 +636,7 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     a.ntn = cdiv(N, 64); a.nblk = ntm * a.ntn;
     hipLaunchKernelGGL(pw_gemm_kernel<64>, dim3(a.nblk), dim3(256), 0, stream, a);
   }
+  if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * N, stream);
   mmd_prof_end(MMD_FAM_PW, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   return mmd_check_launch();
 }
@@ -765,7 +771,7 @@ extern "C" int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, 
                                    int accumulate, hipStream_t stream) {
   // Y'=dx [M,K], X'=dy [M,N], W'=wt [K,N] -> reduction dim is N
   return mmd_pwconv_fwd(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0,
-                        nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, stream);
+                        nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {

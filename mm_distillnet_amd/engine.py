@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -155,6 +156,16 @@ class Net:
             return (None, None, x.act, x.bn[0], x.bn[1], x.bn[2], x.bn[3])
         return (x.scale, x.shift, x.act, None, None, None, 0)
 
+    STATS_SLOTS = 0 if os.environ.get("MMD_NO_SLOTS") else 64
+
+    def _stats_ws(self, stats, M: int, C: int):
+        """(workspace, slots) for a BatchNorm-sum producer over M rows: the thin full-resolution layers would send
+        thousands of same-address f64 atomics (memory-side, ~17 ns each) to 2C addresses; the kernels spread them over
+        `slots` zeroed copies and fold.  Only worth a buffer when M is large (the C side decides whether to use it)."""
+        if stats is None or M < 16384 or not self.STATS_SLOTS:
+            return None, 0
+        return self._zalloc((self.STATS_SLOTS * 2 * C,), torch.float64), self.STATS_SLOTS
+
     def _pw(self, x: Feat, wkey: str, N: int, bias=None, stats=None, out_aff=None, out_act=NONE, residual=None,
             gate=None, y=None, ybs=0, yoff=0, plain_in=False):
         M, K = x.M, x.C
@@ -162,14 +173,15 @@ class Net:
             y = self._alloc(M, N)
         xf = (None, None, NONE, None, None, None, 0) if plain_in else self._xf(x)
         call("mmd_pwconv_fwd", x.z, self.ps.w(wkey), y, M, K, N, *xf, gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
-             residual, stats, ybs, yoff)
+             residual, stats, ybs, yoff, *self._stats_ws(stats, M, N))
         return y
 
     def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None):
         OH, OW = -(-x.H // s), -(-x.W // s)
         y = self._alloc(x.B * OH * OW, x.C)
         call("mmd_dwconv_fwd", x.z, self.ps.w(wkey), y, x.B, x.H, x.W, x.C, k, s, *self._xf(x),
-             out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act, stats, pool)
+             out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act, stats, pool,
+             *self._stats_ws(stats, x.B * OH * OW, x.C))
         return y, OH, OW
 
     def anchors(self, image_size: int) -> torch.Tensor:
@@ -493,7 +505,8 @@ class Net:
         """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated."""
         b = self.ps.bn(bn_name)
         sums = self._zalloc((2 * C,), torch.float64)
-        call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C)
+        call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C,
+             *self._stats_ws(sums, M, C))
         dz = self._alloc(M, C)
         call("mmd_bn_bwd_apply", g_in, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C,
              aff[0], aff[1], act, mul_bc, mul_b, add_bc, rpi)

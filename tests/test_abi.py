@@ -25,8 +25,8 @@ def test_bad_arguments_are_rejected_without_gpu():
     from mm_distillnet_amd import _lib
     dll = _lib.LIB.load()
     # argument validation happens before any launch: null pointers / bad sizes -> -22
-    assert dll.mmd_pwconv_fwd(None, None, None, 0, 0, 0, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None) == -22
-    assert dll.mmd_dwconv_fwd(None, None, None, 1, 8, 8, 16, 4, 1, None, None, 0, None, None, None, 0, None, None, 0, None, None, None) == -22
+    assert dll.mmd_pwconv_fwd(None, None, None, 0, 0, 0, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0, None) == -22
+    assert dll.mmd_dwconv_fwd(None, None, None, 1, 8, 8, 16, 4, 1, None, None, 0, None, None, None, 0, None, None, 0, None, None, None, 0, None) == -22
     with pytest.raises(ValueError):
         import torch
         _lib.call("mmd_colsum", torch.zeros(4, 4), torch.zeros(4), 4, 4)      # host tensor: refused loudly

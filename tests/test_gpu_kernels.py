@@ -60,13 +60,13 @@ def test_pwconv_fwd_full(M, K, N):
     y = torch.empty(M, N, device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
     call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, g(isc), g(ish), 1, None, None, None, 0, g(gate), rpi, g(bias), g(osc), g(osh), 1, g(res),
-         stats, 0, 0)
+         stats, 0, 0, None, 0)
     close(y, ref, 2e-4, 1e-5, "pw fwd")
     close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
     close(stats[N:], (raw.double() ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
     # plain path
     y2 = torch.empty(M, N, device=DEV)
-    call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0)
     close(y2, x @ w.t(), 2e-4, 1e-5, "pw plain")
 
 
@@ -77,7 +77,7 @@ def test_pwconv_fwd_remap():
     out = torch.zeros(B, A_total_rows * 4, device=DEV)
     off = 17 * 4
     call("mmd_pwconv_fwd", g(x), g(w), out, B * HW, K, N, None, None, 0, None, None, None, 0, None, HW, g(bias), None, None, 2, None, None,
-         A_total_rows * 4, off)
+         A_total_rows * 4, off, None, 0)
     ref = torch.sigmoid(x @ w.t() + bias).view(B, HW * N)
     close(out[:, off:off + HW * N], ref, 2e-4, 1e-5)
     assert out[:, :off].abs().max().item() == 0 and out[:, off + HW * N:].abs().max().item() == 0
@@ -126,14 +126,14 @@ def test_dwconv(k, s, H, W, C):
     wn = g(w.detach().reshape(C, k * k).t())
     yo = torch.empty(B * OH * OW, C, device=DEV)
     stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
-    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, None, None, 0, stats, None)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, None, None, 0, stats, None, None, 0)
     close(yo.view(B, OH, OW, C), nhwc(y), 2e-4, 1e-5, "dw fwd")
     close(stats[:C], y.double().sum((0, 2, 3)), 1e-4, 1e-4)
     close(stats[C:], (y.double() ** 2).sum((0, 2, 3)), 1e-4, 1e-5)
     # eval epilogue + pool
     osc, osh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
     pool = torch.zeros(B, C, device=DEV)
-    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, g(osc), g(osh), 1, None, pool)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, g(osc), g(osh), 1, None, pool, None, 0)
     ye = swish(y * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
     close(yo.view(B, OH, OW, C), nhwc(ye), 2e-4, 1e-5, "dw eval")
     close(pool, ye.mean((2, 3)), 2e-4, 1e-5, "pool")
@@ -171,7 +171,7 @@ def test_bn_train_fwd_bwd(M, C, act):
     close(yy, a, 1e-4, 1e-5, "bn apply")
     sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     gy = torch.empty(M, C, device=DEV)
-    call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, gy, sums, M, C)
+    call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, gy, sums, M, C, None, 0)
     dz = torch.empty(M, C, device=DEV)
     dga, dbe = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     call("mmd_bn_bwd_apply", gy, g(z), mu, istd, g(gamma), sums, M, dz, dga, dbe, M, C, None, None, 0, None, None, None, 0)
@@ -179,7 +179,7 @@ def test_bn_train_fwd_bwd(M, C, act):
     close(dga, gamma.grad, 5e-4, 1e-5, "dgamma"); close(dbe, beta.grad, 5e-4, 1e-5, "dbeta")
     # the product path: pass 1 stores no g, pass 2 recomputes it from g_in with the same modifiers
     sums2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
-    call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, None, sums2, M, C)
+    call("mmd_bn_bwd_reduce", g(gin), g(z), sc, sh, mu, istd, act, g(mul_bc), g(mul_b), g(add_bc), rpi, None, sums2, M, C, None, 0)
     close(sums2, sums, 1e-9, 1e-9, "bn sums (no g store)")
     dz2 = torch.empty(M, C, device=DEV)
     dga2, dbe2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
@@ -239,7 +239,7 @@ def test_se_path():
     gy = torch.empty(B * HW, C, device=DEV)
     sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     call("mmd_bn_bwd_reduce", g(gout.reshape(B * HW, C)), g(z), g(sc), g(sh), torch.zeros(C, device=DEV),
-         torch.ones(C, device=DEV), 1, dg, None, dpooled, HW, gy, sums, B * HW, C)
+         torch.ones(C, device=DEV), 1, dg, None, dpooled, HW, gy, sums, B * HW, C, None, 0)
     close(gy * g(sc), z.grad, 3e-4, 1e-5, "dz through SE")
 
 
@@ -272,7 +272,7 @@ def test_stem_im2col(cin, S):
     call("mmd_stem_im2col", g(x), col, B, cin, S, S, Kp)
     wp = torch.zeros(32, Kp); wp[:, :cin * 9] = w.reshape(32, -1)
     y = torch.empty(B * OH * OH, 32, device=DEV)
-    call("mmd_pwconv_fwd", col, g(wp), y, B * OH * OH, Kp, 32, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
+    call("mmd_pwconv_fwd", col, g(wp), y, B * OH * OH, Kp, 32, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0)
     close(y.view(B, OH, OH, 32), nhwc(ref), 2e-4, 1e-5)
 
 
@@ -393,13 +393,13 @@ def test_live_bn_matches_finalized():
     live = (stats, g(gamma), g(beta), M)
     w = torch.randn(N, C) / 7
     y1, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    call("mmd_pwconv_fwd", g(z), g(w), y1, M, C, N, sc, sh, 1, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0)
-    call("mmd_pwconv_fwd", g(z), g(w), y2, M, C, N, None, None, 1, *live, None, 0, None, None, None, 0, None, None, 0, 0)
+    call("mmd_pwconv_fwd", g(z), g(w), y1, M, C, N, sc, sh, 1, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0)
+    call("mmd_pwconv_fwd", g(z), g(w), y2, M, C, N, None, None, 1, *live, None, 0, None, None, None, 0, None, None, 0, 0, None, 0)
     assert torch.equal(y1, y2)
     wd = g(torch.randn(9, C) / 3)
     d1, d2 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
-    call("mmd_dwconv_fwd", g(z), wd, d1, B, H, W, C, 3, 1, sc, sh, 1, None, None, None, 0, None, None, 0, None, None)
-    call("mmd_dwconv_fwd", g(z), wd, d2, B, H, W, C, 3, 1, None, None, 1, *live, None, None, 0, None, None)
+    call("mmd_dwconv_fwd", g(z), wd, d1, B, H, W, C, 3, 1, sc, sh, 1, None, None, None, 0, None, None, 0, None, None, None, 0)
+    call("mmd_dwconv_fwd", g(z), wd, d2, B, H, W, C, 3, 1, None, None, 1, *live, None, None, 0, None, None, None, 0)
     assert torch.equal(d1, d2)
     a1, a2 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
     call("mmd_affine_act", g(z), sc, sh, None, None, None, 0, 1, None, 0, None, a1, M, C)
@@ -463,7 +463,7 @@ def test_pyramid_launches_match_per_level():
         ol = o + l * ls
         yr = torch.empty(rows[l], C, device=DEV)
         call("mmd_dwconv_fwd", g(x[sl]), g(wd), yr, B, h, w, C, 3, 1, g(sc[ol:ol + C]), g(sh[ol:ol + C]), 1, None, None, None, 0,
-             None, None, 0, None, None)
+             None, None, 0, None, None, None, 0)
         assert torch.equal(y[sl], yr), l
         dxr = torch.empty(rows[l], C, device=DEV)
         call("mmd_dwconv_bwd_data", g(dy[sl]), g(wd), dxr, B, h, w, C, 3, 1)
@@ -482,7 +482,7 @@ def test_pyramid_launches_match_per_level():
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         yr = torch.empty(rows[l], C, device=DEV)
         call("mmd_dwconv_fwd", g(x[sl]), g(wd), yr, B, h, w, C, 3, 1, None, None, 1, g(stats[2 * ol:2 * ol + 2 * C]),
-             g(gam[ol:ol + C]), g(bet[ol:ol + C]), rows[l], None, None, 0, None, None)
+             g(gam[ol:ol + C]), g(bet[ol:ol + C]), rows[l], None, None, 0, None, None, None, 0)
         assert torch.equal(yl[sl], yr), l
     # ---- pointwise GEMM with per-level stats and the strided head output
     wp = torch.randn(N, C) / 10; bias = torch.randn(N)
@@ -523,7 +523,7 @@ def test_pyramid_launches_match_per_level():
         cs = slice(ol, ol + C)
         gr = torch.empty(rows[l], C, device=DEV); sr = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
         call("mmd_bn_bwd_reduce", g(dy[sl]), g(x[sl]), g(sc[cs]), g(sh[cs]), g(mu[cs]), g(istd[cs]), 1, None, None, None, 0, gr, sr,
-             rows[l], C)
+             rows[l], C, None, 0)
         dr = torch.empty(rows[l], C, device=DEV); ga, be = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
         call("mmd_bn_bwd_apply", gr, g(x[sl]), g(mu[cs]), g(istd[cs]), g(gam[cs]), sr, rows[l], dr, ga, be, rows[l], C,
              None, None, 0, None, None, None, 0)
@@ -579,7 +579,7 @@ def test_bifpn_node_dw_fused(mode, H, W, C):
     f_ref = torch.empty(B * H * W, C, device=DEV)
     call("mmd_bifpn_fuse_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), f_ref, B, H, W, C)
     z_ref = torch.empty(B * H * W, C, device=DEV)
-    call("mmd_dwconv_fwd", f_ref, g(wd), z_ref, B, H, W, C, 3, 1, None, None, 0, None, None, None, 0, None, None, 0, None, None)
+    call("mmd_dwconv_fwd", f_ref, g(wd), z_ref, B, H, W, C, 3, 1, None, None, 0, None, None, None, 0, None, None, 0, None, None, None, 0)
     f = torch.zeros(B * H * W, C, device=DEV); z = torch.zeros(B * H * W, C, device=DEV)
     call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), f, z, B, H, W, C)
     assert torch.equal(f, f_ref)
@@ -587,3 +587,40 @@ def test_bifpn_node_dw_fused(mode, H, W, C):
     z2 = torch.zeros(B * H * W, C, device=DEV)
     call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), None, z2, B, H, W, C)
     assert torch.equal(z, z2)
+
+
+def test_slotted_bn_sums_match_direct():
+    """Thin full-resolution layers: the producers spread their BatchNorm-sum atomics over workspace slots and fold
+    them (common.h MMD_STATS_DEPTH); the folded sums equal the direct ones and the workspace is left zero."""
+    torch.manual_seed(11)
+    SL = 64
+    # depthwise: 2 x 256 x 256 x 16 -> 2048 tiles per address
+    B, H, C = 2, 256, 16
+    x, wd = torch.randn(B * H * H, C), torch.randn(9, C)
+    y = torch.empty(B * H * H, C, device=DEV)
+    st0 = torch.zeros(2 * C, dtype=torch.float64, device=DEV); st1 = torch.zeros_like(st0)
+    ws = torch.zeros(SL * 2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_dwconv_fwd", g(x), g(wd), y, B, H, H, C, 3, 1, None, None, 0, None, None, None, 0, None, None, 0, st0, None, None, 0)
+    y0 = y.clone()
+    call("mmd_dwconv_fwd", g(x), g(wd), y, B, H, H, C, 3, 1, None, None, 0, None, None, None, 0, None, None, 0, st1, None, ws, SL)
+    assert torch.equal(y, y0)
+    close(st1, st0, 1e-12, 1e-12, "dw slotted sums"); assert float(ws.abs().max()) == 0.0
+    close(st0[:C], y0.double().sum(0), 1e-6, 1e-7); close(st0[C:], (y0.double() ** 2).sum(0), 1e-6, 1e-7)
+    # 1x1 conv: 140000 rows -> 1094 row tiles per address
+    M, K, N = 140000, 16, 16
+    x, w = torch.randn(M, K), torch.randn(N, K)
+    y = torch.empty(M, N, device=DEV)
+    st0.zero_(); st1.zero_()
+    call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, st0, 0, 0, None, 0)
+    call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, st1, 0, 0, ws, SL)
+    close(st1, st0, 1e-12, 1e-12, "pw slotted sums"); assert float(ws.abs().max()) == 0.0
+    close(st0[:N], y.double().sum(0), 1e-6, 1e-7)
+    # BN backward pass 1: 270000 rows -> 1055 row blocks per address
+    M, C = 270000, 16
+    gi, z = torch.randn(M, C), torch.randn(M, C)
+    sc, sh = torch.rand(C) + 0.5, torch.randn(C)
+    mu, istd = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    st0.zero_(); st1.zero_()
+    call("mmd_bn_bwd_reduce", g(gi), g(z), g(sc), g(sh), g(mu), g(istd), 1, None, None, None, 0, None, st0, M, C, None, 0)
+    call("mmd_bn_bwd_reduce", g(gi), g(z), g(sc), g(sh), g(mu), g(istd), 1, None, None, None, 0, None, st1, M, C, ws, SL)
+    close(st1, st0, 1e-12, 1e-12, "bn bwd slotted sums"); assert float(ws.abs().max()) == 0.0
