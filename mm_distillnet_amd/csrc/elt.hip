@@ -318,15 +318,18 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
 }
 
 // ---------------------------------------------------------------- slotted BatchNorm sums (see common.h)
-__global__ void stats_fold_kernel(double* stats, double* ws, int slots, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per sum: lane = slot, so the `slots` loads of an address are in flight together (a per-thread loop over the
+// slots serialises on load->store ordering: ~1 us per slot)
+__global__ __launch_bounds__(256) void stats_fold_kernel(double* stats, double* ws, int slots, int n) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   double s = 0;
-  for (int k = 0; k < slots; ++k) { s += ws[(size_t)k * n + i]; ws[(size_t)k * n + i] = 0; }
-  stats[i] += s;
+  for (int k = lane; k < slots; k += 64) { s += ws[(size_t)k * n + i]; ws[(size_t)k * n + i] = 0; }
+  s = wave_sum_d(s);
+  if (lane == 0) stats[i] += s;
 }
 int mmd_stats_fold(double* stats, double* ws, int slots, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(stats_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, stats, ws, slots, n);
+  hipLaunchKernelGGL(stats_fold_kernel, dim3(cdiv(n, 4)), dim3(256), 0, stream, stats, ws, slots, n);
   return mmd_check_launch();
 }
 
