@@ -47,12 +47,18 @@ __device__ __forceinline__ float wave_max(float v) {
 // "Live" BatchNorm: per-channel (scale, shift) derived on the fly from the raw batch sums a producer kernel accumulated
 // (train-mode forward), so no per-layer finalize launch sits between producer and consumer.  Same arithmetic as
 // bn_finalize_kernel (double mean/var, float invstd), hence bit-identical coefficients in every block.
+// invstd = 1/sqrt(var+eps) in float: hardware rsq (1 ulp) + one Newton step.  The sums and the mean/variance difference
+// stay in double (cancellation); a double sqrt + divide per channel per block was a measurable part of every consumer prologue.
+__device__ __forceinline__ float mmd_bn_invstd(double var, float eps) {
+  const float v = fmaxf((float)var, 0.f) + eps;
+  float r = __frsqrt_rn(v);
+  return r * (1.5f - 0.5f * v * r * r);
+}
 struct BnLive { const double* stats; const float* gamma; const float* beta; double inv_count; int C; float eps; };
 __device__ __forceinline__ void bn_live_coef(const BnLive& b, int c, float& sc, float& sh) {
   double mean = b.stats[c] * b.inv_count;
   double var = b.stats[b.C + c] * b.inv_count - mean * mean;
-  if (var < 0) var = 0;
-  float invstd = (float)(1.0 / sqrt(var + (double)b.eps));
+  float invstd = mmd_bn_invstd(var, b.eps);
   sc = b.gamma[c] * invstd;
   sh = b.beta[c] - (float)mean * sc;
 }

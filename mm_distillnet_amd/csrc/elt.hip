@@ -34,7 +34,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   double mean = stats[c] / count;
   double var = stats[C + c] / count - mean * mean;
   if (var < 0) var = 0;
-  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float invstd = mmd_bn_invstd(var, eps);
   float sc = gamma[c] * invstd;
   scale[c] = sc;
   shift[c] = beta[c] - (float)mean * sc;
@@ -71,7 +71,7 @@ __global__ void bn_finalize_all_kernel(const double* __restrict__ stats, const f
   double mean = stats[2 * (size_t)lo + ci] / n;
   double var = stats[2 * (size_t)lo + lc + ci] / n - mean * mean;
   if (var < 0) var = 0;
-  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float invstd = mmd_bn_invstd(var, eps);
   float sc = gamma[c] * invstd;
   scale[c] = sc;
   shift[c] = beta[c] - (float)mean * sc;

@@ -622,11 +622,12 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   // SIMD, nothing hides the LDS/epilogue latency) -> off unless MMD_STREAM=1; kept as the starting point for a
   // software-pipelined version (profiles/r01_notes.md)
   static const int use_stream = getenv("MMD_STREAM") ? 1 : 0;
+  static const int skinny_tiles = getenv("MMD_SKINNY_TILES") ? atoi(getenv("MMD_SKINNY_TILES")) : 160;
   if (use_stream && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
     else pw_stream_launch<2, 2>(a, stream);
-  } else if ((big_tiles < 160 || K <= k_small) && N > 16) {
+  } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
     hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
   } else if (N <= 32) {

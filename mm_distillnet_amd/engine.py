@@ -491,7 +491,7 @@ class Net:
         issued on their own stream - a parallel branch of the captured graph - ordered after everything the
         current stream has enqueued so far; backward() joins the stream at its end.  Arena buffers are never
         reused within a step, so the only ordering needed is producer -> wgrad."""
-        if not self.ps.flat.is_cuda:
+        if not self.ps.flat.is_cuda or os.environ.get("MMD_NO_WG"):
             yield
             return
         if self._wg is None:
@@ -614,7 +614,7 @@ class Net:
         fork = main_stream.record_event() if main_stream is not None else None
         gparts = []
         for hname, per_anchor, dout in (("classifier", spec.num_classes, dcls_logit), ("regressor", 4, dreg)):
-            use_side = main_stream is not None and hname == "regressor"
+            use_side = main_stream is not None and hname == "regressor" and not os.environ.get("MMD_NO_SIDE")
             if use_side:
                 self._side.wait_event(fork)
             with torch.cuda.stream(self._side if use_side else main_stream):
