@@ -131,7 +131,8 @@ int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, 
 int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scores, const int* label_map, float nms_threshold, int inclusive, float image_size, int B, float* out, int* out_cnt, unsigned long long* mask_ws, int* overflow, hipStream_t stream);
 
 // Cross-teacher concat + nms(0.5) + drop score (src/optimization/train_methods.py:361-411).
-int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2, const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, hipStream_t stream);
+// merge01 != 0: image 1 also takes image 0's rows, in front of its own, when both have rows (augment=True, :379-387).
+int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2, const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, hipStream_t stream);
 
 // Candidate capacity per image of the pseudo-label kernels.
 int mmd_pp_cap(void);
@@ -175,6 +176,13 @@ int mmd_transpose_batched(const float* src_base, float* dst_base, const long lon
 
 // dst[C,R] = src[R,C]^T (refreshes the Wt copies after an optimizer step).
 int mmd_transpose2d(const float* src, float* dst, int R, int C, hipStream_t stream);
+
+// ModelWithNMSLossAugmented.merge_batch_0_1 (src/optimization/train_methods.py:291-308): out = in, except image 1 =
+// log10(max(in[0]^10 + in[1]^10, 1e-7)) (the reference's literal 10th power).  per_image = C*H*W.
+int mmd_audio_merge01(const float* in, float* out, long long per_image, int B, hipStream_t stream);
+
+// ModelWithNMSLossAugmented.average_batch_0_1 (:279-289): f[image 1] = (f[image 0] + f[image 1]) / 2, in place.
+int mmd_avg_image01(float* f, long long per_image, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -585,3 +585,38 @@ extern "C" int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float*
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();
 }
+
+// ---------------------------------------------------------------- "augmented" step variant (ModelWithNMSLossAugmented)
+// merge_batch_0_1 (src/optimization/train_methods.py:291-308): image 1 of the audio batch becomes
+// log10(max(a0^10 + a1^10, 1e-7)) - literally the 10th POWER of the dB-scale spectrogram, as the reference computes it;
+// every other image is copied.  Out of place, so a graph replay does not compound the merge.
+__global__ void audio_merge01_kernel(const float* __restrict__ in, float* __restrict__ out, size_t per, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = in[i];
+  if (i >= per && i < 2 * per) {
+    float a0 = in[i - per];
+    float p0 = a0 * a0; p0 = p0 * p0 * p0 * p0 * (a0 * a0);          // torch.pow(x, 10)
+    float p1 = v * v; p1 = p1 * p1 * p1 * p1 * (v * v);
+    float m = p0 + p1;
+    if (m < 1e-7f) m = 1e-7f;
+    v = log10f(m);
+  }
+  out[i] = v;
+}
+extern "C" int mmd_audio_merge01(const float* in, float* out, long long per_image, int B, hipStream_t stream) {
+  if (!in || !out || per_image <= 0 || B < 2) return MMD_EINVAL;
+  size_t total = (size_t)per_image * B;
+  hipLaunchKernelGGL(audio_merge01_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, in, out, (size_t)per_image, total);
+  return mmd_check_launch();
+}
+// average_batch_0_1 (:279-289): teacher feature map of image 1 <- (image 0 + image 1) / 2, in place
+__global__ void avg_image01_kernel(float* f, size_t per) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < per) f[per + i] = (f[i] + f[per + i]) / 2.f;
+}
+extern "C" int mmd_avg_image01(float* f, long long per_image, hipStream_t stream) {
+  if (!f || per_image <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(avg_image01_kernel, dim3(cdiv(per_image, 256)), dim3(256), 0, stream, f, (size_t)per_image);
+  return mmd_check_launch();
+}

@@ -107,6 +107,8 @@ struct NmsArgs {
   const float* over_scores; const int* label_map; float image_size;
   float* out; int* out_cnt; int out_cols; int out_cap;
   unsigned long long* mask_ws; int* overflow;
+  int merge01;        // mode 1: image 1 takes image 0's rows in front of its own when both have rows
+                      // (ModelWithNMSLossAugmented.forward, augment=True: src/optimization/train_methods.py:379-387)
 };
 
 __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
@@ -120,13 +122,23 @@ __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
   __shared__ int s_n, s_nk;
   const int b = blockIdx.x, tid = threadIdx.x;
   // gather source rows (concatenation order = source order)
-  int cnts[3] = {0, 0, 0}, n = 0;
+  int cnts[3] = {0, 0, 0}, cnts0[3] = {0, 0, 0}, n = 0, n0 = 0;
   for (int s = 0; s < a.nsrc; ++s) { cnts[s] = min(a.cnt[s][b], PP_CAP); n += cnts[s]; }
+  if (a.merge01 && b == 1 && n > 0) {
+    for (int s = 0; s < a.nsrc; ++s) { cnts0[s] = min(a.cnt[s][0], PP_CAP); n0 += cnts0[s]; }
+    n += n0;
+  }
   if (n > PP_CAP) { if (tid == 0) *a.overflow = 1; n = PP_CAP; }
   auto row_ptr = [&](int i) -> const float* {
-    int s = 0;
-    while (s < a.nsrc - 1 && i >= cnts[s]) { i -= cnts[s]; ++s; }
-    return a.src[s] + ((size_t)b * PP_CAP + i) * 6;
+    int s = 0, img = b;
+    if (i < n0) {           // image 0's rows first, teacher order preserved
+      while (s < a.nsrc - 1 && i >= cnts0[s]) { i -= cnts0[s]; ++s; }
+      img = 0;
+    } else {
+      i -= n0;
+      while (s < a.nsrc - 1 && i >= cnts[s]) { i -= cnts[s]; ++s; }
+    }
+    return a.src[s] + ((size_t)img * PP_CAP + i) * 6;
   };
   if (n == 0) { if (tid == 0) a.out_cnt[b] = 0; return; }
   // sort keys
@@ -238,12 +250,13 @@ extern "C" int mmd_nms_teacher(const float* cand, const int* n_keep, const float
 // boxes [B,maxg,5] (x1,y1,x2,y2,label) in NMS keep order, nbox [B]
 extern "C" int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2,
                              const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes,
-                             int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, hipStream_t stream) {
+                             int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01,
+                             hipStream_t stream) {
   if (!t0 || !c0 || !boxes || !nbox || !mask_ws || !overflow || B <= 0 || nteachers < 1 || nteachers > 3 || maxg <= 0) return MMD_EINVAL;
   if ((nteachers > 1 && (!t1 || !c1)) || (nteachers > 2 && (!t2 || !c2))) return MMD_EINVAL;
   NmsArgs a{};
   a.src[0] = t0; a.cnt[0] = c0; a.src[1] = t1; a.cnt[1] = c1; a.src[2] = t2; a.cnt[2] = c2; a.nsrc = nteachers;
-  a.mode = 1; a.thr = iou_threshold; a.inclusive = inclusive;
+  a.mode = 1; a.thr = iou_threshold; a.inclusive = inclusive; a.merge01 = (merge01 && B >= 2) ? 1 : 0;
   a.out = boxes; a.out_cnt = nbox; a.out_cols = 5; a.out_cap = maxg; a.mask_ws = mask_ws; a.overflow = overflow;
   hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
   return mmd_check_launch();

@@ -44,6 +44,7 @@ class StepConfig:
     label_map: Optional[List[int]] = None
     inclusive_nms: bool = False
     max_boxes: int = 512
+    augment: bool = False              # cfg audio_augmentation_merge (ModelWithNMSLossAugmented.forward augment=True)
 
 
 class DistillEngine:
@@ -146,7 +147,12 @@ class DistillEngine:
             # teachers fork from here, before the student forward is enqueued
             fork_event = torch.cuda.current_stream().record_event()
         st.begin_step()
-        cls_s, reg_s, feats_s = st.forward(batch["audio"], train=True, drop_scale=drop_scale)
+        audio = batch["audio"]
+        if cfg.augment and B >= 2:      # merge_batch_0_1: image 1 <- log10(a0^10 + a1^10), out of place
+            merged = st._alloc(*audio.shape)
+            call("mmd_audio_merge01", audio, merged, audio[0].numel(), B)
+            audio = merged
+        cls_s, reg_s, feats_s = st.forward(audio, train=True, drop_scale=drop_scale)
         A = cls_s.shape[1]
         nlv = len(feats_s)
         a_s = [self._attention(f) for f in feats_s]
@@ -167,7 +173,10 @@ class DistillEngine:
                 side.wait_event(fork_event)
             with torch.cuda.stream(side):
                 net.begin_step()
-                cls_t, reg_t, feats_t = net.forward(batch[mod], train=False)
+                cls_t, reg_t, feats_t = net.forward(audio if mod == "audio" else batch[mod], train=False)
+                if cfg.augment and B >= 2:      # average_batch_0_1 on the (already consumed by the heads) feature maps
+                    for f in feats_t:
+                        call("mmd_avg_image01", f.z, f.H * f.W * f.C)
                 r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
                 at = [self._attention(f) for f in feats_t]
             rows_t.append(r); cnt_t.append(c); att_t.append(at)
@@ -193,7 +202,7 @@ class DistillEngine:
         boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
         call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
              rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(cfg.merge_iou),
-             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow)
+             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow, 1 if cfg.augment else 0)
         # focal + smooth-L1 with gradients w.r.t. (pre-sigmoid) classifier logits and regression
         nc = st.spec.num_classes
         assign = self.ws.alloc((B * A,), torch.int32); npos = self.ws.alloc((B,), torch.int32)
@@ -320,7 +329,7 @@ class DistillEngine:
         boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
         call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
              rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(cfg.merge_iou),
-             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow)
+             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow, 0)
         torch.cuda.synchronize()
         cs, nb = cnt_s.cpu().tolist(), nbox.cpu().tolist()
         preds = [rows_s[i, :cs[i]].cpu().numpy() for i in range(B)]

@@ -133,7 +133,7 @@ def logits_to_ground_truth(logits, image_size: int, conf_threshold: float, nms_t
 
 
 def merge_teacher_labels(per_teacher: List[List[np.ndarray]], batch: int, iou: float = 0.5,
-                         inclusive=False) -> List[np.ndarray]:
+                         inclusive=False, merge01=False) -> List[np.ndarray]:
     """Concat each image's [n,6] rows over teachers (teacher order preserved), class-agnostic NMS at 0.5 on
     the int-truncated boxes, drop the score column, reorder by NMS keep order -> [m,5]; empty -> []."""
     merged: List = [[] for _ in range(batch)]
@@ -144,6 +144,9 @@ def merge_teacher_labels(per_teacher: List[List[np.ndarray]], batch: int, iou: f
                 continue
             a = a.reshape(-1, 6)
             merged[i] = a if np.size(merged[i]) == 0 else np.concatenate((merged[i], a), axis=0)
+    # augment=True (src/optimization/train_methods.py:379-387): image 1 also gets image 0's rows, in front, if both have any
+    if merge01 and batch >= 2 and np.size(merged[0]) and np.size(merged[1]):
+        merged[1] = np.concatenate((merged[0], merged[1]), axis=0)
     out = []
     for i in range(batch):
         if np.size(merged[i]) == 0:

@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure only): one distillation step on the CPU.
 
 Restates `ModelWithNMSLoss(.Augmented).forward` (src/optimization/train_methods.py:310-422 /
-436-517, augment falsy as with the shipped cfg), the loss mixing + backward of
+436-517; `augment` = the cfg key audio_augmentation_merge, absent -> falsy in the shipped cfg), the loss mixing + backward of
 `train_traditional` (src/optimization/traditional.py:171-190) and torch.optim.Adam as configured in
 src/optimization/train_methods.py:825-833, on top of the functional oracle net.
 Teachers iterate in the reference's ModuleDict insertion order rgb -> depth -> thermal
@@ -26,10 +26,16 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
                     batch: Dict[str, torch.Tensor], image_size: int, coef: int = 2,
                     drop_masks: Optional[Dict[int, torch.Tensor]] = None, conf_threshold: float = 0.3,
                     nms_threshold: float = 0.5, T: float = 9.0, p: float = 2.0, training: bool = True,
-                    kd_mode: str = "pairwise", inclusive_nms: bool = False):
+                    kd_mode: str = "pairwise", inclusive_nms: bool = False, augment: bool = False):
     """-> dict(reg[1], cls[1], kd: list of Tensor[5] per teacher (pairwise) or [Tensor[5]] (list),
                labels: merged [m,5] per image, logits_s, features_s)"""
-    logits_s, feats_s = net.forward(student, batch["audio"], coef, training, drop_masks)
+    audio = batch["audio"]
+    if augment:      # merge_batch_0_1 (train_methods.py:291-308): literal torch.pow(x, 10), floor 1e-7, log10
+        audio = audio.clone()
+        m = torch.pow(audio[0], 10) + torch.pow(audio[1], 10)
+        m[m < 1e-7] = 1e-7
+        audio[1] = torch.log10(m)
+    logits_s, feats_s = net.forward(student, audio, coef, training, drop_masks)
     per_teacher, kd, feats_all = [], [], []
     B = batch["audio"].shape[0]
     for mod in TEACHER_ORDER:
@@ -38,6 +44,10 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
         with torch.no_grad():
             logits_t, feats_t = net.forward(teachers[mod], batch[mod], coef, False)
             feats_t = [f.detach() for f in feats_t]
+            if augment:      # average_batch_0_1 (:279-289)
+                feats_t = [f.clone() for f in feats_t]
+                for f in feats_t:
+                    f[1] = (f[0] + f[1]) / 2
             per_teacher.append(P.logits_to_ground_truth(logits_t, image_size, conf_threshold, nms_threshold,
                                                         inclusive=inclusive_nms))
         if kd_mode == "pairwise":
@@ -46,7 +56,7 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
             feats_all.append(feats_t)
     if kd_mode != "pairwise":
         kd.append(L.mta_loss(feats_s, feats_all, T, p))
-    labels = P.merge_teacher_labels(per_teacher, B, 0.5, inclusive_nms)
+    labels = P.merge_teacher_labels(per_teacher, B, 0.5, inclusive_nms, merge01=augment)
     reg, cls = L.focal_loss(logits_s[0], logits_s[1], logits_s[2], labels)
     return {"reg": reg, "cls": cls, "kd": kd, "labels": labels, "per_teacher": per_teacher,
             "logits_s": logits_s, "features_s": feats_s}

@@ -157,10 +157,48 @@ def test_postproc_golden(golden_dir):
         srcs.append(g(t)); cnts.append(g(c))
     maxg = 512
     boxes = torch.zeros(3, maxg, 5, device=DEV); nbox = torch.zeros(3, dtype=torch.int32, device=DEV)
-    call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf)
+    call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf, 0)
     assert int(ovf.item()) == 0
     for i in range(3):
         n = int(nbox[i].item())
         r = np.asarray(ref[i], dtype=np.float32).reshape(-1, 5)
         assert n == r.shape[0], (i, n, r.shape)
         np.testing.assert_array_equal(boxes[i, :n].cpu().numpy(), r)
+    # augmented variant: image 1 also takes image 0's rows (in front) before the NMS; then with image 0 empty (no merge)
+    # (rows truncated so that image 0 + image 1 stay within the 1024-candidate capacity of the kernel)
+    per_teacher = [[a[:140] for a in tl] for tl in per_teacher]
+    for c, tl in zip(cnts, per_teacher):
+        c.copy_(torch.tensor([a.shape[0] for a in tl], dtype=torch.int32))
+    for empty0 in (False, True):
+        if empty0:
+            for c in cnts:
+                c[0] = 0
+            per_teacher = [[np.zeros((0, 6), np.float32)] + tl[1:] for tl in per_teacher]
+        ref = P.merge_teacher_labels(per_teacher, 3, 0.5, merge01=True)
+        call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf, 1)
+        assert int(ovf.item()) == 0
+        for i in range(3):
+            n = int(nbox[i].item())
+            r = np.asarray(ref[i], dtype=np.float32).reshape(-1, 5)
+            assert n == r.shape[0], (empty0, i, n, r.shape)
+            np.testing.assert_array_equal(boxes[i, :n].cpu().numpy(), r)
+
+
+def test_augmented_variant_kernels():
+    """merge_batch_0_1 / average_batch_0_1 of ModelWithNMSLossAugmented (src/optimization/train_methods.py:279-308)."""
+    torch.manual_seed(5)
+    a = torch.randn(3, 8, 16, 16) * 15 - 40
+    a[0, 0, 0, :4] = 0.0; a[1, 0, 0, :4] = torch.tensor([0.0, 1e-3, -1e-3, 0.05])      # exercises the 1e-7 floor
+    ref = a.clone()
+    m = torch.pow(ref[0], 10) + torch.pow(ref[1], 10)
+    m[m < 1e-7] = 1e-7
+    ref[1] = torch.log10(m)
+    out = torch.empty_like(a, device=DEV)
+    call("mmd_audio_merge01", g(a), out, a[0].numel(), 3)
+    assert torch.equal(out[0].cpu(), a[0]) and torch.equal(out[2].cpu(), a[2])
+    torch.testing.assert_close(out[1].cpu(), ref[1], rtol=2e-6, atol=2e-6)
+    f = torch.randn(3, 40, 112)
+    fd = g(f).clone()
+    call("mmd_avg_image01", fd, 40 * 112)
+    exp = f.clone(); exp[1] = (f[0] + f[1]) / 2
+    assert torch.equal(fd.cpu(), exp)

@@ -21,7 +21,7 @@ MODS = {"rgb": (3, 21), "depth": (3, 22), "thermal": (1, 23)}
 def build(variant, S=256):
     teachers = {k: make_state(2, cin, seed, k, cls_bias=BIAS[k]) for k, (cin, seed) in MODS.items()}
     spec_s, st_s = make_state(2, 8, 24, "audio")
-    cfg = StepConfig(image_size=S, kd_mode=variant)
+    cfg = StepConfig(image_size=S, kd_mode="list" if variant == "list" else "pairwise", augment=variant == "augmented")
     eng = DistillEngine(spec_s, {k: v[0] for k, v in teachers.items()}, DEV, cfg)
     eng.load(st_s, {k: v[1] for k, v in teachers.items()})
     return eng, spec_s
@@ -33,7 +33,7 @@ def drop_scale_from(gold, spec):
     return torch.stack([masks[b.idx] / (1.0 - b.drop_rate) for b in skip]).to(DEV)
 
 
-@pytest.mark.parametrize("variant", ["pairwise", "list"])
+@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented"])
 def test_step_golden(golden_dir, variant):
     gold = np.load(os.path.join(golden_dir, f"step_d2_256_{variant}.npz"))
     S, B = 256, 2

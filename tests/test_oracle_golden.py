@@ -131,7 +131,7 @@ def test_postproc(golden_dir):
         np.testing.assert_array_equal(gt.reshape(-1, 6), g[f"gt{i}"])
 
 
-@pytest.mark.parametrize("variant", ["pairwise", "list"])
+@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented"])
 def test_step(golden_dir, variant):
     g = np.load(os.path.join(golden_dir, f"step_d2_256_{variant}.npz"))
     S, B = 256, 2
@@ -142,7 +142,9 @@ def test_step(golden_dir, variant):
     st = grad_state(st)
     batch = synth_inputs(B, S, seed=31)
     masks = {int(b): torch.from_numpy(m) for b, m in zip(g["drop_blocks"], g["drop_masks"])}
-    out = ST.distill_forward(st, teachers, batch, S, 2, masks, kd_mode=variant)
+    # "augmented" = ModelWithNMSLossAugmented.forward(..., augment=True): pairwise KD + audio merge / feature averaging / label merge
+    out = ST.distill_forward(st, teachers, batch, S, 2, masks, kd_mode="list" if variant == "list" else "pairwise",
+                             augment=variant == "augmented")
     for ti in range(3):
         for i in range(B):
             np.testing.assert_array_equal(out["per_teacher"][ti][i].reshape(-1, 6), g[f"teacher{ti}_img{i}"])

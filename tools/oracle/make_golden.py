@@ -259,7 +259,11 @@ def golden_step():
     states = {k: make_state(2, cin, seed, k, cls_bias=bias[k])[1] for k, (cin, seed) in mods.items()}
     spec, st_s = make_state(2, 8, 24, "audio")
     batch = synth_inputs(B, S, seed=31)
-    for variant, cls_name in [("pairwise", "ModelWithNMSLoss"), ("list", "ModelWithNMSKDListLoss")]:
+    only = os.environ.get("GOLDEN_STEP_VARIANTS", "pairwise,list,augmented").split(",")
+    for variant, cls_name in [("pairwise", "ModelWithNMSLoss"), ("list", "ModelWithNMSKDListLoss"),
+                              ("augmented", "ModelWithNMSLossAugmented")]:
+        if variant not in only:
+            continue
         teachers = torch.nn.ModuleDict()
         for k in ("rgb", "depth", "thermal"):        # reference insertion order (train.py:123-135)
             teachers[k] = ref_model(2, mods[k][0], states[k])
@@ -273,7 +277,10 @@ def golden_step():
                                        cfg(S), VALID)
         opt = torch.optim.Adam(student.parameters(), lr=1e-4, betas=(0.9, 0.999))
         opt.zero_grad()
-        res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"], None)
+        if variant == "augmented":      # augment=True: audio merge, teacher feature averaging, labels of image 0 -> image 1
+            res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"].clone(), None, augment=True)
+        else:
+            res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"], None)
         regl, clsl, kdl = res[0], res[1], res[2]
         loss_main = torch.mean(torch.stack(regl)) + torch.mean(torch.stack(clsl))
         loss = 1.0 * loss_main + 0.005 * torch.sum(torch.stack(kdl))

@@ -63,7 +63,10 @@ def step_config(cfg) -> StepConfig:
                       nms_threshold=cfg.getfloat("nms_threshold", 0.5), T=float(cfg.get("T", 9)), p=float(cfg.get("p", 2)),
                       w_main=cfg.getfloat("w_main", 1.0), w_kd=cfg.getfloat("w_kd", 0.005), lr=cfg.getfloat("lr", 1e-4),
                       b1=cfg.getfloat("b1", 0.9), b2=cfg.getfloat("b2", 0.999), grad_clip=cfg.getfloat("grad_clip", -1),
-                      kd_mode="list" if "kdlist" in method else "pairwise")
+                      kd_mode="list" if "kdlist" in method else "pairwise",
+                      # src/optimization/traditional.py:136: augment = config.getboolean('audio_augmentation_merge'); only
+                      # ModelWithNMSLossAugmented acts on it (key absent from the shipped cfg -> off)
+                      augment=bool(cfg.getboolean("audio_augmentation_merge", False)) and method == "traditional_nms_augmented")
 
 
 def load_states(cfg, coef=2):
