@@ -184,6 +184,18 @@ int mmd_audio_merge01(const float* in, float* out, long long per_image, int B, h
 // ModelWithNMSLossAugmented.average_batch_0_1 (:279-289): f[image 1] = (f[image 0] + f[image 1]) / 2, in place.
 int mmd_avg_image01(float* f, long long per_image, hipStream_t stream);
 
+// ---- input preparation.  cv2 sampling rules restated (cv2 is not in the reference tree): parity with
+// cv2 itself is unpinned, the kernels are pinned to oracle/input_ref.py.
+// (min, max) of clamp(src, lo, hi) for the thermal min-max stretch (src/datasets/MultimodalDetection.py:196-211). dtype: 0 u8, 1 u16, 2 f32.
+int mmd_image_minmax(const void* src, int dtype, long long n, float lo, float hi, float* mm, hipStream_t stream);
+
+// Normalizer + Resizer + HWC->CHW for one image (src/datasets/transformations.py:315-330,407-433; MultimodalDetection.py:245-255):
+// dst[C,S,S] = letterbox(bilinear((pre(src)*scale - mean)/std)); pre = clamp + round((v-min)*255/(max-min)) when minmax != 0.
+int mmd_image_letterbox(const void* src, int dtype, int H, int W, int C, float scale, const float* mean, const float* stdv, int minmax, float lo, float hi, const float* mm, int common_size, float* dst, hipStream_t stream);
+
+// Resizer's audio branch: cv2.resize(INTER_CUBIC) of an [h,w,C] spectrogram stack to [C,S,S] (transformations.py:435-441).
+int mmd_resize_cubic(const float* src, int h, int w, int C, int common_size, float* dst, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,3 +50,88 @@ def collate(batch):
     items = list(zip(*batch))
     return [torch.stack(items[0]), torch.stack(items[1]), torch.stack(items[2]), torch.stack(items[3]), list(items[4]),
             list(items[5])]
+
+
+class RawSyntheticMultimodalDetection(Dataset):
+    """Raw-format samples as the reference decodes them BEFORE its transforms: rgb uint8 [H,W,3], thermal uint16 [H,W]
+    (sensor counts), depth uint8 [H,W,3], audio float32 [h,w,8] (8 dB-mel spectrograms stacked, MultimodalDetection.py:223-227).
+    Feeds DeviceInputPipeline."""
+
+    def __init__(self, config, mode: str = "train", length: int = 64, frame_hw=(270, 360), mel_hw=(128, 128)):
+        self.length = int(config.get('synthetic_length', length))
+        self.seed = int(config.get('seed', 24)) + (0 if mode == "train" else 100003)
+        self.frame_hw, self.mel_hw = frame_hw, mel_hw
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        H, W = self.frame_hw
+        rgb = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+        thermal = torch.randint(19000, 29000, (H, W), generator=g, dtype=torch.int32).to(torch.int16)   # uint16 bit pattern
+        depth = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+        audio = torch.randn(self.mel_hw[0], self.mel_hw[1], 8, generator=g) * 15.0 - 40.0
+        return {"rgb": rgb, "thermal": thermal, "depth": depth, "audio": audio, "id": i}
+
+
+class DeviceInputPipeline:
+    """The reference's Normalizer + Resizer + HWC->CHW (+ thermal clamp/stretch) on the GPU (csrc/input.hip): raw frames are
+    staged in pinned memory, copied on a dedicated stream and transformed there, so H2D and preprocessing of batch n+1
+    overlap the step of batch n; `wait()` orders the compute stream after the batch is ready.  Replaces the per-sample
+    cv2 work of `MultimodalDetection.__getitem__` + `Resizer` (src/datasets/transformations.py:407-467)."""
+
+    MEAN = (0.485, 0.456, 0.406)
+    STD = (0.229, 0.224, 0.225)
+
+    def __init__(self, image_size: int, device, ir_min: float = 20800.0, ir_max: float = 27000.0):
+        from . import _lib
+        self.call = _lib.call
+        self.S = int(image_size)
+        self.device = torch.device(device)
+        self.ir = (float(ir_min), float(ir_max))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.mean = torch.tensor(self.MEAN, dtype=torch.float32, device=self.device)
+        self.std = torch.tensor(self.STD, dtype=torch.float32, device=self.device)
+        self._pinned = {}
+        self._event = None
+        self._batch = None
+
+    def _stage(self, key, t: torch.Tensor) -> torch.Tensor:
+        p = self._pinned.get(key)
+        if p is None or p.shape != t.shape or p.dtype != t.dtype:
+            p = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            self._pinned[key] = p
+        p.copy_(t)
+        return p.to(self.device, non_blocking=True)
+
+    def submit(self, samples):
+        """samples: list of dicts from RawSyntheticMultimodalDetection (or a real decoder with the same raw formats)."""
+        B, S, call = len(samples), self.S, self.call
+        out = {"rgb": torch.empty(B, 3, S, S, device=self.device), "thermal": torch.empty(B, 1, S, S, device=self.device),
+               "depth": torch.empty(B, 3, S, S, device=self.device), "audio": torch.empty(B, 8, S, S, device=self.device)}
+        mm = torch.empty(B, 2, device=self.device)
+        if self._event is not None:
+            self._event.synchronize()          # the pinned buffers of the previous submit have been consumed
+        with torch.cuda.stream(self.stream):
+            for b, smp in enumerate(samples):
+                rgb = self._stage(("rgb", b), smp["rgb"]); H, W = rgb.shape[:2]
+                call("mmd_image_letterbox", rgb, 0, H, W, 3, 1.0 / 255.0, self.mean, self.std, 0, 0.0, 0.0, None, S, out["rgb"][b])
+                d = self._stage(("depth", b), smp["depth"]); H, W = d.shape[:2]
+                call("mmd_image_letterbox", d, 0, H, W, 3, 1.0 / 255.0, None, None, 0, 0.0, 0.0, None, S, out["depth"][b])
+                t = self._stage(("thermal", b), smp["thermal"]); H, W = t.shape[:2]
+                call("mmd_image_minmax", t, 1, H * W, self.ir[0], self.ir[1], mm[b])
+                call("mmd_image_letterbox", t, 1, H, W, 1, 1.0 / 255.0, None, None, 1, self.ir[0], self.ir[1], mm[b], S,
+                     out["thermal"][b])
+                a = self._stage(("audio", b), smp["audio"]); h, w, c = a.shape
+                call("mmd_resize_cubic", a, h, w, c, S, out["audio"][b])
+            self._event = self.stream.record_event()
+        self._batch = out
+        return self
+
+    def wait(self):
+        """-> dict of [B,C,S,S] float32 device tensors, ordered before later work on the current stream."""
+        torch.cuda.current_stream(self.device).wait_event(self._event)
+        for t in self._batch.values():
+            t.record_stream(torch.cuda.current_stream(self.device))
+        return self._batch

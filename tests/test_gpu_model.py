@@ -110,3 +110,7 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     table = evaluate.main(["--config_file", cfgf, "--checkpoint", str(ck), "--overwrite", ov])
     assert set(table) == {"AP@0.5", "AP@0.75", "AP@Ave"}
     assert (tmp_path / "exp" / "results.0.csv").exists()
+    # same entry point with raw frames + the device-side Normalizer/Resizer pipeline and the augmented merge switched on
+    ov2 = ov[:-1] + ', "input_pipeline": "raw", "audio_augmentation_merge": "True", "exp_name": "exp_raw"}'
+    loss2 = train.main(["--config_file", cfgf, "--overwrite", ov2, "--max_steps", "3"])
+    assert np.isfinite(loss2)

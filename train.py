@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from mm_distillnet_amd.arch import make_spec  # noqa: E402
-from mm_distillnet_amd.data import SyntheticMultimodalDetection, collate  # noqa: E402
+from mm_distillnet_amd.data import SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, collate  # noqa: E402
 from mm_distillnet_amd.model import filter_state_dict  # noqa: E402
 from mm_distillnet_amd.step import DistillEngine, StepConfig  # noqa: E402
 from mm_distillnet_amd.synth import synth_state  # noqa: E402
@@ -150,11 +150,15 @@ def main(argv=None):
         import torch.distributed as dist
         dist.broadcast(eng.student.ps.flat, 0)
         eng.student.refresh()
-    train_set = SyntheticMultimodalDetection(cfg, "train")
+    # input_pipeline = raw: samples arrive as decoded frames (uint8/uint16/float mel stacks) and Normalizer/Resizer/transposes
+    # run on the GPU on a copy stream (mm_distillnet_amd.data.DeviceInputPipeline); default: ready-made tensors
+    raw = cfg.get("input_pipeline", "tensor") == "raw"
+    train_set = RawSyntheticMultimodalDetection(cfg, "train") if raw else SyntheticMultimodalDetection(cfg, "train")
+    pipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank) if world > 1 else None
     loader = torch.utils.data.DataLoader(train_set, batch_size=cfg.getint("batch_size"), shuffle=sampler is None,
-                                         drop_last=True, collate_fn=collate, num_workers=cfg.getint("num_workers", 0),
-                                         sampler=sampler, pin_memory=True)
+                                         drop_last=True, collate_fn=(lambda b: b) if raw else collate,
+                                         num_workers=cfg.getint("num_workers", 0), sampler=sampler, pin_memory=not raw)
     sched = Plateau(eng)
     start_epoch, best_loss, best_epoch = 0, 1e10, 0
     ckpt = f"{cfg['exp_name']}/checkpoint.{rank}.pth.tar"
@@ -168,9 +172,14 @@ def main(argv=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         t0, n_img = time.time(), 0
-        for rgb, thermal, depth, audio, label, ids in loader:
-            batch = {"rgb": rgb.to(dev, non_blocking=True), "thermal": thermal.to(dev, non_blocking=True),
-                     "depth": depth.to(dev, non_blocking=True), "audio": audio.to(dev, non_blocking=True)}
+        for item in loader:
+            if raw:
+                batch = pipe.submit(item).wait()
+                audio = batch["audio"]
+            else:
+                rgb, thermal, depth, audio, label, ids = item
+                batch = {"rgb": rgb.to(dev, non_blocking=True), "thermal": thermal.to(dev, non_blocking=True),
+                         "depth": depth.to(dev, non_blocking=True), "audio": audio.to(dev, non_blocking=True)}
             if not captured:
                 eng.capture(batch); captured = True
             out = eng.replay(batch)
