@@ -15,7 +15,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float mmd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1/(1+e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp): `1.0f / y` expands to the ~10-instruction IEEE division
+// sequence (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup), which made every swish-bearing prologue VALU-bound.
+// Limits are exact: x -> -inf gives rcp(inf) = 0, x -> +inf gives rcp(1) = 1.
+__device__ __forceinline__ float mmd_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float mmd_swish(float x) { return x * mmd_sigmoid(x); }
 // d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))   (reference: SwishImplementation.backward)
 __device__ __forceinline__ float mmd_swish_grad(float x) {
