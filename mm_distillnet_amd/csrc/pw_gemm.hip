@@ -34,7 +34,7 @@ struct PwArgs {
 #define PW_LD 36
 
 template <int BN_T>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(PwArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
   constexpr int NS = BN_T / 32;          // 32-col slabs per wave
   constexpr int NB = BN_T / 32;          // B float4 loads per thread (BN_T*8/256)
   constexpr int LDC = BN_T + 4;            // C staging row stride (floats)
