@@ -78,8 +78,14 @@ int mmd_chan_pool(const float* z, const float* scale, const float* shift, const 
 // Squeeze-excite FCs: gate = sigmoid(We*swish(Wr*pooled+br)+be) (src/YetAnotherEfficientNet.py:471-474).
 int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
 
-// Backward of the squeeze-excite FCs (weight grads +=, dpooled scaled by dpool_scale = 1/HW).
-int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
+// One pass over (z1, g1): out5[5][B][C] += (sum g1*swish(u), sum g1*swish'(u), sum g1*swish'(u)*xhat, sum swish'(u), sum swish'(u)*xhat)
+// per (image, channel): d(gate) for the SE backward plus the partials of the BatchNorm-1 backward sums (autograd of
+// src/YetAnotherEfficientNet.py:466-476), so the expanded tensor is not read again by a BN reduce pass.
+int mmd_chan_pool_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, const float* g1, float* out5, int B, int rows_per_image, int C, hipStream_t stream);
+
+// Backward of the squeeze-excite FCs (weight grads +=, dpooled scaled by dpool_scale = 1/HW).  With pool5 (from
+// mmd_chan_pool_bwd; dgate = pool5[0]) it also finishes the BN-1 sums: bn_sums[c] += sum_b gate*pool5[1] + dpooled*pool5[3], [C+c] likewise with [2],[4].
+int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, const float* pool5, double* bn_sums, hipStream_t stream);
 
 // BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat). g_out may be NULL (g not stored).
 int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, double* stats_ws, int ws_slots, hipStream_t stream);

@@ -194,6 +194,72 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
   return mmd_check_launch();
 }
 
+// Backward companion of the squeeze-excite pool: ONE pass over (z1, g1) yields, per (image, channel), everything the
+// SE backward and the BatchNorm-1 backward need, so no separate BN reduce pass reads the expanded tensor again:
+//   out[0] = sum g1*a      (d gate)            a  = swish(u), u = z*scale+shift
+//   out[1] = sum g1*s'     out[2] = sum g1*s'*xhat      s' = swish'(u), xhat = (z-mean)*invstd
+//   out[3] = sum s'        out[4] = sum s'*xhat
+// With g = (g1*gate + dpooled)*s' (the BN-1 upstream gradient):  sum g = gate*out[1] + dpooled*out[3] summed over images,
+// sum g*xhat = gate*out[2] + dpooled*out[4]  (finished in se_bwd_b_kernel once dpooled is known).   out: [5][B][C], zeroed.
+__global__ __launch_bounds__(256) void chan_pool_bwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ g1,
+                                                            float* __restrict__ out, int B, int rows_per_image, int C,
+                                                            int nsplit) {
+  __shared__ float sRed[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  const int b = blockIdx.y;
+  const bool cok = c < C;
+  float acc[5][4];
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
+  if (cok) {
+    const float4 sc = mmd_ld4(scale + c), sh = mmd_ld4(shift + c), mu = mmd_ld4(mean + c), is = mmd_ld4(invstd + c);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll 2
+    for (int r = blockIdx.z * 16 + (tid >> 4); r < rows_per_image; r += 16 * nsplit) {
+      size_t off = ((size_t)b * rows_per_image + r) * C + c;
+      const float4 zz = mmd_ld4(z + off), gg = mmd_ld4(g1 + off);
+      const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float u = zv[i] * scv[i] + shv[i];
+        float sg = mmd_sigmoid(u);
+        float sp = sg * (1.0f + u * (1.0f - sg));
+        float xh = (zv[i] - muv[i]) * isv[i];
+        acc[0][i] += gv[i] * (u * sg);
+        acc[1][i] += gv[i] * sp;
+        acc[2][i] += gv[i] * sp * xh;
+        acc[3][i] += sp;
+        acc[4][i] += sp * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float s = block_chan_sum(make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]), sRed, tid);
+    if (tid < 64 && blockIdx.x * 64 + tid < C) atomicAdd(&out[((size_t)k * B + b) * C + blockIdx.x * 64 + tid], s);
+    __syncthreads();
+  }
+}
+extern "C" int mmd_chan_pool_bwd(const float* z, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, const float* g1, float* out5, int B, int rows_per_image, int C,
+                                 hipStream_t stream) {
+  if (!z || !scale || !shift || !mean || !invstd || !g1 || !out5 || B <= 0 || rows_per_image <= 0 || C <= 0 || (C & 3))
+    return MMD_EINVAL;
+  int base = cdiv(C, 64) * B;
+  int ns = cdiv(1024, base); int mx = cdiv(rows_per_image, 64); if (ns > mx) ns = mx; if (ns < 1) ns = 1;
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  hipLaunchKernelGGL(chan_pool_bwd_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift, mean, invstd, g1,
+                     out5, B, rows_per_image, C, ns);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * B * (double)rows_per_image * C * 2);
+  return mmd_check_launch();
+}
+
 // ---------------------------------------------------------------- squeeze-excite FCs
 // reference: src/YetAnotherEfficientNet.py:469-474.  wr [S,C], br [S], be [C]; the expand weight is kept TRANSPOSED,
 // wet [S,C] (native layout of the engine), so every access below is coalesced over channels.
@@ -255,7 +321,9 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* __restrict__
 // step 1b: dpr[b,j] = dh[b,j]*swish'(hpre[b,j]); dpooled[b,c] = dpool_scale * sum_j wr[j,c]*dpr[b,j]
 __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* __restrict__ dh, const float* __restrict__ hpre,
                                                        const float* __restrict__ wr, float* __restrict__ dpr,
-                                                       float* __restrict__ dpooled, float dpool_scale, int C, int S) {
+                                                       float* __restrict__ dpooled, float dpool_scale, int C, int S,
+                                                       const float* __restrict__ gate, const float* __restrict__ pool5,
+                                                       double* bn_sums, int B) {
   __shared__ float sd[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int j = tid; j < S; j += 256) {
@@ -268,7 +336,14 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* __restrict__
   if (c >= C) return;
   float acc = 0.f;
   for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sd[j];
-  dpooled[(size_t)b * C + c] = acc * dpool_scale;
+  const float dp = acc * dpool_scale;
+  dpooled[(size_t)b * C + c] = dp;
+  if (bn_sums) {     // BatchNorm-1 sums from the pooled partials (chan_pool_bwd_kernel): B adds per address
+    const size_t i = (size_t)b * C + c, n = (size_t)B * C;
+    const float gt = gate[i];
+    atomicAdd(&bn_sums[c], (double)(gt * pool5[n + i] + dp * pool5[3 * n + i]));
+    atomicAdd(&bn_sums[C + c], (double)(gt * pool5[2 * n + i] + dp * pool5[4 * n + i]));
+  }
 }
 // step 2 (grid over weights, sums over the batch, no atomics):
 //   dwe[c,j] += sum_b dpe[b,c]*swish(hpre[b,j]); dbe[c] += sum_b dpe[b,c]
@@ -304,14 +379,14 @@ __global__ void se_fc_wgrad_kernel(const float* __restrict__ dpe, const float* _
 extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled,
                              const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed,
                              float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B,
-                             int C, int S, hipStream_t stream) {
+                             int C, int S, const float* pool5, double* bn_sums, hipStream_t stream) {
   if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dh_zeroed || !dpooled || !dwr || !dbr ||
       !dwe || !dbe)
     return MMD_EINVAL;
-  if (B <= 0 || C <= 0 || S <= 0 || S > 256) return MMD_EINVAL;
+  if (B <= 0 || C <= 0 || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
   hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, dgate, gate, we, dpe_ws, dh_zeroed, C, S);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dh_zeroed, hpre, wr, dpr_ws, dpooled,
-                     dpool_scale, C, S);
+                     dpool_scale, C, S, gate, pool5, bn_sums, B);
   hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,
                      pooled, dwr, dbr, dwe, dbe, B, C, S);
   return mmd_check_launch();

@@ -510,12 +510,14 @@ class Net:
             yield
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
-                mul_bc=None, mul_b=None, add_bc=None) -> torch.Tensor:
-        """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated."""
+                mul_bc=None, mul_b=None, add_bc=None, sums=None) -> torch.Tensor:
+        """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated.
+        `sums` given = the per-channel sums were produced elsewhere (fused into another pass): pass 2 only."""
         b = self.ps.bn(bn_name)
-        sums = self._zalloc((2 * C,), torch.float64)
-        call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C,
-             *self._stats_ws(sums, M, C))
+        if sums is None:
+            sums = self._zalloc((2 * C,), torch.float64)
+            call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C,
+                 *self._stats_ws(sums, M, C))
         dz = self._alloc(M, C)
         call("mmd_bn_bwd_apply", g_in, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C,
              aff[0], aff[1], act, mul_bc, mul_b, add_bc, rpi)
@@ -714,19 +716,22 @@ class Net:
             if blk.skip:
                 self._acc(slot(inp), dy)
             g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
-            # squeeze-excite backward
-            dgate = self._zalloc((f1.B, blk.cmid))
-            call("mmd_chan_pool", f1.z, f1.scale, f1.shift, None, None, None, 0, SWISH, g1, dgate, 1.0, f1.B, HW1, blk.cmid)
+            # squeeze-excite backward.  One pass over (z1, g1) pools d(gate) AND the partials of the BN-1 backward sums; the
+            # SE kernels finish those sums once dpooled is known, so the expanded tensor is not read by a BN reduce pass
+            a1 = rec["bn1"]
+            pool5 = self._zalloc((5, f1.B, blk.cmid))
+            call("mmd_chan_pool_bwd", f1.z, a1[0], a1[1], a1[2], a1[3], g1, pool5, f1.B, HW1, blk.cmid)
             dpe = self._alloc(f1.B, blk.cmid)
             dpr = self._alloc(f1.B, blk.se)
             dpooled = self._alloc(f1.B, blk.cmid)
             dh = self._zalloc((f1.B, blk.se))
-            call("mmd_se_fc_bwd", dgate, rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
+            sums1 = self._zalloc((2 * blk.cmid,), torch.float64)
+            call("mmd_se_fc_bwd", pool5[0], rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
                  ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, ps.g(f"{q}._se_reduce.conv.weight"),
                  ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"), ps.g(f"{q}._se_expand.conv.bias"),
-                 f1.B, blk.cmid, blk.se)
-            dz1 = self._bn_bwd(g1, f1.z, rec["bn1"], f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
-                               add_bc=dpooled)
+                 f1.B, blk.cmid, blk.se, pool5, sums1)
+            dz1 = self._bn_bwd(g1, f1.z, a1, f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
+                               add_bc=dpooled, sums=sums1)
             f0: Feat = rec.get("f0", inp)
             g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
             if blk.expand != 1:

@@ -232,7 +232,8 @@ def test_se_path():
     dpe, dpr, dpooled = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
     gwr, gbr, gwe, gbe = (torch.zeros_like(t, device=DEV) for t in (wr, br, we.t().contiguous(), be))
     dhz = torch.zeros(B, S, device=DEV)
-    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), wet, dpe, dpr, dhz, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S)
+    call("mmd_se_fc_bwd", dgate, dg, dh, dpool, g(wr), wet, dpe, dpr, dhz, dpooled, 1.0 / HW, gwr, gbr, gwe, gbe, B, C, S,
+         None, None)
     close(gwr, wr.grad, 3e-4, 1e-5, "dwr"); close(gbr, br.grad, 3e-4, 1e-5); close(gwe, we.grad.t(), 3e-4, 1e-5, "dwe")
     close(gbe, be.grad, 3e-4, 1e-5)
     # full dz through bn_bwd_reduce with mul_bc = gate, add_bc = dpooled (identity "BN": mean 0, invstd 1)
@@ -241,6 +242,21 @@ def test_se_path():
     call("mmd_bn_bwd_reduce", g(gout.reshape(B * HW, C)), g(z), g(sc), g(sh), torch.zeros(C, device=DEV),
          torch.ones(C, device=DEV), 1, dg, None, dpooled, HW, gy, sums, B * HW, C, None, 0)
     close(gy * g(sc), z.grad, 3e-4, 1e-5, "dz through SE")
+    # product path: one pooled pass gives d(gate) AND the BatchNorm sums (no reduce pass); non-trivial mean / invstd
+    mu, istd = torch.randn(C) * 0.2, torch.rand(C) + 0.5
+    ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", g(gout.reshape(B * HW, C)), g(z), g(sc), g(sh), g(mu), g(istd), 1, dg, None, dpooled, HW, None, ref,
+         B * HW, C, None, 0)
+    pool5 = torch.zeros(5, B, C, device=DEV)
+    call("mmd_chan_pool_bwd", g(z), g(sc), g(sh), g(mu), g(istd), g(gout.reshape(B * HW, C)), pool5, B, HW, C)
+    close(pool5[0], dgate, 1e-5, 1e-6, "dgate from the pooled backward pass")
+    sums2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    dpooled2 = torch.empty(B, C, device=DEV)
+    g2 = [torch.zeros_like(t) for t in (gwr, gbr, gwe, gbe)]
+    call("mmd_se_fc_bwd", pool5[0], dg, dh, dpool, g(wr), wet, dpe, dpr, dhz.zero_(), dpooled2, 1.0 / HW, *g2, B, C, S, pool5, sums2)
+    close(dpooled2, dpooled, 1e-5, 1e-6); close(g2[0], gwr, 1e-5, 1e-6)
+    close(sums2[:C], ref[:C], 2e-5, 2e-5, "BN-1 sum g from pooled partials")
+    close(sums2[C:], ref[C:], 2e-5, 2e-5, "BN-1 sum g*xhat from pooled partials")
 
 
 def test_colsum_slice_sigmoid():
