@@ -51,8 +51,10 @@ int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, co
 // Replaces Conv2dStaticSamePadding(groups=C) (src/YetAnotherEfficientNet.py:433-435, src/YetAnotherEfficientDet.py:169-170) incl. F.pad (:51-65).
 int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream);
 
-// Input gradient of the depthwise conv.
-int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, hipStream_t stream);
+// Input gradient of the depthwise conv.  With bn_sums (stride 1 only) the launch also accumulates the sums of the BatchNorm(+swish)
+// backward that consumes dx: bn_sums[c] += sum dx*swish'(u), bn_sums[C+c] += sum dx*swish'(u)*xhat, u = bn_z*bn_scale+bn_shift,
+// xhat = (bn_z-bn_mean)*bn_invstd (bn_z = that BN's forward input, same shape as dx); stats_ws/ws_slots as in mmd_dwconv_fwd.
+int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, hipStream_t stream);
 
 // Weight gradient of the depthwise conv, tap-major dw[k*k, C] (+=).
 int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, hipStream_t stream);

@@ -22,6 +22,9 @@ struct DwArgs {
   const float* out_scale; const float* out_shift; int out_act;
   double* stats; float* pool; float pool_scale;
   double* stats_ws; int ws_slots;            // slotted sums (common.h)
+  // input-gradient launch feeding a BatchNorm(+swish) backward: stats become (sum g, sum g*xhat) with g = y * swish'(u),
+  // u = bz*bscale + bshift, xhat = (bz - bmean)*binvstd, bz = the BN's forward input at the output position (y itself is stored)
+  const float* bz; const float* bscale; const float* bshift; const float* bmean; const float* binvstd;
   int tiles_h, tiles_w, cchunks;
   Pyr pyr; long long lev_stride;
 };
@@ -162,14 +165,26 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
   if (a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
+  float4 bsc, bsh, bmu, bis;
+  if (a.bz && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
   const int oh = oh0 + orow;
 #pragma unroll
   for (int o = 0; o < Cf::R; ++o) {
     int ow = ow0 + ocol0 + o;
     if (cok && oh < OH && ow < OW) {
       float4 v = acc[o];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+      if (a.bz) {
+        const float4 zz = mmd_ld4(a.bz + (((size_t)b * OH + oh) * OW + ow) * a.C + c);
+        float4 gg;
+        gg.x = v.x * mmd_swish_grad(zz.x * bsc.x + bsh.x); gg.y = v.y * mmd_swish_grad(zz.y * bsc.y + bsh.y);
+        gg.z = v.z * mmd_swish_grad(zz.z * bsc.z + bsh.z); gg.w = v.w * mmd_swish_grad(zz.w * bsc.w + bsh.w);
+        s.x += gg.x; s.y += gg.y; s.z += gg.z; s.w += gg.w;
+        ss.x += gg.x * (zz.x - bmu.x) * bis.x; ss.y += gg.y * (zz.y - bmu.y) * bis.y;
+        ss.z += gg.z * (zz.z - bmu.z) * bis.z; ss.w += gg.w * (zz.w - bmu.w) * bis.w;
+      } else {
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+      }
       float4 t = v;
       if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
       if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
@@ -337,9 +352,12 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
 
 // dx[B,H,W,C] (=) dwconv^T(dy[B,OH,OW,C], w)
 extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k,
-                                   int stride, hipStream_t stream) {
+                                   int stride, const float* bn_z, const float* bn_scale, const float* bn_shift,
+                                   const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws,
+                                   int ws_slots, hipStream_t stream) {
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
+  if (bn_sums && (stride != 1 || !bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
   int OH, OW;
   int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
@@ -348,6 +366,10 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
     DwArgs a{};
     a.x = dy; a.w = w; a.y = dx; a.B = B; a.H = H; a.W = W; a.C = C; a.OH = H; a.OW = W;
     a.pad_t = k - 1 - pt; a.pad_l = k - 1 - pl; a.flip = 1;
+    if (bn_sums) {
+      a.stats = bn_sums; a.stats_ws = stats_ws; a.ws_slots = ws_slots;
+      a.bz = bn_z; a.bscale = bn_scale; a.bshift = bn_shift; a.bmean = bn_mean; a.binvstd = bn_invstd;
+    }
     rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch<5, 1>(a, stream);
   } else {
     size_t total = (size_t)B * H * W * (C >> 2);

@@ -538,15 +538,22 @@ class Net:
         call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dx, M, K, N, 0)
         return dx
 
-    def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True):
+    def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True, bn_aff=None):
+        """-> dx, or (dx, sums) when `bn_aff` = (scale, shift, mean, invstd) of the BatchNorm(+swish) that produced x: the
+        stride-1 input-gradient launch then also accumulates that BN's backward sums (no separate reduce pass)."""
         ps = self.ps
         with self._wgrad_stream():
             call("mmd_dwconv_bwd_weight", x.z, dzd, ps.g(wkey), x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act)
         if not want_dx:
             return None
         dx = self._alloc(x.M, x.C)
-        call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s)
-        return dx
+        if bn_aff is not None and s == 1:
+            sums = self._zalloc((2 * x.C,), torch.float64)
+            call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, x.z, bn_aff[0], bn_aff[1], bn_aff[2],
+                 bn_aff[3], sums, *self._stats_ws(sums, x.M, x.C))
+            return dx, sums
+        call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, None, None, None, None, None, None, None, 0)
+        return (dx, None) if bn_aff is not None else dx
 
     def _head_bwd(self, hname: str, per_anchor: int, dout: torch.Tensor, tape: dict, pyr: dict, A: int, C: int):
         """Backward of one head over the whole pyramid; returns the gradient w.r.t. the pyramid feature buffer."""
@@ -733,12 +740,13 @@ class Net:
             dz1 = self._bn_bwd(g1, f1.z, a1, f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
                                add_bc=dpooled, sums=sums1)
             f0: Feat = rec.get("f0", inp)
-            g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
             if blk.expand != 1:
-                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid)
+                g0, sums0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, bn_aff=rec["bn0"])
+                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0)
                 dx = self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True)
                 self._acc(slot(inp), dx)
             else:
+                g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
                 self._acc(slot(inp), g0)
         # ---- stem
         colf, stem, mu, istd = tape["stem"]
