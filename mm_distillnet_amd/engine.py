@@ -708,6 +708,7 @@ class Net:
                     self._acc(slot(x), dx)
         # ---- backbone (blocks in reverse)
         P = "backbone_net.model"
+        stem_sums = None
         for blk in reversed(spec.blocks):
             q = f"{P}._blocks.{blk.idx}"
             rec = tape[f"blk{blk.idx}"]
@@ -745,13 +746,19 @@ class Net:
                 dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0)
                 dx = self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True)
                 self._acc(slot(inp), dx)
+            elif blk.idx == 0 and not blk.skip and blk.stride == 1 and slot(inp).t is None:
+                # block 0 consumes the stem activation directly and is its only consumer: the stem BN's backward sums ride
+                # in this input-gradient launch
+                g0, stem_sums = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
+                                             bn_aff=(inp.scale, inp.shift, tape["stem"][2], tape["stem"][3]))
+                self._acc(slot(inp), g0)
             else:
                 g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
                 self._acc(slot(inp), g0)
         # ---- stem
         colf, stem, mu, istd = tape["stem"]
         s = slot(stem)
-        dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C)
+        dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
         self._pw_bwd(dz, colf, f"{P}._conv_stem.conv.weight", stem.C, None, False)
         if self._wg is not None:
             torch.cuda.current_stream().wait_stream(self._wg)
