@@ -28,7 +28,7 @@ int mmd_bifpn_fuse_fwd(const float* in0, const float* in1, const float* up, cons
 int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* f_out, float* zd, int B, int H, int W, int C, hipStream_t stream);
 
 // Backward of the fusion node, part 1: dx = df*swish'(x), wdot[i] += <dx, operand_i>.
-int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W, int C, hipStream_t stream);
+int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream);
 
 // Backward of w = relu(theta)/(sum+1e-4).
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
@@ -88,6 +88,9 @@ int mmd_chan_pool_bwd(const float* z, const float* scale, const float* shift, co
 // Backward of the squeeze-excite FCs (weight grads +=, dpooled scaled by dpool_scale = 1/HW).  With pool5 (from
 // mmd_chan_pool_bwd; dgate = pool5[0]) it also finishes the BN-1 sums: bn_sums[c] += sum_b gate*pool5[1] + dpooled*pool5[3], [C+c] likewise with [2],[4].
 int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, const float* pooled, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed, float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, const float* pool5, double* bn_sums, hipStream_t stream);
+
+// Weight/bias gradients of the SE FCs alone (mmd_se_fc_bwd with dwr == NULL skips them): dpe/dpr are mmd_se_fc_bwd's workspaces.
+int mmd_se_fc_wgrad(const float* dpe, const float* dpr, const float* hpre, const float* pooled, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
 
 // BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat). g_out may be NULL (g not stored).
 int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, double* stats_ws, int ws_slots, hipStream_t stream);

@@ -178,8 +178,11 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
 }
 
 // backward part 1: dx = df * swish'(x) (x recomputed from the operands); wdot[i] += <dx, operand_i>
+// The gradients of the same-resolution operands (in0, in1) are w_i * dx: written / accumulated here (d0, d1 nullable) instead
+// of by a scale_acc launch each; dx itself is stored only when an upsampled or pooled operand still needs it.
 __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a, const float* __restrict__ df, float* __restrict__ dx,
-                                                       float* wdot) {
+                                                       float* wdot, float* __restrict__ d0, int acc0,
+                                                       float* __restrict__ d1, int acc1) {
   __shared__ float sred[4 * 3];
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
@@ -196,7 +199,17 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a, const float* 
     size_t off = (((size_t)b * a.H + h) * a.W + x) * a.C + c;
     float4 g = mmd_ld4(df + off);
     g.x *= mmd_swish_grad(s.x); g.y *= mmd_swish_grad(s.y); g.z *= mmd_swish_grad(s.z); g.w *= mmd_swish_grad(s.w);
-    mmd_st4(dx + off, g);
+    if (dx) mmd_st4(dx + off, g);
+    if (d0) {
+      float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
+      if (acc0) { float4 p = mmd_ld4(d0 + off); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+      mmd_st4(d0 + off, v);
+    }
+    if (d1) {      // in1 present: its weight is w[1]
+      float4 v = make_float4(g.x * w[1], g.y * w[1], g.z * w[1], g.w * w[1]);
+      if (acc1) { float4 p = mmd_ld4(d1 + off); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+      mmd_st4(d1 + off, v);
+    }
     int wi = 0;
     d[wi++] = g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
     if (a.in1) d[wi++] = g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
@@ -212,12 +225,12 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseArgs a, const float* 
 }
 extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool,
                                   const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W,
-                                  int C, hipStream_t stream) {
+                                  int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
-  if (rc || !df || !dx || !wdot) return MMD_EINVAL;
+  if (rc || !df || !wdot || (!dx && !d0) || (d1 && !in1)) return MMD_EINVAL;
   size_t total = (size_t)B * H * W * (C >> 2);
-  hipLaunchKernelGGL(fuse_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, df, dx, wdot);
+  hipLaunchKernelGGL(fuse_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, df, dx, wdot, d0, acc0, d1, acc1);
   return mmd_check_launch();
 }
 

@@ -380,15 +380,23 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
                              const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dh_zeroed,
                              float* dpooled, float dpool_scale, float* dwr, float* dbr, float* dwe, float* dbe, int B,
                              int C, int S, const float* pool5, double* bn_sums, hipStream_t stream) {
-  if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dh_zeroed || !dpooled || !dwr || !dbr ||
-      !dwe || !dbe)
-    return MMD_EINVAL;
+  if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dh_zeroed || !dpooled) return MMD_EINVAL;
+  if (dwr && (!dbr || !dwe || !dbe)) return MMD_EINVAL;         // dwr == NULL: weight gradients left to mmd_se_fc_wgrad
   if (B <= 0 || C <= 0 || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
   hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, dgate, gate, we, dpe_ws, dh_zeroed, C, S);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dh_zeroed, hpre, wr, dpr_ws, dpooled,
                      dpool_scale, C, S, gate, pool5, bn_sums, B);
-  hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,
-                     pooled, dwr, dbr, dwe, dbe, B, C, S);
+  if (dwr)
+    hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,
+                       pooled, dwr, dbr, dwe, dbe, B, C, S);
+  return mmd_check_launch();
+}
+// the weight-gradient half of mmd_se_fc_bwd on its own (a leaf of the backward graph: the engine issues it on the wgrad stream)
+extern "C" int mmd_se_fc_wgrad(const float* dpe, const float* dpr, const float* hpre, const float* pooled, float* dwr, float* dbr,
+                               float* dwe, float* dbe, int B, int C, int S, hipStream_t stream) {
+  if (!dpe || !dpr || !hpre || !pooled || !dwr || !dbr || !dwe || !dbe || B <= 0 || C <= 0 || S <= 0 || S > 256) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe, dpr, hpre, pooled, dwr,
+                     dbr, dwe, dbe, B, C, S);
   return mmd_check_launch();
 }
 

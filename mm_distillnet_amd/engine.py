@@ -659,23 +659,34 @@ class Net:
                 in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
                 th = ps.w(f"{cell}.{rec['theta']}")
                 nth = th.numel()
-                dx = self._alloc(out.M, W)
+                # gradients of the same-resolution operands (in0, in1) come straight out of the fuse backward launch; dx is
+                # only materialised for an upsampled / pooled operand
+                same = []
+                for operand in (in0, in1):
+                    if operand is None:
+                        same += [None, 0]
+                        continue
+                    sl = slot(operand)
+                    accumulate = 0 if sl.t is None else 1
+                    if sl.t is None:
+                        sl.t = self._alloc(operand.M, W)
+                    same += [sl.t, accumulate]
+                assert in1 is None or same[0].data_ptr() != same[2].data_ptr()
+                dx = self._alloc(out.M, W) if (up is not None or pl is not None) else None
                 wdot = self._zalloc((4,))
                 call("mmd_bifpn_fuse_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-                     df, dx, wdot, in0.B, in0.H, in0.W, W)
+                     df, dx, wdot, in0.B, in0.H, in0.W, W, *same)
                 with self._wgrad_stream():
                     call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
-                wi = 0
-                for operand, kind in ((in0, "same"), (in1, "same"), (up, "up"), (pl, "pool")):
+                wi = 1 + (1 if in1 is not None else 0)
+                for operand, kind in ((up, "up"), (pl, "pool")):
                     if operand is None:
                         continue
                     sl = slot(operand)
                     accumulate = 0 if sl.t is None else 1
                     if sl.t is None:
                         sl.t = self._alloc(operand.M, W)
-                    if kind == "same":
-                        call("mmd_scale_acc", dx, sl.t, th, nth, wi, accumulate, dx.numel())
-                    elif kind == "up":
+                    if kind == "up":
                         call("mmd_upsample2_bwd_acc", dx, sl.t, th, nth, wi, accumulate, in0.B, in0.H, in0.W, W)
                     else:
                         call("mmd_maxpool_same_bwd_acc", operand.z, dx, sl.t, th, nth, wi, accumulate, operand.B, operand.H,
@@ -735,9 +746,12 @@ class Net:
             dh = self._zalloc((f1.B, blk.se))
             sums1 = self._zalloc((2 * blk.cmid,), torch.float64)
             call("mmd_se_fc_bwd", pool5[0], rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
-                 ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, ps.g(f"{q}._se_reduce.conv.weight"),
-                 ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"), ps.g(f"{q}._se_expand.conv.bias"),
+                 ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, None, None, None, None,
                  f1.B, blk.cmid, blk.se, pool5, sums1)
+            with self._wgrad_stream():
+                call("mmd_se_fc_wgrad", dpe, dpr, rec["hpre"], rec["pooled"], ps.g(f"{q}._se_reduce.conv.weight"),
+                     ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"), ps.g(f"{q}._se_expand.conv.bias"),
+                     f1.B, blk.cmid, blk.se)
             dz1 = self._bn_bwd(g1, f1.z, a1, f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
                                add_bc=dpooled, sums=sums1)
             f0: Feat = rec.get("f0", inp)

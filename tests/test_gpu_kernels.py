@@ -328,7 +328,19 @@ def test_bifpn_fuse(mode):
     close(out.view(B, H, W, C), nhwc(f), 2e-4, 1e-5, "fuse fwd")
     dx = torch.empty(B * H * W, C, device=DEV)
     wdot = torch.zeros(4, device=DEV)
-    call("mmd_bifpn_fuse_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), gp(df), dx, wdot, B, H, W, C)
+    call("mmd_bifpn_fuse_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), gp(df), dx, wdot, B, H, W, C, None, 0, None, 0)
+    # product path: the same-resolution operand gradients come out of the same launch (accumulating / overwriting)
+    f0 = torch.full((B * H * W, C), 0.25, device=DEV)
+    f1 = torch.full((B * H * W, C), 7.0, device=DEV) if in1 is not None else None
+    dx2 = torch.empty_like(dx) if (up is not None or pl is not None) else None
+    wdot2 = torch.zeros(4, device=DEV)
+    call("mmd_bifpn_fuse_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), gp(df), dx2, wdot2, B, H, W, C, f0, 1, f1, 0)
+    close(f0.view(B, H, W, C), nhwc(in0.grad) + 0.25, 3e-4, 1e-5, "din0 fused")
+    if in1 is not None:
+        close(f1.view(B, H, W, C), nhwc(in1.grad), 3e-4, 1e-5, "din1 fused")
+    if dx2 is not None:
+        assert torch.equal(dx2, dx)
+    close(wdot2, wdot, 1e-5, 1e-6)
     dth = torch.zeros(n, device=DEV)
     call("mmd_bifpn_theta_bwd", g(theta), wdot, dth, n)
     close(dth, theta.grad, 5e-4, 1e-5, "dtheta")
