@@ -33,7 +33,10 @@ struct PwArgs {
 #define PW_BK 32
 #define PW_LD 36
 
-template <int BN_T>
+// NKL = 8-wide k groups of the LAST K tile that hold data (1..4): fp32 MFMA runs at the vector rate (64 cycles per
+// 32x32x2), so multiplying the zero padding of K = 112 / 48 / 24 ... is real time.  Compile-time so the hot loop keeps its schedule
+// (a run-time trip count cost more than the padding).
+template <int BN_T, int NKL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
   constexpr int NS = BN_T / 32;          // 32-col slabs per wave
   constexpr int NB = BN_T / 32;          // B float4 loads per thread (BN_T*8/256)
@@ -121,26 +124,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   const int nk = (a.K + PW_BK - 1) / PW_BK;
   gload(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const float* const pa = &sA[(wave * 32 + r) * PW_LD + h * 4];
+  const float* const pb = &sB[r * PW_LD + h * 4];
+  auto mma = [&](int kk) {
+    float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * PW_LD + kk * 8);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
+    }
+  };
+  for (int kt = 0; kt < nk - 1; ++kt) {
     lstore();
     __syncthreads();
-    if (kt + 1 < nk) gload((kt + 1) * PW_BK);
-    const float* pa = &sA[(wave * 32 + r) * PW_LD + h * 4];
-    const float* pb = &sB[r * PW_LD + h * 4];
+    gload((kt + 1) * PW_BK);
 #pragma unroll
-    for (int kk = 0; kk < PW_BK / 8; ++kk) {
-      float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * PW_LD + kk * 8);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
-      }
-    }
+    for (int kk = 0; kk < PW_BK / 8; ++kk) mma(kk);
     __syncthreads();
   }
+  lstore();                      // last K tile: only its populated 8-wide groups
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < NKL; ++kk) mma(kk);
+  __syncthreads();
 
   // ---- epilogue.  The accumulator (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) is staged through LDS so every
   // thread then owns 4 consecutive columns: dwordx4 stores / residual loads (4x fewer store instructions than
@@ -630,12 +639,18 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
     hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
-  } else if (N <= 32) {
-    a.ntn = cdiv(N, 32); a.nblk = ntm * a.ntn;
-    hipLaunchKernelGGL(pw_gemm_kernel<32>, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
-    a.ntn = cdiv(N, 64); a.nblk = ntm * a.ntn;
-    hipLaunchKernelGGL(pw_gemm_kernel<64>, dim3(a.nblk), dim3(256), 0, stream, a);
+    const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
+    void (*kern)(PwArgs);
+    if (N <= 32) {
+      a.ntn = cdiv(N, 32);
+      kern = nkl == 1 ? pw_gemm_kernel<32, 1> : nkl == 2 ? pw_gemm_kernel<32, 2> : nkl == 3 ? pw_gemm_kernel<32, 3> : pw_gemm_kernel<32, 4>;
+    } else {
+      a.ntn = cdiv(N, 64);
+      kern = nkl == 1 ? pw_gemm_kernel<64, 1> : nkl == 2 ? pw_gemm_kernel<64, 2> : nkl == 3 ? pw_gemm_kernel<64, 3> : pw_gemm_kernel<64, 4>;
+    }
+    a.nblk = ntm * a.ntn;
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
   }
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * N, stream);
   mmd_prof_end(MMD_FAM_PW, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
