@@ -220,8 +220,15 @@ def main():
         for fam in FAMILIES:
             dll.mmd_prof_enable(fam, 1)
         torch.cuda.synchronize()
+        # one eager step on a single stream (teachers, weight-gradient and head side branches folded onto it), so that an
+        # event pair brackets one kernel running alone - the same condition as the serialised rocprofv3 kernel trace
+        conc = eng.concurrent_teachers
+        eng.concurrent_teachers = False
+        os.environ["MMD_NO_WG"] = "1"; os.environ["MMD_NO_SIDE"] = "1"
         eng.step_body(batch if not use_graph else eng.static, eng.static["drop_scale"] if use_graph else eng.make_drop_scale(B))
         torch.cuda.synchronize()
+        eng.concurrent_teachers = conc
+        del os.environ["MMD_NO_WG"], os.environ["MMD_NO_SIDE"]
         import ctypes
         res = {}
         for fam in FAMILIES:
