@@ -642,7 +642,10 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
     void (*kern)(PwArgs);
-    if (N <= 32) {
+    // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
+    static const int bn32_gain = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 10;
+    const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
+    if (N <= 32 || (pad64 - pad32) * 100 > bn32_gain * N) {
       a.ntn = cdiv(N, 32);
       kern = nkl == 1 ? pw_gemm_kernel<32, 1> : nkl == 2 ? pw_gemm_kernel<32, 2> : nkl == 3 ? pw_gemm_kernel<32, 3> : pw_gemm_kernel<32, 4>;
     } else {
