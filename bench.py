@@ -136,13 +136,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MMD_FORCE_DEVICE"):      # dev aid: exercise the N>1 code path on a 1-GPU box (with MMD_DIST_BACKEND=gloo)
+        local = int(os.environ["MMD_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        backend = os.environ.get("MMD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     S, B = args.size, args.batch
     mods = {"rgb": (3, 1), "depth": (3, 2), "thermal": (1, 3)}
     specs = {k: make_spec(2, c) for k, (c, _) in mods.items()}

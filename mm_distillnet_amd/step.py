@@ -280,11 +280,13 @@ class DistillEngine:
         torch.cuda.synchronize()
         for arena in [self.ws, self.student.arena, self.student.zarena] + [a for n in self.teachers.values() for a in (n.arena, n.zarena)]:
             arena.frozen = True
+        # thread_local: with a process group alive, the RCCL watchdog thread polls its own events; under the default
+        # "global" mode such a call from another thread would invalidate the capture
         self.g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_main):
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.step_body(self.static, self.static["drop_scale"])
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self.optimizer_body()
         for dst, src in zip((ps.flat, ps.rmean, ps.rvar, ps.nbt, self.exp_avg, self.exp_avg_sq, self.adam_main,
                              self.adam_head, self.head_active), snap):
