@@ -36,22 +36,29 @@ struct PwArgs {
 // NKL = 8-wide k groups of the LAST K tile that hold data (1..4): fp32 MFMA runs at the vector rate (64 cycles per
 // 32x32x2), so multiplying the zero padding of K = 112 / 48 / 24 ... is real time.  Compile-time so the hot loop keeps its schedule
 // (a run-time trip count cost more than the padding).
-template <int BN_T, int NKL>
+// BM_T = 128: the 4 waves stack along M (32 rows each, all BN_T columns); BM_T = 64: 2 x 2 waves (32 rows x BN_T/2 columns
+// each) - twice the blocks for the small-M layers (16x16 / 32x32 stages), whose 128-row tiling leaves most SIMDs with
+// one wave or none.
+template <int BM_T, int BN_T, int NKL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
-  constexpr int NS = BN_T / 32;          // 32-col slabs per wave
+  constexpr int WM = BM_T / 32;          // waves along M
+  constexpr int WN = 4 / WM;             // waves along N
+  constexpr int NS = BN_T / (32 * WN);   // 32-col slabs per wave
+  constexpr int NA = BM_T / 32;          // A float4 loads per thread (BM_T*8/256)
   constexpr int NB = BN_T / 32;          // B float4 loads per thread (BN_T*8/256)
   constexpr int LDC = BN_T + 4;            // C staging row stride (floats)
-  constexpr int SM = (PW_BM * LDC > (PW_BM + BN_T) * PW_LD) ? PW_BM * LDC : (PW_BM + BN_T) * PW_LD;
+  constexpr int SM = (BM_T * LDC > (BM_T + BN_T) * PW_LD) ? BM_T * LDC : (BM_T + BN_T) * PW_LD;
   __shared__ float smem[SM];              // A|B tiles in the K loop, then the C tile for the vectorised epilogue
   __shared__ float sRed[2 * 4 * BN_T];
   float* const sA = smem;
-  float* const sB = smem + PW_BM * PW_LD;
+  float* const sB = smem + BM_T * PW_LD;
 
   const int tid = threadIdx.x;
   const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
   const int tn = t % a.ntn, tm = t / a.ntn;
-  const int m0 = tm * PW_BM, n0 = tn * BN_T;
+  const int m0 = tm * BM_T, n0 = tn * BN_T;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
   // pyramid launch: this tile lies inside one level; rows beyond the level's valid count are padding
   int Mv = a.M, srow0 = 0, rpi = a.rows_per_image; long long yoff = a.y_offset; double* stats = a.stats;
   if (a.pyr.n) {
@@ -63,10 +70,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int kq = (tid & 7) * 4;          // this thread's k offset inside a K tile
   const int lrow = tid >> 3;             // 0..31
 
-  // per-thread row bookkeeping for the 4 A loads
-  const float* xrow[4]; const float* grow[4]; bool rok[4];
+  // per-thread row bookkeeping for the NA A loads
+  const float* xrow[NA]; const float* grow[NA]; bool rok[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NA; ++i) {
     int row = m0 + lrow + i * 32;
     rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
-  float4 ra[4], rg[4], rb[NB], rsc, rsh;
+  float4 ra[NA], rg[NA], rb[NB], rsc, rsh;
   bool kok;
   auto gload = [&](int k0) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
     else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       ra[i] = mmd_ld4(xrow[i] + kc);
       if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
     }
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
       if (a.in_scale || a.in_bn.stats) {
         v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
@@ -124,8 +131,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   const int nk = (a.K + PW_BK - 1) / PW_BK;
   gload(0);
-  const float* const pa = &sA[(wave * 32 + r) * PW_LD + h * 4];
-  const float* const pb = &sB[r * PW_LD + h * 4];
+  const float* const pa = &sA[(wm * 32 + r) * PW_LD + h * 4];
+  const float* const pb = &sB[(wn * NS * 32 + r) * PW_LD + h * 4];
   auto mma = [&](int kk) {
     float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
 #pragma unroll
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int j = 0; j < NS; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      smem[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * LDC + j * 32 + r] = acc[j][q];
+      smem[(wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * LDC + (wn * NS + j) * 32 + r] = acc[j][q];
   __syncthreads();
   constexpr int CGN = BN_T / 4;            // column groups of 4
   constexpr int RSTEP = 256 / CGN;         // row groups
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < PW_BM / RSTEP; ++i) {
+  for (int i = 0; i < BM_T / RSTEP; ++i) {
     const int rl = rgrp + RSTEP * i, row = m0 + rl;
     if (cok && row < Mv) {
       float4 v = *reinterpret_cast<const float4*>(&smem[rl * LDC + cg * 4]);
@@ -632,25 +639,31 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   // software-pipelined version (profiles/r01_notes.md)
   static const int use_stream = getenv("MMD_STREAM") ? 1 : 0;
   static const int skinny_tiles = getenv("MMD_SKINNY_TILES") ? atoi(getenv("MMD_SKINNY_TILES")) : 160;
+  // 64x64 tiles (2x2 waves) for layers with sq_min <= big_tiles < sq_tiles
+  static const int sq_tiles = getenv("MMD_SQ_TILES") ? atoi(getenv("MMD_SQ_TILES")) : 800;
+  static const int sq_min = getenv("MMD_SQ_MIN") ? atoi(getenv("MMD_SQ_MIN")) : 160;
   if (use_stream && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
     else pw_stream_launch<2, 2>(a, stream);
-  } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16) {
+  } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16 && !(sq_tiles > 0 && big_tiles >= sq_min && big_tiles < sq_tiles && N > 32)) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
     hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
-    void (*kern)(PwArgs);
     // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
     static const int bn32_gain = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 10;
     const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
-    if (N <= 32 || (pad64 - pad32) * 100 > bn32_gain * N) {
+    void (*kern)(PwArgs);
+    if (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles))) {
       a.ntn = cdiv(N, 32);
-      kern = nkl == 1 ? pw_gemm_kernel<32, 1> : nkl == 2 ? pw_gemm_kernel<32, 2> : nkl == 3 ? pw_gemm_kernel<32, 3> : pw_gemm_kernel<32, 4>;
+      kern = nkl == 1 ? pw_gemm_kernel<128, 32, 1> : nkl == 2 ? pw_gemm_kernel<128, 32, 2> : nkl == 3 ? pw_gemm_kernel<128, 32, 3> : pw_gemm_kernel<128, 32, 4>;
+    } else if (sq_tiles > 0 && big_tiles < sq_tiles) {      // 64x64 tiles: small-M layers
+      a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
+      kern = nkl == 1 ? pw_gemm_kernel<64, 64, 1> : nkl == 2 ? pw_gemm_kernel<64, 64, 2> : nkl == 3 ? pw_gemm_kernel<64, 64, 3> : pw_gemm_kernel<64, 64, 4>;
     } else {
       a.ntn = cdiv(N, 64);
-      kern = nkl == 1 ? pw_gemm_kernel<64, 1> : nkl == 2 ? pw_gemm_kernel<64, 2> : nkl == 3 ? pw_gemm_kernel<64, 3> : pw_gemm_kernel<64, 4>;
+      kern = nkl == 1 ? pw_gemm_kernel<128, 64, 1> : nkl == 2 ? pw_gemm_kernel<128, 64, 2> : nkl == 3 ? pw_gemm_kernel<128, 64, 3> : pw_gemm_kernel<128, 64, 4>;
     }
     a.nblk = ntm * a.ntn;
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
