@@ -188,6 +188,11 @@ int mmd_transpose_batched(const float* src_base, float* dst_base, const long lon
 // dst[C,R] = src[R,C]^T (refreshes the Wt copies after an optimizer step).
 int mmd_transpose2d(const float* src, float* dst, int R, int C, hipStream_t stream);
 
+// Stem conv forward, direct: NCHW image -> NHWC rows [B*OH*OW, Cout] (Cout in {32,40,48,56,64}; 3x3, stride 2, TF-SAME; w = the [Cout, Kp] im2col weight
+// layout, k = ci*9 + i*3 + j).  Epilogue: folded BN + swish (frozen nets) or raw output + BatchNorm sums (train; stats_ws/ws_slots
+// as in mmd_dwconv_fwd).  src/YetAnotherEfficientNet.py:519-523,597-604.  mmd_stem_im2col + the GEMM entry points remain for the weight gradient.
+int mmd_stem_conv_fwd(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Kp, int Cout, const float* out_scale, const float* out_shift, int out_act, double* stats, double* stats_ws, int ws_slots, hipStream_t stream);
+
 // ModelWithNMSLossAugmented.merge_batch_0_1 (src/optimization/train_methods.py:291-308): out = in, except image 1 =
 // log10(max(in[0]^10 + in[1]^10, 1e-7)) (the reference's literal 10th power).  per_image = C*H*W.
 int mmd_audio_merge01(const float* in, float* out, long long per_image, int B, hipStream_t stream);

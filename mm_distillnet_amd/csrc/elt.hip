@@ -703,3 +703,100 @@ extern "C" int mmd_avg_image01(float* f, long long per_image, hipStream_t stream
   hipLaunchKernelGGL(avg_image01_kernel, dim3(cdiv(per_image, 256)), dim3(256), 0, stream, f, (size_t)per_image);
   return mmd_check_launch();
 }
+
+// ---------------------------------------------------------------- stem: direct 3x3 / stride-2 TF-SAME conv, NCHW image -> NHWC rows
+// Replaces im2col + GEMM in the forward (the im2col buffer, 58-150 MB per net, is only needed by the weight gradient
+// and is built there): one thread = one output pixel x all 32 output channels, weights broadcast from LDS ([k][32]),
+// input read straight from the NCHW image (neighbouring threads cover neighbouring column pairs).  Epilogue: either the
+// frozen nets' folded BN + swish, or the raw output plus the slotted BatchNorm sums (train).
+// Reference: Conv2dStaticSamePadding(in, 32, k=3, s=2, bias=False) + _bn0 + swish (src/YetAnotherEfficientNet.py:519-523,597-604).
+template <int STEM_CO>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                        int B, int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l, int Kp,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                        double* stats, double* ws, int slots) {
+  extern __shared__ float sW[];                 // [Cin*9][32]
+  __shared__ float sRed[2 * 4 * STEM_CO];
+  const int tid = threadIdx.x, K = Cin * 9;
+  for (int i = tid; i < K * STEM_CO; i += 256) { int k = i / STEM_CO, c = i % STEM_CO; sW[i] = w[(size_t)c * Kp + k]; }
+  __syncthreads();
+  const size_t total = (size_t)B * OH * OW;
+  const size_t m = (size_t)blockIdx.x * 256 + tid;
+  const bool ok = m < total;
+  float acc[STEM_CO];
+#pragma unroll
+  for (int c = 0; c < STEM_CO; ++c) acc[c] = 0.f;
+  if (ok) {
+    const int ow = (int)(m % OW); size_t t = m / OW;
+    const int oh = (int)(t % OH), b = (int)(t / OH);
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int ih = oh * 2 + i - pad_t;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int iw = ow * 2 + j - pad_l;
+          float v = 0.f;
+          if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = xp[(size_t)ih * W + iw];
+          const float4* wk = reinterpret_cast<const float4*>(&sW[(ci * 9 + i * 3 + j) * STEM_CO]);
+#pragma unroll
+          for (int q = 0; q < STEM_CO / 4; ++q) {
+            const float4 wv = wk[q];
+            acc[4 * q] += v * wv.x; acc[4 * q + 1] += v * wv.y; acc[4 * q + 2] += v * wv.z; acc[4 * q + 3] += v * wv.w;
+          }
+        }
+      }
+    }
+  }
+  if (stats) {        // per-channel sum / sum of squares of the raw output: wave reduce, 4 waves through LDS, slotted f64 atomics
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int c = 0; c < STEM_CO; ++c) {
+      float s = wave_sum(ok ? acc[c] : 0.f), q = wave_sum(ok ? acc[c] * acc[c] : 0.f);
+      if (lane == 0) { sRed[wave * STEM_CO + c] = s; sRed[4 * STEM_CO + wave * STEM_CO + c] = q; }
+    }
+    __syncthreads();
+    if (tid < STEM_CO) {
+      double* st = ws ? ws + (size_t)(blockIdx.x % slots) * 2 * STEM_CO : stats;
+      float s = sRed[tid] + sRed[STEM_CO + tid] + sRed[2 * STEM_CO + tid] + sRed[3 * STEM_CO + tid];
+      float q = sRed[4 * STEM_CO + tid] + sRed[5 * STEM_CO + tid] + sRed[6 * STEM_CO + tid] + sRed[7 * STEM_CO + tid];
+      atomicAdd(&st[tid], (double)s);
+      atomicAdd(&st[STEM_CO + tid], (double)q);
+    }
+  }
+  if (!ok) return;
+  float* yo = y + m * STEM_CO;
+#pragma unroll
+  for (int q = 0; q < STEM_CO / 4; ++q) {
+    float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (scale) {
+      const float4 sc = mmd_ld4(scale + 4 * q), sh = mmd_ld4(shift + 4 * q);
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    }
+    if (act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+    mmd_st4(yo + 4 * q, v);
+  }
+}
+extern "C" int mmd_stem_conv_fwd(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Kp, int Cout,
+                                 const float* out_scale, const float* out_shift, int out_act, double* stats,
+                                 double* stats_ws, int ws_slots, hipStream_t stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cin > 64 || H <= 0 || W <= 0 || Kp < Cin * 9) return MMD_EINVAL;
+  if (Cout != 32 && Cout != 40 && Cout != 48 && Cout != 56 && Cout != 64) return MMD_EINVAL;      // EfficientNet b0-b7 stems
+  if ((out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
+  int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  int eh = (OH - 1) * 2 - H + 3, ew = (OW - 1) * 2 - W + 3;
+  if (eh < 0) eh = 0; if (ew < 0) ew = 0;
+  size_t total = (size_t)B * OH * OW;
+  int nb = cdiv(total, 256);
+  const bool slotted = stats && stats_ws && ws_slots > 1 && nb > MMD_STATS_DEPTH;
+  mmd_prof_begin(MMD_FAM_ELT, stream);
+  void (*kern)(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, const float*, const float*, int, double*,
+               double*, int) = Cout == 32 ? stem_conv_kernel<32> : Cout == 40 ? stem_conv_kernel<40> : Cout == 48 ? stem_conv_kernel<48>
+                             : Cout == 56 ? stem_conv_kernel<56> : stem_conv_kernel<64>;
+  hipLaunchKernelGGL(kern, dim3(nb), dim3(256), (size_t)Cin * 9 * Cout * sizeof(float), stream, x, w, y, B, Cin, H, W,
+                     OH, OW, eh / 2, ew / 2, Kp, out_scale, out_shift, out_act, stats, slotted ? stats_ws : nullptr, ws_slots);
+  if (slotted) mmd_stats_fold(stats, stats_ws, ws_slots, 2 * Cout, stream);
+  mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * ((double)B * Cin * H * W + (double)total * Cout));
+  return mmd_check_launch();
+}

@@ -219,19 +219,21 @@ class Net:
         P = "backbone_net.model"
         # ---- stem: im2col + GEMM
         OH = (S + 1) // 2
-        col = self._alloc(B * OH * OH, ps.stem_kp)
-        call("mmd_stem_im2col", x, col, B, Cin, S, S, ps.stem_kp)
-        colf = Feat(col, B, OH, OH, ps.stem_kp)
+        # direct 3x3/s2 stem conv (NCHW image -> NHWC rows); the im2col matrix is only built in the backward, for the
+        # weight gradient, on the wgrad stream
         st = self._bn_stats(f"{P}._bn0", train)
         sc, sh, mu, istd, live = self._bn_aff(f"{P}._bn0", train, st, B * OH * OH)
+        z = self._alloc(B * OH * OH, spec.stem_out)
+        wstem = ps.w(f"{P}._conv_stem.conv.weight")
         if train:
-            z = self._pw(colf, f"{P}._conv_stem.conv.weight", spec.stem_out, stats=st)
+            call("mmd_stem_conv_fwd", x, wstem, z, B, Cin, S, S, ps.stem_kp, spec.stem_out, None, None, NONE, st,
+                 *self._stats_ws(st, B * OH * OH, spec.stem_out))
             cur = Feat(z, B, OH, OH, spec.stem_out, sc, sh, SWISH, live)
-            tape["stem"] = (colf, cur, mu, istd)
+            tape["stem"] = (x, cur, mu, istd)
         else:
-            # frozen net: the folded BN + swish ride in the GEMM epilogue (once per element) instead of the depthwise
+            # frozen net: the folded BN + swish ride in the producer's epilogue (once per element) instead of the depthwise
             # prologue, which would redo them for every halo pixel (1.6x for 3x3, 2.25x for 5x5 tiles)
-            z = self._pw(colf, f"{P}._conv_stem.conv.weight", spec.stem_out, out_aff=(sc, sh), out_act=SWISH)
+            call("mmd_stem_conv_fwd", x, wstem, z, B, Cin, S, S, ps.stem_kp, spec.stem_out, sc, sh, SWISH, None, None, 0)
             cur = Feat(z, B, OH, OH, spec.stem_out)
         taps: List[Feat] = []
         skip_i = 0
@@ -770,9 +772,13 @@ class Net:
                 g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
                 self._acc(slot(inp), g0)
         # ---- stem
-        colf, stem, mu, istd = tape["stem"]
+        ximg, stem, mu, istd = tape["stem"]
         s = slot(stem)
         dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
-        self._pw_bwd(dz, colf, f"{P}._conv_stem.conv.weight", stem.C, None, False)
+        with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
+            col = self._alloc(stem.M, ps.stem_kp)
+            call("mmd_stem_im2col", ximg, col, ximg.shape[0], ximg.shape[1], ximg.shape[2], ximg.shape[3], ps.stem_kp)
+            call("mmd_pwconv_bwd_weight", dz, col, ps.g(f"{P}._conv_stem.conv.weight"), stem.M, ps.stem_kp, stem.C, None, None,
+                 NONE, None, 1)
         if self._wg is not None:
             torch.cuda.current_stream().wait_stream(self._wg)

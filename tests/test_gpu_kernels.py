@@ -300,6 +300,43 @@ def test_stem_im2col(cin, S):
     y = torch.empty(B * OH * OH, 32, device=DEV)
     call("mmd_pwconv_fwd", col, g(wp), y, B * OH * OH, Kp, 32, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0)
     close(y.view(B, OH, OH, 32), nhwc(ref), 2e-4, 1e-5)
+    # direct stem conv (the forward path): raw output + BatchNorm sums, then folded BN + swish
+    y2 = torch.empty_like(y)
+    st = torch.zeros(64, dtype=torch.float64, device=DEV)
+    call("mmd_stem_conv_fwd", g(x), g(wp), y2, B, cin, S, S, Kp, 32, None, None, 0, st, None, 0)
+    close(y2.view(B, OH, OH, 32), nhwc(ref), 2e-4, 1e-5, "direct stem conv")
+    close(st[:32], ref.double().sum((0, 2, 3)), 1e-5, 1e-5); close(st[32:], (ref.double() ** 2).sum((0, 2, 3)), 1e-5, 1e-5)
+    sc, sh = torch.rand(32) + 0.5, torch.randn(32) * 0.1
+    call("mmd_stem_conv_fwd", g(x), g(wp), y2, B, cin, S, S, Kp, 32, g(sc), g(sh), 1, None, None, 0)
+    close(y2.view(B, OH, OH, 32), nhwc(swish(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))), 2e-4, 1e-5, "direct stem conv + BN + swish")
+
+
+def test_stem_conv_b4_width():
+    torch.manual_seed(4)
+    B, cin, S, CO = 2, 3, 20, 48
+    x = torch.randn(B, cin, S, S); w = torch.randn(CO, cin, 3, 3) * 0.3
+    ref = F.conv2d(same_pad(x, 3, 2), w, stride=2)
+    wp = torch.zeros(CO, 28); wp[:, :27] = w.reshape(CO, -1)
+    y = torch.empty(B * 10 * 10, CO, device=DEV)
+    st = torch.zeros(2 * CO, dtype=torch.float64, device=DEV)
+    call("mmd_stem_conv_fwd", g(x), g(wp), y, B, cin, S, S, 28, CO, None, None, 0, st, None, 0)
+    close(y.view(B, 10, 10, CO), nhwc(ref), 2e-4, 1e-5)
+    close(st[:CO], ref.double().sum((0, 2, 3)), 1e-5, 1e-5); close(st[CO:], (ref.double() ** 2).sum((0, 2, 3)), 1e-5, 1e-5)
+
+
+def test_stem_conv_slotted_sums_large():
+    torch.manual_seed(1)
+    B, cin, S = 2, 3, 512            # 131072 output pixels -> 512 blocks > MMD_STATS_DEPTH: slotted path
+    x = torch.randn(B, cin, S, S); w = torch.randn(32, cin, 3, 3) * 0.2
+    ref = F.conv2d(same_pad(x, 3, 2), w, stride=2)
+    wp = torch.zeros(32, 28); wp[:, :27] = w.reshape(32, -1)
+    y = torch.empty(B * 256 * 256, 32, device=DEV)
+    st = torch.zeros(64, dtype=torch.float64, device=DEV)
+    ws = torch.zeros(64 * 64, dtype=torch.float64, device=DEV)
+    call("mmd_stem_conv_fwd", g(x), g(wp), y, B, cin, S, S, 28, 32, None, None, 0, st, ws, 64)
+    close(y.view(B, 256, 256, 32), nhwc(ref), 2e-4, 1e-5)
+    close(st[:32], ref.double().sum((0, 2, 3)), 1e-5, 1e-5); close(st[32:], (ref.double() ** 2).sum((0, 2, 3)), 1e-5, 1e-5)
+    assert float(ws.abs().max()) == 0.0
 
 
 def _maxpool_ref(x):

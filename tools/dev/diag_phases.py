@@ -136,3 +136,27 @@ for mod, net in tn:
     net.forward = (lambda x, train=False, _m=mod: cached[_m])
 torch.cuda.synchronize()
 timeit("step without teacher forwards", cap(lambda: eng.step_body(eng.static, ds)))
+
+# ---- what would software-pipelining the frozen teachers one batch ahead buy?  (teacher graph on a second stream, replayed
+# together with the teacher-less step graph)
+g_noteach = cap(lambda: eng.step_body(eng.static, ds))
+for mod, net in tn:              # restore the real forwards for the teacher graph
+    del net.begin_step, net.forward
+g_teach = cap(teachers_conc)
+s2 = torch.cuda.Stream()
+def both():
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        g_teach.replay()
+    g_noteach.replay()
+    torch.cuda.current_stream().wait_stream(s2)
+for _ in range(3):
+    both()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    both()
+torch.cuda.synchronize()
+print(f"{'teacher graph || teacher-less step graph':<44} {(time.perf_counter() - t0) / 10 * 1e3:8.3f} ms", flush=True)
+timeit("teacher-less step graph alone", g_noteach)
+timeit("teacher graph alone", g_teach)
