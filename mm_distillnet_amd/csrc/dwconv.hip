@@ -12,6 +12,7 @@
 // Epilogue: raw per-channel sum / sum-of-squares for train-mode BN (double atomics), or eval-mode
 // BN+swish and the squeeze-excite average pool.
 #include "common.h"
+#include <cstdlib>
 
 struct DwArgs {
   const float* x; const float* w; float* y;
@@ -242,6 +243,10 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
 }
 // 3x3 / stride 1: narrow channel chunks when C is small (thin 256x256 layers of the backbone)
 static int dw_fwd_launch_31(DwArgs& a, hipStream_t st) {
+  static const int force = getenv("MMD_DW_LANES") ? atoi(getenv("MMD_DW_LANES")) : 0;
+  if (force == 4) return dw_fwd_launch<3, 1, 4>(a, st);
+  if (force == 8) return dw_fwd_launch<3, 1, 8>(a, st);
+  if (force == 16) return dw_fwd_launch<3, 1, 16>(a, st);
   if (a.C <= 16) return dw_fwd_launch<3, 1, 4>(a, st);
   if (a.C <= 32) return dw_fwd_launch<3, 1, 8>(a, st);
   return dw_fwd_launch<3, 1, 16>(a, st);

@@ -45,7 +45,7 @@ for M, C in ((131072, 144), (32768, 288), (43648, 112), (8192, 720), (524288, 32
     bench(f"bn_bwd_reduce swish   M{M} C{C}", lambda: call("mmd_bn_bwd_reduce", y, x, sc, sh, mu, istd, 1, None, None, None, 0, None, sums, M, C, None, 0), 8.0 * M * C)
     bench(f"bn_bwd_apply swish    M{M} C{C}", lambda: call("mmd_bn_bwd_apply", y, x, mu, istd, ga, sums, M, dz, dga, dbe, M, C, sc, sh, 1, None, None, None, 0), 12.0 * M * C)
 
-for B, H, C, k, s in ((8, 128, 144, 3, 1), (8, 256, 32, 3, 1), (8, 256, 16, 3, 1), (8, 64, 288, 5, 1), (8, 32, 720, 5, 1), (8, 256, 96, 3, 2), (8, 16, 1248, 5, 1)):
+for B, H, C, k, s in ((8, 128, 144, 3, 1), (8, 64, 112, 3, 1), (8, 32, 528, 3, 1), (8, 16, 1248, 3, 1), (8, 32, 112, 3, 1), (8, 256, 32, 3, 1), (8, 256, 16, 3, 1), (8, 64, 288, 5, 1), (8, 32, 720, 5, 1), (8, 256, 96, 3, 2), (8, 16, 1248, 5, 1)):
     x = R(B * H * H, C); w = R(k * k, C)
     OH = -(-H // s)
     y = torch.empty(B * OH * OH, C, device=DEV)
@@ -53,6 +53,8 @@ for B, H, C, k, s in ((8, 128, 144, 3, 1), (8, 256, 32, 3, 1), (8, 256, 16, 3, 1
     st = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     by = 4.0 * C * B * (H * H + OH * OH)
     fl = 2.0 * B * OH * OH * C * k * k
+    bench(f"dw plain H{H} C{C} k{k} s{s}", lambda: call("mmd_dwconv_fwd", x, w, y, B, H, H, C, k, s, None, None, 0, None, None, None, 0, None, None, 0, None, None, None, 0), by, fl)
+    bench(f"dw out-affine+swish only H{H} C{C} k{k} s{s}", lambda: call("mmd_dwconv_fwd", x, w, y, B, H, H, C, k, s, None, None, 0, None, None, None, 0, sc, sh, 1, None, None, None, 0), by, fl)
     bench(f"dw eval  H{H} C{C} k{k} s{s}", lambda: call("mmd_dwconv_fwd", x, w, y, B, H, H, C, k, s, sc, sh, 1, None, None, None, 0, None, None, 0, None, None, None, 0), by, fl)
     bench(f"dw train(stats) H{H} C{C} k{k} s{s}", lambda: call("mmd_dwconv_fwd", x, w, y, B, H, H, C, k, s, sc, sh, 1, None, None, None, 0, None, None, 0, st, None, None, 0), by, fl)
     wsb = torch.zeros(16 * 2 * C, dtype=torch.float64, device=DEV)
