@@ -148,3 +148,46 @@ def test_d4_eval_vs_oracle():
     assert relerr(cls, c) < 2e-3 and relerr(reg, r) < 2e-3
     for u, v in zip(feats, f):
         assert relerr(feat_nchw(u), v) < 2e-3
+
+
+def test_d4_train_fwd_bwd_vs_oracle():
+    """BASELINE config-5 architecture (D4, 8-channel student) through the TRAIN forward and the hand-scheduled backward in
+    fp32 against the oracle's autograd: 7 BiFPN cells of width 224, 4-layer heads, 48-channel stem, 32 MBConv blocks."""
+    spec, st = make_state(4, 8, 32, "audio")
+    x = synth_inputs(2, 256, seed=9)["audio"]
+    masks = {b.idx: torch.ones(2) * (1.0 - b.drop_rate) for b in spec.blocks if b.skip}      # x/keep*mask with mask = keep -> x
+    so = grad_state(st)
+    (c, r, a), f = O.forward(so, x, 4, True, masks)
+    loss = c.sum() * 0.01 + (r ** 2).mean() + sum((u ** 2).mean() for u in f)
+    loss.backward()
+    net = Net(spec, DEV, trainable=True)
+    net.load_state(st)
+    skip = [b for b in spec.blocks if b.skip]
+    ds = torch.ones(len(skip), 2, device=DEV)
+    net.begin_step()
+    cls, reg, feats = net.forward(x.to(DEV), train=True, drop_scale=ds)
+    assert relerr(cls, c) < 2e-3 and relerr(reg, r) < 2e-3
+    for u, v in zip(feats, f):
+        assert relerr(feat_nchw(u), v) < 2e-3
+    dcls = (0.01 * cls * (1 - cls)).contiguous()
+    dreg = (2.0 * reg / reg.numel()).contiguous()
+    dfe = [(2.0 * u.z / u.z.numel()).contiguous() for u in feats]
+    net.ps.grad.zero_()
+    net.backward(dcls, dreg, dfe)
+    torch.cuda.synchronize()
+    grads = net.ps.export_grads()
+    # whole gradient: direction and norm; element-wise: all but a few tensors (max-pool ties can flip, see test_gpu_model.py)
+    dot = n1 = n2 = 0.0
+    errs = []
+    gmax = max(v.grad.abs().max().item() for v in so.values() if v.requires_grad)
+    for k, v in so.items():
+        if not v.requires_grad:
+            continue
+        ref, got = v.grad.double(), grads[k].double()
+        dot += float((ref * got).sum()); n1 += float((ref * ref).sum()); n2 += float((got * got).sum())
+        s = ref.abs().max().item()
+        if s > 1e-4 * gmax:
+            errs.append((got - ref).abs().max().item() / s)
+    assert dot / (n1 ** 0.5 * n2 ** 0.5) > 0.9995 and abs((n2 / n1) ** 0.5 - 1.0) < 5e-3
+    errs.sort()
+    assert errs[int(0.95 * len(errs))] < 2e-2, errs[-10:]
