@@ -64,16 +64,17 @@ def tune_teacher_bias(spec, state, x, device, target_per_image=40):
     import math
     net = Net(spec, device, trainable=False)
     xd = x.to(device)
-    for _ in range(4):          # sigmoid saturates: iterate until the count is in range
+    for it in range(8):         # sigmoid saturates: iterate until the count is in range
         net.load_state(state)
         net.begin_step()
-        cls, _, _ = net.forward(xd, train=False)
-        p = cls.double().clamp(1e-12, 1 - 1e-12)
-        logit = torch.log(p / (1 - p))
+        logit, _, _ = net.forward(xd, train=False, raw_logits=True)      # pre-sigmoid: probabilities saturate in fp32
+        logit = logit.double()
         best, arg = logit.max(2)
         car = best[arg == 6]
         n_now = int((car > math.log(0.3 / 0.7)).sum().item())
-        tgt = target_per_image * cls.shape[0]
+        tgt = target_per_image * logit.shape[0]
+        if os.environ.get("MMD_BENCH_DEBUG"):
+            log("tune it %d: over-threshold car candidates %d (target %d), car anchors %d" % (it, n_now, tgt, car.numel()))
         if 0.5 * tgt <= n_now <= 1.5 * tgt or car.numel() <= tgt:
             break
         v = torch.sort(car, descending=True)[0][tgt].item()
@@ -82,21 +83,21 @@ def tune_teacher_bias(spec, state, x, device, target_per_image=40):
     torch.cuda.empty_cache()
 
 
-def cpu_baseline(sstate, tstates, S, sample_b):
+def cpu_baseline(sstate, tstates, S, sample_b, coef=2):
     from oracle import step_ref as ST
     from mm_distillnet_amd.arch import make_spec as ms
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(ncpu, 64)))
     log("cpu baseline on %d threads" % torch.get_num_threads())
     batch = synth_inputs(sample_b, S, seed=77)
-    spec = ms(2, 8)
+    spec = ms(coef, 8)
     ones = {b.idx: torch.ones(sample_b) for b in spec.blocks if b.skip}
 
     def one():
         st = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
               for k, v in sstate.items()}
         t0 = time.time()
-        out = ST.distill_forward(st, tstates, batch, S, 2, ones)
+        out = ST.distill_forward(st, tstates, batch, S, coef, ones)
         loss = ST.total_loss(out)
         if loss.requires_grad:
             loss.backward()
@@ -128,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--coef", type=int, default=2, help="EfficientDet compound coefficient (2 = the BASELINE configs 1-4; 4 with --size 768 = config 5's architecture, run in fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2)
@@ -151,11 +153,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     S, B = args.size, args.batch
     mods = {"rgb": (3, 1), "depth": (3, 2), "thermal": (1, 3)}
-    specs = {k: make_spec(2, c) for k, (c, _) in mods.items()}
+    specs = {k: make_spec(args.coef, c) for k, (c, _) in mods.items()}
     calib = synth_inputs(4, 256, seed=1234)
     log("building states")
     tstates = {k: calibrated_state(specs[k], seed, calib[k], dev) for k, (_, seed) in mods.items()}
-    sspec = make_spec(2, 8)
+    sspec = make_spec(args.coef, 8)
     sstate = calibrated_state(sspec, 4, calib["audio"], dev)
     batch_cpu = synth_inputs(B, S, seed=24 + rank)
     for k in tstates:
@@ -257,7 +259,8 @@ def main():
         fam_key = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd"}[fam]
         try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["families"][fam_key]
-            traffic = round(pm["hbm_bytes_per_step"] / max(n, 1), 1) if fam_key != "bn_bwd" else None
+            # the committed PMC passes are of the default workload only
+            traffic = round(pm["hbm_bytes_per_step"] / max(n, 1), 1) if (args.coef == 2 and S == 512 and B == 8) else None
         except Exception:
             traffic = None
         roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": PEAK[bound], "unit": unit,
@@ -267,13 +270,15 @@ def main():
                 "algorithmic_bytes_per_step": by, "algorithmic_flops_per_step": fl,
                 "all_families_ms": {FAMILIES[f][0].split(" ")[0]: round(res[f][1], 3) for f in res}}
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sstate, tstates, S, args.cpu_sample)
-        line = {"metric": "distillation-step images/sec (3 teachers + audio student, D2, bs=8)", "value": round(value, 2),
+            cpu = cpu_baseline(sstate, tstates, S, args.cpu_sample, args.coef)
+        std = args.coef == 2 and S == 512 and B == 8
+        line = {"metric": "distillation-step images/sec (3 teachers + audio student, D%d, bs=%d)" % (args.coef, B), "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "BASELINE configs[2]: full 3-teacher (RGB+thermal+depth) -> audio student distillation "
-                                       "step, EfficientDet-D2, 512x512, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % B,
+                "config": {"workload": ("BASELINE configs[2]" if std else "non-default shape (BASELINE config 5 = D4 / 768 in bf16; this is fp32)")
+                                       + ": full 3-teacher (RGB+thermal+depth) -> audio student distillation step, EfficientDet-D%d, "
+                                         "%dx%d, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % (args.coef, S, S, B),
                            "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                            "graph": use_graph, "pseudo_label_boxes_per_image": nbox},
                 "roofline": roof, "cpu_baseline": cpu}

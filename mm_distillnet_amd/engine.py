@@ -208,9 +208,11 @@ class Net:
         return self._anchors[image_size]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, train: bool = False, drop_scale: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, train: bool = False, drop_scale: Optional[torch.Tensor] = None,
+                raw_logits: bool = False):
         """x: [B,Cin,S,S] NCHW fp32 on device.  drop_scale: [n_skip_blocks, B] = mask/keep (train only).
-        Returns cls [B,A,NC] (probabilities), reg [B,A,4], features: list of 5 Feat (NHWC rows)."""
+        Returns cls [B,A,NC] (probabilities; pre-sigmoid logits with raw_logits=True, a calibration aid), reg [B,A,4],
+        features: list of 5 Feat (NHWC rows)."""
         if train and not self.trainable:
             raise RuntimeError("train-mode forward on a frozen (teacher) net")
         spec, ps = self.spec, self.ps
@@ -304,7 +306,7 @@ class Net:
         reg = self._alloc(B, A, 4)
         cls = self._alloc(B, A, spec.num_classes)
         self._head("regressor", feats, 4, reg, A, NONE, train, tape)
-        self._head("classifier", feats, spec.num_classes, cls, A, SIGMOID, train, tape)
+        self._head("classifier", feats, spec.num_classes, cls, A, NONE if raw_logits else SIGMOID, train, tape)
         if train:
             tape["feats"] = feats
             tape["A"] = A
