@@ -260,7 +260,7 @@ def main():
         try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["families"][fam_key]
             # the committed PMC passes are of the default workload only
-            traffic = round(pm["hbm_bytes_per_step"] / max(n, 1), 1) if (args.coef == 2 and S == 512 and B == 8) else None
+            traffic = round(pm["hbm_bytes_per_step"] / max(n, 1), 1) if (args.coef == 2 and S == 512 and B == 8 and fam_key != "bn_bwd") else None
         except Exception:
             traffic = None
         roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": PEAK[bound], "unit": unit,
