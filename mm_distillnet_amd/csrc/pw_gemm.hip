@@ -702,10 +702,11 @@ struct WgArgs {
   int mchunk; int ntn; int ntk;
 };
 #define WG_LD 68
+#define WG_BR 32          // rows of the M reduction per step (64 measured no faster)
 
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
-  __shared__ float sD[32 * WG_LD];
-  __shared__ float sX[32 * WG_LD];
+  __shared__ float sD[WG_BR * WG_LD];
+  __shared__ float sX[WG_BR * WG_LD];
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   const int tk = b % a.ntk; b /= a.ntk;
@@ -725,11 +726,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 
-  float4 rd[2], rx[2], rg[2];
-  bool rok[2];
+  constexpr int NL = WG_BR / 16;      // float4 loads per thread and operand
+  float4 rd[NL], rx[NL], rg[NL];
+  bool rok[NL];
   auto gload = [&](int mb) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NL; ++i) {
       int row = mb + lrow + i * 16;
       rok[i] = row < mend;
       const int rc = rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NL; ++i) {
       float4 v = rx[i];
       if (a.in_scale) {
         v.x = v.x * xsc.x + xsh.x; v.y = v.y * xsc.y + xsh.y; v.z = v.z * xsc.z + xsh.z; v.w = v.w * xsc.w + xsh.w;
@@ -754,14 +756,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   };
 
   if (mbeg < mend) gload(mbeg);
-  for (int mb = mbeg; mb < mend; mb += 32) {
+  for (int mb = mbeg; mb < mend; mb += WG_BR) {
     lstore();
     __syncthreads();
-    if (mb + 32 < mend) gload(mb + 32);
+    if (mb + WG_BR < mend) gload(mb + WG_BR);
     const float* pd = &sD[h * WG_LD + wn * 32 + r];
     const float* px = &sX[h * WG_LD + wk * 32 + r];
 #pragma unroll
-    for (int tt = 0; tt < 16; ++tt)
+    for (int tt = 0; tt < WG_BR / 2; ++tt)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[tt * 2 * WG_LD], px[tt * 2 * WG_LD], acc, 0, 0, 0);
     __syncthreads();
   }
@@ -788,7 +790,7 @@ extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw,
   // keep at least 256 rows per split so the atomic traffic stays well below the streamed bytes
   int splits = 1024 / tiles; if (splits < 1) splits = 1;
   int maxs = cdiv(M, 256); if (splits > maxs) splits = maxs;
-  a.mchunk = cdiv(cdiv(M, splits), 32) * 32;
+  a.mchunk = cdiv(cdiv(M, splits), WG_BR) * WG_BR;
   splits = cdiv(M, a.mchunk);
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wg M%lld K%lld N%lld s%lld", M, K, N, splits);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
