@@ -31,6 +31,13 @@ __global__ __launch_bounds__(256) void pp_score_kernel(const float* __restrict__
 // ---- pass 2: ordered compaction (one 1024-thread block per image)
 // over_scores[b, i]      : score of the i-th over-threshold anchor (anchor order)
 // cand[b, i, 0..5]       : (x1,y1,x2,y2,score,class) of the i-th over-threshold AND valid-class anchor
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {      // exclusive prefix sum over the 64 lanes
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  return x - v;
+}
+#define PP_PER 4      // consecutive anchors per thread and sweep: 4096 anchors per barrier round instead of 1024
 __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restrict__ reg, const float* __restrict__ anchors,
                                                           const float* __restrict__ score, const unsigned char* __restrict__ clsid,
                                                           const unsigned char* __restrict__ flags, int A, float image_size,
@@ -41,27 +48,34 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) { base_o = 0; base_k = 0; }
   __syncthreads();
-  for (int a0 = 0; a0 < A; a0 += 1024) {
-    const int a = a0 + tid;
-    unsigned char f = (a < A) ? flags[(size_t)b * A + a] : 0;
-    unsigned long long mo = __ballot(f & 1), mk = __ballot((f >> 1) & 1);
-    unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int po = __popcll(mo & lt), pk = __popcll(mk & lt);
-    if (lane == 0) { s_o[wave] = __popcll(mo); s_k[wave] = __popcll(mk); }
+  for (int a0 = 0; a0 < A; a0 += 1024 * PP_PER) {
+    const int a = a0 + tid * PP_PER;
+    unsigned char f[PP_PER];
+    int co = 0, ck = 0;
+#pragma unroll
+    for (int i = 0; i < PP_PER; ++i) {
+      f[i] = (a + i < A) ? flags[(size_t)b * A + a + i] : 0;
+      co += f[i] & 1; ck += (f[i] >> 1) & 1;
+    }
+    const int po = wave_excl_scan(co, lane), pk = wave_excl_scan(ck, lane);
+    if (lane == 63) { s_o[wave] = po + co; s_k[wave] = pk + ck; }
     __syncthreads();
     int wo = 0, wk = 0, to = 0, tk = 0;
     for (int i = 0; i < 16; ++i) { if (i < wave) { wo += s_o[i]; wk += s_k[i]; } to += s_o[i]; tk += s_k[i]; }
     const int bo = base_o, bk = base_k;
-    if (f & 1) {
-      int pos = bo + wo + po;
-      float sc = score[(size_t)b * A + a];
+    int pos = bo + wo + po, kp = bk + wk + pk;
+#pragma unroll
+    for (int i = 0; i < PP_PER; ++i) {
+      if (!(f[i] & 1)) continue;
+      const int ai = a + i;
+      float sc = score[(size_t)b * A + ai];
       // only the first PP_CAP entries can ever be indexed (index < n_keep <= PP_CAP), so a longer list is not an error
       if (pos < PP_CAP) over_scores[(size_t)b * PP_CAP + pos] = sc;
-      if (f & 2) {
-        int kp = bk + wk + pk;
+      ++pos;
+      if (f[i] & 2) {
         if (kp < PP_CAP) {
-          float4 an = mmd_ld4(anchors + (size_t)a * 4);                 // y1,x1,y2,x2
-          float4 r = mmd_ld4(reg + ((size_t)b * A + a) * 4);            // dy,dx,dh,dw
+          float4 an = mmd_ld4(anchors + (size_t)ai * 4);                 // y1,x1,y2,x2
+          float4 r = mmd_ld4(reg + ((size_t)b * A + ai) * 4);            // dy,dx,dh,dw
           float yca = __fdiv_rn(__fadd_rn(an.x, an.z), 2.f), xca = __fdiv_rn(__fadd_rn(an.y, an.w), 2.f);
           float ha = __fsub_rn(an.z, an.x), wa = __fsub_rn(an.w, an.y);
           float w = __fmul_rn(expf(r.w), wa), h = __fmul_rn(expf(r.z), ha);
@@ -70,8 +84,9 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
           float x2 = __fadd_rn(xc, __fdiv_rn(w, 2.f)), y2 = __fadd_rn(yc, __fdiv_rn(h, 2.f));
           x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, image_size); y2 = fminf(y2, image_size);
           float* o = cand + ((size_t)b * PP_CAP + kp) * 6;
-          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)clsid[(size_t)b * A + a];
+          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)clsid[(size_t)b * A + ai];
         } else *overflow = 1;
+        ++kp;
       }
     }
     __syncthreads();
