@@ -76,7 +76,9 @@ def load_states(cfg, coef=2):
     tspecs = {m: make_spec(coef, _MOD_CH[m]) for m in mods}
     tstates = {}
     for i, m in enumerate(mods):
-        st = synth_state(tspecs[m], seed=101 + i)
+        # synthetic_cls_bias (float, optional): classifier-header bias of the synthetic stand-in teachers, so that they emit
+        # pseudo-labels (the default -4 emits none and only the KD term trains)
+        st = synth_state(tspecs[m], seed=101 + i, cls_bias=cfg.getfloat("synthetic_cls_bias", -4.0))
         if os.path.exists(_MOD_PATH[m]):
             st.update(filter_state_dict({k: v.shape for k, v in st.items()}, torch.load(_MOD_PATH[m], map_location="cpu")))
         else:
