@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   __shared__ float sW[K * K * CC];
   __shared__ float sRed[2 * 4 * CC];
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
+  // XCD-aware order: blocks are dealt round-robin to the 8 XCDs; remap so that each XCD's L2 sees a contiguous run of tiles
+  // (neighbouring tiles share halo rows / columns)
+  int bid = a.pyr.n ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   // pyramid launch (k=3, s=1): pick this block's level (unrolled selects: no dynamic indexing of the argument arrays)
   int H = a.H, W = a.W, OH = a.OH, OW = a.OW, tiles_h = a.tiles_h, tiles_w = a.tiles_w, lev = 0;
   size_t ro = 0;
