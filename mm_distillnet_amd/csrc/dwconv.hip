@@ -26,6 +26,7 @@ struct DwArgs {
   // input-gradient launch feeding a BatchNorm(+swish) backward: stats become (sum g, sum g*xhat) with g = y * swish'(u),
   // u = bz*bscale + bshift, xhat = (bz - bmean)*binvstd, bz = the BN's forward input at the output position (y itself is stored)
   const float* bz; const float* bscale; const float* bshift; const float* bmean; const float* binvstd;
+  int noswz;
   int tiles_h, tiles_w, cchunks;
   Pyr pyr; long long lev_stride;
 };
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   const int tid = threadIdx.x;
   // XCD-aware order: blocks are dealt round-robin to the 8 XCDs; remap so that each XCD's L2 sees a contiguous run of tiles
   // (neighbouring tiles share halo rows / columns)
-  int bid = a.pyr.n ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
+  int bid = (a.pyr.n || a.noswz) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   // pyramid launch (k=3, s=1): pick this block's level (unrolled selects: no dynamic indexing of the argument arrays)
   int H = a.H, W = a.W, OH = a.OH, OW = a.OW, tiles_h = a.tiles_h, tiles_w = a.tiles_w, lev = 0;
   size_t ro = 0;
@@ -238,6 +239,8 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   using Cf = DwCfg<K, S, LANES>;
   a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = cdiv(a.C, Cf::CC);
   long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
+  static const int noswz = getenv("MMD_DW_NOSWZ") ? 1 : 0;
+  a.noswz = noswz;
   if (!a.stats || a.ws_slots < 2 || nb / a.cchunks <= MMD_STATS_DEPTH) a.stats_ws = nullptr;
   hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES>), dim3((unsigned)nb), dim3(256), 0, st, a);
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * a.C, st);
