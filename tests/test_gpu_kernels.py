@@ -416,6 +416,23 @@ def test_maxpool(H, W):
     close(dx.view(B, H, W, C), nhwc(x.grad))
 
 
+def test_maxpool_all_negative_input_zero_pad_wins():
+    """zero padding takes part in the max; with an all-negative map every window that touches the pad outputs 0
+    and routes no gradient (MaxPool2dStaticSamePadding pads with zeros, src/YetAnotherEfficientNet.py:68-104)."""
+    B, C, H, W = 2, 8, 8, 8
+    x = (-torch.rand(B, C, H, W) - 0.1).requires_grad_(True)
+    y = _maxpool_ref(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    out = torch.empty(B * 4 * 4, C, device=DEV)
+    call("mmd_maxpool_same_fwd", g(nhwc(x)), out, B, H, W, C)
+    assert torch.equal(out.view(B, 4, 4, C).cpu(), nhwc(y.detach()))
+    assert float(out.view(B, 4, 4, C)[:, 3, :, :].abs().max()) == 0.0          # bottom row of windows sees the pad
+    dx = torch.full((B * H * W, C), 7.0, device=DEV)
+    call("mmd_maxpool_same_bwd_acc", g(nhwc(x)), g(nhwc(dy)), dx, None, 0, 0, 0, B, H, W, C)
+    close(dx.view(B, H, W, C), nhwc(x.grad))
+
+
 def test_adam_and_clip():
     torch.manual_seed(5)
     n = 4096 + 8

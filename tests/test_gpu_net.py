@@ -117,17 +117,18 @@ def test_net_train_fwd_bwd(golden_dir):
             check_summary(gold, "grad." + name, grads[name], 2e-2, 1e-3)
 
 
-def test_net_eval_512_vs_oracle():
-    """BASELINE config-1 shape (one RGB teacher forward, 512x512) at B=2 against the oracle."""
+@pytest.mark.parametrize("B", [1, 2, 8])
+def test_net_eval_512_vs_oracle(B):
+    """BASELINE config-1 shape (one RGB teacher forward, 512x512) at B = 1, 2 and the benchmark's 8 against the oracle."""
     spec, st = make_state(2, 3, 11, "rgb")
     net = Net(spec, DEV, trainable=False)
     net.load_state(st)
-    x = synth_inputs(2, 512, seed=3)["rgb"]
+    x = synth_inputs(B, 512, seed=3)["rgb"]
     net.begin_step()
     cls, reg, feats = net.forward(x.to(DEV), train=False)
     with torch.no_grad():
         (c, r, a), f = O.forward(st, x, 2, False)
-    assert cls.shape == (2, 49104, 20) and reg.shape == (2, 49104, 4)
+    assert cls.shape == (B, 49104, 20) and reg.shape == (B, 49104, 4)
     assert relerr(cls, c) < 1e-3 and relerr(reg, r) < 1e-3
     for u, v in zip(feats, f):
         assert relerr(feat_nchw(u), v) < 1e-3
