@@ -10,6 +10,8 @@ their gradients, the student backward, gradient all-reduce (RCCL, student gradie
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -226,7 +228,9 @@ class DistillEngine:
             return
         import torch.distributed as dist
         g = self.student.ps.grad
-        nb = 4
+        # one collective for the whole 32 MB buffer: nothing overlaps with it yet (it sits between the two graphs), so
+        # buckets would only add per-collective latency; see DESIGN.md §8 for the planned split of the backward graph
+        nb = int(os.environ.get("MMD_AR_BUCKETS", "1"))
         per = (g.numel() // nb + 3) // 4 * 4
         for i in range(nb):
             seg = g[i * per:min(g.numel(), (i + 1) * per)]
