@@ -164,6 +164,14 @@ def main():
         tune_teacher_bias(specs[k], tstates[k], batch_cpu[k], dev)
     log("teacher biases tuned")
     eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S), world_size=world, process_group=pg)
+    if world == 1 and os.environ.get("MMD_FORCE_DP"):
+        # dev aid for a 1-GPU box: a one-rank RCCL group, the split backward and the phased all-reduce calls exactly as at
+        # N > 1 (measures what the split + the collectives' launches cost when there is nothing to exchange)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        eng.force_ar = True
+        eng.ar_split = eng._default_split()
     eng.load(sstate, tstates)
     if world > 1:   # identical initial student on every rank (DDP broadcasts parameters at construction)
         import torch.distributed as dist
@@ -234,6 +242,7 @@ def main():
         eng.concurrent_teachers = False
         os.environ["MMD_NO_WG"] = "1"; os.environ["MMD_NO_SIDE"] = "1"
         eng.step_body(batch if not use_graph else eng.static, eng.static["drop_scale"] if use_graph else eng.make_drop_scale(B))
+        eng.backward_tail()
         torch.cuda.synchronize()
         eng.concurrent_teachers = conc
         del os.environ["MMD_NO_WG"], os.environ["MMD_NO_SIDE"]

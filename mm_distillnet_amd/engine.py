@@ -610,13 +610,17 @@ class Net:
                  None, None, None, 0)
         return g
 
-    def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]]):
+    def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]],
+                 stop_before: Optional[int] = None):
         """Accumulates parameter gradients into ps.grad.  dcls_logit [B,A,NC] is the gradient w.r.t. the
-        classifier header's PRE-sigmoid output, dreg [B,A,4], dfeats[l] (nullable) w.r.t. the BiFPN outputs."""
+        classifier header's PRE-sigmoid output, dreg [B,A,4], dfeats[l] (nullable) w.r.t. the BiFPN outputs.
+        stop_before=k: stop after backbone block k (heads, BiFPN and blocks >= k done, weight-gradient stream joined), so
+        that the caller can start the all-reduce of those gradients; backward_finish() runs blocks < k and the stem."""
         spec, ps, tape = self.spec, self.ps, self.tape
         feats: List[Feat] = tape["feats"]
         A = tape["A"]
         slots: Dict[int, GradSlot] = {}
+        self._bw = {"slots": slots, "stem_sums": None}
 
         def slot(f: Feat) -> GradSlot:
             return slots.setdefault(f.z.data_ptr(), GradSlot())
@@ -721,10 +725,28 @@ class Net:
                     dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C)
                     dx = self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, None, True)
                     self._acc(slot(x), dx)
-        # ---- backbone (blocks in reverse)
+        self._backward_blocks([b for b in spec.blocks if stop_before is None or b.idx >= stop_before])
+        if stop_before is None:
+            self.backward_finish(0)
+        elif self._wg is not None:
+            torch.cuda.current_stream().wait_stream(self._wg)
+
+    def backward_finish(self, stop_before: int):
+        """Second part of a split backward: backbone blocks < stop_before, then the stem."""
+        self._backward_blocks([b for b in self.spec.blocks if b.idx < stop_before])
+        self._backward_stem()
+
+    def _backward_blocks(self, blocks):
+        """Backbone blocks in reverse."""
+        spec, ps, tape = self.spec, self.ps, self.tape
+        slots = self._bw["slots"]
+
+        def slot(f: Feat) -> GradSlot:
+            return slots.setdefault(f.z.data_ptr(), GradSlot())
+
         P = "backbone_net.model"
-        stem_sums = None
-        for blk in reversed(spec.blocks):
+        stem_sums = self._bw["stem_sums"]
+        for blk in reversed(blocks):
             q = f"{P}._blocks.{blk.idx}"
             rec = tape[f"blk{blk.idx}"]
             out: Feat = rec["out"]
@@ -773,9 +795,14 @@ class Net:
             else:
                 g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
                 self._acc(slot(inp), g0)
-        # ---- stem
+        self._bw["stem_sums"] = stem_sums
+
+    def _backward_stem(self):
+        ps, tape = self.ps, self.tape
+        P = "backbone_net.model"
+        stem_sums = self._bw["stem_sums"]
         ximg, stem, mu, istd = tape["stem"]
-        s = slot(stem)
+        s = self._bw["slots"].setdefault(stem.z.data_ptr(), GradSlot())
         dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
         with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
             col = self._alloc(stem.M, ps.stem_kp)

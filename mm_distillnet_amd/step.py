@@ -84,6 +84,16 @@ class DistillEngine:
         self.static: Dict[str, torch.Tensor] = {}
         self.out: Dict[str, torch.Tensor] = {}
         self.n_skip = sum(1 for b in student_spec.blocks if b.skip)
+        # data-parallel gradient exchange overlapped with the backward: the backward is issued (and captured) in two
+        # segments split before backbone block `ar_split`; the gradients of everything behind it (heads, BiFPN, blocks >=
+        # ar_split: ~98 % of the buffer, they sit at the tail of the conv region) are reduced on RCCL's stream while
+        # the high-resolution early blocks - about half of the backward's time - still run
+        self.ar_split: Optional[int] = self._default_split() if world_size > 1 else None
+        env = os.environ.get("MMD_AR_SPLIT")
+        if env is not None:
+            self.ar_split = None if env in ("", "none", "-1") else int(env)
+        self._ar_work = None
+        self.force_ar = False        # dev aid: issue the collectives on a one-rank group (bench.py MMD_FORCE_DP)
         self.keep = torch.tensor([1.0 - b.drop_rate for b in student_spec.blocks if b.skip], device=device).view(-1, 1)
 
     # ------------------------------------------------------------------
@@ -100,6 +110,32 @@ class DistillEngine:
         assert all(e.off >= b0 for e in conv) and all(
             (not k.startswith(("regressor", "classifier"))) or ps.entries[k].off >= b0 for k in ps.order)
         return (b0, e0, ps.gamma_off + lo, ps.gamma_off + hi, ps.beta_off + lo, ps.beta_off + hi)
+
+    def _block_off(self, k: int) -> int:
+        ps = self.student.ps
+        q = f"backbone_net.model._blocks.{k}."
+        return min(e.off for key, e in ps.entries.items() if key.startswith(q))
+
+    def _default_split(self) -> int:
+        """First backbone block with more than 2 % of the conv parameters in front of it (D2: block 8, the 64x64 -> 32x32
+        stage; the blocks before it own 1.6 % of the gradients and roughly half of the backward's kernel time)."""
+        ps = self.student.ps
+        k = 1
+        for b in self.student.spec.blocks[1:]:
+            if self._block_off(b.idx) > 0.02 * ps.n_conv:
+                break
+            k = b.idx
+        return k
+
+    def grad_buckets(self):
+        """[(begin, end)] float ranges of the flat gradient buffer per all-reduce phase.  Phase 0 is complete when the
+        first backward segment ends, phase 1 (early backbone blocks + all BatchNorm gammas/betas) when the backward ends."""
+        ps = self.student.ps
+        if self.ar_split is None:
+            return [[], [(0, ps.n_params)]]
+        o = self._block_off(self.ar_split)
+        assert o % 4 == 0
+        return [[(o, ps.n_conv)], [(0, o), (ps.n_conv, ps.n_params)]]
 
     def load(self, student_state, teacher_states: Dict[str, dict]):
         self.student.load_state(student_state)
@@ -214,29 +250,40 @@ class DistillEngine:
              float(cfg.w_main), 1, self.head_active)
         # backward + optimizer
         call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
-        st.backward(dcls, dreg, dfe)
+        st.backward(dcls, dreg, dfe, stop_before=self.ar_split)
         self.out = {"reg": main[0:1], "cls": main[1:2], "kd": kd, "boxes": boxes, "nbox": nbox,
                     "cls_s": cls_s, "reg_s": reg_s, "feats_s": feats_s, "rows_t": rows_t, "cnt_t": cnt_t}
         return self.out
 
-    def allreduce_grads(self):
+    def backward_tail(self):
+        """Second backward segment (backbone blocks < ar_split + stem); a no-op when the backward is not split."""
+        if self.ar_split is not None:
+            self.student.backward_finish(self.ar_split)
+
+    def allreduce_grads(self, phase: Optional[int] = None):
         """RCCL all-reduce(sum) of the flat student gradient buffer (teachers are frozen: nothing else is
         exchanged).  The 1/world average is folded into the optimizer's grad_scale.  head_active is reduced
         with max so that every rank gates the same parameter ranges (ranks may disagree on whether their
-        batch had pseudo-labels)."""
-        if self.world_size <= 1:
+        batch had pseudo-labels).
+
+        phase 0: issued after the first backward segment, asynchronously - the collective runs on the process group's
+        own stream (ordered after everything enqueued so far) next to the second backward segment.  phase 1: the
+        remaining ranges after the backward's end; it also makes the current stream wait for phase 0.  phase None: both."""
+        if self.world_size <= 1 and not self.force_ar:
             return
         import torch.distributed as dist
         g = self.student.ps.grad
-        # one collective for the whole 32 MB buffer: nothing overlaps with it yet (it sits between the two graphs), so
-        # buckets would only add per-collective latency; see DESIGN.md §8 for the planned split of the backward graph
-        nb = int(os.environ.get("MMD_AR_BUCKETS", "1"))
-        per = (g.numel() // nb + 3) // 4 * 4
-        for i in range(nb):
-            seg = g[i * per:min(g.numel(), (i + 1) * per)]
-            if seg.numel():
-                dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.pg)
-        dist.all_reduce(self.head_active, op=dist.ReduceOp.MAX, group=self.pg)
+        buckets = self.grad_buckets()
+        if phase in (0, None):
+            self._ar_work = [dist.all_reduce(g[b:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                             for b, e in buckets[0]]
+            self._ar_work.append(dist.all_reduce(self.head_active, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+        if phase in (1, None):
+            work = (self._ar_work or []) + [dist.all_reduce(g[b:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                                            for b, e in buckets[1]]
+            for w in work:
+                w.wait()
+            self._ar_work = None
 
     def optimizer_body(self):
         cfg, ps = self.cfg, self.student.ps
@@ -259,13 +306,16 @@ class DistillEngine:
         if drop_scale is None:
             drop_scale = self.make_drop_scale(B)
         out = self.step_body(batch, drop_scale)
-        self.allreduce_grads()
+        self.allreduce_grads(0)
+        self.backward_tail()
+        self.allreduce_grads(1)
         self.optimizer_body()
         return out
 
     def capture(self, batch: Dict[str, torch.Tensor]):
-        """Warm up eagerly (sizes the arenas), then capture forward+loss+backward and the optimizer as two
-        hipGraphs; the gradient all-reduce runs between them (RCCL is launched eagerly, not captured)."""
+        """Warm up eagerly (sizes the arenas), then capture forward+loss+backward and the optimizer as
+        hipGraphs (the backward in two segments when world_size > 1); the gradient all-reduce is launched eagerly between
+        them (RCCL is not captured) and overlaps with the second backward segment."""
         B = batch["audio"].shape[0]
         self.static = {k: v.clone() for k, v in batch.items()}
         self.static["drop_scale"] = self.make_drop_scale(B)
@@ -279,6 +329,7 @@ class DistillEngine:
         with torch.cuda.stream(s):
             for _ in range(2):
                 self.step_body(self.static, self.static["drop_scale"])
+                self.backward_tail()
                 self.optimizer_body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -289,6 +340,11 @@ class DistillEngine:
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.step_body(self.static, self.static["drop_scale"])
+        self.g_tail = None
+        if self.ar_split is not None:
+            self.g_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
+                self.backward_tail()
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self.optimizer_body()
@@ -306,7 +362,10 @@ class DistillEngine:
         B = self.static["audio"].shape[0]
         self.static["drop_scale"].copy_(drop_scale if drop_scale is not None else self.make_drop_scale(B))
         self.g_main.replay()
-        self.allreduce_grads()
+        self.allreduce_grads(0)
+        if self.g_tail is not None:
+            self.g_tail.replay()
+        self.allreduce_grads(1)
         self.g_opt.replay()
         return self.out
 

@@ -14,7 +14,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, split):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mm_distillnet_amd.arch import make_spec
@@ -31,18 +31,34 @@ def _worker(rank, world, port, q):
     mine = g.clone()
     both = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(both, mine)
-    eng.allreduce_grads()
+    if split:
+        # the overlapped schedule: phase 0 (heads, BiFPN, late backbone blocks) is launched asynchronously after the first
+        # backward segment, phase 1 (early blocks + BatchNorm affine) after the second; phase 1 also waits for phase 0
+        eng.ar_split = eng._default_split()
+        (p0,), tail = eng.grad_buckets()
+        eng.allreduce_grads(0)
+        assert eng._ar_work is not None and len(eng._ar_work) == 2
+        eng.allreduce_grads(1)
+        assert eng._ar_work is None
+        covered = torch.zeros(g.numel(), dtype=torch.int32)
+        for b, e in [p0] + tail:
+            covered[b:e] += 1
+        assert bool((covered == 1).all())
+    else:
+        assert eng.ar_split is not None         # world_size > 1 splits by default
+        eng.allreduce_grads()
     ok = bool(torch.allclose(g, both[0] + both[1]))
     q.put((rank, ok, float(g.double().sum()), int(eng.head_active.item()), eng.head_ranges, eng.student.ps.n_params))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_allreduce_two_ranks():
+@pytest.mark.parametrize("split", [False, True])
+def test_allreduce_two_ranks(split):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, split)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
