@@ -34,6 +34,7 @@ FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
             3: ("dw_bwd kernels (depthwise conv backward)", "hbm"),
             4: ("row-streaming kernels (BN backward / affine / pools)", "hbm")}
 PEAK = {"mfma": 157.3, "hbm": 8000.0}      # TFLOP/s fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
+PEAK_BF16 = 2500.0                         # dense bf16 MFMA TFLOP/s
 
 
 def calibrated_state(spec, seed, x, device, cls_bias=-4.0):
@@ -130,6 +131,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--coef", type=int, default=2, help="EfficientDet compound coefficient (2 = the BASELINE configs 1-4; 4 with --size 768 = config 5's architecture, run in fp32)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = mixed precision (BASELINE config 5): 1x1-conv GEMMs on the bf16 MFMA, fp32 accumulate; the default "
+                         "workload is fp32 like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2)
@@ -163,7 +167,7 @@ def main():
     for k in tstates:
         tune_teacher_bias(specs[k], tstates[k], batch_cpu[k], dev)
     log("teacher biases tuned")
-    eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S), world_size=world, process_group=pg)
+    eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S, precision=args.precision), world_size=world, process_group=pg)
     if world == 1 and os.environ.get("MMD_FORCE_DP"):
         # dev aid for a 1-GPU box: a one-rank RCCL group, the split backward and the phased all-reduce calls exactly as at
         # N > 1 (measures what the split + the collectives' launches cost when there is nothing to exchange)
@@ -272,19 +276,22 @@ def main():
             traffic = round(pm["hbm_bytes_per_step"] / max(n, 1), 1) if (args.coef == 2 and S == 512 and B == 8 and fam_key != "bn_bwd") else None
         except Exception:
             traffic = None
-        roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": PEAK[bound], "unit": unit,
-                "frac": round(achieved / PEAK[bound], 4), "traffic": traffic,
+        peak = PEAK_BF16 if (bound == "mfma" and args.precision == "bf16") else PEAK[bound]
+        if args.precision == "bf16":
+            traffic = None          # the committed PMC passes are of the fp32 kernels
+        roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(by / max(n, 1), 1), "launches_per_step": int(n),
                 "avg_launch_us": round(tms * 1e3 / max(n, 1), 2), "family_ms_per_step": round(tms, 3),
                 "algorithmic_bytes_per_step": by, "algorithmic_flops_per_step": fl,
                 "all_families_ms": {FAMILIES[f][0].split(" ")[0]: round(res[f][1], 3) for f in res}}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sstate, tstates, S, args.cpu_sample, args.coef)
-        std = args.coef == 2 and S == 512 and B == 8
+        std = args.coef == 2 and S == 512 and B == 8 and args.precision == "fp32"
         line = {"metric": "distillation-step images/sec (3 teachers + audio student, D%d, bs=%d)" % (args.coef, B), "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands in the 1x1 convs, f32 elsewhere", "data": "synthetic",
                 "config": {"workload": ("BASELINE configs[2]" if std else "non-default shape (BASELINE config 5 = D4 / 768 in bf16; this is fp32)")
                                        + ": full 3-teacher (RGB+thermal+depth) -> audio student distillation step, EfficientDet-D%d, "
                                          "%dx%d, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % (args.coef, S, S, B),

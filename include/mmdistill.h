@@ -182,6 +182,18 @@ int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int
 // dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
 int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);
 
+// --- bf16 mixed-precision variants of the four 1x1-conv entry points (BASELINE config 5: "bf16 mixed precision, MFMA bf16").
+// Same contracts and fp32 tensors; the two MFMA operands are rounded to bf16 (round-to-nearest-even) right before
+// v_mfma_f32_32x32x16_bf16, accumulation / prologue / epilogue / BatchNorm statistics stay fp32.  The reference has no
+// reduced-precision path ("no AMP anywhere"); this is what torch.autocast(bf16) would make of its nn.Conv2d(k=1).
+int mmd_pwconv_fwd_bf16(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, hipStream_t stream);
+
+int mmd_pwconv_fwd_pyr_bf16(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
+
+int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);
+
+int mmd_pwconv_bwd_data_bf16(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);
+
 // Every 1x1 weight of the student transposed in one launch (desc rows: src_off, dst_off, R, C, first_tile).
 int mmd_transpose_batched(const float* src_base, float* dst_base, const long long* desc, int n, int total_tiles, hipStream_t stream);
 

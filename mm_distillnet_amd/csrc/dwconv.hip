@@ -370,6 +370,7 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
   if (bn_sums && (stride != 1 || !bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
   int OH, OW;
   int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
+  mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
   int rc;
   if (stride == 1) {
@@ -516,6 +517,7 @@ extern "C" int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw,
   a.x = x; a.dy = dy; a.dw = dw; a.B = B; a.H = H; a.W = W; a.C = C;
   a.pad_t = same_pad_lo(H, k, stride, &a.OH); a.pad_l = same_pad_lo(W, k, stride, &a.OW);
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  mmd_prof_tag(MMD_FAM_DW_BWD, "dwwg H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
   int rc;
   if (k == 3 && stride == 1) rc = dw_wgrad_launch<3, 1>(a, stream);
@@ -547,6 +549,7 @@ extern "C" int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float
     nb += a.B * a.cchunks * ns;
   }
   for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nb;
+  mmd_prof_tag(MMD_FAM_DW_BWD, "dwwgpyr C%lld", C, 0, 0, 0);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
   hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(nb), dim3(256), 0, stream, a);
   double rows = a.pyr.row0[a.pyr.n];

@@ -140,6 +140,7 @@ extern "C" int mmd_affine_act(const float* z, const float* scale, const float* s
   if (!z || !y || M <= 0 || C <= 0 || (C & 3) || (rowscale && rows_per_image <= 0)) return MMD_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
   if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
+  mmd_prof_tag(MMD_FAM_ELT, "affine M%lld C%lld r%lld", M, C, (long long)(res?1:0), 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(affine_act_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, z, scale, shift,
                      mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, rowscale, rows_per_image, res, y, M, C);
@@ -187,6 +188,7 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
   if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   int base = cdiv(C, 64) * B;
   int ns = cdiv(1024, base); int mx = cdiv(rows_per_image, 64); if (ns > mx) ns = mx; if (ns < 1) ns = 1;
+  mmd_prof_tag(MMD_FAM_ELT, "cpool B%lld R%lld C%lld", B, rows_per_image, C, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(chan_pool_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift,
                      mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, g, out, out_scale, rows_per_image, C, ns);
@@ -253,6 +255,7 @@ extern "C" int mmd_chan_pool_bwd(const float* z, const float* scale, const float
     return MMD_EINVAL;
   int base = cdiv(C, 64) * B;
   int ns = cdiv(1024, base); int mx = cdiv(rows_per_image, 64); if (ns > mx) ns = mx; if (ns < 1) ns = 1;
+  mmd_prof_tag(MMD_FAM_ELT, "cpoolbwd B%lld R%lld C%lld", B, rows_per_image, C, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(chan_pool_bwd_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift, mean, invstd, g1,
                      out5, B, rows_per_image, C, ns);
@@ -482,6 +485,7 @@ extern "C" int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float*
                                  double* sums, int M, int C, double* stats_ws, int ws_slots, hipStream_t stream) {
   if (!g_in || !z || !scale || !shift || !mean || !invstd || !sums || M <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
+  mmd_prof_tag(MMD_FAM_ELT, "bnred M%lld C%lld o%lld", M, C, (long long)(g_out?1:0), 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   const bool slotted = stats_ws && ws_slots > 1 && cdiv(M, ROWS_PER_BLOCK) > MMD_STATS_DEPTH;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g_in, z, scale,
@@ -548,6 +552,7 @@ extern "C" int mmd_bn_bwd_apply(const float* g, const float* z, const float* mea
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
   if (act != MMD_ACT_NONE && (act != MMD_ACT_SWISH || !scale || !shift)) return MMD_EINVAL;
   if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
+  mmd_prof_tag(MMD_FAM_ELT, "bnapp M%lld C%lld", M, C, 0, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g, z, mean,
                      invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C, Pyr{}, 0, ROWS_PER_BLOCK,
@@ -646,6 +651,7 @@ extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const fl
   Pyr p;
   if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
   int M = p.row0[p.n];
+  mmd_prof_tag(MMD_FAM_ELT, "bnredpyr C%lld", C, 0, 0, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, g_in, z, scale, shift, mean,
                      invstd, act, nullptr, nullptr, nullptr, 1, g_out, sums, M, C, p, lev_stride, 128, nullptr, 0);
@@ -662,6 +668,7 @@ extern "C" int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float*
   Pyr p;
   if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
   int M = p.row0[p.n];
+  mmd_prof_tag(MMD_FAM_ELT, "bnapppyr C%lld", C, 0, 0, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, g, z, mean, invstd, gamma, sums,
                      1.0, dz, dgamma, dbeta, M, C, p, lev_stride, 128, BnBwdMod{scale, shift, act, nullptr, nullptr, nullptr, 1});
@@ -790,6 +797,7 @@ extern "C" int mmd_stem_conv_fwd(const float* x, const float* w, float* y, int B
   size_t total = (size_t)B * OH * OW;
   int nb = cdiv(total, 256);
   const bool slotted = stats && stats_ws && ws_slots > 1 && nb > MMD_STATS_DEPTH;
+  mmd_prof_tag(MMD_FAM_ELT, "stem B%lld Cin%lld H%lld Co%lld", B, Cin, H, Cout);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   void (*kern)(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, const float*, const float*, int, double*,
                double*, int) = Cout == 32 ? stem_conv_kernel<32> : Cout == 40 ? stem_conv_kernel<40> : Cout == 48 ? stem_conv_kernel<48>

@@ -27,7 +27,25 @@ struct PwArgs {
   long long y_batch_stride; long long y_offset;
   int ntn; int nblk;
   Pyr pyr; long long yoff_lev[MMD_MAX_LEV]; long long lev_stride;
+  int bf16;                                  // host-side: operands rounded to bf16 at the MFMA input (mixed-precision mode)
 };
+
+// ---- bf16 mixed precision (BASELINE config 5): the SAME kernels with the inner product on v_mfma_f32_32x32x16_bf16.
+// Activations and weights stay fp32 in HBM and LDS; each lane converts its 8 consecutive k (RNE, v_cvt_pk_bf16_f32) right
+// before the MFMA, accumulation and every prologue / epilogue stay fp32.  16x the fp32 MFMA rate: the layers become
+// load/store-bound.  A lane (r = lane & 31, h = lane >> 5) supplies row r, k = 8h .. 8h+7 of a 16-wide k group, for A and B.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
+  u32x4_t u = {pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
+  return __builtin_bit_cast(bf16x8, u);
+}
 
 #define PW_BM 128
 #define PW_BK 32
@@ -39,7 +57,7 @@ struct PwArgs {
 // BM_T = 128: the 4 waves stack along M (32 rows each, all BN_T columns); BM_T = 64: 2 x 2 waves (32 rows x BN_T/2 columns
 // each) - twice the blocks for the small-M layers (16x16 / 32x32 stages), whose 128-row tiling leaves most SIMDs with
 // one wave or none.
-template <int BM_T, int BN_T, int NKL>
+template <int BM_T, int BN_T, int NKL, bool BF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
   constexpr int WM = BM_T / 32;          // waves along M
   constexpr int WN = 4 / WM;             // waves along N
@@ -144,18 +162,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
     }
   };
+  const float* const pa16 = &sA[(wm * 32 + r) * PW_LD + h * 8];
+  const float* const pb16 = &sB[(wn * NS * 32 + r) * PW_LD + h * 8];
+  auto mma16 = [&](int g) {      // one 16-wide k group on the bf16 MFMA
+    const bf16x8 av = pack_bf16x8(*reinterpret_cast<const float4*>(pa16 + g * 16), *reinterpret_cast<const float4*>(pa16 + g * 16 + 4));
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const float* q = pb16 + j * 32 * PW_LD + g * 16;
+      const bf16x8 bv = pack_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+    }
+  };
   for (int kt = 0; kt < nk - 1; ++kt) {
     lstore();
     __syncthreads();
     gload((kt + 1) * PW_BK);
+    if constexpr (BF) {
 #pragma unroll
-    for (int kk = 0; kk < PW_BK / 8; ++kk) mma(kk);
+      for (int g = 0; g < PW_BK / 16; ++g) mma16(g);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < PW_BK / 8; ++kk) mma(kk);
+    }
     __syncthreads();
   }
-  lstore();                      // last K tile: only its populated 8-wide groups
+  lstore();                      // last K tile: only its populated 8-wide groups (the tile is zero-filled beyond K)
   __syncthreads();
+  if constexpr (BF) {
 #pragma unroll
-  for (int kk = 0; kk < NKL; ++kk) mma(kk);
+    for (int g = 0; g < (NKL + 1) / 2; ++g) mma16(g);
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < NKL; ++kk) mma(kk);
+  }
   __syncthreads();
 
   // ---- epilogue.  The accumulator (col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)) is staged through LDS so every
@@ -233,6 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define SK_BK 128
 #define SK_LD 132
 
+template <bool BF>
 __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
   __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
@@ -314,6 +354,20 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     lstore();
     __syncthreads();
     if (kt + 1 < nk) gload((kt + 1) * SK_BK);
+    if constexpr (BF) {
+      const float* pa = &sA[r * SK_LD + wave * 32 + h * 8];
+      const float* pb = &sB[r * SK_LD + wave * 32 + h * 8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const bf16x8 av = pack_bf16x8(*reinterpret_cast<const float4*>(pa + g * 16), *reinterpret_cast<const float4*>(pa + g * 16 + 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float* q = pb + j * 32 * SK_LD + g * 16;
+          const bf16x8 bv = pack_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    } else {
     const float* pa = &sA[r * SK_LD + wave * 32 + h * 4];
     const float* pb = &sB[r * SK_LD + wave * 32 + h * 4];
 #pragma unroll
@@ -327,6 +381,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
       }
+    }
     }
     __syncthreads();
   }
@@ -606,14 +661,22 @@ static int pw_stream_launch(PwArgs& a, hipStream_t stream) {
 
 static int pw_dispatch(PwArgs& a, hipStream_t stream);
 
-extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N,
+template <int BM_T, int BN_T>
+static void (*pw_pick(int nkl, int bf))(PwArgs) {
+  if (bf) return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, true> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, true>
+               : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, true> : pw_gemm_kernel<BM_T, BN_T, 4, true>;
+  return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, false> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, false>
+       : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, false> : pw_gemm_kernel<BM_T, BN_T, 4, false>;
+}
+
+static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, int N,
                               const float* in_scale, const float* in_shift, int in_act,
                               const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                               const float* gate, int rows_per_image,
                               const float* bias, const float* out_scale, const float* out_shift, int out_act,
                               const float* residual, double* stats,
                               long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots,
-                              hipStream_t stream) {
+                              hipStream_t stream, int bf16) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !x || !w || !y) return MMD_EINVAL;
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
@@ -622,10 +685,23 @@ extern "C" int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, i
   PwArgs a{x, w, y, M, K, N, in_scale, in_shift, in_act, mmd_make_bn(in_stats, in_gamma, in_beta, in_count, K), gate,
            rows_per_image > 0 ? rows_per_image : 1,
            bias, out_scale, out_shift, out_act, residual, stats, nullptr, 0, y_batch_stride, y_offset, 0, 0, Pyr{},
-           {0, 0, 0, 0, 0}, 0};
+           {0, 0, 0, 0, 0}, 0, bf16};
   if (stats && stats_ws && ws_slots > 1 && cdiv(M, PW_BM) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
   return pw_dispatch(a, stream);
 }
+
+#define PW_FWD_PARAMS const float* x, const float* w, float* y, int M, int K, int N, \
+                      const float* in_scale, const float* in_shift, int in_act, \
+                      const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, \
+                      const float* gate, int rows_per_image, \
+                      const float* bias, const float* out_scale, const float* out_shift, int out_act, \
+                      const float* residual, double* stats, \
+                      long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, hipStream_t stream
+#define PW_FWD_ARGS x, w, y, M, K, N, in_scale, in_shift, in_act, in_stats, in_gamma, in_beta, in_count, gate, rows_per_image, \
+                    bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, stats_ws, ws_slots, stream
+extern "C" int mmd_pwconv_fwd(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 0); }
+// same contract, operands rounded to bf16 at the MFMA input (fp32 accumulate, fp32 in/out tensors)
+extern "C" int mmd_pwconv_fwd_bf16(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 1); }
 
 static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   const int M = a.M, K = a.K, N = a.N;
@@ -648,7 +724,7 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     else pw_stream_launch<2, 2>(a, stream);
   } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16 && !(sq_tiles > 0 && big_tiles >= sq_min && big_tiles < sq_tiles && N > 32)) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
-    hipLaunchKernelGGL(pw_gemm_skinny_kernel, dim3(a.nblk), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(a.bf16 ? pw_gemm_skinny_kernel<true> : pw_gemm_skinny_kernel<false>, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
     // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
@@ -657,13 +733,13 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     void (*kern)(PwArgs);
     if (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles))) {
       a.ntn = cdiv(N, 32);
-      kern = nkl == 1 ? pw_gemm_kernel<128, 32, 1> : nkl == 2 ? pw_gemm_kernel<128, 32, 2> : nkl == 3 ? pw_gemm_kernel<128, 32, 3> : pw_gemm_kernel<128, 32, 4>;
+      kern = pw_pick<128, 32>(nkl, a.bf16);
     } else if (sq_tiles > 0 && big_tiles < sq_tiles) {      // 64x64 tiles: small-M layers
       a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
-      kern = nkl == 1 ? pw_gemm_kernel<64, 64, 1> : nkl == 2 ? pw_gemm_kernel<64, 64, 2> : nkl == 3 ? pw_gemm_kernel<64, 64, 3> : pw_gemm_kernel<64, 64, 4>;
+      kern = pw_pick<64, 64>(nkl, a.bf16);
     } else {
       a.ntn = cdiv(N, 64);
-      kern = nkl == 1 ? pw_gemm_kernel<128, 64, 1> : nkl == 2 ? pw_gemm_kernel<128, 64, 2> : nkl == 3 ? pw_gemm_kernel<128, 64, 3> : pw_gemm_kernel<128, 64, 4>;
+      kern = pw_pick<128, 64>(nkl, a.bf16);
     }
     a.nblk = ntm * a.ntn;
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
@@ -676,9 +752,9 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
 // Shared-weight head layer over a whole feature pyramid in one launch (see Pyr in common.h).  x, y: pyramid row
 // buffers [row0[n], K] / [row0[n], N] (or, with y_batch_stride != 0, the concatenated [B, A_total, c] head output with
 // per-level offsets y_off_lev).  stats (nullable): level l accumulates into stats + 2*l*lev_stride.
-extern "C" int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N,
+static int pw_fwd_pyr_impl(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N,
                                   const float* bias, int out_act, double* stats, long long lev_stride,
-                                  long long y_batch_stride, const long long* y_off_lev, hipStream_t stream) {
+                                  long long y_batch_stride, const long long* y_off_lev, hipStream_t stream, int bf16) {
   if (!x || !w || !y || !pyr_desc || K <= 0 || N <= 0 || (K & 3) || (N & 3)) return MMD_EINVAL;
   if (y_batch_stride && !y_off_lev) return MMD_EINVAL;
   PwArgs a{};
@@ -687,7 +763,18 @@ extern "C" int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, cons
   a.bias = bias; a.out_act = out_act; a.stats = stats; a.lev_stride = lev_stride; a.y_batch_stride = y_batch_stride;
   a.in_bn = mmd_make_bn(nullptr, nullptr, nullptr, 0, K);
   for (int l = 0; l < a.pyr.n; ++l) a.yoff_lev[l] = y_off_lev ? y_off_lev[l] : 0;
+  a.bf16 = bf16;
   return pw_dispatch(a, stream);
+}
+extern "C" int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N,
+                                  const float* bias, int out_act, double* stats, long long lev_stride,
+                                  long long y_batch_stride, const long long* y_off_lev, hipStream_t stream) {
+  return pw_fwd_pyr_impl(x, w, y, pyr_desc, K, N, bias, out_act, stats, lev_stride, y_batch_stride, y_off_lev, stream, 0);
+}
+extern "C" int mmd_pwconv_fwd_pyr_bf16(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N,
+                                       const float* bias, int out_act, double* stats, long long lev_stride,
+                                       long long y_batch_stride, const long long* y_off_lev, hipStream_t stream) {
+  return pw_fwd_pyr_impl(x, w, y, pyr_desc, K, N, bias, out_act, stats, lev_stride, y_batch_stride, y_off_lev, stream, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -704,6 +791,7 @@ struct WgArgs {
 #define WG_LD 68
 #define WG_BR 32          // rows of the M reduction per step (64 measured no faster)
 
+template <bool BF>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   __shared__ float sD[WG_BR * WG_LD];
   __shared__ float sX[WG_BR * WG_LD];
@@ -762,9 +850,23 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
     if (mb + WG_BR < mend) gload(mb + WG_BR);
     const float* pd = &sD[h * WG_LD + wn * 32 + r];
     const float* px = &sX[h * WG_LD + wk * 32 + r];
+    if constexpr (BF) {
+      // the reduction runs over rows: lane (r, h) gathers rows 16g + 8h .. + 7 of its column (8 ds_read_b32 per operand)
+#pragma unroll
+      for (int g = 0; g < WG_BR / 16; ++g) {
+        const float* qd = &sD[(g * 16 + h * 8) * WG_LD + wn * 32 + r];
+        const float* qx = &sX[(g * 16 + h * 8) * WG_LD + wk * 32 + r];
+        const bf16x8 dv = pack_bf16x8(make_float4(qd[0], qd[WG_LD], qd[2 * WG_LD], qd[3 * WG_LD]),
+                                      make_float4(qd[4 * WG_LD], qd[5 * WG_LD], qd[6 * WG_LD], qd[7 * WG_LD]));
+        const bf16x8 xv = pack_bf16x8(make_float4(qx[0], qx[WG_LD], qx[2 * WG_LD], qx[3 * WG_LD]),
+                                      make_float4(qx[4 * WG_LD], qx[5 * WG_LD], qx[6 * WG_LD], qx[7 * WG_LD]));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv, xv, acc, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int tt = 0; tt < WG_BR / 2; ++tt)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[tt * 2 * WG_LD], px[tt * 2 * WG_LD], acc, 0, 0, 0);
+    }
     __syncthreads();
   }
   const int kcol = k0 + wk * 32 + r;
@@ -777,9 +879,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   }
 }
 
-extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N,
+static int pw_wgrad_impl(const float* dy, const float* x, float* dw, int M, int K, int N,
                                      const float* in_scale, const float* in_shift, int in_act,
-                                     const float* gate, int rows_per_image, hipStream_t stream) {
+                                     const float* gate, int rows_per_image, hipStream_t stream, int bf16) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !dy || !x || !dw) return MMD_EINVAL;
   if (gate && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
@@ -794,9 +896,19 @@ extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw,
   splits = cdiv(M, a.mchunk);
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wg M%lld K%lld N%lld s%lld", M, K, N, splits);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
-  hipLaunchKernelGGL(pw_wgrad_kernel, dim3(tiles * splits), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(bf16 ? pw_wgrad_kernel<true> : pw_wgrad_kernel<false>, dim3(tiles * splits), dim3(256), 0, stream, a);
   mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   return mmd_check_launch();
+}
+extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N,
+                                     const float* in_scale, const float* in_shift, int in_act,
+                                     const float* gate, int rows_per_image, hipStream_t stream) {
+  return pw_wgrad_impl(dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, 0);
+}
+extern "C" int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N,
+                                          const float* in_scale, const float* in_shift, int in_act,
+                                          const float* gate, int rows_per_image, hipStream_t stream) {
+  return pw_wgrad_impl(dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, 1);
 }
 
 // dX[M,K] = dY[M,N] * W[N,K]: same MFMA kernel with the transposed weight copy Wt[K,N]
@@ -806,6 +918,11 @@ extern "C" int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, 
   // Y'=dx [M,K], X'=dy [M,N], W'=wt [K,N] -> reduction dim is N
   return mmd_pwconv_fwd(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, nullptr, 0, stream);
+}
+extern "C" int mmd_pwconv_bwd_data_bf16(const float* dy, const float* wt, float* dx, int M, int K, int N,
+                                        int accumulate, hipStream_t stream) {
+  return mmd_pwconv_fwd_bf16(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                             nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {

@@ -54,7 +54,13 @@ class GradSlot:
 
 class Net:
     def __init__(self, spec: NetSpec, device, trainable: bool, arena: Optional[Arena] = None,
-                 zarena: Optional[Arena] = None):
+                 zarena: Optional[Arena] = None, precision: str = "fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"Unsupported precision {precision}")
+        # "bf16" = mixed precision: the 1x1-conv GEMMs (forward, input- and weight-gradient) feed the bf16 MFMA, fp32
+        # accumulate; tensors in HBM, depthwise convs, BatchNorm statistics, losses and Adam stay fp32
+        self.precision = precision
+        self._sfx = "_bf16" if precision == "bf16" else ""
         self.spec = spec
         self.device = device
         self.trainable = trainable
@@ -172,7 +178,7 @@ class Net:
         if y is None:
             y = self._alloc(M, N)
         xf = (None, None, NONE, None, None, None, 0) if plain_in else self._xf(x)
-        call("mmd_pwconv_fwd", x.z, self.ps.w(wkey), y, M, K, N, *xf, gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
+        call("mmd_pwconv_fwd" + self._sfx, x.z, self.ps.w(wkey), y, M, K, N, *xf, gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
              residual, stats, ybs, yoff, *self._stats_ws(stats, M, N))
         return y
 
@@ -466,7 +472,7 @@ class Net:
             call("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride)
             z = self._alloc_pyr(pyr, C)
             st = self.stats_flat[2 * o:] if train else None
-            call("mmd_pwconv_fwd_pyr", zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
+            call("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
                  ps.w(f"{cname}.pointwise_conv.conv.bias"), NONE, st, lev_stride, 0, None)
             if train:
                 for lvl in range(5):
@@ -484,7 +490,7 @@ class Net:
             yoff.append(aoff * per_anchor)
             aoff += h * w * spec.num_anchors
         yoff_c = (ctypes.c_longlong * 5)(*yoff)
-        call("mmd_pwconv_fwd_pyr", zd, ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, desc, C, nout,
+        call("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, desc, C, nout,
              ps.w(f"{hname}.header.pointwise_conv.conv.bias"), out_act, None, 0, A * per_anchor, yoff_c)
         if train:
             tape[hname] = {"layers": layers, "hx": cur, "hx_off": off0 + (nl - 1) * C, "hzd": zd, "yoff": yoff,
@@ -534,12 +540,12 @@ class Net:
         with self._wgrad_stream():
             if bias_key:
                 call("mmd_colsum", dz, ps.g(bias_key), M, N)
-            call("mmd_pwconv_bwd_weight", dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
+            call("mmd_pwconv_bwd_weight" + self._sfx, dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
                  None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W)
         if not want_dx:
             return None
         dx = self._alloc(M, K)
-        call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dx, M, K, N, 0)
+        call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dx, M, K, N, 0)
         return dx
 
     def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True, bn_aff=None):
@@ -572,9 +578,9 @@ class Net:
         hw_key = f"{hname}.header.pointwise_conv.conv.weight"
         with self._wgrad_stream():
             call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
-            call("mmd_pwconv_bwd_weight", dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
+            call("mmd_pwconv_bwd_weight" + self._sfx, dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
         dzd = self._alloc_pyr(pyr, C)
-        call("mmd_pwconv_bwd_data", dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
+        call("mmd_pwconv_bwd_data" + self._sfx, dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
         with self._wgrad_stream():
             call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
@@ -597,9 +603,9 @@ class Net:
                  SWISH)
             wkey = f"{cname}.pointwise_conv.conv.weight"
             with self._wgrad_stream():
-                call("mmd_pwconv_bwd_weight", dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
+                call("mmd_pwconv_bwd_weight" + self._sfx, dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
             dzd = self._alloc_pyr(pyr, C)
-            call("mmd_pwconv_bwd_data", dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
+            call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
             with self._wgrad_stream():
                 call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,

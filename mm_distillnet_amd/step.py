@@ -47,6 +47,7 @@ class StepConfig:
     inclusive_nms: bool = False
     max_boxes: int = 512
     augment: bool = False              # cfg audio_augmentation_merge (ModelWithNMSLossAugmented.forward augment=True)
+    precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors)
 
 
 class DistillEngine:
@@ -56,8 +57,8 @@ class DistillEngine:
         self.device = device
         self.world_size = world_size
         self.pg = process_group
-        self.student = Net(student_spec, device, trainable=True)
-        self.teachers: Dict[str, Net] = {m: Net(teacher_specs[m], device, trainable=False)
+        self.student = Net(student_spec, device, trainable=True, precision=cfg.precision)
+        self.teachers: Dict[str, Net] = {m: Net(teacher_specs[m], device, trainable=False, precision=cfg.precision)
                                          for m in TEACHER_ORDER if m in teacher_specs}
         ps = self.student.ps
         n = ps.n_params

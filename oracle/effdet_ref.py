@@ -77,8 +77,27 @@ def same_pad_2d(x, k, s):
     return F.pad(x, [l, eh - l, t, ev - t])
 
 
+# Oracle-only switch for the build's bf16 mixed-precision mode (BASELINE config 5; the reference itself has no reduced-
+# precision path): when True, the two operands of every 1x1 convolution outside the squeeze-excite block are rounded to
+# bf16 (round-to-nearest-even) and multiplied/accumulated in fp32 - the arithmetic of mmd_pwconv_fwd_bf16.  Straight-
+# through in autograd (the backward stays fp32).
+BF16_PW = False
+
+
+def _bf16_ste(t):
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def pw_conv(x, weight, bias=None):
+    if BF16_PW:
+        x, weight = _bf16_ste(x), _bf16_ste(weight)
+    return F.conv2d(x, weight, bias)
+
+
 def conv_same(x, weight, bias=None, stride=1, groups=1):
     k = weight.shape[-1]
+    if k == 1 and groups == 1 and stride == 1:
+        return pw_conv(x, weight, bias)
     return F.conv2d(same_pad_2d(x, k, stride), weight, bias, stride=stride, groups=groups)
 
 
@@ -146,7 +165,7 @@ def backbone(state, x, coef, training, drop_masks):
 
 def sepconv(state, p, x, training, norm=True, act=False, bn_prefix=None):
     x = conv_same(x, state[p + ".depthwise_conv.conv.weight"], groups=x.shape[1])
-    x = F.conv2d(x, state[p + ".pointwise_conv.conv.weight"], state[p + ".pointwise_conv.conv.bias"])
+    x = pw_conv(x, state[p + ".pointwise_conv.conv.weight"], state[p + ".pointwise_conv.conv.bias"])
     if norm:
         x = batchnorm(state, bn_prefix or (p + ".bn"), x, training)
     if act:
@@ -165,7 +184,7 @@ def _up(x):
 
 def bifpn_cell(state, p, feats, first, training):
     def dc(name, x):
-        x = F.conv2d(x, state[f"{p}.{name}.0.conv.weight"], state[f"{p}.{name}.0.conv.bias"])
+        x = pw_conv(x, state[f"{p}.{name}.0.conv.weight"], state[f"{p}.{name}.0.conv.bias"])
         return batchnorm(state, f"{p}.{name}.1", x, training)
 
     if first:

@@ -716,3 +716,73 @@ def test_slotted_bn_sums_match_direct():
     call("mmd_bn_bwd_reduce", g(gi), g(z), g(sc), g(sh), g(mu), g(istd), 1, None, None, None, 0, None, st0, M, C, None, 0)
     call("mmd_bn_bwd_reduce", g(gi), g(z), g(sc), g(sh), g(mu), g(istd), 1, None, None, None, 0, None, st1, M, C, ws, SL)
     close(st1, st0, 1e-12, 1e-12, "bn bwd slotted sums"); assert float(ws.abs().max()) == 0.0
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# shapes chosen to reach every kernel variant: skinny, 64x64 tiles, 128x64, 128x32, and K tails of 1..4 populated groups
+@pytest.mark.parametrize("M,K,N", [(300, 24, 40), (513, 352, 112), (8192, 120, 720), (12800, 40, 512), (20480, 144, 24),
+                                   (2048, 208, 1248), (1000, 88, 528)])
+def test_pwconv_bf16_fwd(M, K, N):
+    """bf16 mixed-precision 1x1 conv: both MFMA operands (the prologue's output and the weight) are rounded to bf16
+    (RNE), products and accumulation are fp32 - so the result equals an fp32 GEMM of the ROUNDED operands up to
+    summation order; against the unrounded fp32 GEMM it differs by bf16's 2^-9 per operand."""
+    torch.manual_seed(M + K + N)
+    B = 4 if M % 4 == 0 else 1
+    rpi = M // B
+    x = torch.randn(M, K); w = torch.randn(N, K) / math.sqrt(K)
+    isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+    gate = torch.rand(B, K)
+    bias = torch.randn(N) * 0.1
+    a = swish(x * isc + ish) * gate.repeat_interleave(rpi, 0)
+    raw = (_bf(a).double() @ _bf(w).double().t()).float() + bias
+    y = torch.empty(M, N, device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    call("mmd_pwconv_fwd_bf16", g(x), g(w), y, M, K, N, g(isc), g(ish), 1, None, None, None, 0, g(gate), rpi, g(bias), None, None, 0, None,
+         stats, 0, 0, None, 0)
+    # the prologue runs with the hardware reciprocal: a value that lands on a bf16 rounding boundary can flip -> a few
+    # elements differ by one bf16 ulp of one operand; bound the error by that instead of demanding equality
+    close(y, raw, 2e-3, 2e-3, "pw bf16 fwd")
+    assert (y.cpu() - raw).abs().mean().item() < 2e-4
+    close(stats[:N], raw.double().sum(0), 1e-3, 5e-2, "stats sum")
+    y2 = torch.empty(M, N, device=DEV)
+    call("mmd_pwconv_fwd_bf16", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0)
+    close(y2, (_bf(x).double() @ _bf(w).double().t()).float(), 1e-4, 1e-4, "pw bf16 plain (exact operands)")
+    # and it is a bf16 GEMM, not an fp32 one: the unrounded product differs at the 2^-9 level
+    full = x @ w.t()
+    err = (y2.cpu() - full).abs().max().item()
+    assert 1e-4 < err < 0.1
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 24, 40), (4096, 16, 96), (1000, 528, 88), (130, 112, 180)])
+def test_pwconv_bf16_bwd(M, K, N):
+    torch.manual_seed(M)
+    x = torch.randn(M, K); w = torch.randn(N, K) / math.sqrt(K)
+    dy = torch.randn(M, N)
+    dw = torch.zeros(N, K, device=DEV)
+    call("mmd_pwconv_bwd_weight_bf16", g(dy), g(x), dw, M, K, N, None, None, 0, None, 1)
+    close(dw, (_bf(dy).double().t() @ _bf(x).double()).float(), 2e-4, 2e-3, "dW bf16")
+    wt = g(w.t().contiguous())
+    dx = torch.full((M, K), 0.5, device=DEV)
+    call("mmd_pwconv_bwd_data_bf16", g(dy), wt, dx, M, K, N, 1)
+    ref = (_bf(dy).double() @ _bf(w).double()).float()
+    close(dx, ref + 0.5, 2e-4, 2e-4, "dX bf16 acc")
+    call("mmd_pwconv_bwd_data_bf16", g(dy), wt, dx, M, K, N, 0)
+    close(dx, ref, 2e-4, 2e-4, "dX bf16")
+
+
+def test_pwconv_pyr_bf16():
+    import ctypes
+    torch.manual_seed(4)
+    B, C, N = 4, 112, 112
+    sizes = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    desc, row0, rows = _pyr(B, sizes)
+    Mt = row0[-1]
+    x = torch.randn(Mt, C); w = torch.randn(N, C) / 10; bias = torch.randn(N)
+    z = torch.zeros(Mt, N, device=DEV)
+    call("mmd_pwconv_fwd_pyr_bf16", g(x), g(w), z, desc, C, N, g(bias), 0, None, 0, 0, None)
+    for l in range(5):
+        sl = slice(row0[l], row0[l] + rows[l])
+        close(z[sl], (_bf(x[sl]).double() @ _bf(w).double().t()).float() + bias, 2e-4, 2e-4, f"pyr bf16 L{l}")

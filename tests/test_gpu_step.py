@@ -18,10 +18,11 @@ BIAS = {"rgb": -2.0, "depth": -3.2, "thermal": -2.0}
 MODS = {"rgb": (3, 21), "depth": (3, 22), "thermal": (1, 23)}
 
 
-def build(variant, S=256):
+def build(variant, S=256, precision="fp32"):
     teachers = {k: make_state(2, cin, seed, k, cls_bias=BIAS[k]) for k, (cin, seed) in MODS.items()}
     spec_s, st_s = make_state(2, 8, 24, "audio")
-    cfg = StepConfig(image_size=S, kd_mode="list" if variant == "list" else "pairwise", augment=variant == "augmented")
+    cfg = StepConfig(image_size=S, kd_mode="list" if variant == "list" else "pairwise", augment=variant == "augmented",
+                     precision=precision)
     eng = DistillEngine(spec_s, {k: v[0] for k, v in teachers.items()}, DEV, cfg)
     eng.load(st_s, {k: v[1] for k, v in teachers.items()})
     return eng, spec_s
@@ -157,3 +158,36 @@ def test_split_backward_matches_unsplit():
     fa, fc = eng_a.student.ps.flat, eng_c.student.ps.flat
     assert torch.isfinite(fc).all()
     assert (fa - fc).abs().max().item() <= 2.5e-4            # one Adam step moves a weight by at most lr = 1e-4
+
+
+def test_bf16_step_runs_and_replays():
+    """cfg `precision = bf16`: the whole distillation step (three teachers, student, losses, backward, Adam) with the 1x1
+    convs on the bf16 MFMA.  At this test size (2 x 128^2, train-mode BatchNorm over a handful of samples) rounding noise
+    is amplified far beyond what a real batch sees (tests/test_gpu_net.py), so only coarse agreement with the fp32 step
+    is asserted; the exact statements are that the step is finite, trains (Adam moves every touched weight by ~lr) and
+    that the captured graphs reproduce the eager bf16 step."""
+    S, B = 128, 2
+    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
+    eng_a, spec = build("pairwise", S)
+    eng_b, _ = build("pairwise", S, precision="bf16")
+    eng_c, _ = build("pairwise", S, precision="bf16")
+    assert eng_b.student._sfx == "_bf16" and all(t._sfx == "_bf16" for t in eng_b.teachers.values())
+    g = torch.Generator(device=DEV).manual_seed(1)
+    ds = eng_a.make_drop_scale(B, g)
+    p0 = eng_b.student.ps.flat.clone()
+    oa = eng_a.step(batch, ds)
+    ob = eng_b.step(batch, ds)
+    torch.cuda.synchronize()
+    kd_a, kd_b = oa["kd"].cpu().numpy(), ob["kd"].cpu().numpy()
+    assert np.isfinite(kd_b).all()
+    assert not np.array_equal(kd_a, kd_b)                       # the bf16 kernels really ran
+    np.testing.assert_allclose(kd_b.sum(), kd_a.sum(), rtol=0.5)
+    db = eng_b.student.ps.flat - p0
+    assert torch.isfinite(db).all() and 0.5e-4 < db.abs().max().item() < 2.5e-4
+    eng_c.capture(batch)
+    eng_c.replay(batch, ds)
+    torch.cuda.synchronize()
+    oc = eng_c.out
+    assert oc["nbox"].tolist() == ob["nbox"].tolist()
+    np.testing.assert_allclose(oc["kd"].cpu().numpy(), kd_b, rtol=1e-4, atol=1e-7)
+    assert (eng_c.student.ps.flat - eng_b.student.ps.flat).abs().max().item() <= 2.5e-4

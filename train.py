@@ -66,7 +66,9 @@ def step_config(cfg) -> StepConfig:
                       kd_mode="list" if "kdlist" in method else "pairwise",
                       # src/optimization/traditional.py:136: augment = config.getboolean('audio_augmentation_merge'); only
                       # ModelWithNMSLossAugmented acts on it (key absent from the shipped cfg -> off)
-                      augment=bool(cfg.getboolean("audio_augmentation_merge", False)) and method == "traditional_nms_augmented")
+                      augment=bool(cfg.getboolean("audio_augmentation_merge", False)) and method == "traditional_nms_augmented",
+                      # extension key (absent from the reference's cfg files -> fp32): "bf16" = 1x1 convs on the bf16 MFMA
+                      precision=cfg.get("precision", "fp32"))
 
 
 def load_states(cfg, coef=2):
