@@ -8,6 +8,7 @@ from mm_distillnet_amd import _lib
 call = _lib.call
 DEV = "cuda:0"
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+SFX = "_bf16" if os.environ.get("GEMM_BENCH_BF16") else ""      # the bf16 mixed-precision entry points
 
 
 def timeit(fn, reps=10):
@@ -38,7 +39,7 @@ for line in open(os.path.join(ROOT, "tools/dev/pw_shapes.csv")):
     y = torch.empty(M, N, device=DEV)
     if f < 0:
         dw = torch.zeros(N, K, device=DEV)
-        t = timeit(lambda: call("mmd_pwconv_bwd_weight", y, x, dw, M, K, N, None, None, 0, None, 1))
+        t = timeit(lambda: call("mmd_pwconv_bwd_weight" + SFX, y, x, dw, M, K, N, None, None, 0, None, 1))
     else:
         rpi = 4096 if M % 4096 == 0 else M
         sc = torch.rand(K, device=DEV) + 0.5 if f & 1 else None
@@ -49,7 +50,7 @@ for line in open(os.path.join(ROOT, "tools/dev/pw_shapes.csv")):
         res_ = torch.randn(M, N, device=DEV) if f & 8 else None
         osc = torch.rand(N, device=DEV) if f & 16 else None
         osh = torch.randn(N, device=DEV) if f & 16 else None
-        t = timeit(lambda: call("mmd_pwconv_fwd", x, w, y, M, K, N, sc, sh, 1 if f & 1 else 0, None, None, None, 0, gate, rpi, None,
+        t = timeit(lambda: call("mmd_pwconv_fwd" + SFX, x, w, y, M, K, N, sc, sh, 1 if f & 1 else 0, None, None, None, 0, gate, rpi, None,
                                 osc, osh, 0, res_, st, 0, 0, ws, 64 if ws is not None else 0))
     res.append((M, K, N, f, cnt, t))
     del x, w, y
