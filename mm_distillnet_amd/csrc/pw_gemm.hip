@@ -16,6 +16,40 @@
 #include "common.h"
 #include <cstdlib>
 
+// BatchNorm(+swish, +drop-connect row scale) backward as a GEMM operand prologue: instead of a separate pass that writes
+//   dz[m,c] = scale_c * ( g'[m,c] - m1_c - (z[m,c] - mean_c) * invstd_c * m2_c ),   g' = g * mul_b[image(m)] * swish'(z*scale_c + shift_c)
+// (scale = gamma*invstd, shift = beta - mean*scale; m1 = sum(g')/count, m2 = sum(g'*xhat)/count from the reduce pass), the
+// input-gradient and weight-gradient GEMMs of the conv in front of the BatchNorm read (g, z) and evaluate dz while staging
+// their tile.  Removes one launch and one [M, C] write + two reads per BatchNorm from the backward's main chain.
+// Reference: autograd of nn.BatchNorm2d in train mode, call sites src/YetAnotherEfficientNet.py:428,447,477.
+struct BnBwdOp {
+  const float* z; const float* scale; const float* shift; const float* mean; const float* invstd;
+  const double* sums; double inv_count; int C; int act; const float* mul_b; int rows_per_image;
+};
+// per-channel coefficients: dz = a1*g' + a2*(z - mu) + a3
+__device__ __forceinline__ void bn_bwd_coef(const BnBwdOp& b, int c, float& a1, float& a2, float& a3, float& mu, float& sh) {
+  const float m1 = (float)(b.sums[c] * b.inv_count), m2 = (float)(b.sums[b.C + c] * b.inv_count);
+  const float is = b.invstd[c];
+  a1 = b.scale[c]; mu = b.mean[c]; sh = b.shift[c];
+  a2 = -a1 * is * m2; a3 = -a1 * m1;
+}
+struct BnBwdCoef4 { float4 a1, a2, a3, mu, sh; };
+__device__ __forceinline__ void bn_bwd_coef4(const BnBwdOp& b, int c, BnBwdCoef4& o) {
+  bn_bwd_coef(b, c, o.a1.x, o.a2.x, o.a3.x, o.mu.x, o.sh.x); bn_bwd_coef(b, c + 1, o.a1.y, o.a2.y, o.a3.y, o.mu.y, o.sh.y);
+  bn_bwd_coef(b, c + 2, o.a1.z, o.a2.z, o.a3.z, o.mu.z, o.sh.z); bn_bwd_coef(b, c + 3, o.a1.w, o.a2.w, o.a3.w, o.mu.w, o.sh.w);
+}
+__device__ __forceinline__ float bn_bwd_eval(float g, float z, float rs, int act, float a1, float a2, float a3, float mu, float sh) {
+  g *= rs;
+  if (act == MMD_ACT_SWISH) g *= mmd_swish_grad(z * a1 + sh);
+  return a1 * g + a2 * (z - mu) + a3;
+}
+__device__ __forceinline__ float4 bn_bwd_eval4(float4 g, float4 z, float rs, int act, const BnBwdCoef4& q) {
+  return make_float4(bn_bwd_eval(g.x, z.x, rs, act, q.a1.x, q.a2.x, q.a3.x, q.mu.x, q.sh.x),
+                     bn_bwd_eval(g.y, z.y, rs, act, q.a1.y, q.a2.y, q.a3.y, q.mu.y, q.sh.y),
+                     bn_bwd_eval(g.z, z.z, rs, act, q.a1.z, q.a2.z, q.a3.z, q.mu.z, q.sh.z),
+                     bn_bwd_eval(g.w, z.w, rs, act, q.a1.w, q.a2.w, q.a3.w, q.mu.w, q.sh.w));
+}
+
 struct PwArgs {
   const float* x; const float* w; float* y;
   int M, K, N;
@@ -28,6 +62,7 @@ struct PwArgs {
   int ntn; int nblk;
   Pyr pyr; long long yoff_lev[MMD_MAX_LEV]; long long lev_stride;
   int bf16;                                  // host-side: operands rounded to bf16 at the MFMA input (mixed-precision mode)
+  BnBwdOp bb;                                // PRO == 1: the A operand is a BatchNorm backward evaluated on the fly
 };
 
 // ---- bf16 mixed precision (BASELINE config 5): the SAME kernels with the inner product on v_mfma_f32_32x32x16_bf16.
@@ -57,7 +92,8 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
 // BM_T = 128: the 4 waves stack along M (32 rows each, all BN_T columns); BM_T = 64: 2 x 2 waves (32 rows x BN_T/2 columns
 // each) - twice the blocks for the small-M layers (16x16 / 32x32 stages), whose 128-row tiling leaves most SIMDs with
 // one wave or none.
-template <int BM_T, int BN_T, int NKL, bool BF>
+// PRO = 1: the A operand is BnBwdOp(a.x = g, a.bb.z = z) evaluated while staging (input-gradient GEMM behind a BatchNorm).
+template <int BM_T, int BN_T, int NKL, bool BF, int PRO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
   constexpr int WM = BM_T / 32;          // waves along M
   constexpr int WN = 4 / WM;             // waves along N
@@ -89,14 +125,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int lrow = tid >> 3;             // 0..31
 
   // per-thread row bookkeeping for the NA A loads
-  const float* xrow[NA]; const float* grow[NA]; bool rok[NA];
+  const float* xrow[NA]; const float* grow[NA]; bool rok[NA]; float rowsc[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int row = m0 + lrow + i * 32;
     rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
     xrow[i] = a.x + (size_t)rr * a.K;
-    grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
+    if constexpr (PRO == 1) {
+      grow[i] = a.bb.z + (size_t)rr * a.K;                 // the second A tensor rides in the gate's registers
+      rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
+    } else {
+      grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
+    }
   }
   const float* wrow[NB]; bool wok[NB];
 #pragma unroll
@@ -113,6 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
   float4 ra[NA], rg[NA], rb[NB], rsc, rsh;
+  BnBwdCoef4 bq;
   bool kok;
   auto gload = [&](int k0) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
@@ -120,12 +162,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int k = k0 + kq;
     kok = k < a.K;
     const int kc = kok ? k : 0;
-    if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
-    else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
+    if constexpr (PRO == 1) {
+      bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      ra[i] = mmd_ld4(xrow[i] + kc);
-      if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
+      for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
+    } else {
+      if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
+      else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        ra[i] = mmd_ld4(xrow[i] + kc);
+        if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
@@ -134,11 +182,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
+      if constexpr (PRO == 1) {
+        v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
+      } else {
       if (a.in_scale || a.in_bn.stats) {
         v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
       }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      }
       if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
       *reinterpret_cast<float4*>(&sA[(lrow + i * 32) * PW_LD + kq]) = v;
     }
@@ -272,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define SK_BK 128
 #define SK_LD 132
 
-template <bool BF>
+template <bool BF, int PRO>
 __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
   __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
@@ -291,14 +343,19 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   const int kq = (tid & 31) * 4;          // k offset inside the 128-wide step
   const int lrow = tid >> 5;              // 0..7
 
-  const float* xrow[4]; const float* grow[4]; bool rok[4];
+  const float* xrow[4]; const float* grow[4]; bool rok[4]; float rowsc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int row = m0 + lrow + i * 8;
     rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
     xrow[i] = a.x + (size_t)rr * a.K;
-    grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
+    if constexpr (PRO == 1) {
+      grow[i] = a.bb.z + (size_t)rr * a.K;
+      rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
+    } else {
+      grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
+    }
   }
   const float* wrow[8]; bool wok[8];
 #pragma unroll
@@ -314,6 +371,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
   float4 ra[4], rg[4], rb[8], rsc, rsh;
+  BnBwdCoef4 bq;
   bool kok;
   auto gload = [&](int k0) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
@@ -321,12 +379,18 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     int k = k0 + kq;
     kok = k < a.K;
     const int kc = kok ? k : 0;
-    if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
-    else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
+    if constexpr (PRO == 1) {
+      bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = mmd_ld4(xrow[i] + kc);
-      if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
+      for (int i = 0; i < 4; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
+    } else {
+      if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
+      else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = mmd_ld4(xrow[i] + kc);
+        if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
@@ -335,11 +399,15 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = ra[i];
+      if constexpr (PRO == 1) {
+        v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
+      } else {
       if (a.in_scale || a.in_bn.stats) {
         v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
       }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      }
       if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
       *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
@@ -661,12 +729,12 @@ static int pw_stream_launch(PwArgs& a, hipStream_t stream) {
 
 static int pw_dispatch(PwArgs& a, hipStream_t stream);
 
-template <int BM_T, int BN_T>
+template <int BM_T, int BN_T, int PRO>
 static void (*pw_pick(int nkl, int bf))(PwArgs) {
-  if (bf) return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, true> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, true>
-               : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, true> : pw_gemm_kernel<BM_T, BN_T, 4, true>;
-  return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, false> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, false>
-       : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, false> : pw_gemm_kernel<BM_T, BN_T, 4, false>;
+  if (bf) return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, true, PRO> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, true, PRO>
+               : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, true, PRO> : pw_gemm_kernel<BM_T, BN_T, 4, true, PRO>;
+  return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, false, PRO> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, false, PRO>
+       : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, false, PRO> : pw_gemm_kernel<BM_T, BN_T, 4, false, PRO>;
 }
 
 static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, int N,
@@ -724,22 +792,25 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     else pw_stream_launch<2, 2>(a, stream);
   } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16 && !(sq_tiles > 0 && big_tiles >= sq_min && big_tiles < sq_tiles && N > 32)) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
-    hipLaunchKernelGGL(a.bf16 ? pw_gemm_skinny_kernel<true> : pw_gemm_skinny_kernel<false>, dim3(a.nblk), dim3(256), 0, stream, a);
+    void (*sk)(PwArgs) = a.bb.z ? (a.bf16 ? pw_gemm_skinny_kernel<true, 1> : pw_gemm_skinny_kernel<false, 1>)
+                                : (a.bf16 ? pw_gemm_skinny_kernel<true, 0> : pw_gemm_skinny_kernel<false, 0>);
+    hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
     // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
     static const int bn32_gain = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 10;
     const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
     void (*kern)(PwArgs);
-    if (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles))) {
+    if (!a.bb.z && (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles)))) {
       a.ntn = cdiv(N, 32);
-      kern = pw_pick<128, 32>(nkl, a.bf16);
-    } else if (sq_tiles > 0 && big_tiles < sq_tiles) {      // 64x64 tiles: small-M layers
+      kern = pw_pick<128, 32, 0>(nkl, a.bf16);
+    } else if ((sq_tiles > 0 && big_tiles < sq_tiles) || a.bb.z) {      // 64x64 tiles: small-M layers (and every BatchNorm-
+      // backward operand launch: its two-tensor prologue does not fit the 128-row variants' 128-VGPR budget)
       a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
-      kern = pw_pick<64, 64>(nkl, a.bf16);
+      kern = a.bb.z ? pw_pick<64, 64, 1>(nkl, a.bf16) : pw_pick<64, 64, 0>(nkl, a.bf16);
     } else {
       a.ntn = cdiv(N, 64);
-      kern = pw_pick<128, 64>(nkl, a.bf16);
+      kern = pw_pick<128, 64, 0>(nkl, a.bf16);
     }
     a.nblk = ntm * a.ntn;
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
@@ -787,11 +858,12 @@ struct WgArgs {
   const float* in_scale; const float* in_shift; int in_act;
   const float* gate; int rows_per_image;
   int mchunk; int ntn; int ntk;
+  BnBwdOp bb; float* dgamma; float* dbeta;      // BNP: dy is BnBwd(dy = g, bb.z) evaluated on the fly; dgamma/dbeta (+)= from bb.sums
 };
 #define WG_LD 68
 #define WG_BR 32          // rows of the M reduction per step (64 measured no faster)
 
-template <bool BF>
+template <bool BF, bool BNP>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   __shared__ float sD[WG_BR * WG_LD];
   __shared__ float sX[WG_BR * WG_LD];
@@ -809,13 +881,25 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   const bool nok = (n0 + c4) < a.N, kok = (k0 + c4) < a.K;
   float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
   if (a.in_scale && kok) { xsc = mmd_ld4(a.in_scale + k0 + c4); xsh = mmd_ld4(a.in_shift + k0 + c4); }
+  BnBwdCoef4 bq;
+  if constexpr (BNP) {
+    bn_bwd_coef4(a.bb, nok ? n0 + c4 : 0, bq);       // this thread's 4 dY columns are fixed for the whole M loop
+    if (tk == 0 && b == 0 && lrow == 0 && nok && a.dgamma) {      // BatchNorm affine gradients straight from the reduce pass' sums
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a.dgamma[n0 + c4 + i] += (float)a.bb.sums[a.bb.C + n0 + c4 + i];
+        a.dbeta[n0 + c4 + i] += (float)a.bb.sums[n0 + c4 + i];
+      }
+    }
+  }
 
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 
   constexpr int NL = WG_BR / 16;      // float4 loads per thread and operand
-  float4 rd[NL], rx[NL], rg[NL];
+  float4 rd[NL], rx[NL], rg[NL], rz[NL];
+  float rrs[NL];
   bool rok[NL];
   auto gload = [&](int mb) {
 #pragma unroll
@@ -824,6 +908,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
       rok[i] = row < mend;
       const int rc = rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
       rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+      if constexpr (BNP) {
+        rz[i] = mmd_ld4(a.bb.z + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+        rrs[i] = a.bb.mul_b ? a.bb.mul_b[rc / a.bb.rows_per_image] : 1.f;
+      }
       rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
       if (a.gate) rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
     }
@@ -839,7 +927,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
       if (!(rok[i] && kok)) v = make_float4(0, 0, 0, 0);
       *reinterpret_cast<float4*>(&sX[(lrow + i * 16) * WG_LD + c4]) = v;
-      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = (rok[i] && nok) ? rd[i] : make_float4(0, 0, 0, 0);
+      float4 d = rd[i];
+      if constexpr (BNP) d = bn_bwd_eval4(d, rz[i], rrs[i], a.bb.act, bq);
+      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = (rok[i] && nok) ? d : make_float4(0, 0, 0, 0);
     }
   };
 
@@ -881,11 +971,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
 
 static int pw_wgrad_impl(const float* dy, const float* x, float* dw, int M, int K, int N,
                                      const float* in_scale, const float* in_shift, int in_act,
-                                     const float* gate, int rows_per_image, hipStream_t stream, int bf16) {
+                                     const float* gate, int rows_per_image, hipStream_t stream, int bf16,
+                                     const BnBwdOp* bb = nullptr, float* dgamma = nullptr, float* dbeta = nullptr) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !dy || !x || !dw) return MMD_EINVAL;
   if (gate && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
-  WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0};
+  WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0, BnBwdOp{}, nullptr, nullptr};
+  if (bb) { a.bb = *bb; a.dgamma = dgamma; a.dbeta = dbeta; }
   a.ntn = cdiv(N, 64); a.ntk = cdiv(K, 64);
   int tiles = a.ntn * a.ntk;
   // enough blocks to fill 256 CUs a few times over, but every split ends in N*K fp32 atomics (1.3 TB/s chip-wide):
@@ -896,7 +988,9 @@ static int pw_wgrad_impl(const float* dy, const float* x, float* dw, int M, int 
   splits = cdiv(M, a.mchunk);
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wg M%lld K%lld N%lld s%lld", M, K, N, splits);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
-  hipLaunchKernelGGL(bf16 ? pw_wgrad_kernel<true> : pw_wgrad_kernel<false>, dim3(tiles * splits), dim3(256), 0, stream, a);
+  void (*wk)(WgArgs) = bb ? (bf16 ? pw_wgrad_kernel<true, true> : pw_wgrad_kernel<false, true>)
+                          : (bf16 ? pw_wgrad_kernel<true, false> : pw_wgrad_kernel<false, false>);
+  hipLaunchKernelGGL(wk, dim3(tiles * splits), dim3(256), 0, stream, a);
   mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   return mmd_check_launch();
 }
@@ -905,6 +999,27 @@ extern "C" int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw,
                                      const float* gate, int rows_per_image, hipStream_t stream) {
   return pw_wgrad_impl(dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, 0);
 }
+// dW[N,K] += BnBwd(g, z)^T * pro(X): weight gradient of a 1x1 conv in front of a BatchNorm, with the BatchNorm backward evaluated
+// on the dY operand while staging; dgamma / dbeta (nullable) (+)= [sum g'*xhat, sum g'] taken from `sums`.
+static int pw_wgrad_bn_impl(const float* g, const float* z, const float* x, float* dw, int M, int K, int N,
+                            const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image,
+                            const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums,
+                            long long count, int act, const float* mul_b, int bn_rows_per_image, float* dgamma, float* dbeta,
+                            hipStream_t stream, int bf16) {
+  if (!z || !scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
+  if (mul_b && bn_rows_per_image <= 0) return MMD_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  BnBwdOp bb{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, bn_rows_per_image > 0 ? bn_rows_per_image : 1};
+  return pw_wgrad_impl(g, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, bf16, &bb, dgamma, dbeta);
+}
+#define PW_WGBN_PARAMS const float* g, const float* z, const float* x, float* dw, int M, int K, int N, \
+                       const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, \
+                       const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, \
+                       long long count, int act, const float* mul_b, int bn_rows_per_image, float* dgamma, float* dbeta, hipStream_t stream
+#define PW_WGBN_ARGS g, z, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, scale, shift, mean, invstd, sums, count, act, \
+                     mul_b, bn_rows_per_image, dgamma, dbeta, stream
+extern "C" int mmd_pwconv_bwd_weight_bn(PW_WGBN_PARAMS) { return pw_wgrad_bn_impl(PW_WGBN_ARGS, 0); }
+extern "C" int mmd_pwconv_bwd_weight_bn_bf16(PW_WGBN_PARAMS) { return pw_wgrad_bn_impl(PW_WGBN_ARGS, 1); }
 extern "C" int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N,
                                           const float* in_scale, const float* in_shift, int in_act,
                                           const float* gate, int rows_per_image, hipStream_t stream) {
@@ -918,6 +1033,34 @@ extern "C" int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, 
   // Y'=dx [M,K], X'=dy [M,N], W'=wt [K,N] -> reduction dim is N
   return mmd_pwconv_fwd(dy, wt, dx, M, /*K=*/N, /*N=*/K, nullptr, nullptr, MMD_ACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0,
                         nullptr, nullptr, nullptr, MMD_ACT_NONE, accumulate ? dx : nullptr, nullptr, 0, 0, nullptr, 0, stream);
+}
+// dX[M,K] = BnBwd(g, z)[M,N] * W[N,K]: input gradient of a 1x1 conv whose output goes through BatchNorm (+swish, +per-image
+// drop-connect scale), with the BatchNorm backward evaluated in the operand prologue (see BnBwdOp).  sums = [sum g', sum g'*xhat].
+static int pw_bwd_data_bn_impl(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
+                               const float* scale, const float* shift, const float* mean, const float* invstd,
+                               const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
+                               hipStream_t stream, int bf16) {
+  if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
+  if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
+  if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
+  PwArgs a{};
+  a.x = g; a.w = wt; a.y = dx; a.M = M; a.K = N; a.N = K; a.rows_per_image = 1;
+  a.in_bn = mmd_make_bn(nullptr, nullptr, nullptr, 0, N);
+  a.bf16 = bf16;
+  a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1};
+  return pw_dispatch(a, stream);
+}
+extern "C" int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
+                                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                                      const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
+                                      hipStream_t stream) {
+  return pw_bwd_data_bn_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, stream, 0);
+}
+extern "C" int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
+                                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                                           const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
+                                           hipStream_t stream) {
+  return pw_bwd_data_bn_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, stream, 1);
 }
 extern "C" int mmd_pwconv_bwd_data_bf16(const float* dy, const float* wt, float* dx, int M, int K, int N,
                                         int accumulate, hipStream_t stream) {

@@ -52,6 +52,24 @@ class GradSlot:
         self.t: Optional[torch.Tensor] = None
 
 
+@dataclass
+class LazyDz:
+    """A BatchNorm backward that is not materialised: the input- and weight-gradient GEMMs of the conv in front of the
+    BatchNorm evaluate dz = BnBwd(g, z) in their operand prologues (mmd_pwconv_bwd_data_bn / _weight_bn)."""
+    g: torch.Tensor
+    z: torch.Tensor
+    aff: tuple                  # (scale, shift, mean, invstd, ...)
+    sums: torch.Tensor
+    act: int
+    mul_b: Optional[torch.Tensor]
+    rpi: int
+    bn_name: str
+    count: int
+
+
+LAZY_BN = not os.environ.get("MMD_NO_LAZY_BN")
+
+
 class Net:
     def __init__(self, spec: NetSpec, device, trainable: bool, arena: Optional[Arena] = None,
                  zarena: Optional[Arena] = None, precision: str = "fp32"):
@@ -95,6 +113,7 @@ class Net:
             self.wt_desc = torch.tensor(descs, dtype=torch.int64, device=device)
             self.wt_tiles = tiles
         self.tape: Dict[str, object] = {}
+        self._wg_read_done = None
         self._anchors: Dict[int, torch.Tensor] = {}
         self._side = None
         self._wg = None           # weight-gradient stream: nothing downstream of a wgrad until the optimizer
@@ -520,14 +539,17 @@ class Net:
             yield
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
-                mul_bc=None, mul_b=None, add_bc=None, sums=None) -> torch.Tensor:
+                mul_bc=None, mul_b=None, add_bc=None, sums=None, lazy: bool = False):
         """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated.
-        `sums` given = the per-channel sums were produced elsewhere (fused into another pass): pass 2 only."""
+        `sums` given = the per-channel sums were produced elsewhere (fused into another pass): pass 2 only.
+        lazy: no pass 2 at all - returns a LazyDz that the 1x1 conv's two gradient GEMMs evaluate in their prologues."""
         b = self.ps.bn(bn_name)
         if sums is None:
             sums = self._zalloc((2 * C,), torch.float64)
             call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C,
                  *self._stats_ws(sums, M, C))
+        if lazy and LAZY_BN and mul_bc is None and add_bc is None:
+            return LazyDz(g_in, z, aff, sums, act, mul_b, rpi, bn_name, M)
         dz = self._alloc(M, C)
         call("mmd_bn_bwd_apply", g_in, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C,
              aff[0], aff[1], act, mul_bc, mul_b, add_bc, rpi)
@@ -537,6 +559,20 @@ class Net:
                 gate=None, plain_in=False) -> Optional[torch.Tensor]:
         ps = self.ps
         M, K = x.M, x.C
+        if isinstance(dz, LazyDz):
+            # BatchNorm backward in the operand prologues (a bias in front of a BatchNorm has an exactly-zero gradient)
+            L, b = dz, ps.bn(dz.bn_name)
+            bnargs = (L.aff[0], L.aff[1], L.aff[2], L.aff[3], L.sums, L.count, L.act, L.mul_b, L.rpi)
+            with self._wgrad_stream():
+                call("mmd_pwconv_bwd_weight_bn" + self._sfx, L.g, L.z, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
+                     None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W, *bnargs, b["dgamma"], b["dbeta"])
+                # whoever overwrites L.g afterwards (in-place accumulation into an adopted gradient slot) waits for this event
+                self._wg_read_done = torch.cuda.current_stream().record_event() if ps.flat.is_cuda else None
+            if not want_dx:
+                return None
+            dx = self._alloc(M, K)
+            call("mmd_pwconv_bwd_data_bn" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs)
+            return dx
         with self._wgrad_stream():
             if bias_key:
                 call("mmd_colsum", dz, ps.g(bias_key), M, N)
@@ -667,7 +703,7 @@ class Net:
                     continue          # node output unused downstream (cannot happen in this topology)
                 name = f"{cell}.{rec['conv']}"
                 W = out.C
-                dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W)
+                dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W, lazy=True)
                 dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
                 df = self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1)
                 in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
@@ -728,7 +764,7 @@ class Net:
                     if s.t is None:
                         continue
                     x: Feat = rec["x"]
-                    dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C)
+                    dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C, lazy=True)
                     dx = self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, None, True)
                     self._acc(slot(x), dx)
         self._backward_blocks([b for b in spec.blocks if stop_before is None or b.idx >= stop_before])
@@ -763,10 +799,14 @@ class Net:
             dy = s.t
             f1: Feat = rec["f1"]
             M1, HW1 = f1.M, f1.H * f1.W
-            dz2 = self._bn_bwd(dy, rec["z2"], rec["bn2"], f"{q}._bn2", NONE, M1, blk.cout, rpi=HW1, mul_b=rec["rs"])
+            dz2 = self._bn_bwd(dy, rec["z2"], rec["bn2"], f"{q}._bn2", NONE, M1, blk.cout, rpi=HW1, mul_b=rec["rs"], lazy=True)
+            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
+            # the skip branch may ADOPT dy as the gradient slot of the block input, and the block's own input gradient is later
+            # accumulated into that buffer in place; with a lazy BatchNorm backward the project conv's weight-gradient GEMM (side
+            # stream) still reads dy, so that later accumulation waits for it (the event is long past by then)
+            dy_read = self._wg_read_done if (blk.skip and isinstance(dz2, LazyDz)) else None
             if blk.skip:
                 self._acc(slot(inp), dy)
-            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
             # squeeze-excite backward.  One pass over (z1, g1) pools d(gate) AND the partials of the BN-1 backward sums; the
             # SE kernels finish those sums once dpooled is known, so the expanded tensor is not read by a BN reduce pass
             a1 = rec["bn1"]
@@ -789,8 +829,10 @@ class Net:
             f0: Feat = rec.get("f0", inp)
             if blk.expand != 1:
                 g0, sums0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, bn_aff=rec["bn0"])
-                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0)
+                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0, lazy=True)
                 dx = self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True)
+                if dy_read is not None:
+                    torch.cuda.current_stream().wait_event(dy_read)
                 self._acc(slot(inp), dx)
             elif blk.idx == 0 and not blk.skip and blk.stride == 1 and slot(inp).t is None:
                 # block 0 consumes the stem activation directly and is its only consumer: the stem BN's backward sums ride
@@ -800,6 +842,8 @@ class Net:
                 self._acc(slot(inp), g0)
             else:
                 g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
+                if dy_read is not None:
+                    torch.cuda.current_stream().wait_event(dy_read)
                 self._acc(slot(inp), g0)
         self._bw["stem_sums"] = stem_sums
 

@@ -786,3 +786,47 @@ def test_pwconv_pyr_bf16():
     for l in range(5):
         sl = slice(row0[l], row0[l] + rows[l])
         close(z[sl], (_bf(x[sl]).double() @ _bf(w).double().t()).float() + bias, 2e-4, 2e-4, f"pyr bf16 L{l}")
+
+
+@pytest.mark.parametrize("M,K,N,act,rowscale", [(512, 40, 24, 0, True), (4096, 96, 16, 1, False), (1000, 528, 88, 1, False),
+                                                 (8192, 112, 112, 0, False), (20480, 24, 144, 1, False), (130, 208, 1248, 0, True)])
+@pytest.mark.parametrize("sfx", ["", "_bf16"])
+def test_pwconv_bwd_bn_prologue(M, K, N, act, rowscale, sfx):
+    """Input- and weight-gradient GEMMs of a 1x1 conv with the BatchNorm(+swish, +drop-connect row scale) backward evaluated in
+    the operand prologue (no dz tensor) against torch autograd of conv1x1 -> BatchNorm2d(train) -> [swish] -> * rowscale."""
+    torch.manual_seed(M + N)
+    B = 2
+    rpi = M // B
+    x = torch.randn(M, K); w = (torch.randn(N, K) / math.sqrt(K)).requires_grad_(True)
+    gamma = (torch.rand(N) + 0.5).requires_grad_(True); beta = (torch.randn(N) * 0.2).requires_grad_(True)
+    g = torch.randn(M, N)
+    rs = torch.tensor([1.25, 0.0]) if rowscale else None
+    xr = x.clone().requires_grad_(True)
+    z = xr @ w.t()
+    mean = z.mean(0); var = z.var(0, unbiased=False)
+    invstd = (var + 1e-3).rsqrt()
+    y = (z - mean) * invstd * gamma + beta
+    a = swish(y) if act else y
+    if rowscale:
+        a = a * rs.repeat_interleave(rpi).view(-1, 1)
+    (a * g).sum().backward()
+    zc = z.detach()
+    scale = (gamma * invstd).detach(); shift = (beta - mean * gamma * invstd).detach()
+    sums = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    gd, zd = g.to(DEV).contiguous(), zc.to(DEV).contiguous()
+    dsc, dsh, dmu, dis = (t.detach().to(DEV).contiguous() for t in (scale, shift, mean, invstd))
+    rsd = rs.to(DEV) if rowscale else None
+    call("mmd_bn_bwd_reduce", gd, zd, dsc, dsh, dmu, dis, act, None, rsd, None, rpi, None, sums, M, N, None, 0)
+    wt = w.detach().t().contiguous().to(DEV)            # [K, N]: the transposed copy the input-gradient GEMM reads
+    dx = torch.empty(M, K, device=DEV)
+    call("mmd_pwconv_bwd_data_bn" + sfx, gd, zd, wt, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi)
+    dw = torch.zeros(N, K, device=DEV)
+    dga = torch.zeros(N, device=DEV); dbe = torch.zeros(N, device=DEV)
+    call("mmd_pwconv_bwd_weight_bn" + sfx, gd, zd, x.to(DEV).contiguous(), dw, M, K, N, None, None, 0, None, 1,
+         dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dga, dbe)
+    tol = dict(rtol=2e-2, atol=2e-2) if sfx else dict(rtol=5e-4, atol=2e-4)
+    sx, sw = xr.grad.abs().max().item(), w.grad.abs().max().item()
+    assert (dx.cpu() - xr.grad).abs().max().item() <= tol["rtol"] * sx + (tol["atol"] * sx if sfx else 1e-5), "dX"
+    assert (dw.cpu() - w.grad).abs().max().item() <= tol["rtol"] * sw + (tol["atol"] * sw if sfx else 1e-5), "dW"
+    close(dga, gamma.grad, 5e-4, 5e-4 * gamma.grad.abs().max().item(), "dgamma")
+    close(dbe, beta.grad, 5e-4, 5e-4 * max(beta.grad.abs().max().item(), 1.0), "dbeta")
