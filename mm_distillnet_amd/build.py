@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmmdistill_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-std=c++17", "-Wno-unused-value",
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("MMD_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def needs_build() -> bool:

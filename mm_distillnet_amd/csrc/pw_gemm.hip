@@ -857,18 +857,23 @@ struct WgArgs {
   int M, K, N;
   const float* in_scale; const float* in_shift; int in_act;
   const float* gate; int rows_per_image;
-  int mchunk; int ntn; int ntk;
+  int mchunk; int ntn; int ntk; int nblk;
   BnBwdOp bb; float* dgamma; float* dbeta;      // BNP: dy is BnBwd(dy = g, bb.z) evaluated on the fly; dgamma/dbeta (+)= from bb.sums
 };
 #define WG_LD 68
+#ifndef WG_BR
 #define WG_BR 32          // rows of the M reduction per step (64 measured no faster)
+#endif
 
-template <bool BF, bool BNP>
+template <bool BF, bool BNP, int PF>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   __shared__ float sD[WG_BR * WG_LD];
   __shared__ float sX[WG_BR * WG_LD];
   const int tid = threadIdx.x;
-  int b = blockIdx.x;
+  // XCD-aware order: the ntn*ntk tiles that re-read one M slab sit on ONE XCD (one L2), slabs are dealt to the XCDs in
+  // contiguous runs; the grid is padded to a multiple of 8 (the surplus blocks leave)
+  int b = mmd_xcd_swizzle(blockIdx.x, gridDim.x);
+  if (b >= a.nblk) return;
   const int tk = b % a.ntk; b /= a.ntk;
   const int tn = b % a.ntn; b /= a.ntn;
   const int mbeg = b * a.mchunk;
@@ -898,49 +903,48 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 
   constexpr int NL = WG_BR / 16;      // float4 loads per thread and operand
-  float4 rd[NL], rx[NL], rg[NL], rz[NL];
-  float rrs[NL];
-  bool rok[NL];
-  auto gload = [&](int mb) {
+  // PF register stages: the loads of the next PF row steps are in flight while one step is multiplied.  A block needs
+  // PF * (load latency / MFMA time per step) >= 1 to stay MFMA-bound on its own, and few blocks mean few atomics at the
+  // end (N*K fp32 atomics per block at ~1.3 TB/s chip-wide are what bounded the many-small-blocks form of this kernel).
+  struct Stage { float4 rd[NL], rx[NL], rg[NL], rz[NL]; float rrs[NL]; bool rok[NL]; };
+  Stage st[PF];
+  auto gload = [&](int mb, Stage& s) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       int row = mb + lrow + i * 16;
-      rok[i] = row < mend;
-      const int rc = rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
-      rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+      s.rok[i] = row < mend;
+      const int rc = s.rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
+      s.rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
       if constexpr (BNP) {
-        rz[i] = mmd_ld4(a.bb.z + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
-        rrs[i] = a.bb.mul_b ? a.bb.mul_b[rc / a.bb.rows_per_image] : 1.f;
+        s.rz[i] = mmd_ld4(a.bb.z + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+        s.rrs[i] = a.bb.mul_b ? a.bb.mul_b[rc / a.bb.rows_per_image] : 1.f;
       }
-      rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
-      if (a.gate) rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
+      s.rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
+      if (a.gate) s.rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const Stage& s) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      float4 v = rx[i];
+      float4 v = s.rx[i];
       if (a.in_scale) {
         v.x = v.x * xsc.x + xsh.x; v.y = v.y * xsc.y + xsh.y; v.z = v.z * xsc.z + xsh.z; v.w = v.w * xsc.w + xsh.w;
       }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
-      if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
-      if (!(rok[i] && kok)) v = make_float4(0, 0, 0, 0);
+      if (a.gate) { v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w; }
+      if (!(s.rok[i] && kok)) v = make_float4(0, 0, 0, 0);
       *reinterpret_cast<float4*>(&sX[(lrow + i * 16) * WG_LD + c4]) = v;
-      float4 d = rd[i];
-      if constexpr (BNP) d = bn_bwd_eval4(d, rz[i], rrs[i], a.bb.act, bq);
-      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = (rok[i] && nok) ? d : make_float4(0, 0, 0, 0);
+      float4 d = s.rd[i];
+      if constexpr (BNP) d = bn_bwd_eval4(d, s.rz[i], s.rrs[i], a.bb.act, bq);
+      *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * WG_LD + c4]) = (s.rok[i] && nok) ? d : make_float4(0, 0, 0, 0);
     }
   };
-
-  if (mbeg < mend) gload(mbeg);
-  for (int mb = mbeg; mb < mend; mb += WG_BR) {
-    lstore();
-    __syncthreads();
-    if (mb + WG_BR < mend) gload(mb + WG_BR);
+  const bool idle = n0 + wn * 32 >= a.N || k0 + wk * 32 >= a.K;      // a wave whose 32x32 sub-tile is all N / K padding (thin layers)
+  auto mma = [&]() {
     const float* pd = &sD[h * WG_LD + wn * 32 + r];
     const float* px = &sX[h * WG_LD + wk * 32 + r];
-    if constexpr (BF) {
+    if (idle) {
+    } else if constexpr (BF) {
       // the reduction runs over rows: lane (r, h) gathers rows 16g + 8h .. + 7 of its column (8 ds_read_b32 per operand)
 #pragma unroll
       for (int g = 0; g < WG_BR / 16; ++g) {
@@ -954,10 +958,26 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
       }
     } else {
 #pragma unroll
-    for (int tt = 0; tt < WG_BR / 2; ++tt)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[tt * 2 * WG_LD], px[tt * 2 * WG_LD], acc, 0, 0, 0);
+      for (int tt = 0; tt < WG_BR / 2; ++tt)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[tt * 2 * WG_LD], px[tt * 2 * WG_LD], acc, 0, 0, 0);
     }
-    __syncthreads();
+  };
+
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (mbeg + s * WG_BR < mend) gload(mbeg + s * WG_BR, st[s]);
+  for (int mb = mbeg; mb < mend; mb += PF * WG_BR) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int m = mb + s * WG_BR;
+      if (m < mend) {                              // block-uniform
+        lstore(st[s]);
+        __syncthreads();
+        if (m + PF * WG_BR < mend) gload(m + PF * WG_BR, st[s]);
+        mma();
+        __syncthreads();
+      }
+    }
   }
   const int kcol = k0 + wk * 32 + r;
   if (kcol < a.K) {
@@ -976,21 +996,27 @@ static int pw_wgrad_impl(const float* dy, const float* x, float* dw, int M, int 
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !dy || !x || !dw) return MMD_EINVAL;
   if (gate && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
-  WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0, BnBwdOp{}, nullptr, nullptr};
+  WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0, 0, BnBwdOp{}, nullptr, nullptr};
   if (bb) { a.bb = *bb; a.dgamma = dgamma; a.dbeta = dbeta; }
   a.ntn = cdiv(N, 64); a.ntk = cdiv(K, 64);
   int tiles = a.ntn * a.ntk;
   // enough blocks to fill 256 CUs a few times over, but every split ends in N*K fp32 atomics (1.3 TB/s chip-wide):
   // keep at least 256 rows per split so the atomic traffic stays well below the streamed bytes
-  int splits = 1024 / tiles; if (splits < 1) splits = 1;
-  int maxs = cdiv(M, 256); if (splits > maxs) splits = maxs;
+  static const int wg_blocks = getenv("MMD_WG_BLOCKS") ? atoi(getenv("MMD_WG_BLOCKS")) : 1024;
+  int splits = wg_blocks / tiles; if (splits < 1) splits = 1;
+  // small M (the 16x16-and-below BiFPN levels): 64-row splits - a handful of blocks walking 256 rows each is a chain of exposed
+  // load latencies, and N*K atomics per split are cheap next to that
+  int maxs = cdiv(M, M <= 8192 ? 64 : 256); if (splits > maxs) splits = maxs;
   a.mchunk = cdiv(cdiv(M, splits), WG_BR) * WG_BR;
   splits = cdiv(M, a.mchunk);
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wg M%lld K%lld N%lld s%lld", M, K, N, splits);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
-  void (*wk)(WgArgs) = bb ? (bf16 ? pw_wgrad_kernel<true, true> : pw_wgrad_kernel<false, true>)
-                          : (bf16 ? pw_wgrad_kernel<true, false> : pw_wgrad_kernel<false, false>);
-  hipLaunchKernelGGL(wk, dim3(tiles * splits), dim3(256), 0, stream, a);
+  // PF = 1: deeper register prefetch (2, 4 stages) with 256-512 blocks measured no faster (1.89 -> 1.99-2.27 ms weighted): the
+  // launch is base (~8 us: launch, first load, staging + barriers) + MFMA (~12-14 us) + atomics, added up rather than overlapped
+  void (*wk)(WgArgs) = bb ? (bf16 ? pw_wgrad_kernel<true, true, 1> : pw_wgrad_kernel<false, true, 1>)
+                          : (bf16 ? pw_wgrad_kernel<true, false, 1> : pw_wgrad_kernel<false, false, 1>);
+  a.nblk = tiles * splits;
+  hipLaunchKernelGGL(wk, dim3((a.nblk + 7) / 8 * 8), dim3(256), 0, stream, a);
   mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   return mmd_check_launch();
 }

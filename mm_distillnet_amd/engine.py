@@ -536,6 +536,14 @@ class Net:
             self._wg = torch.cuda.Stream()
         self._wg.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(self._wg):
+            if os.environ.get("MMD_DEV_SKIP_WG"):      # timing experiment only (gradients are WRONG): what do the weight-gradient
+                global call                            # kernels cost the step through contention with the main chain?
+                saved, call = call, (lambda *a, **k: 0)
+                try:
+                    yield
+                finally:
+                    call = saved
+                return
             yield
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
