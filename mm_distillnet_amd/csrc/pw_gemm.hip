@@ -801,9 +801,12 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     static const int bn32_gain = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 10;
     const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
     void (*kern)(PwArgs);
-    if (!a.bb.z && (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles)))) {
+    if ((!a.bb.z && (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles)))) ||
+        (a.bb.z && N <= 32)) {
+      // (BatchNorm-backward operand launches take the 128x32 variant only for the thin layers, N <= 32, where 64-wide tiles
+      // would multiply 2-4x padding; it holds two VGPRs in scratch there)
       a.ntn = cdiv(N, 32);
-      kern = pw_pick<128, 32, 0>(nkl, a.bf16);
+      kern = a.bb.z ? pw_pick<128, 32, 1>(nkl, a.bf16) : pw_pick<128, 32, 0>(nkl, a.bf16);
     } else if ((sq_tiles > 0 && big_tiles < sq_tiles) || a.bb.z) {      // 64x64 tiles: small-M layers (and every BatchNorm-
       // backward operand launch: its two-tensor prologue does not fit the 128-row variants' 128-VGPR budget)
       a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
