@@ -117,6 +117,12 @@ int mmd_mta_attention(const float* f, float* a, int rows, int C, float p, hipStr
 int mmd_mta_kl(const float* a_s, const float* a_t0, const float* a_t1, const float* a_t2, int nteachers, int B, int HW, float T, float* loss, float* da_s, float gscale, int accumulate, hipStream_t stream);
 
 // df (+)= da * p * f^(p-1) / C.
+// Every (pyramid level, teacher) pair of one step in a single launch (host arrays of device pointers: a_s[nlev], a_t[nteachers*nlev]
+// teacher-major, da_s[nlev] nullable, HW[nlev]).  list_mode = 0: pairwise MTALoss calls (src/optimization/train_methods.py:341-346),
+// loss[t*nlev + l], da_s[l] accumulated over teachers with atomics (zero on entry when nteachers > 1); list_mode = 1: the list form
+// (src/loss/MTALoss.py:36-52), loss[l].
+int mmd_mta_kl_multi(const float* const* a_s, const float* const* a_t, float* const* da_s, const int* HW, int nlev, int nteachers, int list_mode, int B, float T, float* loss, float gscale, hipStream_t stream);
+
 int mmd_mta_attention_bwd(const float* f, const float* da, float* df, int rows, int C, float p, int accumulate, hipStream_t stream);
 
 // YetAnotherFocalLoss forward + gradients (src/loss/YetAnotherFocalLoss.py:27-190).

@@ -48,12 +48,12 @@ __device__ __forceinline__ float block_max(float v, float* sm, int tid) {
 // One block per image. a_s [B,HW]; a_t0..2 [B,HW] raw attention means of nt teachers (nt==1: pairwise;
 // nt>1: list mode = L1-normalised product of the L2-normalised maps).  loss[0] += sum_j v*(log v - u) / B.
 // If da_s != null: da_s[b,j] (+)= dL/d a_s[b,j] * gscale   (student side only; teachers are constants).
-__global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a_s, const float* __restrict__ t0,
-                                                     const float* __restrict__ t1, const float* __restrict__ t2, int nt,
-                                                     int HW, int B, float T, float* loss, float* da_s, float gscale,
-                                                     int accumulate) {
-  __shared__ float sm[8];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// accumulate: 0 = store, 1 = read-modify-write (sequential launches), 2 = atomic (concurrent blocks write the same da_s)
+__device__ __forceinline__ void mta_kl_body(const float* __restrict__ a_s, const float* __restrict__ t0,
+                                            const float* __restrict__ t1, const float* __restrict__ t2, int nt,
+                                            int HW, int B, float T, float* loss, float* da_s, float gscale,
+                                            int accumulate, int b, float* sm) {
+  const int tid = threadIdx.x;
   const float* as = a_s + (size_t)b * HW;
   const float* tp[3] = {t0 + (size_t)b * HW, t1 ? t1 + (size_t)b * HW : nullptr, t2 ? t2 + (size_t)b * HW : nullptr};
   // L2 norms
@@ -117,8 +117,54 @@ __global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a
     float dah = u * (-v - dot_gu) / T;
     float d = (dah - ah * dot_ad) / ns * sc;
     size_t o = (size_t)b * HW + j;
-    da_s[o] = accumulate ? da_s[o] + d : d;
+    if (accumulate == 2) atomicAdd(&da_s[o], d);
+    else da_s[o] = accumulate ? da_s[o] + d : d;
   }
+}
+__global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a_s, const float* __restrict__ t0,
+                                                     const float* __restrict__ t1, const float* __restrict__ t2, int nt,
+                                                     int HW, int B, float T, float* loss, float* da_s, float gscale,
+                                                     int accumulate) {
+  __shared__ float sm[8];
+  mta_kl_body(a_s, t0, t1, t2, nt, HW, B, T, loss, da_s, gscale, accumulate, blockIdx.x, sm);
+}
+
+// Every (level, teacher) pair of a step in ONE launch: grid (B, levels, pairs).  The per-pair launches are 8-block kernels
+// of ~10 dependent block reductions each (5-19 us apiece, 15 of them back to back on the step's critical path).
+//   pairwise mode (ModelWithNMSLoss): pairs = teachers, loss[t*nlev + l]; da_s[l] accumulates over teachers with atomics (zero on entry)
+//   list mode (ModelWithNMSKDListLoss): pairs = 1, each block multiplies the nt teacher maps, loss[l]
+#define MTA_MAX_LEV 5
+#define MTA_MAX_T 3
+struct MtaMulti {
+  const float* a_s[MTA_MAX_LEV]; const float* a_t[MTA_MAX_T][MTA_MAX_LEV]; float* da[MTA_MAX_LEV]; int HW[MTA_MAX_LEV];
+  int nt, list_mode, B; float T, gscale; float* loss;
+};
+__global__ __launch_bounds__(256) void mta_kl_multi_kernel(MtaMulti m) {
+  __shared__ float sm[8];
+  const int l = blockIdx.y, t = blockIdx.z, nlev = gridDim.y;
+  if (m.list_mode)
+    mta_kl_body(m.a_s[l], m.a_t[0][l], m.nt > 1 ? m.a_t[1][l] : nullptr, m.nt > 2 ? m.a_t[2][l] : nullptr, m.nt, m.HW[l], m.B, m.T,
+                m.loss + l, m.da[l], m.gscale, 0, blockIdx.x, sm);
+  else
+    mta_kl_body(m.a_s[l], m.a_t[t][l], nullptr, nullptr, 1, m.HW[l], m.B, m.T, m.loss + t * nlev + l, m.da[l], m.gscale,
+                m.nt > 1 ? 2 : 0, blockIdx.x, sm);
+}
+extern "C" int mmd_mta_kl_multi(const float* const* a_s, const float* const* a_t, float* const* da_s, const int* HW, int nlev,
+                                int nteachers, int list_mode, int B, float T, float* loss, float gscale, hipStream_t stream) {
+  if (!a_s || !a_t || !HW || !loss || nlev < 1 || nlev > MTA_MAX_LEV || nteachers < 1 || nteachers > MTA_MAX_T || B <= 0 || !(T > 0.f))
+    return MMD_EINVAL;
+  MtaMulti m{};
+  for (int l = 0; l < nlev; ++l) {
+    if (!a_s[l] || HW[l] <= 0) return MMD_EINVAL;
+    m.a_s[l] = a_s[l]; m.HW[l] = HW[l]; m.da[l] = da_s ? da_s[l] : nullptr;
+    for (int t = 0; t < nteachers; ++t) {
+      if (!a_t[t * nlev + l]) return MMD_EINVAL;
+      m.a_t[t][l] = a_t[t * nlev + l];
+    }
+  }
+  m.nt = nteachers; m.list_mode = list_mode; m.B = B; m.T = T; m.gscale = gscale; m.loss = loss;
+  hipLaunchKernelGGL(mta_kl_multi_kernel, dim3(B, nlev, list_mode ? 1 : nteachers), dim3(256), 0, stream, m);
+  return mmd_check_launch();
 }
 extern "C" int mmd_mta_kl(const float* a_s, const float* a_t0, const float* a_t1, const float* a_t2, int nteachers,
                           int B, int HW, float T, float* loss, float* da_s, float gscale, int accumulate,

@@ -10,6 +10,7 @@ their gradients, the student backward, gradient all-reduce (RCCL, student gradie
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 from dataclasses import dataclass, field
@@ -166,10 +167,13 @@ class DistillEngine:
              1 if self.cfg.inclusive_nms else 0, float(S), B, rows, cnt, mask_ws, self.overflow)
         return rows, cnt
 
-    def _attention(self, f: Feat) -> torch.Tensor:
-        a = self.ws.alloc((f.M,))
-        call("mmd_mta_attention", f.z, a, f.M, f.C, float(self.cfg.p))
-        return a
+    def _attention(self, net: Net):
+        """Spatial attention maps a[b, j] = mean_c f^p of the five BiFPN outputs of `net` in ONE launch: the final cell writes
+        them into one pyramid row buffer (engine._bifpn), so the maps are row slices of one vector.  -> (all, [per level])"""
+        pyr, fcat = net._pyr, net._fcat
+        a = self.ws.alloc((pyr["total"],))
+        call("mmd_mta_attention", fcat, a, pyr["total"], fcat.shape[1], float(self.cfg.p))
+        return a, [a[pyr["row0"][l]:pyr["row0"][l] + pyr["rows"][l]] for l in range(len(pyr["rows"]))]
 
     def step_body(self, batch: Dict[str, torch.Tensor], drop_scale: torch.Tensor):
         """Issues the whole step on the current stream.  batch tensors are NCHW fp32 on device."""
@@ -194,8 +198,12 @@ class DistillEngine:
         cls_s, reg_s, feats_s = st.forward(audio, train=True, drop_scale=drop_scale)
         A = cls_s.shape[1]
         nlv = len(feats_s)
-        a_s = [self._attention(f) for f in feats_s]
-        da = [self.ws.alloc((f.M,)) for f in feats_s]
+        _, a_s = self._attention(st)
+        # gradient w.r.t. the student's maps, one vector over the pyramid rows (zeroed: teachers accumulate into it
+        # with atomics, and the padding rows of a pyramid must read as zero in the backward)
+        da_all = self.ws.alloc((st._pyr["total"],))
+        call("mmd_memset_async", da_all, 0, da_all.numel() * 4)
+        da = [da_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
         nt = len(self.teachers)
         kd = self.ws.alloc((nt if cfg.kd_mode == "pairwise" else 1, nlv))
         call("mmd_memset_async", kd, 0, kd.numel() * 4)
@@ -217,25 +225,22 @@ class DistillEngine:
                     for f in feats_t:
                         call("mmd_avg_image01", f.z, f.H * f.W * f.C)
                 r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
-                at = [self._attention(f) for f in feats_t]
+                _, at = self._attention(net)
             rows_t.append(r); cnt_t.append(c); att_t.append(at)
         if concurrent:
             for side in self.side_streams:
                 main_stream.wait_stream(side)
-        if cfg.kd_mode == "pairwise":
-            for ti, at in enumerate(att_t):
-                for l, f in enumerate(feats_s):
-                    call("mmd_mta_kl", a_s[l], at[l], None, None, 1, B, f.H * f.W, float(cfg.T), kd[ti, l:l + 1], da[l],
-                         float(cfg.w_kd), 1 if ti > 0 else 0)
-        if cfg.kd_mode != "pairwise":
-            for l, f in enumerate(feats_s):
-                call("mmd_mta_kl", a_s[l], att_t[0][l], att_t[1][l] if nt > 1 else None, att_t[2][l] if nt > 2 else None,
-                     nt, B, f.H * f.W, float(cfg.T), kd[0, l:l + 1], da[l], float(cfg.w_kd), 0)
-        dfe = []
-        for l, f in enumerate(feats_s):
-            d = st._alloc(f.M, f.C)
-            call("mmd_mta_attention_bwd", f.z, da[l], d, f.M, f.C, float(cfg.p), 0)
-            dfe.append(d)
+        # every (level, teacher) KL of the step in one launch (pairwise: nt x 5 losses; list: 5), then one launch for d attention / d f
+        vp = ctypes.c_void_p
+        p_as = (vp * nlv)(*[t.data_ptr() for t in a_s])
+        p_at = (vp * (nt * nlv))(*[att_t[ti][l].data_ptr() for ti in range(nt) for l in range(nlv)])
+        p_da = (vp * nlv)(*[t.data_ptr() for t in da])
+        hw = (ctypes.c_int * nlv)(*[f.H * f.W for f in feats_s])
+        call("mmd_mta_kl_multi", p_as, p_at, p_da, hw, nlv, nt, 0 if cfg.kd_mode == "pairwise" else 1, B, float(cfg.T), kd,
+             float(cfg.w_kd))
+        d_all = st._alloc(st._pyr["total"], feats_s[0].C)
+        call("mmd_mta_attention_bwd", st._fcat, da_all, d_all, st._pyr["total"], feats_s[0].C, float(cfg.p), 0)
+        dfe = [d_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
         # cross-teacher merge -> annotations
         G = cfg.max_boxes
         boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)

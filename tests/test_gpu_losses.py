@@ -115,6 +115,61 @@ def test_mta_golden(golden_dir, name):
         assert np.abs(dfs[i].numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, i
 
 
+def _mta_multi(fs, fts, T, p, list_mode, gscale=1.0):
+    """All (level, teacher) pairs through mmd_mta_kl_multi (one launch).  -> (loss [nt or 1, 5], da per level)"""
+    import ctypes
+    B, nt = fs[0].shape[0], len(fts)
+    a_s, a_t, das, hw = [], [[] for _ in fts], [], []
+    for lvl in range(5):
+        f = fs[lvl]
+        C, HW = f.shape[1], f.shape[2] * f.shape[3]
+        a = torch.empty(B * HW, device=DEV)
+        call("mmd_mta_attention", g(rows(f)), a, B * HW, C, p)
+        a_s.append(a); hw.append(HW); das.append(torch.zeros(B * HW, device=DEV))
+        for k, ft in enumerate(fts):
+            at = torch.empty(B * HW, device=DEV)
+            call("mmd_mta_attention", g(rows(ft[lvl])), at, B * HW, C, p)
+            a_t[k].append(at)
+    loss = torch.zeros(1 if list_mode else nt, 5, device=DEV)
+    vp = ctypes.c_void_p
+    call("mmd_mta_kl_multi", (vp * 5)(*[t.data_ptr() for t in a_s]),
+         (vp * (nt * 5))(*[a_t[k][l].data_ptr() for k in range(nt) for l in range(5)]), (vp * 5)(*[t.data_ptr() for t in das]),
+         (ctypes.c_int * 5)(*hw), 5, nt, 1 if list_mode else 0, B, T, loss, gscale)
+    return loss.cpu(), das, a_s, a_t, hw
+
+
+@pytest.mark.parametrize("name", ["stock", "peaky"])
+def test_mta_multi_matches_per_pair_and_golden(golden_dir, name):
+    """One launch for every (level, teacher) pair: losses equal the reference's per-pair MTALoss values (golden `pair` for
+    teacher 0, `list` for the list form), and the student-map gradient is the SUM over teachers of the per-pair gradients
+    (atomics on a zeroed buffer) - what three accumulate=1 launches of mmd_mta_kl produce."""
+    gold = np.load(os.path.join(golden_dir, f"loss_mta_{name}.npz"))
+    T = float(gold["T"])
+    fs = [torch.from_numpy(gold[f"fs{i}"]) for i in range(5)]
+    fts = [[torch.from_numpy(gold[f"ft{k}_{i}"]) for i in range(5)] for k in range(3)]
+    B = fs[0].shape[0]
+    loss, das, a_s, a_t, hw = _mta_multi(fs, fts, T, 2.0, list_mode=False, gscale=0.005)
+    np.testing.assert_allclose(loss[0].numpy(), gold["pair"], rtol=1e-4, atol=2e-6)
+    for lvl in range(5):
+        ref = torch.zeros(B * hw[lvl], device=DEV)
+        l2 = torch.zeros(1, device=DEV)
+        for k in range(3):
+            l2.zero_()
+            call("mmd_mta_kl", a_s[lvl], a_t[k][lvl], None, None, 1, B, hw[lvl], T, l2, ref, 0.005, 1 if k else 0)
+            np.testing.assert_allclose(loss[k, lvl].item(), l2.item(), rtol=1e-5, atol=1e-7)
+        assert (das[lvl] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-12
+    loss, das, a_s, a_t, hw = _mta_multi(fs, fts, T, 2.0, list_mode=True)
+    np.testing.assert_allclose(loss[0].numpy(), gold["list"], rtol=1e-4, atol=2e-6)
+    for lvl in range(5):
+        f = fs[lvl]
+        C = f.shape[1]
+        df = torch.empty(B * hw[lvl], C, device=DEV)
+        call("mmd_mta_attention_bwd", g(rows(f)), das[lvl], df, B * hw[lvl], C, 2.0, 0)
+        ref = gold[f"list_dfs{lvl}"]
+        got = df.view(B, f.shape[2], f.shape[3], C).permute(0, 3, 1, 2).cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, lvl
+
+
 def run_postproc(cls, reg, anchors, S, thr=0.3, nms=0.5):
     B, A, NC = cls.shape
     cap = int(_lib.LIB.load().mmd_pp_cap())
