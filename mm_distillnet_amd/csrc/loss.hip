@@ -260,8 +260,7 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict
       int lab = -1;
       const float* bx = boxes + ((size_t)b * maxg + (as >= 0 ? as : 0)) * 5;
       if (as >= 0) lab = (int)bx[4];
-      for (int c = 0; c < NC; ++c) {
-        float raw = p[c];
+      auto term = [&](float raw, int c, float& gv) -> float {      // focal term of one (anchor, class) and its gradient
         float q = fminf(fmaxf(raw, 1e-4f), 1.f - 1e-4f);
         bool inside = raw >= 1e-4f && raw <= 1.f - 1e-4f;
         float l = 0.f, d = 0.f;
@@ -276,11 +275,25 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict
             d = (1.f - alpha) * (-2.f * q * lg + q * q / om);
           }
         }
-        lc += (double)l;
-        if (dp) {
-          float gv = inside ? d * gs : 0.f;
-          if (to_logit) gv *= raw * (1.f - raw);
-          dp[c] = gv;
+        gv = inside ? d * gs : 0.f;
+        if (to_logit) gv *= raw * (1.f - raw);
+        return l;
+      };
+      if ((NC & 3) == 0) {
+        // an anchor's NC probabilities are 16-byte aligned: dwordx4 loads / stores (a per-class dword loop touches 64 cache
+        // lines per instruction); the per-anchor sum of <= NC terms in fp32, the reduction across anchors in fp64
+        float ls = 0.f;
+        for (int c = 0; c < NC; c += 4) {
+          float4 r4 = mmd_ld4(p + c), g4v;
+          ls += term(r4.x, c, g4v.x) + term(r4.y, c + 1, g4v.y) + term(r4.z, c + 2, g4v.z) + term(r4.w, c + 3, g4v.w);
+          if (dp) mmd_st4(dp + c, g4v);
+        }
+        lc = (double)ls;
+      } else {
+        for (int c = 0; c < NC; ++c) {
+          float gv;
+          lc += (double)term(p[c], c, gv);
+          if (dp) dp[c] = gv;
         }
       }
       lc /= (double)norm;
