@@ -234,6 +234,109 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
   return mmd_check_launch();
 }
 
+// Fused node backward: the depthwise 3x3 input gradient  df = dwconv^T(dzd, w)  is computed from an LDS tile of dzd (8x8
+// pixels + halo, 64-channel chunk) and fed straight into the fusion backward above - one launch instead of two and no df
+// round trip through HBM (mirror of fuse_dw_fwd_kernel; 40 launches on the backward's serial chain).
+__global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
+                                                         const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
+                                                         float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
+                                                         int tiles_h, int tiles_w, int cchunks) {
+  constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
+  __shared__ float sIn[IH * IW * 64];
+  __shared__ float sW[9 * 64];
+  __shared__ float sred[4 * 3];
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int cc = bid % cchunks; bid /= cchunks;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h; bid /= tiles_h;
+  const int b = bid;
+  const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  const bool cok = c < a.C;
+  const int oh0 = th * TH, ow0 = tw * TW;
+  for (int i = tid; i < 9 * 16; i += 256) {        // flipped taps: the transpose of a stride-1 SAME correlation
+    int tap = i >> 4, q = (i & 15) * 4;
+    float4 wv = (c0 + q < a.C) ? mmd_ld4(wdw + (size_t)(8 - tap) * a.C + c0 + q) : make_float4(0, 0, 0, 0);
+    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
+  }
+  for (int p = tid >> 4; p < IH * IW; p += 16) {
+    const int ih = oh0 - 1 + p / IW, iw = ow0 - 1 + p % IW;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = mmd_ld4(dzd + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
+    *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+  }
+  __syncthreads();
+  const int p = tid >> 4;
+  const int orow = p / (TW / R);
+  const int ocol0 = (p % (TW / R)) * R;
+  float4 acc[R];
+#pragma unroll
+  for (int o = 0; o < R; ++o) acc[o] = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float4 in[SEG];
+    const float* prow = &sIn[((orow + i) * IW + ocol0) * 64 + c4];
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * 3 + j) * 64 + c4]);
+#pragma unroll
+      for (int o = 0; o < R; ++o) {
+        acc[o].x += in[o + j].x * wv.x; acc[o].y += in[o + j].y * wv.y;
+        acc[o].z += in[o + j].z * wv.z; acc[o].w += in[o + j].w * wv.w;
+      }
+    }
+  }
+  float d[3] = {0.f, 0.f, 0.f};
+  const int oh = oh0 + orow;
+#pragma unroll
+  for (int o = 0; o < R; ++o) {
+    const int ow = ow0 + ocol0 + o;
+    if (cok && oh < a.H && ow < a.W) {
+      float4 t[4];
+      float4 sv = fuse_presum(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3]);
+      const size_t off = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
+      float4 g = acc[o];
+      g.x *= mmd_swish_grad(sv.x); g.y *= mmd_swish_grad(sv.y); g.z *= mmd_swish_grad(sv.z); g.w *= mmd_swish_grad(sv.w);
+      if (dx) mmd_st4(dx + off, g);
+      if (d0) {
+        float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
+        if (acc0) { float4 q = mmd_ld4(d0 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        mmd_st4(d0 + off, v);
+      }
+      if (d1) {
+        float4 v = make_float4(g.x * w[1], g.y * w[1], g.z * w[1], g.w * w[1]);
+        if (acc1) { float4 q = mmd_ld4(d1 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        mmd_st4(d1 + off, v);
+      }
+      int wi = 0;
+      d[wi++] += g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
+      if (a.in1) d[wi++] += g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
+      if (a.up) d[wi++] += g.x * t[2].x + g.y * t[2].y + g.z * t[2].z + g.w * t[2].w;
+      if (a.pl) d[wi++] += g.x * t[3].x + g.y * t[3].y + g.z * t[3].z + g.w * t[3].w;
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { float v = wave_sum(d[i]); if (lane == 0) sred[wave * 3 + i] = v; }
+  __syncthreads();
+  if (tid < a.ntheta) atomicAdd(&wdot[tid], sred[tid] + sred[3 + tid] + sred[6 + tid] + sred[9 + tid]);
+}
+extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool,
+                                     const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
+                                     int H, int W, int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream) {
+  FuseArgs a{};
+  int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1)) return MMD_EINVAL;
+  int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
+  hipLaunchKernelGGL(fuse_dw_bwd_kernel, dim3((unsigned)(B * th * tw * cc)), dim3(256), 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0,
+                     d1, acc1, th, tw, cc);
+  return mmd_check_launch();
+}
+
 // d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   
 __global__ void fuse_theta_bwd_kernel(const float* theta, const float* wdot, float* dtheta, int n) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;

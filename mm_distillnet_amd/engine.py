@@ -713,7 +713,8 @@ class Net:
                 W = out.C
                 dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W, lazy=True)
                 dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
-                df = self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1)
+                # depthwise weight gradient on the side stream; its input gradient is computed inside the fusion-backward launch
+                self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1, want_dx=False)
                 in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
                 th = ps.w(f"{cell}.{rec['theta']}")
                 nth = th.numel()
@@ -732,8 +733,8 @@ class Net:
                 assert in1 is None or same[0].data_ptr() != same[2].data_ptr()
                 dx = self._alloc(out.M, W) if (up is not None or pl is not None) else None
                 wdot = self._zalloc((4,))
-                call("mmd_bifpn_fuse_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-                     df, dx, wdot, in0.B, in0.H, in0.W, W, *same)
+                call("mmd_bifpn_node_dw_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                     ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same)
                 with self._wgrad_stream():
                     call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
                 wi = 1 + (1 if in1 is not None else 0)

@@ -830,3 +830,37 @@ def test_pwconv_bwd_bn_prologue(M, K, N, act, rowscale, sfx):
     assert (dw.cpu() - w.grad).abs().max().item() <= tol["rtol"] * sw + (tol["atol"] * sw if sfx else 1e-5), "dW"
     close(dga, gamma.grad, 5e-4, 5e-4 * gamma.grad.abs().max().item(), "dgamma")
     close(dbe, beta.grad, 5e-4, 5e-4 * max(beta.grad.abs().max().item(), 1.0), "dbeta")
+
+
+@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 48), ("p7", 4, 4, 112), ("td", 6, 10, 224)])
+def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
+    """Fused node backward (depthwise input gradient from an LDS tile + fusion backward) against the two launches it
+    replaces: same dx, same operand gradients (written and accumulated), same theta dot products."""
+    torch.manual_seed(13)
+    B = 2
+    in0 = torch.randn(B * H * W, C)
+    in1 = torch.randn(B * H * W, C) if mode == "bu" else None
+    up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
+    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7") else None
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    wd = torch.randn(9, C) / 3
+    dzd = torch.randn(B * H * W, C)
+    gp = lambda t: g(t) if t is not None else None
+    df = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_dwconv_bwd_data", g(dzd), g(wd), df, B, H, W, C, 3, 1, None, None, None, None, None, None, None, 0)
+    base0 = torch.randn(B * H * W, C)
+    outs = {}
+    for name in ("ref", "fused"):
+        dx = torch.zeros(B * H * W, C, device=DEV)
+        wdot = torch.zeros(4, device=DEV)
+        d0 = g(base0.clone())                       # accumulated into
+        d1 = torch.zeros(B * H * W, C, device=DEV) if in1 is not None else None      # written
+        if name == "ref":
+            call("mmd_bifpn_fuse_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), df, dx, wdot, B, H, W, C, d0, 1, d1, 0)
+        else:
+            call("mmd_bifpn_node_dw_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(dzd), dx, wdot, B, H, W, C, d0, 1,
+                 d1, 0)
+        outs[name] = (dx, wdot, d0, d1)
+    for a, b, what in zip(outs["ref"], outs["fused"], ("dx", "wdot", "d0", "d1")):
+        if a is not None:
+            close(b, a, 1e-5, 1e-5 if what != "wdot" else 1e-3, what)
