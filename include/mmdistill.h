@@ -32,8 +32,9 @@ int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, cons
 
 // Backward of w = relu(theta)/(sum+1e-4).
 // Node backward in one launch: depthwise 3x3 input gradient (from an LDS tile of dzd, the gradient w.r.t. the depthwise output)
-// + fusion backward (same outputs as mmd_bifpn_fuse_bwd fed with df = dwconv^T(dzd, w_dw)).
-int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream);
+// + fusion backward (same outputs as mmd_bifpn_fuse_bwd fed with df = dwconv^T(dzd, w_dw)); dup (nullable, needs `up`): the gradient of
+// the nearest-upsampled operand [B, H/2, W/2, C] (=|+=) w_up * 2x2 block sums, written here instead of by mmd_upsample2_bwd_acc.
+int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, hipStream_t stream);
 
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
 

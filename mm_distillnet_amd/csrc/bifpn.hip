@@ -240,6 +240,7 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
+                                                         float* __restrict__ dup, int acc_up,
                                                          int tiles_h, int tiles_w, int cchunks) {
   constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
   __shared__ float sIn[IH * IW * 64];
@@ -292,15 +293,18 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
   float d[3] = {0.f, 0.f, 0.f};
   const int oh = oh0 + orow;
+  float4 gq[R];
 #pragma unroll
   for (int o = 0; o < R; ++o) {
     const int ow = ow0 + ocol0 + o;
+    gq[o] = make_float4(0, 0, 0, 0);
     if (cok && oh < a.H && ow < a.W) {
       float4 t[4];
       float4 sv = fuse_presum(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3]);
       const size_t off = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
       float4 g = acc[o];
       g.x *= mmd_swish_grad(sv.x); g.y *= mmd_swish_grad(sv.y); g.z *= mmd_swish_grad(sv.z); g.w *= mmd_swish_grad(sv.w);
+      gq[o] = g;
       if (dx) mmd_st4(dx + off, g);
       if (d0) {
         float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
@@ -320,6 +324,25 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     }
   }
   const int wave = tid >> 6, lane = tid & 63;
+  if (dup) {
+    // gradient of the nearest-upsampled operand: w_up * (sum over the 2x2 block).  A thread holds 4 pixels of one row (two
+    // horizontal pairs); the row below belongs to lane ^ 32 of the same wave (pixel groups 4w..4w+3 = rows 2w, 2w, 2w+1, 2w+1),
+    // tiles start on even rows / columns, so every 2x2 block is complete inside one wave: no atomics
+    const float wu = w[1 + (a.in1 ? 1 : 0)];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float4 sv = make_float4(gq[2 * q].x + gq[2 * q + 1].x, gq[2 * q].y + gq[2 * q + 1].y, gq[2 * q].z + gq[2 * q + 1].z,
+                              gq[2 * q].w + gq[2 * q + 1].w);
+      sv.x += __shfl_xor(sv.x, 32, 64); sv.y += __shfl_xor(sv.y, 32, 64); sv.z += __shfl_xor(sv.z, 32, 64); sv.w += __shfl_xor(sv.w, 32, 64);
+      const int uy = oh >> 1, ux = ((ow0 + ocol0) >> 1) + q;
+      if (lane < 32 && cok && uy < (a.H >> 1) && ux < (a.W >> 1)) {
+        float* o = dup + (((size_t)b * (a.H >> 1) + uy) * (a.W >> 1) + ux) * a.C + c;
+        sv.x *= wu; sv.y *= wu; sv.z *= wu; sv.w *= wu;
+        if (acc_up) { float4 pv = mmd_ld4(o); sv.x += pv.x; sv.y += pv.y; sv.z += pv.z; sv.w += pv.w; }
+        mmd_st4(o, sv);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { float v = wave_sum(d[i]); if (lane == 0) sred[wave * 3 + i] = v; }
   __syncthreads();
@@ -327,13 +350,14 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
 }
 extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool,
                                      const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
-                                     int H, int W, int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream) {
+                                     int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                     hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
-  if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1)) return MMD_EINVAL;
+  if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   hipLaunchKernelGGL(fuse_dw_bwd_kernel, dim3((unsigned)(B * th * tw * cc)), dim3(256), 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0,
-                     d1, acc1, th, tw, cc);
+                     d1, acc1, dup, acc_up, th, tw, cc);
   return mmd_check_launch();
 }
 

@@ -731,10 +731,17 @@ class Net:
                         sl.t = self._alloc(operand.M, W)
                     same += [sl.t, accumulate]
                 assert in1 is None or same[0].data_ptr() != same[2].data_ptr()
-                dx = self._alloc(out.M, W) if (up is not None or pl is not None) else None
+                # the gradient of an upsampled operand leaves the same launch (2x2 block sums); dx is only materialised for a
+                # pooled operand (its scatter follows the arg-max of overlapping windows)
+                dx = self._alloc(out.M, W) if pl is not None else None
+                upargs = (None, 0)
+                if up is not None:
+                    su = slot(up)
+                    upargs = (su.t, 1) if su.t is not None else (self._alloc(up.M, W), 0)
+                    su.t = upargs[0]
                 wdot = self._zalloc((4,))
                 call("mmd_bifpn_node_dw_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-                     ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same)
+                     ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs)
                 with self._wgrad_stream():
                     call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
                 wi = 1 + (1 if in1 is not None else 0)
@@ -746,7 +753,7 @@ class Net:
                     if sl.t is None:
                         sl.t = self._alloc(operand.M, W)
                     if kind == "up":
-                        call("mmd_upsample2_bwd_acc", dx, sl.t, th, nth, wi, accumulate, in0.B, in0.H, in0.W, W)
+                        pass          # written by the node launch above
                     else:
                         call("mmd_maxpool_same_bwd_acc", operand.z, dx, sl.t, th, nth, wi, accumulate, operand.B, operand.H,
                              operand.W, W)

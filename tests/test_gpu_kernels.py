@@ -855,12 +855,22 @@ def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
         wdot = torch.zeros(4, device=DEV)
         d0 = g(base0.clone())                       # accumulated into
         d1 = torch.zeros(B * H * W, C, device=DEV) if in1 is not None else None      # written
+        dup_w = torch.zeros(B * (H // 2) * (W // 2), C, device=DEV) if up is not None else None       # written
+        dup_a = g(torch.ones(B * (H // 2) * (W // 2), C)) if up is not None else None                 # accumulated into
+        nth = theta.numel()
         if name == "ref":
             call("mmd_bifpn_fuse_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), df, dx, wdot, B, H, W, C, d0, 1, d1, 0)
+            if up is not None:
+                call("mmd_upsample2_bwd_acc", dx, dup_w, g(theta), nth, 1, 0, B, H, W, C)
+                call("mmd_upsample2_bwd_acc", dx, dup_a, g(theta), nth, 1, 1, B, H, W, C)
         else:
             call("mmd_bifpn_node_dw_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(dzd), dx, wdot, B, H, W, C, d0, 1,
-                 d1, 0)
-        outs[name] = (dx, wdot, d0, d1)
-    for a, b, what in zip(outs["ref"], outs["fused"], ("dx", "wdot", "d0", "d1")):
+                 d1, 0, dup_w, 0)
+            if up is not None:       # second launch: accumulate form, dx not materialised (the top-down nodes' configuration)
+                wd2 = torch.zeros(4, device=DEV)
+                call("mmd_bifpn_node_dw_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(dzd), None, wd2, B, H, W, C,
+                     g(base0.clone()), 1, None, 0, dup_a, 1)
+        outs[name] = (dx, wdot, d0, d1, dup_w, dup_a)
+    for a, b, what in zip(outs["ref"], outs["fused"], ("dx", "wdot", "d0", "d1", "dup (write)", "dup (accumulate)")):
         if a is not None:
             close(b, a, 1e-5, 1e-5 if what != "wdot" else 1e-3, what)
