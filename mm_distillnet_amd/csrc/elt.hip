@@ -5,6 +5,7 @@
 // Per-channel reductions: shuffle over the 4 row-groups of a wave (lanes l^16, l^32), then LDS over
 // the 4 waves, then one double/float atomic per channel per block.
 #include "common.h"
+#include <cstdlib>
 
 #define ROWS_PER_BLOCK 256
 
@@ -785,6 +786,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     mmd_st4(yo + 4 * q, v);
   }
 }
+int mmd_pw_stem_gemm(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l,
+                     int Kp, int Cout, const float* out_scale, const float* out_shift, int out_act, double* stats,
+                     double* stats_ws, int ws_slots, hipStream_t stream);      // pw_gemm.hip
 extern "C" int mmd_stem_conv_fwd(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int Kp, int Cout,
                                  const float* out_scale, const float* out_shift, int out_act, double* stats,
                                  double* stats_ws, int ws_slots, hipStream_t stream) {
@@ -799,6 +803,14 @@ extern "C" int mmd_stem_conv_fwd(const float* x, const float* w, float* y, int B
   const bool slotted = stats && stats_ws && ws_slots > 1 && nb > MMD_STATS_DEPTH;
   mmd_prof_tag(MMD_FAM_ELT, "stem B%lld Cin%lld H%lld Co%lld", B, Cin, H, Cout);
   mmd_prof_begin(MMD_FAM_ELT, stream);
+  static const int direct = getenv("MMD_STEM_DIRECT") ? 1 : 0;
+  if (!direct && !(Kp & 3) && !(Cout & 3)) {
+    // implicit GEMM on the MFMA kernel (pw_gemm.hip, StemOp): the image is gathered while the A tile is staged
+    int rc = mmd_pw_stem_gemm(x, w, y, B, Cin, H, W, OH, OW, eh / 2, ew / 2, Kp, Cout, out_scale, out_shift, out_act, stats,
+                              stats_ws, ws_slots, stream);
+    mmd_prof_end(MMD_FAM_ELT, stream, 2.0 * total * Kp * Cout, 4.0 * ((double)B * Cin * H * W + (double)total * Cout));
+    return rc;
+  }
   void (*kern)(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, const float*, const float*, int, double*,
                double*, int) = Cout == 32 ? stem_conv_kernel<32> : Cout == 40 ? stem_conv_kernel<40> : Cout == 48 ? stem_conv_kernel<48>
                              : Cout == 56 ? stem_conv_kernel<56> : stem_conv_kernel<64>;

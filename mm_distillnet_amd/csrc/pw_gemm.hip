@@ -50,6 +50,12 @@ __device__ __forceinline__ float4 bn_bwd_eval4(float4 g, float4 z, float rs, int
                      bn_bwd_eval(g.w, z.w, rs, act, q.a1.w, q.a2.w, q.a3.w, q.mu.w, q.sh.w));
 }
 
+// Stem 3x3 / stride-2 TF-SAME convolution as an implicit GEMM: row m = output pixel (b, oh, ow), k = ci*9 + i*3 + j, the A
+// element is x[b, ci, 2*oh + i - pad_t, 2*ow + j - pad_l] (zero outside the image), gathered from the NCHW image while staging;
+// the weight is the stem's native [Cout, Kp] matrix (mmd_stem_im2col's column order).  Replaces the direct VALU kernel
+// (one thread per pixel x all output channels: 188 us for the 8-channel student stem).
+struct StemOp { int Cin, H, W, OH, OW, pad_t, pad_l; };
+
 struct PwArgs {
   const float* x; const float* w; float* y;
   int M, K, N;
@@ -63,6 +69,7 @@ struct PwArgs {
   Pyr pyr; long long yoff_lev[MMD_MAX_LEV]; long long lev_stride;
   int bf16;                                  // host-side: operands rounded to bf16 at the MFMA input (mixed-precision mode)
   BnBwdOp bb;                                // PRO == 1: the A operand is a BatchNorm backward evaluated on the fly
+  StemOp st;                                 // PRO == 2: the A operand is the im2col of an NCHW image, gathered on the fly
 };
 
 // ---- bf16 mixed precision (BASELINE config 5): the SAME kernels with the inner product on v_mfma_f32_32x32x16_bf16.
@@ -126,13 +133,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // per-thread row bookkeeping for the NA A loads
   const float* xrow[NA]; const float* grow[NA]; bool rok[NA]; float rowsc[NA];
+  int sih[NA], siw[NA];                  // PRO == 2: top-left input coordinate of the row's 3x3 window
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int row = m0 + lrow + i * 32;
     rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
     xrow[i] = a.x + (size_t)rr * a.K;
-    if constexpr (PRO == 1) {
+    if constexpr (PRO == 2) {
+      const int ow = rr % a.st.OW, t1 = rr / a.st.OW, oh = t1 % a.st.OH, b = t1 / a.st.OH;
+      sih[i] = oh * 2 - a.st.pad_t; siw[i] = ow * 2 - a.st.pad_l;
+      xrow[i] = a.x + (size_t)b * a.st.Cin * a.st.H * a.st.W;
+      grow[i] = nullptr;
+    } else if constexpr (PRO == 1) {
       grow[i] = a.bb.z + (size_t)rr * a.K;                 // the second A tensor rides in the gate's registers
       rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
     } else {
@@ -156,13 +169,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float4 ra[NA], rg[NA], rb[NB], rsc, rsh;
   BnBwdCoef4 bq;
   bool kok;
+  unsigned smask = 0;                     // PRO == 2: validity bit per (row slot, element), applied in lstore
   auto gload = [&](int k0) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
     // branch per load and a full vmcnt(0) drain, which serialises the prefetch
     int k = k0 + kq;
     kok = k < a.K;
     const int kc = kok ? k : 0;
-    if constexpr (PRO == 1) {
+    if constexpr (PRO == 2) {
+      smask = 0;
+      const int HW = a.st.H * a.st.W;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ke = kc + e, ci = ke / 9, t9 = ke - ci * 9, di = t9 / 3, dj = t9 - di * 3;
+        const bool kv = ci < a.st.Cin;                      // k beyond Cin*9 is the weight matrix' zero padding
+        const int cic = kv ? ci : 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int ih = sih[i] + di, iw = siw[i] + dj;
+          const bool ok = kv && ih >= 0 && ih < a.st.H && iw >= 0 && iw < a.st.W;
+          const int ihc = min(max(ih, 0), a.st.H - 1), iwc = min(max(iw, 0), a.st.W - 1);
+          const float v = xrow[i][(size_t)cic * HW + (size_t)ihc * a.st.W + iwc];
+          if (e == 0) ra[i].x = v; else if (e == 1) ra[i].y = v; else if (e == 2) ra[i].z = v; else ra[i].w = v;
+          smask |= (ok ? 1u : 0u) << (i * 4 + e);
+        }
+      }
+    } else if constexpr (PRO == 1) {
       bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
       for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
@@ -182,7 +214,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
-      if constexpr (PRO == 1) {
+      if constexpr (PRO == 2) {
+        const unsigned mk = smask >> (i * 4);
+        v.x = (mk & 1) ? v.x : 0.f; v.y = (mk & 2) ? v.y : 0.f; v.z = (mk & 4) ? v.z : 0.f; v.w = (mk & 8) ? v.w : 0.f;
+      } else if constexpr (PRO == 1) {
         v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
       } else {
       if (a.in_scale || a.in_bn.stats) {
@@ -729,6 +764,11 @@ static int pw_stream_launch(PwArgs& a, hipStream_t stream) {
 
 static int pw_dispatch(PwArgs& a, hipStream_t stream);
 
+// (internal, called by mmd_stem_conv_fwd in elt.hip)  y[B*OH*OW, Cout] = im2col(x) * w[Cout, Kp]^T with the 1x1 kernel's epilogue
+int mmd_pw_stem_gemm(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l,
+                     int Kp, int Cout, const float* out_scale, const float* out_shift, int out_act, double* stats,
+                     double* stats_ws, int ws_slots, hipStream_t stream);
+
 template <int BM_T, int BN_T, int PRO>
 static void (*pw_pick(int nkl, int bf))(PwArgs) {
   if (bf) return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, true, PRO> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, true, PRO>
@@ -770,6 +810,23 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
 extern "C" int mmd_pwconv_fwd(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 0); }
 // same contract, operands rounded to bf16 at the MFMA input (fp32 accumulate, fp32 in/out tensors)
 extern "C" int mmd_pwconv_fwd_bf16(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 1); }
+
+int mmd_pw_stem_gemm(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l,
+                     int Kp, int Cout, const float* out_scale, const float* out_shift, int out_act, double* stats,
+                     double* stats_ws, int ws_slots, hipStream_t stream) {
+  PwArgs a{};
+  a.x = x; a.w = w; a.y = y; a.M = B * OH * OW; a.K = Kp; a.N = Cout; a.rows_per_image = 1;
+  a.in_bn = mmd_make_bn(nullptr, nullptr, nullptr, 0, Kp);
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act; a.stats = stats;
+  a.st = StemOp{Cin, H, W, OH, OW, pad_t, pad_l};
+  const int ntm = cdiv(a.M, PW_BM);
+  if (stats && stats_ws && ws_slots > 1 && ntm > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
+  a.ntn = cdiv(Cout, 32); a.nblk = ntm * a.ntn;
+  const int nkl = ((Kp - 1) % PW_BK) / 8 + 1;
+  hipLaunchKernelGGL((pw_pick<128, 32, 2>(nkl, 0)), dim3(a.nblk), dim3(256), 0, stream, a);
+  if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * Cout, stream);
+  return mmd_check_launch();
+}
 
 static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   const int M = a.M, K = a.K, N = a.N;
