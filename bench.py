@@ -17,6 +17,14 @@ import os
 import sys
 import time
 
+
+# Hardware queues (opt-in): the step's graph has six concurrent branches (main chain, three teachers, weight gradients,
+# regressor head); the HIP runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).
+# MMD_HW_QUEUES=8 measured 21.35 ms/step (mean of 12 runs) against 21.73 with the default; left off by default because the
+# runtime proved fragile away from its default (2 queues: 40.7 ms/step or a segfault inside graph replay) - profiles/r01_notes.md.
+# Must be in the environment before the HIP runtime initialises, i.e. before torch is imported.
+if os.environ.get("MMD_HW_QUEUES"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ["MMD_HW_QUEUES"])
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
