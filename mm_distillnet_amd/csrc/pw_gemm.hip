@@ -100,8 +100,12 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
 // each) - twice the blocks for the small-M layers (16x16 / 32x32 stages), whose 128-row tiling leaves most SIMDs with
 // one wave or none.
 // PRO = 1: the A operand is BnBwdOp(a.x = g, a.bb.z = z) evaluated while staging (input-gradient GEMM behind a BatchNorm).
+// PRO = 3: "plain" A operand (no producer transform, no gate); PRO = 4: squeeze-excite gate only (the frozen nets' project convs).
+// The unused gate / coefficient registers and branches are compiled out: 62-80 VGPRs instead of 90-128, i.e. five to six waves
+// per SIMD instead of four (pw_gemm_kernel_lean) - the K loops of these layers are 1-7 tiles long, so what hides the load ->
+// LDS -> MFMA chain of one block is the other blocks on the CU (weighted over a step's shapes: 8.78 -> 8.29 ms).
 template <int BM_T, int BN_T, int NKL, bool BF, int PRO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
+__device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   constexpr int WM = BM_T / 32;          // waves along M
   constexpr int WN = 4 / WM;             // waves along N
   constexpr int NS = BN_T / (32 * WN);   // 32-col slabs per wave
@@ -148,6 +152,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     } else if constexpr (PRO == 1) {
       grow[i] = a.bb.z + (size_t)rr * a.K;                 // the second A tensor rides in the gate's registers
       rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
+    } else if constexpr (PRO == 3) {
+      grow[i] = nullptr;
+    } else if constexpr (PRO == 4) {
+      grow[i] = a.gate + (size_t)(rr / a.rows_per_image) * a.K;
     } else {
       grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
     }
@@ -198,6 +206,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
       for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
+    } else if constexpr (PRO == 3) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = mmd_ld4(xrow[i] + kc);
+    } else if constexpr (PRO == 4) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
     } else {
       if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
       else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
@@ -219,6 +233,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         v.x = (mk & 1) ? v.x : 0.f; v.y = (mk & 2) ? v.y : 0.f; v.z = (mk & 4) ? v.z : 0.f; v.w = (mk & 8) ? v.w : 0.f;
       } else if constexpr (PRO == 1) {
         v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
+      } else if constexpr (PRO == 3) {
+      } else if constexpr (PRO == 4) {
+        v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w;
       } else {
       if (a.in_scale || a.in_bn.stats) {
         v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
@@ -347,6 +364,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
+}
+
+template <int BM_T, int BN_T, int NKL, bool BF, int PRO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
+  pw_gemm_body<BM_T, BN_T, NKL, BF, PRO>(a);
+}
+// register-lean operand modes (PRO 3 / 4) at a higher occupancy target (WAVES per SIMD)
+template <int BM_T, int BN_T, int NKL, bool BF, int PRO, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pw_gemm_kernel_lean(PwArgs a) {
+  pw_gemm_body<BM_T, BN_T, NKL, BF, PRO>(a);
+}
+template <int BM_T, int BN_T, int PRO, int WAVES>
+static void (*pw_pick_lean(int nkl, int bf))(PwArgs) {
+  if (bf) return nkl == 1 ? pw_gemm_kernel_lean<BM_T, BN_T, 1, true, PRO, WAVES> : nkl == 2 ? pw_gemm_kernel_lean<BM_T, BN_T, 2, true, PRO, WAVES>
+               : nkl == 3 ? pw_gemm_kernel_lean<BM_T, BN_T, 3, true, PRO, WAVES> : pw_gemm_kernel_lean<BM_T, BN_T, 4, true, PRO, WAVES>;
+  return nkl == 1 ? pw_gemm_kernel_lean<BM_T, BN_T, 1, false, PRO, WAVES> : nkl == 2 ? pw_gemm_kernel_lean<BM_T, BN_T, 2, false, PRO, WAVES>
+       : nkl == 3 ? pw_gemm_kernel_lean<BM_T, BN_T, 3, false, PRO, WAVES> : pw_gemm_kernel_lean<BM_T, BN_T, 4, false, PRO, WAVES>;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -854,6 +888,10 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
+    // plain A operand (no producer transform, no gate) or gate only: register-lean variants at a higher occupancy
+    static const int lean_on = getenv("MMD_NO_LEAN") ? 0 : 1;
+    const bool noxf = lean_on && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
+    const bool plain = noxf && !a.gate, gated = noxf && a.gate;
     // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
     static const int bn32_gain = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 10;
     const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
@@ -863,14 +901,18 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
       // (BatchNorm-backward operand launches take the 128x32 variant only for the thin layers, N <= 32, where 64-wide tiles
       // would multiply 2-4x padding; it holds two VGPRs in scratch there)
       a.ntn = cdiv(N, 32);
-      kern = a.bb.z ? pw_pick<128, 32, 1>(nkl, a.bf16) : pw_pick<128, 32, 0>(nkl, a.bf16);
+      kern = a.bb.z ? pw_pick<128, 32, 1>(nkl, a.bf16) : plain ? pw_pick_lean<128, 32, 3, 6>(nkl, a.bf16)
+           : gated ? pw_pick_lean<128, 32, 4, 4>(nkl, a.bf16) : pw_pick<128, 32, 0>(nkl, a.bf16);
     } else if ((sq_tiles > 0 && big_tiles < sq_tiles) || a.bb.z) {      // 64x64 tiles: small-M layers (and every BatchNorm-
       // backward operand launch: its two-tensor prologue does not fit the 128-row variants' 128-VGPR budget)
       a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
+      if (plain) kern = pw_pick_lean<64, 64, 3, 6>(nkl, a.bf16);
+      else if (gated) kern = pw_pick_lean<64, 64, 4, 6>(nkl, a.bf16);
+      else
       kern = a.bb.z ? pw_pick<64, 64, 1>(nkl, a.bf16) : pw_pick<64, 64, 0>(nkl, a.bf16);
     } else {
       a.ntn = cdiv(N, 64);
-      kern = pw_pick<128, 64, 0>(nkl, a.bf16);
+      kern = plain ? pw_pick_lean<128, 64, 3, 5>(nkl, a.bf16) : gated ? pw_pick_lean<128, 64, 4, 5>(nkl, a.bf16) : pw_pick<128, 64, 0>(nkl, a.bf16);
     }
     a.nblk = ntm * a.ntn;
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
