@@ -393,7 +393,10 @@ static void (*pw_pick_lean(int nkl, int bf))(PwArgs) {
 #define SK_BK 128
 #define SK_LD 132
 
-template <bool BF, int PRO>
+// PF = register prefetch depth.  The skinny launches have at most one or two blocks per CU, so nothing but the block itself hides
+// its load latency: with PF = 2 the loads of K steps t+1 and t+2 are in flight while step t is multiplied (two register stages,
+// ~250 VGPRs - occupancy is irrelevant at these grid sizes).
+template <bool BF, int PRO, int PF>
 __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
   __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
@@ -422,6 +425,10 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     if constexpr (PRO == 1) {
       grow[i] = a.bb.z + (size_t)rr * a.K;
       rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
+    } else if constexpr (PRO == 3) {
+      grow[i] = nullptr;
+    } else if constexpr (PRO == 4) {
+      grow[i] = a.gate + (size_t)(rr / a.rows_per_image) * a.K;
     } else {
       grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
     }
@@ -439,58 +446,60 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
-  float4 ra[4], rg[4], rb[8], rsc, rsh;
-  BnBwdCoef4 bq;
-  bool kok;
-  auto gload = [&](int k0) {
+  struct Stage { float4 ra[4], rg[4], rb[8], rsc, rsh; BnBwdCoef4 bq; bool kok; };
+  Stage st[PF];
+  auto gload = [&](int k0, Stage& s) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
     // branch per load and a full vmcnt(0) drain, which serialises the prefetch
     int k = k0 + kq;
-    kok = k < a.K;
-    const int kc = kok ? k : 0;
+    s.kok = k < a.K;
+    const int kc = s.kok ? k : 0;
     if constexpr (PRO == 1) {
-      bn_bwd_coef4(a.bb, kc, bq);
+      bn_bwd_coef4(a.bb, kc, s.bq);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
+      for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ld4(xrow[i] + kc); s.rg[i] = mmd_ld4(grow[i] + kc); }
+    } else if constexpr (PRO == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.ra[i] = mmd_ld4(xrow[i] + kc);
+    } else if constexpr (PRO == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ld4(xrow[i] + kc); s.rg[i] = mmd_ld4(grow[i] + kc); }
     } else {
-      if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
-      else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
+      if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, s.rsc, s.rsh);
+      else if (a.in_scale) { s.rsc = mmd_ld4(a.in_scale + kc); s.rsh = mmd_ld4(a.in_shift + kc); }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ra[i] = mmd_ld4(xrow[i] + kc);
-        if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
+        s.ra[i] = mmd_ld4(xrow[i] + kc);
+        if (a.gate) s.rg[i] = mmd_ld4(grow[i] + kc);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
+    for (int i = 0; i < 8; ++i) s.rb[i] = mmd_ld4(wrow[i] + kc);
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const Stage& s) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float4 v = ra[i];
+      float4 v = s.ra[i];
       if constexpr (PRO == 1) {
-        v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
+        v = bn_bwd_eval4(v, s.rg[i], rowsc[i], a.bb.act, s.bq);
+      } else if constexpr (PRO == 3) {
+      } else if constexpr (PRO == 4) {
+        v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w;
       } else {
       if (a.in_scale || a.in_bn.stats) {
-        v.x = v.x * rsc.x + rsh.x; v.y = v.y * rsc.y + rsh.y; v.z = v.z * rsc.z + rsh.z; v.w = v.w * rsc.w + rsh.w;
+        v.x = v.x * s.rsc.x + s.rsh.x; v.y = v.y * s.rsc.y + s.rsh.y; v.z = v.z * s.rsc.z + s.rsh.z; v.w = v.w * s.rsc.w + s.rsh.w;
       }
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
-      if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+      if (a.gate) { v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w; }
       }
-      if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
+      if (!(s.kok && rok[i])) v = make_float4(0, 0, 0, 0);
       *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
+      *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = (s.kok && wok[i]) ? s.rb[i] : make_float4(0, 0, 0, 0);
   };
-
-  const int nk = (a.K + SK_BK - 1) / SK_BK;
-  gload(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    lstore();
-    __syncthreads();
-    if (kt + 1 < nk) gload((kt + 1) * SK_BK);
+  auto mma = [&]() {
     if constexpr (BF) {
       const float* pa = &sA[r * SK_LD + wave * 32 + h * 8];
       const float* pb = &sB[r * SK_LD + wave * 32 + h * 8];
@@ -505,22 +514,42 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
         }
       }
     } else {
-    const float* pa = &sA[r * SK_LD + wave * 32 + h * 4];
-    const float* pb = &sB[r * SK_LD + wave * 32 + h * 4];
+      const float* pa = &sA[r * SK_LD + wave * 32 + h * 4];
+      const float* pb = &sB[r * SK_LD + wave * 32 + h * 4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
+      for (int kk = 0; kk < 4; ++kk) {
+        float4 av = *reinterpret_cast<const float4*>(pa + kk * 8);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * SK_LD + kk * 8);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * SK_LD + kk * 8);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
+        }
       }
     }
+  };
+
+  const int nk = (a.K + SK_BK - 1) / SK_BK;
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    if (s < nk) gload(s * SK_BK, st[s]);
+    if constexpr (PF > 1) __builtin_amdgcn_sched_barrier(0);     // keep the stages' loads in issue order (the counted waits rely on it)
+  }
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int kt = kt0 + s;
+      if (kt < nk) {                               // block-uniform
+        lstore(st[s]);
+        __syncthreads();
+        if (kt + PF < nk) gload((kt + PF) * SK_BK, st[s]);
+        if constexpr (PF > 1) __builtin_amdgcn_sched_barrier(0);
+        mma();
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
   // ---- cross-wave K reduction through LDS: part[wave][row][col], row-major 32 x 64
   float* part = sB;
@@ -883,8 +912,15 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     else pw_stream_launch<2, 2>(a, stream);
   } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16 && !(sq_tiles > 0 && big_tiles >= sq_min && big_tiles < sq_tiles && N > 32)) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
-    void (*sk)(PwArgs) = a.bb.z ? (a.bf16 ? pw_gemm_skinny_kernel<true, 1> : pw_gemm_skinny_kernel<false, 1>)
-                                : (a.bf16 ? pw_gemm_skinny_kernel<true, 0> : pw_gemm_skinny_kernel<false, 0>);
+    static const int sk_lean = getenv("MMD_NO_LEAN") ? 0 : 1;
+    const bool noxf = sk_lean && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
+    const int pro = a.bb.z ? 1 : noxf ? (a.gate ? 4 : 3) : 0;
+    void (*sk)(PwArgs);
+#define SK_PICK(P, F) (a.bf16 ? pw_gemm_skinny_kernel<true, P, F> : pw_gemm_skinny_kernel<false, P, F>)
+    // (PF = 2 instantiates and runs, but hipcc drains both register stages before each LDS store - its waitcnt pass counts down to
+    // vmcnt(0) across the per-lane masking branches - so it measured 1 % slower than PF = 1; see profiles/r01_notes.md)
+    sk = pro == 1 ? SK_PICK(1, 1) : pro == 3 ? SK_PICK(3, 1) : pro == 4 ? SK_PICK(4, 1) : SK_PICK(0, 1);
+#undef SK_PICK
     hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
