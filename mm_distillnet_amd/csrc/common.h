@@ -63,7 +63,7 @@ __device__ __forceinline__ void bn_live_coef(const BnLive& b, int c, float& sc, 
   double var = b.stats[b.C + c] * b.inv_count - mean * mean;
   float invstd = mmd_bn_invstd(var, b.eps);
   sc = b.gamma[c] * invstd;
-  sh = b.beta[c] - (float)mean * sc;
+  sh = __fmaf_rn(-(float)mean, sc, b.beta[c]);      // explicit fma (not left to contraction): the finalize kernels compute the same
 }
 __device__ __forceinline__ void bn_live_coef4(const BnLive& b, int c, float4& sc, float4& sh) {
   bn_live_coef(b, c, sc.x, sh.x); bn_live_coef(b, c + 1, sc.y, sh.y);

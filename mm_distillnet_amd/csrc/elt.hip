@@ -38,7 +38,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   float invstd = mmd_bn_invstd(var, eps);
   float sc = gamma[c] * invstd;
   scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
+  shift[c] = __fmaf_rn(-(float)mean, sc, beta[c]);      // explicit fma: must equal bn_live_coef (common.h) bit for bit
   if (mean_out) { mean_out[c] = (float)mean; invstd_out[c] = invstd; }
   if (rmean) {
     double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -75,7 +75,7 @@ __global__ void bn_finalize_all_kernel(const double* __restrict__ stats, const f
   float invstd = mmd_bn_invstd(var, eps);
   float sc = gamma[c] * invstd;
   scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
+  shift[c] = __fmaf_rn(-(float)mean, sc, beta[c]);      // explicit fma: must equal bn_live_coef (common.h) bit for bit
   mean_out[c] = (float)mean; invstd_out[c] = invstd;
   double unb = n > 1.0 ? var * n / (n - 1.0) : var;
   rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
