@@ -56,7 +56,17 @@ for line in open(os.path.join(ROOT, "tools/dev/pw_shapes.csv")):
         continue
     x, y = torch.randn(M, K, device=DEV), torch.randn(M, N, device=DEV)
     dwt = torch.zeros(N, K, device=DEV)
-    t = timeit(lambda: call("mmd_pwconv_bwd_weight", y, x, dwt, M, K, N, None, None, 0, None, 1))
+    if os.environ.get("WG_BNP"):      # the in-step form: BatchNorm backward evaluated on the dY operand (90 of 99 launches)
+        z = torch.randn(M, N, device=DEV)
+        sc, sh = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV) * 0.1
+        mu, istd = torch.randn(N, device=DEV) * 0.1, torch.rand(N, device=DEV) + 0.5
+        sums = torch.randn(2 * N, dtype=torch.float64, device=DEV)
+        dga, dbe = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+        act = 1 if os.environ["WG_BNP"] == "2" else 0
+        t = timeit(lambda: call("mmd_pwconv_bwd_weight_bn", y, z, x, dwt, M, K, N, None, None, 0, None, 1, sc, sh, mu, istd, sums, M, act,
+                                None, 1, dga, dbe))
+    else:
+        t = timeit(lambda: call("mmd_pwconv_bwd_weight", y, x, dwt, M, K, N, None, None, 0, None, 1))
     rows.append(("pw M%d K%d N%d" % (M, K, N), cnt, t, 4.0 * M * (K + N)))
     del x, y
 print("weighted: dw %.3f ms   pw %.3f ms" % (sum(c * t for n, c, t, b in rows if n.startswith("dw")) / 1e3,
