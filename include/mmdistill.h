@@ -209,11 +209,12 @@ int mmd_pwconv_bwd_data_bf16(const float* dy, const float* wt, float* dx, int M,
 // [M, N] round trip less per BatchNorm on the backward's main chain).  (g, z): gradient w.r.t. the BatchNorm(+swish) output and the
 // conv's raw output, both [M, N]; scale = gamma*invstd, shift = beta - mean*scale; sums[2N] = [sum g', sum g'*xhat] from
 // mmd_bn_bwd_reduce (or the depthwise input-gradient epilogue); g' = g * mul_b[image] * swish'(z*scale+shift) (act = 1) - the same
-// rule as mmd_bn_bwd_apply.  Autograd of nn.BatchNorm2d (train) behind nn.Conv2d(k=1): src/YetAnotherEfficientNet.py:427-428,446-447,477;
+// rule as mmd_bn_bwd_apply.  mmd_pwconv_bwd_data_bn side outputs (nullable): dz_out [M, N] = the evaluated BatchNorm backward, stored once
+// so that the weight gradient can be the plain mmd_pwconv_bwd_weight(dz_out, x); dgamma / dbeta (+)= [sum g'*xhat, sum g'].  Autograd of nn.BatchNorm2d (train) behind nn.Conv2d(k=1): src/YetAnotherEfficientNet.py:427-428,446-447,477;
 // src/YetAnotherEfficientDet.py:171-176.
-int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, hipStream_t stream);
+int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
 
-int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, hipStream_t stream);
+int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
 
 int mmd_pwconv_bwd_weight_bn(const float* g, const float* z, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int bn_rows_per_image, float* dgamma, float* dbeta, hipStream_t stream);
 

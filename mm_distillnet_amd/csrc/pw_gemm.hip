@@ -25,6 +25,10 @@
 struct BnBwdOp {
   const float* z; const float* scale; const float* shift; const float* mean; const float* invstd;
   const double* sums; double inv_count; int C; int act; const float* mul_b; int rows_per_image;
+  // input-gradient launch only: the evaluated dz is also stored once ([M, C], by the blocks of the first column panel), so the
+  // weight-gradient GEMM reads ONE plain tensor instead of re-evaluating the BatchNorm backward from (g, z) (+18-31 % on
+  // that kernel); dgamma / dbeta (+)= the reduce pass' sums
+  float* dz_out; float* dgamma; float* dbeta;
 };
 // per-channel coefficients: dz = a1*g' + a2*(z - mu) + a3
 __device__ __forceinline__ void bn_bwd_coef(const BnBwdOp& b, int c, float& a1, float& a2, float& a3, float& mu, float& sh) {
@@ -178,6 +182,11 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   BnBwdCoef4 bq;
   bool kok;
   unsigned smask = 0;                     // PRO == 2: validity bit per (row slot, element), applied in lstore
+  int kcur = 0;                           // PRO == 1: k of the staged group (for the dz side output)
+  if constexpr (PRO == 1) {
+    if (a.bb.dgamma && t == 0)
+      for (int c = tid; c < a.K; c += 256) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
+  }
   auto gload = [&](int k0) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
     // branch per load and a full vmcnt(0) drain, which serialises the prefetch
@@ -203,6 +212,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
         }
       }
     } else if constexpr (PRO == 1) {
+      kcur = kc;
       bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
       for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
@@ -233,6 +243,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
         v.x = (mk & 1) ? v.x : 0.f; v.y = (mk & 2) ? v.y : 0.f; v.z = (mk & 4) ? v.z : 0.f; v.w = (mk & 8) ? v.w : 0.f;
       } else if constexpr (PRO == 1) {
         v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
+        if (a.bb.dz_out && tn == 0 && kok && rok[i]) mmd_st4(a.bb.dz_out + (size_t)(m0 + lrow + i * 32) * a.K + kcur, v);
       } else if constexpr (PRO == 3) {
       } else if constexpr (PRO == 4) {
         v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w;
@@ -445,8 +456,12 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+  if constexpr (PRO == 1) {
+    if (a.bb.dgamma && t == 0)
+      for (int c = tid; c < a.K; c += 256) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
+  }
 
-  struct Stage { float4 ra[4], rg[4], rb[8], rsc, rsh; BnBwdCoef4 bq; bool kok; };
+  struct Stage { float4 ra[4], rg[4], rb[8], rsc, rsh; BnBwdCoef4 bq; bool kok; int kc; };
   Stage st[PF];
   auto gload = [&](int k0, Stage& s) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
@@ -454,6 +469,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     int k = k0 + kq;
     s.kok = k < a.K;
     const int kc = s.kok ? k : 0;
+    s.kc = kc;
     if constexpr (PRO == 1) {
       bn_bwd_coef4(a.bb, kc, s.bq);
 #pragma unroll
@@ -482,6 +498,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       float4 v = s.ra[i];
       if constexpr (PRO == 1) {
         v = bn_bwd_eval4(v, s.rg[i], rowsc[i], a.bb.act, s.bq);
+        if (a.bb.dz_out && tn == 0 && s.kok && rok[i]) mmd_st4(a.bb.dz_out + (size_t)(m0 + lrow + i * 8) * a.K + s.kc, v);
       } else if constexpr (PRO == 3) {
       } else if constexpr (PRO == 4) {
         v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w;
@@ -1173,7 +1190,8 @@ static int pw_wgrad_bn_impl(const float* g, const float* z, const float* x, floa
   if (!z || !scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
   if (mul_b && bn_rows_per_image <= 0) return MMD_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
-  BnBwdOp bb{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, bn_rows_per_image > 0 ? bn_rows_per_image : 1};
+  BnBwdOp bb{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, bn_rows_per_image > 0 ? bn_rows_per_image : 1,
+             nullptr, nullptr, nullptr};
   return pw_wgrad_impl(g, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, bf16, &bb, dgamma, dbeta);
 }
 #define PW_WGBN_PARAMS const float* g, const float* z, const float* x, float* dw, int M, int K, int N, \
@@ -1203,28 +1221,32 @@ extern "C" int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, 
 static int pw_bwd_data_bn_impl(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                const float* scale, const float* shift, const float* mean, const float* invstd,
                                const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
-                               hipStream_t stream, int bf16) {
+                               float* dz_out, float* dgamma, float* dbeta, hipStream_t stream, int bf16) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
   if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
   if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
   PwArgs a{};
   a.x = g; a.w = wt; a.y = dx; a.M = M; a.K = N; a.N = K; a.rows_per_image = 1;
   a.in_bn = mmd_make_bn(nullptr, nullptr, nullptr, 0, N);
   a.bf16 = bf16;
-  a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1};
+  a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1,
+                 dz_out, dgamma, dbeta};
   return pw_dispatch(a, stream);
 }
 extern "C" int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                       const float* scale, const float* shift, const float* mean, const float* invstd,
                                       const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
-                                      hipStream_t stream) {
-  return pw_bwd_data_bn_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, stream, 0);
+                                      float* dz_out, float* dgamma, float* dbeta, hipStream_t stream) {
+  return pw_bwd_data_bn_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, dz_out, dgamma,
+                             dbeta, stream, 0);
 }
 extern "C" int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                            const float* scale, const float* shift, const float* mean, const float* invstd,
                                            const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
-                                           hipStream_t stream) {
-  return pw_bwd_data_bn_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, stream, 1);
+                                           float* dz_out, float* dgamma, float* dbeta, hipStream_t stream) {
+  return pw_bwd_data_bn_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, dz_out, dgamma,
+                             dbeta, stream, 1);
 }
 extern "C" int mmd_pwconv_bwd_data_bf16(const float* dy, const float* wt, float* dx, int M, int K, int N,
                                         int accumulate, hipStream_t stream) {

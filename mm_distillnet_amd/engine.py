@@ -568,18 +568,24 @@ class Net:
         ps = self.ps
         M, K = x.M, x.C
         if isinstance(dz, LazyDz):
-            # BatchNorm backward in the operand prologues (a bias in front of a BatchNorm has an exactly-zero gradient)
+            # BatchNorm backward in the operand prologue of the input-gradient GEMM (a bias in front of a BatchNorm has an exactly-
+            # zero gradient).  That launch also stores the evaluated dz once and adds dgamma / dbeta, so the weight gradient - a
+            # leaf on the side stream, ordered behind it - is the plain GEMM on one tensor
             L, b = dz, ps.bn(dz.bn_name)
             bnargs = (L.aff[0], L.aff[1], L.aff[2], L.aff[3], L.sums, L.count, L.act, L.mul_b, L.rpi)
-            with self._wgrad_stream():
-                call("mmd_pwconv_bwd_weight_bn" + self._sfx, L.g, L.z, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
-                     None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W, *bnargs, b["dgamma"], b["dbeta"])
-                # whoever overwrites L.g afterwards (in-place accumulation into an adopted gradient slot) waits for this event
-                self._wg_read_done = torch.cuda.current_stream().record_event() if ps.flat.is_cuda else None
+            xargs = (None if plain_in else x.scale, None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W)
+            self._wg_read_done = None
             if not want_dx:
+                with self._wgrad_stream():
+                    call("mmd_pwconv_bwd_weight_bn" + self._sfx, L.g, L.z, x.z, ps.g(wkey), M, K, N, *xargs, *bnargs, b["dgamma"],
+                         b["dbeta"])
+                    self._wg_read_done = torch.cuda.current_stream().record_event() if ps.flat.is_cuda else None
                 return None
             dx = self._alloc(M, K)
-            call("mmd_pwconv_bwd_data_bn" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs)
+            dzm = self._alloc(M, N)
+            call("mmd_pwconv_bwd_data_bn" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"])
+            with self._wgrad_stream():
+                call("mmd_pwconv_bwd_weight" + self._sfx, dzm, x.z, ps.g(wkey), M, K, N, *xargs)
             return dx
         with self._wgrad_stream():
             if bias_key:

@@ -819,15 +819,25 @@ def test_pwconv_bwd_bn_prologue(M, K, N, act, rowscale, sfx):
     call("mmd_bn_bwd_reduce", gd, zd, dsc, dsh, dmu, dis, act, None, rsd, None, rpi, None, sums, M, N, None, 0)
     wt = w.detach().t().contiguous().to(DEV)            # [K, N]: the transposed copy the input-gradient GEMM reads
     dx = torch.empty(M, K, device=DEV)
-    call("mmd_pwconv_bwd_data_bn" + sfx, gd, zd, wt, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi)
+    dzm = torch.full((M, N), float("nan"), device=DEV)
+    dga2 = torch.zeros(N, device=DEV); dbe2 = torch.zeros(N, device=DEV)
+    call("mmd_pwconv_bwd_data_bn" + sfx, gd, zd, wt, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dzm, dga2, dbe2)
     dw = torch.zeros(N, K, device=DEV)
     dga = torch.zeros(N, device=DEV); dbe = torch.zeros(N, device=DEV)
     call("mmd_pwconv_bwd_weight_bn" + sfx, gd, zd, x.to(DEV).contiguous(), dw, M, K, N, None, None, 0, None, 1,
          dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dga, dbe)
+    # side outputs of the input-gradient launch: the evaluated dz (every element written exactly once) and the affine gradients;
+    # the plain weight-gradient GEMM on that dz is what the engine runs
+    assert torch.isfinite(dzm).all()
+    dz_ref = xr.grad.new_zeros(0)           # dz itself is not exposed by autograd: check it through dW = dz^T x below
+    dw2 = torch.zeros(N, K, device=DEV)
+    call("mmd_pwconv_bwd_weight" + sfx, dzm, x.to(DEV).contiguous(), dw2, M, K, N, None, None, 0, None, 1)
+    assert torch.equal(dga2, dga) and torch.equal(dbe2, dbe)
     tol = dict(rtol=2e-2, atol=2e-2) if sfx else dict(rtol=5e-4, atol=2e-4)
     sx, sw = xr.grad.abs().max().item(), w.grad.abs().max().item()
     assert (dx.cpu() - xr.grad).abs().max().item() <= tol["rtol"] * sx + (tol["atol"] * sx if sfx else 1e-5), "dX"
     assert (dw.cpu() - w.grad).abs().max().item() <= tol["rtol"] * sw + (tol["atol"] * sw if sfx else 1e-5), "dW"
+    assert (dw2.cpu() - w.grad).abs().max().item() <= tol["rtol"] * sw + (tol["atol"] * sw if sfx else 1e-5), "dW via dz_out"
     close(dga, gamma.grad, 5e-4, 5e-4 * gamma.grad.abs().max().item(), "dgamma")
     close(dbe, beta.grad, 5e-4, 5e-4 * max(beta.grad.abs().max().item(), 1.0), "dbeta")
 

