@@ -139,6 +139,11 @@ int mmd_adam_step(float* p, const float* g, float* m, float* v, float* state, co
 // Adam over the whole flat buffer with the head (regressor/classifier) ranges skipped until they first receive a gradient.
 int mmd_adam_step_gated(float* p, const float* g, float* m, float* v, float* state_main, float* state_head, const float* hyper, const int* head_active, long long b0, long long e0, long long b1, long long e1, long long b2, long long e2, float grad_scale, long long n, hipStream_t stream);
 
+// The reference's other optimizers on the same flat, head-gated pass (cfg `optimizer` = SGD | Adam | AdamW,
+// src/optimization/train_methods.py:808-836): mode 0 Adam, 1 AdamW, 2 SGD(momentum, weight_decay; m = momentum buffer).
+// hyper6: device floats [lr, beta1, beta2, eps, weight_decay, momentum].
+int mmd_opt_step_gated(int mode, float* p, const float* g, float* m, float* v, float* state_main, float* state_head, const float* hyper6, const int* head_active, long long b0, long long e0, long long b1, long long e1, long long b2, long long e2, float grad_scale, long long n, hipStream_t stream);
+
 // hipMemsetAsync wrapper (graph-capturable zeroing of stats / gradient buffers).
 int mmd_memset_async(void* p, int value, long long bytes, hipStream_t stream);
 
@@ -147,16 +152,22 @@ int mmd_clip_grad_norm(float* g, long long n, float max_norm, double* sumsq_ws, 
 
 // Box decode + clip + conf threshold + class filter, ordered compaction
 // (src/YetAnotherEfficientDet.py:574-602, src/utils/utils.py:123-204).
-int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, int B, int A, int NC, float conf_threshold, unsigned long long valid_class_mask, float image_size, float* score_ws, unsigned char* clsid_ws, unsigned char* flags_ws, float* over_scores, float* cand, int* n_over, int* n_keep, int* overflow, hipStream_t stream);
+int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, int B, int A, int NC, float conf_threshold, unsigned long long valid_class_mask, float image_size, float* score_ws, unsigned char* clsid_ws, unsigned char* flags_ws, float* over_scores, float* cand, int* n_over, int* n_keep, int* overflow, int cap, hipStream_t stream);
 
 // Per-teacher batched_nms + int truncation + label remap (src/utils/utils.py:205-231,285-323).
-int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scores, const int* label_map, float nms_threshold, int inclusive, float image_size, int B, float* out, int* out_cnt, unsigned long long* mask_ws, int* overflow, hipStream_t stream);
+// cand / out: [B, cap, 6] rows; mask_ws: B*1024*16 words; big_ws (nullable when cap <= 1024): B * mmd_nms_ws_floats(cap) floats.
+// The reference runs torchvision's NMS over EVERY over-threshold anchor (src/utils/utils.py:179-205, no cap): lists longer than
+// 1024 rows take a chunked (1024 rows at a time, exact greedy) path through big_ws.
+int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scores, const int* label_map, float nms_threshold, int inclusive, float image_size, int B, float* out, int* out_cnt, unsigned long long* mask_ws, int* overflow, int cap, float* big_ws, hipStream_t stream);
 
 // Cross-teacher concat + nms(0.5) + drop score (src/optimization/train_methods.py:361-411).
 // merge01 != 0: image 1 also takes image 0's rows, in front of its own, when both have rows (augment=True, :379-387).
-int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2, const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, hipStream_t stream);
+int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2, const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, int cap, float* big_ws, hipStream_t stream);
 
-// Candidate capacity per image of the pseudo-label kernels.
+// Floats per image of `big_ws` for NMS lists of up to nmax rows (0 when nmax <= 1024).  mmd_nms_merge: nmax = nteachers * cap * (merge01 ? 2 : 1).
+int mmd_nms_ws_floats(int nmax);
+
+// Rows per image the single-pass (all-in-LDS) NMS handles; the arrays' capacity itself is the run-time `cap` argument.
 int mmd_pp_cap(void);
 
 // Profiling hooks for bench.py (hipEvents on the launch stream).

@@ -158,3 +158,60 @@ extern "C" int mmd_adam_step_gated(float* p, const float* g, float* m, float* v,
                      head_active, r, grad_scale, n4);
   return mmd_check_launch();
 }
+
+
+// The reference's other optimizers behind the same flat, head-gated pass (src/optimization/train_methods.py:808-836: cfg `optimizer`
+// = SGD(lr, momentum, weight_decay) | Adam(lr, betas) | AdamW(lr, betas; torch's default weight_decay 1e-2)).
+//   mode 0 Adam, 1 AdamW (decoupled decay: p *= 1 - lr*wd before the Adam update), 2 SGD (d = g + wd*p; buf = d on a parameter's
+//   first step, else momentum*buf + d; p -= lr*buf - torch.optim.SGD with dampening 0, no nesterov; `m` is the momentum buffer, `v` unused).
+// hyper: device floats [lr, beta1, beta2, eps, weight_decay, momentum].
+template <int MODE>
+__global__ __launch_bounds__(256) void opt2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* st_main, const float* st_head,
+                                                   const float* hyper, const int* head_active, AdamRanges r, float gscale,
+                                                   size_t n4) {
+  const int hact = *head_active;
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], mom = hyper[5];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    long long e0 = (long long)i * 4;
+    bool head = (e0 >= r.b[0] && e0 < r.e[0]) || (e0 >= r.b[1] && e0 < r.e[1]) || (e0 >= r.b[2] && e0 < r.e[2]);
+    if (head && !hact) continue;
+    const float* st = head ? st_head : st_main;
+    const float step_size = st[1], inv_sqrt_bc2 = st[2];
+    const bool first = st[0] == 1.f;
+    float4 pp = mmd_ld4(p + i * 4), gg = mmd_ld4(g + i * 4), mm = mmd_ld4(m + i * 4), vv = make_float4(0, 0, 0, 0);
+    if (MODE != 2) vv = mmd_ld4(v + i * 4);
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = G[k] * gscale;
+      if (MODE == 2) {
+        float d = gk + wd * P[k];
+        if (mom != 0.f) { M[k] = first ? d : mom * M[k] + d; d = M[k]; }
+        P[k] -= lr * d;
+      } else {
+        if (MODE == 1) P[k] *= 1.f - lr * wd;
+        M[k] = b1 * M[k] + (1.f - b1) * gk;
+        V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+        float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
+        P[k] -= step_size * (M[k] / denom);
+      }
+    }
+    mmd_st4(p + i * 4, pp); mmd_st4(m + i * 4, mm);
+    if (MODE != 2) mmd_st4(v + i * 4, vv);
+  }
+}
+extern "C" int mmd_opt_step_gated(int mode, float* p, const float* g, float* m, float* v, float* state_main, float* state_head,
+                                  const float* hyper6, const int* head_active, long long b0, long long e0, long long b1,
+                                  long long e1, long long b2, long long e2, float grad_scale, long long n, hipStream_t stream) {
+  if (!p || !g || !m || !v || !state_main || !state_head || !hyper6 || !head_active || n <= 0 || (n & 3)) return MMD_EINVAL;
+  if ((b0 | e0 | b1 | e1 | b2 | e2) & 3) return MMD_EINVAL;
+  if (mode < 0 || mode > 2) return MMD_EINVAL;
+  AdamRanges r{{b0, b1, b2}, {e0, e1, e2}};
+  hipLaunchKernelGGL(adam_prep2_kernel, dim3(1), dim3(64), 0, stream, state_main, state_head, hyper6, head_active);
+  size_t n4 = (size_t)n / 4;
+  int blocks = cdiv(n4, 256); if (blocks > 2048) blocks = 2048;
+  auto k = mode == 0 ? opt2_kernel<0> : mode == 1 ? opt2_kernel<1> : opt2_kernel<2>;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, stream, p, g, m, v, state_main, state_head, hyper6, head_active, r, grad_scale, n4);
+  return mmd_check_launch();
+}

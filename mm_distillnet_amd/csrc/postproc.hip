@@ -9,7 +9,11 @@
 // candidate, idx being the box's index in the class-filtered list (src/utils/utils.py:193-213).
 #include "common.h"
 
-#define PP_CAP 1024          // candidates per image handled by one NMS block
+#define PP_CAP 1024          // candidates per image the single-pass (all-in-LDS) NMS handles; longer lists take the chunked path
+// Capacities are run-time arguments (`cap` = rows per image of the candidate / label arrays).  The reference has no cap at all
+// (src/utils/utils.py:179-205 runs torchvision's NMS over every over-threshold anchor), so the host sizes the arrays for
+// the worst case (cap = A anchors) and nothing is ever truncated; lists of up to PP_CAP candidates - every realistic
+// teacher - stay on the one-pass kernel path.
 
 // ---- pass 1: per anchor best class/score and flags
 __global__ __launch_bounds__(256) void pp_score_kernel(const float* __restrict__ cls, int A, int NC, float thr,
@@ -42,7 +46,8 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
                                                           const float* __restrict__ score, const unsigned char* __restrict__ clsid,
                                                           const unsigned char* __restrict__ flags, int A, float image_size,
                                                           float* __restrict__ over_scores, float* __restrict__ cand,
-                                                          int* __restrict__ n_over, int* __restrict__ n_keep, int* overflow) {
+                                                          int* __restrict__ n_over, int* __restrict__ n_keep, int* overflow,
+                                                          int cap) {
   __shared__ int s_o[16], s_k[16];
   __shared__ int base_o, base_k;
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -69,11 +74,11 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
       if (!(f[i] & 1)) continue;
       const int ai = a + i;
       float sc = score[(size_t)b * A + ai];
-      // only the first PP_CAP entries can ever be indexed (index < n_keep <= PP_CAP), so a longer list is not an error
-      if (pos < PP_CAP) over_scores[(size_t)b * PP_CAP + pos] = sc;
+      // only the first `cap` entries can ever be indexed (index < n_keep <= cap), so a longer list is not an error
+      if (pos < cap) over_scores[(size_t)b * cap + pos] = sc;
       ++pos;
       if (f[i] & 2) {
-        if (kp < PP_CAP) {
+        if (kp < cap) {
           float4 an = mmd_ld4(anchors + (size_t)ai * 4);                 // y1,x1,y2,x2
           float4 r = mmd_ld4(reg + ((size_t)b * A + ai) * 4);            // dy,dx,dh,dw
           float yca = __fdiv_rn(__fadd_rn(an.x, an.z), 2.f), xca = __fdiv_rn(__fadd_rn(an.y, an.w), 2.f);
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
           float x1 = __fsub_rn(xc, __fdiv_rn(w, 2.f)), y1 = __fsub_rn(yc, __fdiv_rn(h, 2.f));
           float x2 = __fadd_rn(xc, __fdiv_rn(w, 2.f)), y2 = __fadd_rn(yc, __fdiv_rn(h, 2.f));
           x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, image_size); y2 = fminf(y2, image_size);
-          float* o = cand + ((size_t)b * PP_CAP + kp) * 6;
+          float* o = cand + ((size_t)b * cap + kp) * 6;
           o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)clsid[(size_t)b * A + ai];
         } else *overflow = 1;
         ++kp;
@@ -93,21 +98,21 @@ __global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restric
     if (tid == 0) { base_o = bo + to; base_k = bk + tk; }
     __syncthreads();
   }
-  if (tid == 0) { n_over[b] = min(base_o, PP_CAP); n_keep[b] = min(base_k, PP_CAP); }
+  if (tid == 0) { n_over[b] = min(base_o, cap); n_keep[b] = min(base_k, cap); }
 }
 
 extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, int B, int A, int NC,
                                  float conf_threshold, unsigned long long valid_class_mask, float image_size,
                                  float* score_ws, unsigned char* clsid_ws, unsigned char* flags_ws,
-                                 float* over_scores, float* cand, int* n_over, int* n_keep, int* overflow,
+                                 float* over_scores, float* cand, int* n_over, int* n_keep, int* overflow, int cap,
                                  hipStream_t stream) {
   if (!cls || !reg || !anchors || !score_ws || !clsid_ws || !flags_ws || !over_scores || !cand || !n_over || !n_keep || !overflow)
     return MMD_EINVAL;
-  if (B <= 0 || A <= 0 || NC <= 0 || NC > 64) return MMD_EINVAL;
+  if (B <= 0 || A <= 0 || NC <= 0 || NC > 64 || cap <= 0) return MMD_EINVAL;
   hipLaunchKernelGGL(pp_score_kernel, dim3(cdiv(A, 256), B), dim3(256), 0, stream, cls, A, NC, conf_threshold,
                      valid_class_mask, score_ws, clsid_ws, flags_ws);
   hipLaunchKernelGGL(pp_compact_kernel, dim3(B), dim3(1024), 0, stream, reg, anchors, score_ws, clsid_ws, flags_ws, A,
-                     image_size, over_scores, cand, n_over, n_keep, overflow);
+                     image_size, over_scores, cand, n_over, n_keep, overflow, cap);
   return mmd_check_launch();
 }
 
@@ -116,6 +121,10 @@ extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float
 //         out row = (int(x1),int(y1),int(min(x2,S)),int(min(y2,S)), over_scores[orig idx], label_map[label])
 // mode 1 (cross-teacher merge): rows gathered from up to 3 sources in order, class-agnostic;
 //         out row = (x1,y1,x2,y2,label)  [5 columns]
+// n <= PP_CAP rows: everything lives in LDS (sort, boxes, suppression bitmask).  n > PP_CAP (an untrained student at evaluation time, a badly
+// calibrated teacher): the same greedy algorithm in 1024-row chunks of the sorted list - a chunk is first tested against every box
+// kept so far, then resolved internally with the bitmask - with the sorted order, the kept list and the chunk bitmask in a global
+// workspace.  Greedy NMS only ever compares a candidate with EARLIER KEPT boxes, so the chunked result is the sequential one, bit for bit.
 struct NmsArgs {
   const float* src[3]; const int* cnt[3]; int nsrc;
   int mode; float thr; int inclusive;
@@ -124,7 +133,20 @@ struct NmsArgs {
   unsigned long long* mask_ws; int* overflow;
   int merge01;        // mode 1: image 1 takes image 0's rows in front of its own when both have rows
                       // (ModelWithNMSLossAugmented.forward, augment=True: src/optimization/train_methods.py:379-387)
+  int in_cap;         // rows per image of every source array (and of over_scores)
+  float* big_ws; long long big_stride; int P;      // chunked path: per image key[P] | idx[P] | kbox[4*nmax] | karea[nmax] | kidx[nmax]
+  int nmax;           // upper bound of n: nsrc * in_cap (* 2 with merge01)
 };
+
+__device__ __forceinline__ bool nms_hit(float ix1, float iy1, float ix2, float iy2, float ia, float jx1, float jy1, float jx2, float jy2,
+                                        float ja, float thr, int inclusive) {
+  float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+  float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+  float ww = fmaxf(0.f, __fsub_rn(xx2, xx1)), hh = fmaxf(0.f, __fsub_rn(yy2, yy1));
+  float inter = __fmul_rn(ww, hh);
+  float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ia, ja), inter));
+  return inclusive ? (ovr >= thr) : (ovr > thr);
+}
 
 __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
   __shared__ float skey[PP_CAP];
@@ -134,16 +156,17 @@ __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
   __shared__ unsigned long long smask[3584];      // 28 KB: used when n * words <= 3584
   __shared__ int skeep[PP_CAP];
   __shared__ float sred[16];
+  __shared__ unsigned long long sdead[16];
   __shared__ int s_n, s_nk;
   const int b = blockIdx.x, tid = threadIdx.x;
   // gather source rows (concatenation order = source order)
   int cnts[3] = {0, 0, 0}, cnts0[3] = {0, 0, 0}, n = 0, n0 = 0;
-  for (int s = 0; s < a.nsrc; ++s) { cnts[s] = min(a.cnt[s][b], PP_CAP); n += cnts[s]; }
+  for (int s = 0; s < a.nsrc; ++s) { cnts[s] = min(a.cnt[s][b], a.in_cap); n += cnts[s]; }
   if (a.merge01 && b == 1 && n > 0) {
-    for (int s = 0; s < a.nsrc; ++s) { cnts0[s] = min(a.cnt[s][0], PP_CAP); n0 += cnts0[s]; }
+    for (int s = 0; s < a.nsrc; ++s) { cnts0[s] = min(a.cnt[s][0], a.in_cap); n0 += cnts0[s]; }
     n += n0;
   }
-  if (n > PP_CAP) { if (tid == 0) *a.overflow = 1; n = PP_CAP; }
+  if (n > PP_CAP && (!a.big_ws || n > a.nmax)) { if (tid == 0) *a.overflow = 1; n = PP_CAP; }      // no workspace: the old hard limit
   auto row_ptr = [&](int i) -> const float* {
     int s = 0, img = b;
     if (i < n0) {           // image 0's rows first, teacher order preserved
@@ -153,126 +176,225 @@ __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
       i -= n0;
       while (s < a.nsrc - 1 && i >= cnts[s]) { i -= cnts[s]; ++s; }
     }
-    return a.src[s] + ((size_t)img * PP_CAP + i) * 6;
+    return a.src[s] + ((size_t)img * a.in_cap + i) * 6;
   };
   if (n == 0) { if (tid == 0) a.out_cnt[b] = 0; return; }
-  // sort keys
-  float myscore = -INFINITY;
-  if (tid < n) myscore = row_ptr(tid)[4];
-  skey[tid] = myscore; sidx[tid] = tid;
-  __syncthreads();
-  // bitonic sort, descending score, ascending index on ties (1024 slots)
-  for (int k = 2; k <= PP_CAP; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      int ixj = tid ^ j;
-      if (ixj > tid) {
-        float k0 = skey[tid], k1 = skey[ixj]; int i0 = sidx[tid], i1 = sidx[ixj];
-        bool first_before = (k0 > k1) || (k0 == k1 && i0 < i1);     // "tid element sorts before ixj element"
-        bool up = ((tid & k) == 0);
-        if (up ? !first_before : first_before) { skey[tid] = k1; skey[ixj] = k0; sidx[tid] = i1; sidx[ixj] = i0; }
-      }
-      __syncthreads();
-    }
-  // max coordinate for the class offset
+  // max coordinate for the class offset (mode 0), over ALL n rows
   float maxc = -INFINITY;
   if (a.mode == 0) {
-    if (tid < n) { const float* r = row_ptr(tid); maxc = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])); }
+    for (int i = tid; i < n; i += 1024) { const float* r = row_ptr(i); maxc = fmaxf(maxc, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]))); }
     maxc = wave_max(maxc);
     if ((tid & 63) == 0) sred[tid >> 6] = maxc;
     __syncthreads();
     maxc = sred[0];
     for (int i = 1; i < 16; ++i) maxc = fmaxf(maxc, sred[i]);
   }
-  if (tid < n) {
-    const float* r = row_ptr(sidx[tid]);
-    float off = 0.f;
-    if (a.mode == 0) off = __fmul_rn(r[5], __fadd_rn(maxc, 1.f));
-    float x1 = __fadd_rn(r[0], off), y1 = __fadd_rn(r[1], off), x2 = __fadd_rn(r[2], off), y2 = __fadd_rn(r[3], off);
-    sbox[tid * 4] = x1; sbox[tid * 4 + 1] = y1; sbox[tid * 4 + 2] = x2; sbox[tid * 4 + 3] = y2;
-    sarea[tid] = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
-  }
-  __syncthreads();
-  const int words = (n + 63) >> 6;
-  const bool in_lds = n * words <= 3584;
-  unsigned long long* mask = in_lds ? smask : a.mask_ws + (size_t)b * PP_CAP * (PP_CAP / 64);
-  for (int e = tid; e < n * words; e += 1024) {
-    int i = e / words, w = e % words;
-    unsigned long long bits = 0ull;
-    float ix1 = sbox[i * 4], iy1 = sbox[i * 4 + 1], ix2 = sbox[i * 4 + 2], iy2 = sbox[i * 4 + 3], ia = sarea[i];
-    int j0 = w * 64;
-    for (int q = 0; q < 64; ++q) {
-      int j = j0 + q;
-      if (j <= i || j >= n) continue;
-      float xx1 = fmaxf(ix1, sbox[j * 4]), yy1 = fmaxf(iy1, sbox[j * 4 + 1]);
-      float xx2 = fminf(ix2, sbox[j * 4 + 2]), yy2 = fminf(iy2, sbox[j * 4 + 3]);
-      float ww = fmaxf(0.f, __fsub_rn(xx2, xx1)), hh = fmaxf(0.f, __fsub_rn(yy2, yy1));
-      float inter = __fmul_rn(ww, hh);
-      float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ia, sarea[j]), inter));
-      bool hit = a.inclusive ? (ovr >= a.thr) : (ovr > a.thr);
-      if (hit) bits |= 1ull << q;
-    }
-    mask[(size_t)i * words + w] = bits;
-  }
-  __syncthreads();
-  if (!in_lds) __threadfence();
-  __syncthreads();
-  if (tid < 64) {
-    unsigned long long removed = 0ull;     // lane w owns word w (w < words <= 16)
-    int nk = 0;
-    for (int i = 0; i < n; ++i) {
-      unsigned long long rw = __shfl(removed, i >> 6, 64);
-      if (!((rw >> (i & 63)) & 1ull)) {
-        if (tid == 0) skeep[nk] = i;
-        ++nk;
-        if (tid < words) removed |= mask[(size_t)i * words + tid];
-      }
-    }
-    if (tid == 0) { s_nk = nk; s_n = n; }
-  }
-  __syncthreads();
-  int nk = s_nk;
-  if (nk > a.out_cap) { if (tid == 0) *a.overflow = 1; nk = a.out_cap; }
-  if (tid == 0) a.out_cnt[b] = nk;
-  for (int k = tid; k < nk; k += 1024) {
-    int oi = sidx[skeep[k]];
+  auto emit = [&](int k, int oi) {          // k-th kept row <- source row oi
     const float* r = row_ptr(oi);
     float* o = a.out + ((size_t)b * a.out_cap + k) * a.out_cols;
     if (a.mode == 0) {
       o[0] = (float)(int)fmaxf(r[0], 0.f); o[1] = (float)(int)fmaxf(r[1], 0.f);
       o[2] = (float)(int)fminf(r[2], a.image_size); o[3] = (float)(int)fminf(r[3], a.image_size);
-      o[4] = a.over_scores[(size_t)b * PP_CAP + oi];            // reference quirk, see header
+      o[4] = a.over_scores[(size_t)b * a.in_cap + oi];            // reference quirk, see header
       o[5] = (float)a.label_map[(int)r[5]];
     } else {
       o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[5];
     }
+  };
+  auto stage_box = [&](int t, int oi) {     // LDS slot t <- (class-offset) box of source row oi
+    const float* r = row_ptr(oi);
+    float off = 0.f;
+    if (a.mode == 0) off = __fmul_rn(r[5], __fadd_rn(maxc, 1.f));
+    float x1 = __fadd_rn(r[0], off), y1 = __fadd_rn(r[1], off), x2 = __fadd_rn(r[2], off), y2 = __fadd_rn(r[3], off);
+    sbox[t * 4] = x1; sbox[t * 4 + 1] = y1; sbox[t * 4 + 2] = x2; sbox[t * 4 + 3] = y2;
+    sarea[t] = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+  };
+
+  if (n <= PP_CAP) {
+    // ---------------- one pass, all in LDS
+    float myscore = -INFINITY;
+    if (tid < n) myscore = row_ptr(tid)[4];
+    skey[tid] = myscore; sidx[tid] = tid;
+    __syncthreads();
+    // bitonic sort, descending score, ascending index on ties (1024 slots)
+    for (int k = 2; k <= PP_CAP; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        int ixj = tid ^ j;
+        if (ixj > tid) {
+          float k0 = skey[tid], k1 = skey[ixj]; int i0 = sidx[tid], i1 = sidx[ixj];
+          bool first_before = (k0 > k1) || (k0 == k1 && i0 < i1);     // "tid element sorts before ixj element"
+          bool up = ((tid & k) == 0);
+          if (up ? !first_before : first_before) { skey[tid] = k1; skey[ixj] = k0; sidx[tid] = i1; sidx[ixj] = i0; }
+        }
+        __syncthreads();
+      }
+    if (tid < n) stage_box(tid, sidx[tid]);
+    __syncthreads();
+    const int words = (n + 63) >> 6;
+    const bool in_lds = n * words <= 3584;
+    unsigned long long* mask = in_lds ? smask : a.mask_ws + (size_t)b * PP_CAP * (PP_CAP / 64);
+    for (int e = tid; e < n * words; e += 1024) {
+      int i = e / words, w = e % words;
+      unsigned long long bits = 0ull;
+      float ix1 = sbox[i * 4], iy1 = sbox[i * 4 + 1], ix2 = sbox[i * 4 + 2], iy2 = sbox[i * 4 + 3], ia = sarea[i];
+      int j0 = w * 64;
+      for (int q = 0; q < 64; ++q) {
+        int j = j0 + q;
+        if (j <= i || j >= n) continue;
+        if (nms_hit(ix1, iy1, ix2, iy2, ia, sbox[j * 4], sbox[j * 4 + 1], sbox[j * 4 + 2], sbox[j * 4 + 3], sarea[j], a.thr, a.inclusive))
+          bits |= 1ull << q;
+      }
+      mask[(size_t)i * words + w] = bits;
+    }
+    __syncthreads();
+    if (!in_lds) __threadfence();
+    __syncthreads();
+    if (tid < 64) {
+      unsigned long long removed = 0ull;     // lane w owns word w (w < words <= 16)
+      int nk = 0;
+      for (int i = 0; i < n; ++i) {
+        unsigned long long rw = __shfl(removed, i >> 6, 64);
+        if (!((rw >> (i & 63)) & 1ull)) {
+          if (tid == 0) skeep[nk] = i;
+          ++nk;
+          if (tid < words) removed |= mask[(size_t)i * words + tid];
+        }
+      }
+      if (tid == 0) { s_nk = nk; s_n = n; }
+    }
+    __syncthreads();
+    int nk = s_nk;
+    if (nk > a.out_cap) { if (tid == 0) *a.overflow = 1; nk = a.out_cap; }
+    if (tid == 0) a.out_cnt[b] = nk;
+    for (int k = tid; k < nk; k += 1024) emit(k, sidx[skeep[k]]);
+    return;
   }
+
+  // ---------------- chunked path (n > PP_CAP)
+  float* ws = a.big_ws + (size_t)b * a.big_stride;
+  float* gkey = ws;
+  int* gidx = reinterpret_cast<int*>(ws + a.P);
+  float* kbox = ws + 2 * (size_t)a.P;
+  float* karea = kbox + 4 * (size_t)a.nmax;
+  int* kidx = reinterpret_cast<int*>(karea + a.nmax);
+  int P = 2048; while (P < n) P <<= 1;          // sort width for this image (<= a.P)
+  for (int e = tid; e < P; e += 1024) { gkey[e] = e < n ? row_ptr(e)[4] : -INFINITY; gidx[e] = e; }
+  __syncthreads();
+  // bitonic sort in global memory (one workgroup = one CU = one vector L1: workgroup-scope visibility through the barrier)
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = tid; e < P; e += 1024) {
+        int ixj = e ^ j;
+        if (ixj > e) {
+          float k0 = gkey[e], k1 = gkey[ixj]; int i0 = gidx[e], i1 = gidx[ixj];
+          bool first_before = (k0 > k1) || (k0 == k1 && i0 < i1);
+          bool up = ((e & k) == 0);
+          if (up ? !first_before : first_before) { gkey[e] = k1; gkey[ixj] = k0; gidx[e] = i1; gidx[ixj] = i0; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  unsigned long long* mask = a.mask_ws + (size_t)b * PP_CAP * (PP_CAP / 64);
+  int nkept = 0;
+  for (int c0 = 0; c0 < n; c0 += PP_CAP) {
+    const int m = min(PP_CAP, n - c0);
+    if (tid < m) { const int oi = gidx[c0 + tid]; sidx[tid] = oi; stage_box(tid, oi); }
+    __syncthreads();
+    // against every box kept by the earlier chunks
+    bool alive = tid < m;
+    if (alive) {
+      const float ix1 = sbox[tid * 4], iy1 = sbox[tid * 4 + 1], ix2 = sbox[tid * 4 + 2], iy2 = sbox[tid * 4 + 3], ia = sarea[tid];
+      for (int kk = 0; kk < nkept; ++kk) {
+        const float4 kb = *reinterpret_cast<const float4*>(kbox + 4 * (size_t)kk);
+        // operand order as in the sequential algorithm: the kept (earlier, higher-score) box is "i", the candidate is "j"
+        if (nms_hit(kb.x, kb.y, kb.z, kb.w, karea[kk], ix1, iy1, ix2, iy2, ia, a.thr, a.inclusive)) { alive = false; break; }
+      }
+    }
+    const unsigned long long live = __ballot(alive);
+    if ((tid & 63) == 0) sdead[tid >> 6] = ~live;
+    // inside the chunk: suppression bitmask of the pairs (i < j)
+    const int words = (m + 63) >> 6;
+    for (int e = tid; e < m * words; e += 1024) {
+      int i = e / words, w = e % words;
+      unsigned long long bits = 0ull;
+      float ix1 = sbox[i * 4], iy1 = sbox[i * 4 + 1], ix2 = sbox[i * 4 + 2], iy2 = sbox[i * 4 + 3], ia = sarea[i];
+      int j0 = w * 64;
+      for (int q = 0; q < 64; ++q) {
+        int j = j0 + q;
+        if (j <= i || j >= m) continue;
+        if (nms_hit(ix1, iy1, ix2, iy2, ia, sbox[j * 4], sbox[j * 4 + 1], sbox[j * 4 + 2], sbox[j * 4 + 3], sarea[j], a.thr, a.inclusive))
+          bits |= 1ull << q;
+      }
+      mask[(size_t)i * words + w] = bits;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 64) {
+      unsigned long long removed = tid < words ? sdead[tid] : 0ull;
+      int nk = 0;
+      for (int i = 0; i < m; ++i) {
+        unsigned long long rw = __shfl(removed, i >> 6, 64);
+        if (!((rw >> (i & 63)) & 1ull)) {
+          if (tid == 0) skeep[nk] = i;
+          ++nk;
+          if (tid < words) removed |= mask[(size_t)i * words + tid];
+        }
+      }
+      if (tid == 0) s_nk = nk;
+    }
+    __syncthreads();
+    const int nkc = s_nk;
+    for (int k = tid; k < nkc; k += 1024) {
+      const int i = skeep[k];
+      *reinterpret_cast<float4*>(kbox + 4 * (size_t)(nkept + k)) = make_float4(sbox[i * 4], sbox[i * 4 + 1], sbox[i * 4 + 2], sbox[i * 4 + 3]);
+      karea[nkept + k] = sarea[i];
+      kidx[nkept + k] = sidx[i];
+    }
+    nkept += nkc;
+    __threadfence_block();
+    __syncthreads();
+  }
+  int nk = nkept;
+  if (nk > a.out_cap) { if (tid == 0) *a.overflow = 1; nk = a.out_cap; }
+  if (tid == 0) a.out_cnt[b] = nk;
+  for (int k = tid; k < nk; k += 1024) emit(k, kidx[k]);
 }
 
-// per-teacher NMS: cand [B,PP_CAP,6] + n_keep -> out [B,PP_CAP,6] (truncated coords, quirk score, mapped label), out_cnt [B]
+static int pp_pow2(int n) { int p = 2048; while (p < n) p <<= 1; return p; }
+// floats of chunked-path workspace per image for lists of up to nmax rows
+extern "C" int mmd_nms_ws_floats(int nmax) { return nmax <= PP_CAP ? 0 : (int)(2ll * pp_pow2(nmax) + 6ll * nmax); }
+
+// per-teacher NMS: cand [B,cap,6] + n_keep -> out [B,cap,6] (truncated coords, quirk score, mapped label), out_cnt [B].
+// mask_ws: B * 1024 * 16 words.  big_ws (nullable when cap <= 1024): B * mmd_nms_ws_floats(cap) floats.
 extern "C" int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scores, const int* label_map,
                                float nms_threshold, int inclusive, float image_size, int B, float* out, int* out_cnt,
-                               unsigned long long* mask_ws, int* overflow, hipStream_t stream) {
-  if (!cand || !n_keep || !over_scores || !label_map || !out || !out_cnt || !mask_ws || !overflow || B <= 0) return MMD_EINVAL;
+                               unsigned long long* mask_ws, int* overflow, int cap, float* big_ws, hipStream_t stream) {
+  if (!cand || !n_keep || !over_scores || !label_map || !out || !out_cnt || !mask_ws || !overflow || B <= 0 || cap <= 0) return MMD_EINVAL;
   NmsArgs a{};
   a.src[0] = cand; a.cnt[0] = n_keep; a.nsrc = 1; a.mode = 0; a.thr = nms_threshold; a.inclusive = inclusive;
   a.over_scores = over_scores; a.label_map = label_map; a.image_size = image_size;
-  a.out = out; a.out_cnt = out_cnt; a.out_cols = 6; a.out_cap = PP_CAP; a.mask_ws = mask_ws; a.overflow = overflow;
+  a.out = out; a.out_cnt = out_cnt; a.out_cols = 6; a.out_cap = cap; a.mask_ws = mask_ws; a.overflow = overflow;
+  a.in_cap = cap; a.nmax = cap; a.big_ws = big_ws; a.P = pp_pow2(a.nmax); a.big_stride = mmd_nms_ws_floats(a.nmax);
   hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
   return mmd_check_launch();
 }
 
-// cross-teacher merge: up to 3 per-teacher outputs ([B,PP_CAP,6] + counts, in teacher order) ->
-// boxes [B,maxg,5] (x1,y1,x2,y2,label) in NMS keep order, nbox [B]
+// cross-teacher merge: up to 3 per-teacher outputs ([B,cap,6] + counts, in teacher order) ->
+// boxes [B,maxg,5] (x1,y1,x2,y2,label) in NMS keep order, nbox [B].  big_ws (nullable when the concatenation cannot exceed 1024
+// rows): B * mmd_nms_ws_floats(nteachers * cap * (merge01 ? 2 : 1)) floats.
 extern "C" int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2,
                              const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes,
-                             int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01,
+                             int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, int cap, float* big_ws,
                              hipStream_t stream) {
-  if (!t0 || !c0 || !boxes || !nbox || !mask_ws || !overflow || B <= 0 || nteachers < 1 || nteachers > 3 || maxg <= 0) return MMD_EINVAL;
+  if (!t0 || !c0 || !boxes || !nbox || !mask_ws || !overflow || B <= 0 || nteachers < 1 || nteachers > 3 || maxg <= 0 || cap <= 0) return MMD_EINVAL;
   if ((nteachers > 1 && (!t1 || !c1)) || (nteachers > 2 && (!t2 || !c2))) return MMD_EINVAL;
   NmsArgs a{};
   a.src[0] = t0; a.cnt[0] = c0; a.src[1] = t1; a.cnt[1] = c1; a.src[2] = t2; a.cnt[2] = c2; a.nsrc = nteachers;
   a.mode = 1; a.thr = iou_threshold; a.inclusive = inclusive; a.merge01 = (merge01 && B >= 2) ? 1 : 0;
   a.out = boxes; a.out_cnt = nbox; a.out_cols = 5; a.out_cap = maxg; a.mask_ws = mask_ws; a.overflow = overflow;
+  a.in_cap = cap; a.nmax = nteachers * cap * (a.merge01 ? 2 : 1); a.big_ws = big_ws; a.P = pp_pow2(a.nmax);
+  a.big_stride = mmd_nms_ws_floats(a.nmax);
   hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
   return mmd_check_launch();
 }

@@ -46,7 +46,9 @@ class StepConfig:
     valid_prediction_ids: tuple = (6,)  # VOC id of "car" (src/datasets/BaseDataset.py:141-165)
     label_map: Optional[List[int]] = None
     inclusive_nms: bool = False
-    max_boxes: int = 512
+    max_boxes: int = 0                 # merged pseudo-labels per image handed to the focal loss; 0 = sized for the worst case
+    cand_cap: int = 0                  # rows per image of the candidate / pseudo-label arrays; 0 = every anchor (the reference
+                                       # has no cap, src/utils/utils.py:179-205), so nothing can overflow
     augment: bool = False              # cfg audio_augmentation_merge (ModelWithNMSLossAugmented.forward augment=True)
     precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors)
 
@@ -78,7 +80,7 @@ class DistillEngine:
         self.valid_mask = 0
         for i in cfg.valid_prediction_ids:
             self.valid_mask |= 1 << int(i)
-        self.cap = int(_lib.LIB.load().mmd_pp_cap())
+        self.cap = int(cfg.cand_cap)     # 0: set to the anchor count at the first step
         self.graph = None
         self.concurrent_teachers = True
         self.side_streams: List = []
@@ -153,18 +155,39 @@ class DistillEngine:
         return torch.floor(self.keep + u) / self.keep
 
     # ------------------------------------------------------------------
+    def _caps(self, A: int):
+        if self.cap <= 0:
+            self.cap = A
+        return self.cap
+
+    def _nms_ws(self, B: int, nmax: int):
+        n = int(_lib.LIB.load().mmd_nms_ws_floats(nmax))
+        return self.ws.alloc((B * n,)) if n else None
+
+    def _merge(self, rows_t, cnt_t, B: int, augment: bool):
+        """cross-teacher concat + NMS -> (boxes [B,G,5], nbox [B], G)"""
+        nt, cap = len(rows_t), self.cap
+        nmax = nt * cap * (2 if (augment and B >= 2) else 1)
+        G = self.cfg.max_boxes if self.cfg.max_boxes > 0 else nmax
+        boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
+        call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
+             rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(self.cfg.merge_iou),
+             1 if self.cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow, 1 if augment else 0, cap,
+             self._nms_ws(B, nmax))
+        return boxes, nbox, G
+
     def _pseudo_labels(self, net: Net, cls, reg, B: int, A: int, S: int):
-        ws, cap = self.ws, self.cap
+        ws, cap = self.ws, self._caps(A)
         nc = net.spec.num_classes
         score = ws.alloc((B * A,)); clsid = ws.alloc((B * A,), torch.uint8); flags = ws.alloc((B * A,), torch.uint8)
         over = ws.alloc((B, cap)); cand = ws.alloc((B, cap, 6))
         n_over = ws.alloc((B,), torch.int32); n_keep = ws.alloc((B,), torch.int32)
         call("mmd_decode_filter", cls, reg, net.anchors(S), B, A, nc, float(self.cfg.conf_threshold), self.valid_mask, float(S),
-             score, clsid, flags, over, cand, n_over, n_keep, self.overflow)
+             score, clsid, flags, over, cand, n_over, n_keep, self.overflow, cap)
         rows = ws.alloc((B, cap, 6)); cnt = ws.alloc((B,), torch.int32)
-        mask_ws = ws.alloc((B * cap * (cap // 64),), torch.int64)      # per teacher: teachers run concurrently
+        mask_ws = ws.alloc((B * 1024 * 16,), torch.int64)      # per teacher: teachers run concurrently
         call("mmd_nms_teacher", cand, n_keep, over, self.label_map, float(self.cfg.nms_threshold),
-             1 if self.cfg.inclusive_nms else 0, float(S), B, rows, cnt, mask_ws, self.overflow)
+             1 if self.cfg.inclusive_nms else 0, float(S), B, rows, cnt, mask_ws, self.overflow, cap, self._nms_ws(B, cap))
         return rows, cnt
 
     def _attention(self, net: Net):
@@ -175,14 +198,37 @@ class DistillEngine:
         call("mmd_mta_attention", fcat, a, pyr["total"], fcat.shape[1], float(self.cfg.p))
         return a, [a[pyr["row0"][l]:pyr["row0"][l] + pyr["rows"][l]] for l in range(len(pyr["rows"]))]
 
-    def step_body(self, batch: Dict[str, torch.Tensor], drop_scale: torch.Tensor):
-        """Issues the whole step on the current stream.  batch tensors are NCHW fp32 on device."""
+    def labels_from_rows(self, per_teacher: List[List], A: int) -> List[tuple]:
+        """Host pseudo-labels -> the device form `step_body(teacher_labels=...)` takes: per teacher a list of B arrays [n,6]
+        (x1, y1, x2, y2, score, class: what `logits_to_ground_truth(include_scores=True)` returns,
+        src/utils/utils.py:234-324) -> (rows [B, cap, 6] fp32, count [B] int32)."""
+        import numpy as np
+        self._caps(A)
+        out = []
+        for lab in per_teacher:
+            B = len(lab)
+            rows = torch.zeros(B, self.cap, 6)
+            cnt = torch.zeros(B, dtype=torch.int32)
+            for i, a in enumerate(lab):
+                a = np.asarray(a, dtype=np.float32).reshape(-1, 6)
+                if a.shape[0] > self.cap:
+                    raise ValueError("more pseudo-labels than the candidate arena holds")
+                rows[i, :a.shape[0]] = torch.from_numpy(a)
+                cnt[i] = a.shape[0]
+            out.append((rows.to(self.device), cnt.to(self.device)))
+        return out
+
+    def step_body(self, batch: Dict[str, torch.Tensor], drop_scale: torch.Tensor, teacher_labels: Optional[List[tuple]] = None):
+        """Issues the whole step on the current stream.  batch tensors are NCHW fp32 on device.
+        teacher_labels (optional): per teacher (rows [B, cap, 6], count [B]) pseudo-labels computed elsewhere (cached labels of the
+        frozen teachers, or a reference run's labels in the parity tests); the teachers' own decode + NMS is then skipped, their
+        forward still feeds the MTA loss."""
         cfg = self.cfg
         st = self.student
         S = cfg.image_size
         B = batch["audio"].shape[0]
         self.ws.reset()
-        self.mask_ws = self.ws.alloc((B * self.cap * (self.cap // 64),), torch.int64)
+        self.mask_ws = self.ws.alloc((B * 1024 * 16,), torch.int64)
         if self.fork_stream is None:
             self.concurrent_teachers = False
         fork_event = None
@@ -197,6 +243,7 @@ class DistillEngine:
             audio = merged
         cls_s, reg_s, feats_s = st.forward(audio, train=True, drop_scale=drop_scale)
         A = cls_s.shape[1]
+        self._caps(A)
         nlv = len(feats_s)
         _, a_s = self._attention(st)
         # gradient w.r.t. the student's maps, one vector over the pyramid rows (zeroed: teachers accumulate into it
@@ -224,7 +271,10 @@ class DistillEngine:
                 if cfg.augment and B >= 2:      # average_batch_0_1 on the (already consumed by the heads) feature maps
                     for f in feats_t:
                         call("mmd_avg_image01", f.z, f.H * f.W * f.C)
-                r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
+                if teacher_labels is not None:
+                    r, c = teacher_labels[ti]
+                else:
+                    r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
                 _, at = self._attention(net)
             rows_t.append(r); cnt_t.append(c); att_t.append(at)
         if concurrent:
@@ -242,11 +292,7 @@ class DistillEngine:
         call("mmd_mta_attention_bwd", st._fcat, da_all, d_all, st._pyr["total"], feats_s[0].C, float(cfg.p), 0)
         dfe = [d_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
         # cross-teacher merge -> annotations
-        G = cfg.max_boxes
-        boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
-        call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
-             rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(cfg.merge_iou),
-             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow, 1 if cfg.augment else 0)
+        boxes, nbox, G = self._merge(rows_t, cnt_t, B, cfg.augment)
         # focal + smooth-L1 with gradients w.r.t. (pre-sigmoid) classifier logits and regression
         nc = st.spec.num_classes
         assign = self.ws.alloc((B * A,), torch.int32); npos = self.ws.alloc((B,), torch.int32)
@@ -382,7 +428,7 @@ class DistillEngine:
         cfg, S = self.cfg, self.cfg.image_size
         B = batch["audio"].shape[0]
         self.ws.reset()
-        self.mask_ws = self.ws.alloc((B * self.cap * (self.cap // 64),), torch.int64)
+        self.mask_ws = self.ws.alloc((B * 1024 * 16,), torch.int64)
         st = self.student
         st.refresh()
         st.begin_step()
@@ -395,12 +441,7 @@ class DistillEngine:
             cls_t, reg_t, _ = net.forward(batch[mod], train=False)
             r, c = self._pseudo_labels(net, cls_t, reg_t, B, A, S)
             rows_t.append(r); cnt_t.append(c)
-        nt = len(rows_t)
-        G = cfg.max_boxes
-        boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
-        call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
-             rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(cfg.merge_iou),
-             1 if cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow, 0)
+        boxes, nbox, G = self._merge(rows_t, cnt_t, B, False)
         torch.cuda.synchronize()
         cs, nb = cnt_s.cpu().tolist(), nbox.cpu().tolist()
         preds = [rows_s[i, :cs[i]].cpu().numpy() for i in range(B)]
@@ -409,4 +450,5 @@ class DistillEngine:
 
     def check_overflow(self):
         if int(self.overflow.item()):
-            raise RuntimeError("pseudo-label candidate capacity exceeded (more than %d candidates per image)" % self.cap)
+            raise RuntimeError("pseudo-label capacity exceeded (cfg cand_cap = %d rows / max_boxes = %d per image; 0 = unlimited)"
+                               % (self.cfg.cand_cap, self.cfg.max_boxes))

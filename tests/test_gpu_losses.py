@@ -170,20 +170,25 @@ def test_mta_multi_matches_per_pair_and_golden(golden_dir, name):
         assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, lvl
 
 
-def run_postproc(cls, reg, anchors, S, thr=0.3, nms=0.5):
+def nms_ws(B, nmax):
+    n = int(_lib.LIB.load().mmd_nms_ws_floats(nmax))
+    return torch.zeros(B * n, device=DEV) if n else None
+
+
+def run_postproc(cls, reg, anchors, S, thr=0.3, nms=0.5, cap=None):
     B, A, NC = cls.shape
-    cap = int(_lib.LIB.load().mmd_pp_cap())
+    cap = cap or int(_lib.LIB.load().mmd_pp_cap())
     score = torch.empty(B * A, device=DEV); clsid = torch.empty(B * A, dtype=torch.uint8, device=DEV)
     flags = torch.empty(B * A, dtype=torch.uint8, device=DEV)
     over = torch.zeros(B, cap, device=DEV); cand = torch.zeros(B, cap, 6, device=DEV)
     n_over = torch.zeros(B, dtype=torch.int32, device=DEV); n_keep = torch.zeros(B, dtype=torch.int32, device=DEV)
     ovf = torch.zeros(1, dtype=torch.int32, device=DEV)
     call("mmd_decode_filter", g(cls), g(reg), g(anchors[0]), B, A, NC, thr, 1 << 6, float(S), score, clsid, flags, over, cand,
-         n_over, n_keep, ovf)
+         n_over, n_keep, ovf, cap)
     out = torch.zeros(B, cap, 6, device=DEV); cnt = torch.zeros(B, dtype=torch.int32, device=DEV)
-    mask = torch.zeros(B * cap * (cap // 64), dtype=torch.int64, device=DEV)
+    mask = torch.zeros(B * 1024 * 16, dtype=torch.int64, device=DEV)
     label_map = torch.arange(NC, dtype=torch.int32, device=DEV)
-    call("mmd_nms_teacher", cand, n_keep, over, label_map, nms, 0, float(S), B, out, cnt, mask, ovf)
+    call("mmd_nms_teacher", cand, n_keep, over, label_map, nms, 0, float(S), B, out, cnt, mask, ovf, cap, nms_ws(B, cap))
     return out, cnt, ovf, mask
 
 
@@ -212,7 +217,8 @@ def test_postproc_golden(golden_dir):
         srcs.append(g(t)); cnts.append(g(c))
     maxg = 512
     boxes = torch.zeros(3, maxg, 5, device=DEV); nbox = torch.zeros(3, dtype=torch.int32, device=DEV)
-    call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf, 0)
+    call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf, 0, cap,
+         nms_ws(3, 3 * cap))
     assert int(ovf.item()) == 0
     for i in range(3):
         n = int(nbox[i].item())
@@ -230,12 +236,59 @@ def test_postproc_golden(golden_dir):
                 c[0] = 0
             per_teacher = [[np.zeros((0, 6), np.float32)] + tl[1:] for tl in per_teacher]
         ref = P.merge_teacher_labels(per_teacher, 3, 0.5, merge01=True)
-        call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf, 1)
+        call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, 3, boxes, nbox, maxg, mask, ovf, 1, cap,
+             nms_ws(3, 6 * cap))
         assert int(ovf.item()) == 0
         for i in range(3):
             n = int(nbox[i].item())
             r = np.asarray(ref[i], dtype=np.float32).reshape(-1, 5)
             assert n == r.shape[0], (empty0, i, n, r.shape)
+            np.testing.assert_array_equal(boxes[i, :n].cpu().numpy(), r)
+
+
+def test_postproc_no_candidate_cap():
+    """The reference has no cap on over-threshold candidates (src/utils/utils.py:179-205 hands every one of them to torchvision's
+    NMS).  ~5 000 candidates per image - an untrained student at evaluation time, a badly calibrated teacher - take the chunked
+    NMS path (1024 sorted rows at a time against the kept list); result bit-identical to the oracle, per teacher and after
+    the cross-teacher merge (3 x ~1 500-2 500 kept rows, with and without the augmented image-0 -> image-1 merge)."""
+    S, B = 256, 3
+    anchors = O.anchors_for(S, 2)
+    A = anchors.shape[1]
+    gen = torch.Generator().manual_seed(11)
+    cls = torch.sigmoid(torch.randn(B, A, 20, generator=gen) * 1.5 - 3.0)
+    cls[:, :, 6] = torch.sigmoid(torch.randn(B, A, generator=gen) * 2.0 - 1.0)      # ~40 % of the anchors pass 0.3 as "car"
+    cls[2, 2000:] *= 0.1                                                              # one image stays on the one-pass path
+    reg = torch.randn(B, A, 4, generator=gen) * 0.4
+    ref = P.logits_to_ground_truth([cls, reg, anchors], S, 0.3, 0.5)
+    out, cnt, ovf, mask = run_postproc(cls, reg, anchors, S, cap=A)
+    assert int(ovf.item()) == 0
+    n_cand = [int(((cls[i].max(1)[0] > 0.3) & (cls[i].argmax(1) == 6)).sum()) for i in range(B)]
+    assert n_cand[0] >= 4000 and n_cand[1] >= 4000 and n_cand[2] <= 1024, n_cand
+    for i in range(B):
+        n = int(cnt[i].item())
+        r = np.asarray(ref[i], dtype=np.float32).reshape(-1, 6)
+        assert n == r.shape[0], (i, n, r.shape)
+        np.testing.assert_array_equal(out[i, :n].cpu().numpy(), r)
+    # merge of three "teachers" (the same rows rotated over the images), class-agnostic NMS over up to 3 x n rows
+    gts = [np.asarray(ref[i], dtype=np.float32).reshape(-1, 6) for i in range(B)]
+    per_teacher = [[gts[0], gts[1], gts[2]], [gts[1], gts[2], gts[0]], [gts[2], gts[0], gts[1]]]
+    srcs, cnts = [], []
+    for tl in per_teacher:
+        t = torch.zeros(B, A, 6); c = torch.zeros(B, dtype=torch.int32)
+        for i, a in enumerate(tl):
+            t[i, :a.shape[0]] = torch.from_numpy(a); c[i] = a.shape[0]
+        srcs.append(g(t)); cnts.append(g(c))
+    for merge01 in (0, 1):
+        want = P.merge_teacher_labels(per_teacher, B, 0.5, merge01=bool(merge01))
+        nmax = 3 * A * (2 if merge01 else 1)
+        boxes = torch.zeros(B, nmax, 5, device=DEV); nbox = torch.zeros(B, dtype=torch.int32, device=DEV)
+        call("mmd_nms_merge", srcs[0], cnts[0], srcs[1], cnts[1], srcs[2], cnts[2], 3, 0.5, 0, B, boxes, nbox, nmax, mask, ovf,
+             merge01, A, nms_ws(B, nmax))
+        assert int(ovf.item()) == 0
+        for i in range(B):
+            n = int(nbox[i].item())
+            r = np.asarray(want[i], dtype=np.float32).reshape(-1, 5)
+            assert n == r.shape[0], (merge01, i, n, r.shape)
             np.testing.assert_array_equal(boxes[i, :n].cpu().numpy(), r)
 
 

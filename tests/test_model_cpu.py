@@ -54,3 +54,53 @@ def test_metrics_small_case():
     t = ap_table(preds, labels)
     # one TP then one FP, 2 ground-truth boxes -> recall 0.5 at precision 1 -> AP 0.5 at every IoU
     assert abs(t["AP@0.5"] - 50.0) < 1e-6 and abs(t["AP@Ave"] - 50.0) < 1e-6
+
+
+def _ragged(rows, counts, cols):
+    out, o = [], 0
+    for c in counts:
+        out.append(rows[o:o + c].reshape(-1, cols)); o += c
+    return out
+
+
+def test_metrics_reference_golden(golden_dir):
+    """metrics.py against the reference's own get_batch_statistics / ap_per_class / get_batch_central_distances and the
+    AP@Ave / AP@0.5 / AP@0.75 / CDx / CDy row its evaluate() wrote for the same synthetic detections
+    (tests/golden/metrics_eval.npz, tools/oracle/make_golden.py metrics)."""
+    import os
+    from mm_distillnet_amd import metrics as M
+    g = np.load(os.path.join(golden_dir, "metrics_eval.npz"))
+    S = int(g["image_size"])
+    preds = _ragged(g["pred_rows"], g["pred_counts"], 6)
+    labs = _ragged(g["lab_rows"], g["lab_counts"], 5)
+    bs = 4
+    all_pred = [preds[i:i + bs] for i in range(0, len(preds), bs)]
+    all_lab = [labs[i:i + bs] for i in range(0, len(labs), bs)]
+    labels = [float(r[4]) for l in labs for r in l]
+    for iou in (0.5, 0.75, 0.9):
+        sm = []
+        for bp, bl in zip(all_pred, all_lab):
+            sm += M.get_batch_statistics(bp, bl, iou)
+        tp, sc, lb = [np.concatenate(x, 0) for x in zip(*sm)]
+        np.testing.assert_array_equal(tp, g[f"tp@{iou}"])
+        np.testing.assert_array_equal(sc, g[f"score@{iou}"])
+        np.testing.assert_array_equal(lb, g[f"label@{iou}"])
+        p, r, ap, f1, cls, ratio = M.ap_per_class(tp, sc, lb, labels)
+        np.testing.assert_array_equal(p, g[f"precision@{iou}"]); np.testing.assert_array_equal(r, g[f"recall@{iou}"])
+        np.testing.assert_array_equal(ap, g[f"ap@{iou}"]); np.testing.assert_array_equal(f1, g[f"f1@{iou}"])
+        np.testing.assert_array_equal(cls, g[f"ap_class@{iou}"])
+        assert ratio == float(g[f"score_ratio@{iou}"])
+    cdx, cdy = [], []
+    for bp, bl in zip(all_pred, all_lab):
+        x, y = M.get_batch_central_distances(bp, bl, S, S)
+        cdx.extend(x); cdy.extend(y)
+    np.testing.assert_array_equal(np.array(cdx, dtype=np.float64), g["cd_x"])
+    np.testing.assert_array_equal(np.array(cdy, dtype=np.float64), g["cd_y"])
+    table = M.evaluate_table(all_pred, all_lab, labels, S)
+    for k in ("AP@Ave", "AP@0.5", "AP@0.75"):      # float64 through the csv's 15 printed digits
+        assert abs(table[k] - float(g["table." + k])) <= 1e-12 * abs(table[k]), (k, table[k], float(g["table." + k]))
+    for k in ("CDx", "CDy"):      # the csv round trip prints 7-8 significant digits of a float32 mean
+        assert abs(table[k] - float(g["table." + k])) <= 1e-6 * abs(table[k]), (k, table[k], float(g["table." + k]))
+    # the reference's sentinel row when nothing was predicted
+    empty = M.evaluate_table([[np.zeros((0, 6), np.float32)]], [[labs[0] if len(labs[0]) else labs[2]]], [6.0], S)
+    assert empty["AP@0.5"] == 0.0 and empty["CDx"] == 10000.0 and empty["CDy"] == 10000.0

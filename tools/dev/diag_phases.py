@@ -75,7 +75,7 @@ timeit("one teacher forward", cap(one_teacher))
 def one_teacher_pl():
     mod, net = tn[0]
     eng.ws.reset()
-    eng.mask_ws = eng.ws.alloc((B * eng.cap * (eng.cap // 64),), torch.int64)
+    eng.mask_ws = eng.ws.alloc((B * 1024 * 16,), torch.int64)
     net.begin_step()
     c, r, f = net.forward(eng.static[mod], train=False)
     eng._pseudo_labels(net, c, r, B, c.shape[1], S)

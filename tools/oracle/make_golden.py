@@ -259,13 +259,16 @@ def golden_step():
     states = {k: make_state(2, cin, seed, k, cls_bias=bias[k])[1] for k, (cin, seed) in mods.items()}
     spec, st_s = make_state(2, 8, 24, "audio")
     batch = synth_inputs(B, S, seed=31)
-    only = os.environ.get("GOLDEN_STEP_VARIANTS", "pairwise,list,augmented").split(",")
+    only = os.environ.get("GOLDEN_STEP_VARIANTS", "pairwise,list,augmented,rgb1").split(",")
     for variant, cls_name in [("pairwise", "ModelWithNMSLoss"), ("list", "ModelWithNMSKDListLoss"),
-                              ("augmented", "ModelWithNMSLossAugmented")]:
+                              ("augmented", "ModelWithNMSLossAugmented"), ("rgb1", "ModelWithNMSLoss")]:
         if variant not in only:
             continue
+        # "rgb1" = BASELINE configs[1]: use_thermal = use_depth = False -> the ModuleDict holds the RGB teacher only
+        # (train.py:123-135; the step module loops over whichever teachers are present, train_methods.py:441)
+        tmods = ("rgb",) if variant == "rgb1" else ("rgb", "depth", "thermal")
         teachers = torch.nn.ModuleDict()
-        for k in ("rgb", "depth", "thermal"):        # reference insertion order (train.py:123-135)
+        for k in tmods:        # reference insertion order (train.py:123-135)
             teachers[k] = ref_model(2, mods[k][0], states[k])
         teachers.eval()
         for p_ in teachers.parameters():
@@ -312,7 +315,7 @@ def golden_step():
         # merged labels as seen by the loss: recompute through the reference helpers for the record
         with torch.no_grad():
             per = []
-            for k in ("rgb", "depth", "thermal"):
+            for k in tmods:
                 pred, _ = teachers[k](batch[k])
                 per.append(RU.logits_to_ground_truth(pred, None, VALID, cfg(S), include_scores=True))
         for ti, lab in enumerate(per):
@@ -320,11 +323,112 @@ def golden_step():
                 d[f"teacher{ti}_img{i}"] = np.asarray(lab[i], dtype=np.float32).reshape(-1, 6)
         np.savez_compressed(os.path.join(OUT, f"step_d2_256_{variant}.npz"), **d)
         print("step", variant, d["reg"], d["cls"], d["kd"].reshape(-1)[:5], d["loss"],
-              [d[f"teacher{t}_img{i}"].shape[0] for t in range(3) for i in range(B)])
+              [d[f"teacher{t}_img{i}"].shape[0] for t in range(len(tmods)) for i in range(B)])
+
+
+def synth_detections(seed=41, n_batches=5, bs=4, S=512):
+    """Synthetic evaluation set: per image pseudo ground truth [m,5] (x1,y1,x2,y2,label) and student detections [n,6]
+    (x1,y1,x2,y2,score,label) - jittered copies of some ground-truth boxes, false positives, wrong-class boxes, images with no
+    detection / no ground truth.  Shared by the golden generator and tests/test_model_cpu.py (deterministic from the seed)."""
+    rng = np.random.RandomState(seed)
+    all_pred, all_lab = [], []
+    for b in range(n_batches):
+        bp, bl = [], []
+        for i in range(bs):
+            m = int(rng.randint(0, 6)) if (b, i) != (0, 1) else 0
+            gt = []
+            for _ in range(m):
+                x1, y1 = rng.randint(0, S - 80, size=2)
+                w, h = rng.randint(20, 160, size=2)
+                gt.append([x1, y1, min(x1 + w, S), min(y1 + h, S), int(rng.choice([6, 6, 6, 14, 1]))])
+            gt = np.array(gt, dtype=np.float32).reshape(-1, 5)
+            det = []
+            for g_ in gt:
+                r = rng.rand()
+                if r < 0.75:      # detected, jittered (some land below IoU 0.75 / 0.5)
+                    j = rng.randint(-14, 15, size=4) * (1.0 if rng.rand() < 0.6 else 2.5)
+                    lab = g_[4] if rng.rand() < 0.9 else 14.0
+                    det.append([max(g_[0] + j[0], 0), max(g_[1] + j[1], 0), min(g_[2] + j[2], S), min(g_[3] + j[3], S),
+                                0.3 + 0.7 * rng.rand(), lab])
+                if r > 0.9:       # duplicate detection of the same object
+                    det.append([g_[0] + 2, g_[1] + 1, g_[2] - 3, g_[3] + 2, 0.3 + 0.5 * rng.rand(), g_[4]])
+            for _ in range(int(rng.randint(0, 3))):      # false positives
+                x1, y1 = rng.randint(0, S - 60, size=2)
+                det.append([x1, y1, x1 + rng.randint(10, 60), y1 + rng.randint(10, 60), 0.3 + 0.4 * rng.rand(), 6.0])
+            if (b, i) == (1, 2):
+                det = []
+            det = np.array(det, dtype=np.float32).reshape(-1, 6)
+            det = np.floor(det * [1, 1, 1, 1, 1e4, 1]) / [1, 1, 1, 1, 1e4, 1]
+            if det.shape[0]:
+                det = det[np.argsort(-det[:, 4], kind="stable")]      # NMS emits rows in score order
+            bp.append(det.astype(np.float32)); bl.append(gt)
+        all_pred.append(bp); all_lab.append(bl)
+    labels = [float(r[4]) for bl in all_lab for g_ in bl for r in g_]
+    return all_pred, all_lab, labels
+
+
+def golden_metrics():
+    """The reference's evaluate() AP / CD table (src/utils/utils.py:2018-2181) and its building blocks
+    get_batch_statistics (:1058-1136), ap_per_class (:1188-1252), compute_ap (:1255-1280), get_batch_central_distances
+    (:993-1055) on a synthetic detection set.  evaluate() itself is driven with get_predictions_multiteacher patched to return
+    that set (the models are never called) and its results.<rank>.csv read back."""
+    import tempfile
+    import pandas as pd
+    S = 512
+    all_pred, all_lab, labels = synth_detections(S=S)
+    d = {"image_size": np.int64(S), "seed": np.int64(41)}
+    flat_p = [p_ for bp in all_pred for p_ in bp]
+    flat_l = [l_ for bl in all_lab for l_ in bl]
+    d["pred_rows"] = np.concatenate(flat_p, 0); d["pred_counts"] = np.array([p_.shape[0] for p_ in flat_p], dtype=np.int64)
+    d["lab_rows"] = np.concatenate(flat_l, 0); d["lab_counts"] = np.array([l_.shape[0] for l_ in flat_l], dtype=np.int64)
+    for iou in (0.5, 0.75, 0.9):
+        sm = []
+        for bp, bl in zip(all_pred, all_lab):
+            sm += RU.get_batch_statistics(bp, bl, iou)
+        tp, sc, lb = [np.concatenate(x, 0) for x in zip(*sm)]
+        d[f"tp@{iou}"] = tp; d[f"score@{iou}"] = sc; d[f"label@{iou}"] = lb
+        p_, r_, ap_, f1_, cls_, score_ = RU.ap_per_class(tp, sc, lb, labels)
+        d[f"precision@{iou}"] = p_; d[f"recall@{iou}"] = r_; d[f"ap@{iou}"] = ap_; d[f"f1@{iou}"] = f1_
+        d[f"ap_class@{iou}"] = cls_; d[f"score_ratio@{iou}"] = np.float64(score_)
+    cdx, cdy = [], []
+    for bp, bl in zip(all_pred, all_lab):
+        x_, y_ = RU.get_batch_central_distances(bp, bl, S, S)
+        cdx.extend(x_); cdy.extend(y_)
+    d["cd_x"] = np.array(cdx, dtype=np.float64); d["cd_y"] = np.array(cdy, dtype=np.float64)
+    # evaluate(): the whole table
+    tmp = tempfile.mkdtemp()
+    c = configparser.ConfigParser()
+    c["DEFAULT"] = {"exp_name": tmp, "rank": "0", "use_rgb": "True", "use_thermal": "True", "use_depth": "True",
+                    "student": "YetAnotherEfficientDet_D2", "image_size": str(S)}
+
+    class _Set:
+        classes = [f"c{i}" for i in range(21)]
+
+    def ragged(batch):      # evaluate()'s debug line calls np.array(batch).shape, which numpy >= 1.24 refuses for ragged lists
+        o = np.empty(len(batch), dtype=object)
+        for i_, a_ in enumerate(batch):
+            o[i_] = a_
+        return o
+
+    saved = RU.get_predictions_multiteacher
+    RU.get_predictions_multiteacher = lambda *a, **k: ([ragged(b_) for b_ in all_pred], [ragged(b_) for b_ in all_lab], labels)
+    try:
+        RU.evaluate({"rgb": None, "depth": None, "thermal": None}, torch.nn.Linear(2, 2), _Set(), c["DEFAULT"])
+    finally:
+        RU.get_predictions_multiteacher = saved
+    row = pd.read_csv(os.path.join(tmp, "results.0.csv")).iloc[0]
+    for k in ("AP@Ave", "AP@0.5", "AP@0.75", "CDx", "CDy"):
+        d["table." + k] = np.float64(row[k])
+    assert row["modality"] == "ALL"
+    np.savez_compressed(os.path.join(OUT, "metrics_eval.npz"), **d)
+    print("metrics", {k: float(d["table." + k]) for k in ("AP@Ave", "AP@0.5", "AP@0.75", "CDx", "CDy")},
+          "n_pred", int(d["pred_counts"].sum()), "n_gt", int(d["lab_counts"].sum()))
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step"]
+    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step", "metrics"]
+    if "metrics" in which:
+        golden_metrics()
     if "keys" in which:
         golden_state_keys()
     if "net" in which:
