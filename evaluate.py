@@ -5,7 +5,8 @@
 
 The student's detections (score > conf_threshold, class filter, NMS — the same device kernels that make the
 teachers' pseudo-labels) are scored against the merged multi-teacher pseudo ground truth with the reference's
-AP@0.5 / AP@0.75 / AP@Ave definitions (mm_distillnet_amd/metrics.py) and written to <exp>/results.<rank>.csv.
+AP@0.5 / AP@0.75 / AP@Ave / CDx / CDy definitions (mm_distillnet_amd/metrics.py, pinned by the reference's evaluate() through
+tests/golden/metrics_eval.npz) and written to <exp>/results.<rank>.csv with the reference's columns.
 """
 import argparse
 import os
@@ -27,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 import train as T  # noqa: E402
 from mm_distillnet_amd.data import SyntheticMultimodalDetection, collate  # noqa: E402
-from mm_distillnet_amd.metrics import ap_table  # noqa: E402
+from mm_distillnet_amd.metrics import evaluate_table  # noqa: E402
 from mm_distillnet_amd.step import DistillEngine  # noqa: E402
 
 
@@ -49,17 +50,23 @@ def main(argv=None):
     eng.load(sstate, tstates)
     test_set = SyntheticMultimodalDetection(cfg, "test")
     loader = torch.utils.data.DataLoader(test_set, batch_size=cfg.getint("batch_size"), shuffle=False, collate_fn=collate)
-    preds, labels = [], []
+    # get_predictions_multiteacher (src/utils/utils.py:1720-1830): per batch the student's detections and the merged teacher
+    # pseudo ground truth, plus the flat list of ground-truth class ids
+    all_pred, all_lab, labels = [], [], []
     for rgb, thermal, depth, audio, _, ids in loader:
         batch = {"rgb": rgb.to(dev), "thermal": thermal.to(dev), "depth": depth.to(dev), "audio": audio.to(dev)}
         p, l = eng.predict(batch)
-        preds += p; labels += l
+        all_pred.append(p); all_lab.append(l)
+        labels += [float(r[4]) for t in l for r in np.asarray(t, np.float32).reshape(-1, 5)]
     eng.check_overflow()
-    table = ap_table(preds, labels)
+    # evaluate() (src/utils/utils.py:2018-2181): one row per testing point; 'ALL' when the three teachers are in use
+    mods = [m for m in ("rgb", "depth", "thermal") if cfg.getboolean(f"use_{m}", True)]
+    modality = "ALL" if len(mods) == 3 else ",".join(mods)
+    table = evaluate_table(all_pred, all_lab, labels, cfg.getint("image_size"))
     print({k: round(v, 3) for k, v in table.items()})
     if os.path.exists(cfg["exp_name"]):
         import pandas as pd
-        pd.DataFrame([dict(exp_name=cfg["exp_name"], modality="ALL", **table)]).to_csv(
+        pd.DataFrame([dict(exp_name=cfg["exp_name"], modality=modality, **table)]).to_csv(
             f"{cfg['exp_name']}/results.{cfg['rank']}.csv", index=False)
     return table
 

@@ -27,7 +27,7 @@ class SyntheticMultimodalDetection(Dataset):
     def __init__(self, config, mode: str = "train", length: int = 64):
         self.size = int(config['image_size'])
         self.length = int(config.get('synthetic_length', length))
-        self.seed = int(config.get('seed', 24)) + (0 if mode == "train" else 100003)
+        self.seed = int(config.get('seed', 24)) + {"train": 0, "val": 50021}.get(mode, 100003)
         self.classes = CLASSES
         vl = config.get('valid_labels', None)
         self.valid_classes_dict = valid_classes_dict(tuple(vl.split(',')) if vl else None)
@@ -59,7 +59,7 @@ class RawSyntheticMultimodalDetection(Dataset):
 
     def __init__(self, config, mode: str = "train", length: int = 64, frame_hw=(270, 360), mel_hw=(128, 128)):
         self.length = int(config.get('synthetic_length', length))
-        self.seed = int(config.get('seed', 24)) + (0 if mode == "train" else 100003)
+        self.seed = int(config.get('seed', 24)) + {"train": 0, "val": 50021}.get(mode, 100003)
         self.frame_hw, self.mel_hw = frame_hw, mel_hw
 
     def __len__(self):
@@ -108,12 +108,15 @@ class DeviceInputPipeline:
     def submit(self, samples):
         """samples: list of dicts from RawSyntheticMultimodalDetection (or a real decoder with the same raw formats)."""
         B, S, call = len(samples), self.S, self.call
-        out = {"rgb": torch.empty(B, 3, S, S, device=self.device), "thermal": torch.empty(B, 1, S, S, device=self.device),
-               "depth": torch.empty(B, 3, S, S, device=self.device), "audio": torch.empty(B, 8, S, S, device=self.device)}
-        mm = torch.empty(B, 2, device=self.device)
         if self._event is not None:
             self._event.synchronize()          # the pinned buffers of the previous submit have been consumed
         with torch.cuda.stream(self.stream):
+            # allocated ON the copy stream: the caching allocator then owns these blocks for that stream, and wait()'s
+            # record_stream(compute stream) defers their reuse until the step that reads them has finished (a block handed back
+            # by the compute stream's pool could still be read by a queued replay while this stream overwrites it)
+            out = {"rgb": torch.empty(B, 3, S, S, device=self.device), "thermal": torch.empty(B, 1, S, S, device=self.device),
+                   "depth": torch.empty(B, 3, S, S, device=self.device), "audio": torch.empty(B, 8, S, S, device=self.device)}
+            mm = torch.empty(B, 2, device=self.device)
             for b, smp in enumerate(samples):
                 rgb = self._stage(("rgb", b), smp["rgb"]); H, W = rgb.shape[:2]
                 call("mmd_image_letterbox", rgb, 0, H, W, 3, 1.0 / 255.0, self.mean, self.std, 0, 0.0, 0.0, None, S, out["rgb"][b])

@@ -25,6 +25,7 @@ from .store import Arena
 
 call = _lib.call
 TEACHER_ORDER = ("rgb", "depth", "thermal")     # ModuleDict insertion order in train.py:123-135
+OPT_MODES = {"Adam": 0, "AdamW": 1, "SGD": 2}
 
 
 @dataclass
@@ -42,6 +43,9 @@ class StepConfig:
     b2: float = 0.999
     eps: float = 1e-8
     grad_clip: float = -1.0
+    optimizer: str = "Adam"            # cfg `optimizer`: SGD | Adam | AdamW (src/optimization/train_methods.py:808-836)
+    momentum: float = 0.0              # SGD
+    weight_decay: float = 0.0          # SGD: cfg weight_decay; AdamW: torch's default 1e-2 (the reference passes none)
     kd_mode: str = "pairwise"          # "pairwise" = ModelWithNMSLoss(.Augmented); "list" = ModelWithNMSKDListLoss
     valid_prediction_ids: tuple = (6,)  # VOC id of "car" (src/datasets/BaseDataset.py:141-165)
     label_map: Optional[List[int]] = None
@@ -69,7 +73,12 @@ class DistillEngine:
         self.exp_avg_sq = torch.zeros(n, device=device)
         self.adam_main = torch.zeros(4, device=device)
         self.adam_head = torch.zeros(4, device=device)
-        self.hyper = torch.tensor([cfg.lr, cfg.b1, cfg.b2, cfg.eps], device=device)
+        if cfg.optimizer not in OPT_MODES:
+            raise Exception(f"Unsupported optimizer {cfg.optimizer}")
+        self.opt_mode = OPT_MODES[cfg.optimizer]
+        self.lr = float(cfg.lr)
+        # device-side hyper-parameters [lr, beta1, beta2, eps, weight_decay, momentum]: a captured graph sees scheduler updates
+        self.hyper = torch.tensor([cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.weight_decay, cfg.momentum], device=device)
         self.head_active = torch.zeros(1, dtype=torch.int32, device=device)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
         self.ws = Arena(device, 256 << 20)        # loss / pseudo-label workspaces (bump, reset per step)
@@ -147,6 +156,7 @@ class DistillEngine:
             net.load_state(teacher_states[m])
 
     def set_lr(self, lr: float):
+        self.lr = float(lr)            # host copy in double (checkpoints carry it; the device copy is its fp32 rounding)
         self.hyper[0] = lr
 
     def make_drop_scale(self, batch: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -218,11 +228,14 @@ class DistillEngine:
             out.append((rows.to(self.device), cnt.to(self.device)))
         return out
 
-    def step_body(self, batch: Dict[str, torch.Tensor], drop_scale: torch.Tensor, teacher_labels: Optional[List[tuple]] = None):
+    def step_body(self, batch: Dict[str, torch.Tensor], drop_scale: Optional[torch.Tensor], teacher_labels: Optional[List[tuple]] = None,
+                  train: bool = True):
         """Issues the whole step on the current stream.  batch tensors are NCHW fp32 on device.
         teacher_labels (optional): per teacher (rows [B, cap, 6], count [B]) pseudo-labels computed elsewhere (cached labels of the
         frozen teachers, or a reference run's labels in the parity tests); the teachers' own decode + NMS is then skipped, their
-        forward still feeds the MTA loss."""
+        forward still feeds the MTA loss.
+        train=False: the losses of `validate()` (src/optimization/train_methods.py:1083-1185): eval-mode student (running
+        BatchNorm statistics, no drop-connect), same pseudo-labels and loss terms, no backward."""
         cfg = self.cfg
         st = self.student
         S = cfg.image_size
@@ -241,7 +254,7 @@ class DistillEngine:
             merged = st._alloc(*audio.shape)
             call("mmd_audio_merge01", audio, merged, audio[0].numel(), B)
             audio = merged
-        cls_s, reg_s, feats_s = st.forward(audio, train=True, drop_scale=drop_scale)
+        cls_s, reg_s, feats_s = st.forward(audio, train=train, drop_scale=drop_scale if train else None)
         A = cls_s.shape[1]
         self._caps(A)
         nlv = len(feats_s)
@@ -288,9 +301,10 @@ class DistillEngine:
         hw = (ctypes.c_int * nlv)(*[f.H * f.W for f in feats_s])
         call("mmd_mta_kl_multi", p_as, p_at, p_da, hw, nlv, nt, 0 if cfg.kd_mode == "pairwise" else 1, B, float(cfg.T), kd,
              float(cfg.w_kd))
-        d_all = st._alloc(st._pyr["total"], feats_s[0].C)
-        call("mmd_mta_attention_bwd", st._fcat, da_all, d_all, st._pyr["total"], feats_s[0].C, float(cfg.p), 0)
-        dfe = [d_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
+        if train:
+            d_all = st._alloc(st._pyr["total"], feats_s[0].C)
+            call("mmd_mta_attention_bwd", st._fcat, da_all, d_all, st._pyr["total"], feats_s[0].C, float(cfg.p), 0)
+            dfe = [d_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
         # cross-teacher merge -> annotations
         boxes, nbox, G = self._merge(rows_t, cnt_t, B, cfg.augment)
         # focal + smooth-L1 with gradients w.r.t. (pre-sigmoid) classifier logits and regression
@@ -299,10 +313,11 @@ class DistillEngine:
         acc = self.ws.alloc((2 * B,), torch.float64); main = self.ws.alloc((2,))
         dcls = st._alloc(B, A, nc); dreg = st._alloc(B, A, 4)
         call("mmd_focal_loss", cls_s, reg_s, st.anchors(S), boxes, nbox, G, B, A, nc, assign, npos, acc, main, dcls, dreg,
-             float(cfg.w_main), 1, self.head_active)
+             float(cfg.w_main), 1, self.head_active if train else self.ws.alloc((1,), torch.int32))
         # backward + optimizer
-        call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
-        st.backward(dcls, dreg, dfe, stop_before=self.ar_split)
+        if train:
+            call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
+            st.backward(dcls, dreg, dfe, stop_before=self.ar_split)
         self.out = {"reg": main[0:1], "cls": main[1:2], "kd": kd, "boxes": boxes, "nbox": nbox,
                     "cls_s": cls_s, "reg_s": reg_s, "feats_s": feats_s, "rows_t": rows_t, "cnt_t": cnt_t}
         return self.out
@@ -347,8 +362,12 @@ class DistillEngine:
             ws = self.ws.alloc((1,), torch.float64)
             call("mmd_clip_grad_norm", ps.grad, ps.grad.numel(), float(cfg.grad_clip), ws)
         r = self.head_ranges
-        call("mmd_adam_step_gated", ps.flat, ps.grad, self.exp_avg, self.exp_avg_sq, self.adam_main, self.adam_head,
-             self.hyper, self.head_active, r[0], r[1], r[2], r[3], r[4], r[5], float(gs), ps.n_params)
+        if self.opt_mode == 0:
+            call("mmd_adam_step_gated", ps.flat, ps.grad, self.exp_avg, self.exp_avg_sq, self.adam_main, self.adam_head,
+                 self.hyper, self.head_active, r[0], r[1], r[2], r[3], r[4], r[5], float(gs), ps.n_params)
+        else:
+            call("mmd_opt_step_gated", self.opt_mode, ps.flat, ps.grad, self.exp_avg, self.exp_avg_sq, self.adam_main, self.adam_head,
+                 self.hyper, self.head_active, r[0], r[1], r[2], r[3], r[4], r[5], float(gs), ps.n_params)
         self.student.refresh_wt()
 
     # ------------------------------------------------------------------ eager / graph drivers
@@ -447,6 +466,13 @@ class DistillEngine:
         preds = [rows_s[i, :cs[i]].cpu().numpy() for i in range(B)]
         labels = [boxes[i, :nb[i]].cpu().numpy() for i in range(B)]
         return preds, labels
+
+    @torch.no_grad()
+    def eval_losses(self, batch: Dict[str, torch.Tensor]):
+        """-> (reg, cls, kd_sum) python floats of one validation batch (eval-mode student; validate() upstream)."""
+        self.student.refresh()
+        out = self.step_body(batch, None, train=False)
+        return out["reg"].item(), out["cls"].item(), out["kd"].sum().item()
 
     def check_overflow(self):
         if int(self.overflow.item()):

@@ -458,6 +458,40 @@ def test_adam_and_clip():
     close(gbuf, refg, 1e-5, 1e-7)
 
 
+@pytest.mark.parametrize("name", ["Adam", "AdamW", "SGD", "SGD0"])
+def test_optimizers_match_torch(name):
+    """cfg `optimizer` = SGD | Adam | AdamW (src/optimization/train_methods.py:808-836) on the flat head-gated pass against
+    torch.optim, including the gating: a "head" range receives no update (and no momentum / moment state) until head_active."""
+    torch.manual_seed(7)
+    n = 4096
+    hb, he = 1024, 2048                       # the gated range
+    p0 = torch.randn(n)
+    main_idx = torch.cat([torch.arange(0, hb), torch.arange(he, n)])
+    ref_main = torch.nn.Parameter(p0[main_idx].clone()); ref_head = torch.nn.Parameter(p0[hb:he].clone())
+    lr, wd, mom = 1e-3, (1e-2 if name == "AdamW" else 1e-3 if name.startswith("SGD") else 0.0), (0.9 if name == "SGD" else 0.0)
+    if name == "Adam":
+        opt = torch.optim.Adam([ref_main, ref_head], lr=lr, betas=(0.9, 0.999)); mode = 0
+    elif name == "AdamW":
+        opt = torch.optim.AdamW([ref_main, ref_head], lr=lr, betas=(0.9, 0.999)); mode = 1
+    else:
+        opt = torch.optim.SGD([ref_main, ref_head], lr=lr, momentum=mom, weight_decay=wd); mode = 2
+    dp, dm, dv = g(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    st_m, st_h = torch.zeros(4, device=DEV), torch.zeros(4, device=DEV)
+    hyper = torch.tensor([lr, 0.9, 0.999, 1e-8, wd, mom], device=DEV)
+    active = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for it in range(4):
+        gg = torch.randn(n) * 0.01 * (it + 1)
+        ref_main.grad = gg[main_idx].clone()
+        ref_head.grad = None if it < 2 else gg[hb:he].clone()      # no pseudo-labels in the first two batches
+        if it == 2:
+            active.fill_(1)
+        opt.step()
+        call("mmd_opt_step_gated", mode, dp, g(gg), dm, dv, st_m, st_h, hyper, active, hb, he, 0, 0, 0, 0, 1.0, n)
+    want = p0.clone(); want[main_idx] = ref_main.detach(); want[hb:he] = ref_head.detach()
+    close(dp, want, 1e-6, 1e-7, name)
+    assert st_m[0].item() == 4.0 and st_h[0].item() == 2.0
+
+
 def test_live_bn_matches_finalized():
     """Forward consumers that derive (scale, shift) on the fly from raw batch sums must agree bit for bit with the
     finalize kernel's coefficients (same arithmetic), for every consumer kind; plus the batched finalize."""

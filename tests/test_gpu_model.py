@@ -1,4 +1,5 @@
 """GPU: the reference-shaped Python surface (nn.Module facade, loss modules, train.py / evaluate.py) on the HIP engine."""
+import json
 import os
 import sys
 
@@ -107,9 +108,29 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     assert ck.exists()
     c = torch.load(ck, map_location="cpu", weights_only=False)
     assert set(c) >= {"epoch", "state_dict", "best_loss", "best_epoch", "optimizer", "scheduler"}
+    # torch-format optimizer / scheduler payloads (resume_from_checkpoint upstream feeds them to torch's load_state_dict)
+    assert set(c["optimizer"]) >= {"state", "param_groups"} and c["optimizer"]["param_groups"][0]["lr"] == 1e-4
+    assert c["optimizer"]["state"][0]["step"] == 3 and "num_bad_epochs" in c["scheduler"] and "mode" in c["scheduler"]
+    assert (tmp_path / "exp" / "only_parameters_student_best.0").exists() and (tmp_path / "exp" / "best.0.pth.tar").exists()
+    logs = json.load(open(tmp_path / "exp" / "all_logs.0.json"))
+    assert {"exp/Train/Total_loss", "exp/Train_/Regression_loss", "exp/Train/KD", "exp/Test/Total_loss"} <= set(logs)
     table = evaluate.main(["--config_file", cfgf, "--checkpoint", str(ck), "--overwrite", ov])
-    assert set(table) == {"AP@0.5", "AP@0.75", "AP@Ave"}
+    assert set(table) == {"AP@0.5", "AP@0.75", "AP@Ave", "CDx", "CDy"}
     assert (tmp_path / "exp" / "results.0.csv").exists()
+    # resume: epoch counter, weights, Adam moments and step counts come back; one more epoch runs from there
+    ov_r = ov[:-1] + ', "resume": "True", "num_epoches": 2}'
+    train.main(["--config_file", cfgf, "--overwrite", ov_r, "--max_steps", "2"])
+    c2 = torch.load(ck, map_location="cpu", weights_only=False)
+    assert c2["epoch"] == 2 and c2["optimizer"]["state"][0]["step"] == 5
+    # unsupported cfg values raise like upstream instead of silently training something else
+    for bad in ('"optimizer": "RMSprop"', '"scheduler": "OneCycle"', '"train_method": "traditional_nms_kdlist_augmented"'):
+        with pytest.raises(Exception, match="Unsupported"):
+            train.main(["--config_file", cfgf, "--overwrite", ov[:-1] + ", " + bad + "}", "--max_steps", "1"])
+    # SGD / StepLR run through the same flat optimizer pass
+    ov_s = ov[:-1] + ', "optimizer": "SGD", "momentum": 0.9, "weight_decay": 1e-4, "scheduler": "StepLR", "step_size": 1, "gamma": 0.5, "exp_name": "exp_sgd"}'
+    assert np.isfinite(train.main(["--config_file", cfgf, "--overwrite", ov_s, "--max_steps", "3"]))
+    cs = torch.load(tmp_path / "exp_sgd" / "checkpoint.0.pth.tar", map_location="cpu", weights_only=False)
+    assert cs["optimizer"]["param_groups"][0]["lr"] == 0.5e-4 and "momentum_buffer" in cs["optimizer"]["state"][0]
     # same entry point with raw frames + the device-side Normalizer/Resizer pipeline and the augmented merge switched on
     ov2 = ov[:-1] + ', "input_pipeline": "raw", "audio_augmentation_merge": "True", "exp_name": "exp_raw"}'
     loss2 = train.main(["--config_file", cfgf, "--overwrite", ov2, "--max_steps", "3"])

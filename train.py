@@ -7,7 +7,10 @@ One process per GPU.  With `engine=DistributedDataParallel` (or WORLD_SIZE>1 fro
 rendezvous at MASTER_ADDR/MASTER_PORT (default 127.0.0.1:23457 as upstream) over RCCL ("nccl") and exchange
 student gradients only.  The step itself is mm_distillnet_amd.step.DistillEngine (HIP kernels, graph-captured).
 Checkpoints keep the upstream format: <exp>/checkpoint.<rank>.pth.tar / best.<rank>.pth.tar with keys
-epoch, state_dict, best_loss, best_epoch, optimizer, scheduler (src/optimization/train_methods.py:1049-1064,1239-1254).
+epoch, state_dict, best_loss, best_epoch, optimizer, scheduler (src/optimization/train_methods.py:1049-1064,1239-1254); `optimizer`
+is a torch.optim state_dict over named_parameters() order and `scheduler` torch's scheduler state_dict (mm_distillnet_amd/trainer.py),
+so upstream can resume from these files and this script from upstream's.  Epoch logic as upstream (:966-1064): scheduler step on the
+epoch's last training loss, validate() every val_interval epochs, best / early stopping on the validation loss.
 """
 import argparse
 import configparser
@@ -32,7 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from mm_distillnet_amd.arch import make_spec  # noqa: E402
-from mm_distillnet_amd.data import SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, collate  # noqa: E402
+from mm_distillnet_amd.data import (SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, collate,  # noqa: E402
+                                    valid_classes_dict)
+from mm_distillnet_amd import trainer as TR  # noqa: E402
 from mm_distillnet_amd.model import filter_state_dict  # noqa: E402
 from mm_distillnet_amd.step import DistillEngine, StepConfig  # noqa: E402
 from mm_distillnet_amd.synth import synth_state  # noqa: E402
@@ -67,16 +72,26 @@ def parse_config(argv=None):
 
 def step_config(cfg) -> StepConfig:
     method = cfg.get("train_method", "traditional_nms_augmented")
+    if method not in TR.SUPPORTED_METHODS:
+        # traditional_nms_kdlist_augmented (src/optimization/train_methods.py:50-162) needs the dataset's yield_batch / merge_audios
+        # (librosa re-synthesis of two recordings, src/datasets/MultimodalDetection.py:329-367); the adversarial / generator / BOHB
+        # methods are outside the hot path.  Upstream: raise Exception(f"Unsupported train method ...") (:1000)
+        raise Exception(f"Unsupported train method {method} provided")
+    # valid_labels -> VOC ids of the classes a teacher prediction must have (src/datasets/BaseDataset.py:141-165, utils.py:285-323)
+    vl = cfg.get("valid_labels", "car")
+    vcd = valid_classes_dict(tuple(v.strip() for v in vl.split(",")) if vl else None)
     return StepConfig(image_size=cfg.getint("image_size"), conf_threshold=cfg.getfloat("conf_threshold", 0.3),
                       nms_threshold=cfg.getfloat("nms_threshold", 0.5), T=float(cfg.get("T", 9)), p=float(cfg.get("p", 2)),
                       w_main=cfg.getfloat("w_main", 1.0), w_kd=cfg.getfloat("w_kd", 0.005), lr=cfg.getfloat("lr", 1e-4),
                       b1=cfg.getfloat("b1", 0.9), b2=cfg.getfloat("b2", 0.999), grad_clip=cfg.getfloat("grad_clip", -1),
                       kd_mode="list" if "kdlist" in method else "pairwise",
+                      valid_prediction_ids=tuple(sorted(vcd["predictions_i2txt"].keys())),
                       # src/optimization/traditional.py:136: augment = config.getboolean('audio_augmentation_merge'); only
                       # ModelWithNMSLossAugmented acts on it (key absent from the shipped cfg -> off)
                       augment=bool(cfg.getboolean("audio_augmentation_merge", False)) and method == "traditional_nms_augmented",
                       # extension key (absent from the reference's cfg files -> fp32): "bf16" = 1x1 convs on the bf16 MFMA
-                      precision=cfg.get("precision", "fp32"))
+                      precision=cfg.get("precision", "fp32"),
+                      **TR.optimizer_settings(cfg))
 
 
 def load_states(cfg, coef=2):
@@ -102,43 +117,6 @@ def load_states(cfg, coef=2):
     return sspec, sstate, tspecs, tstates
 
 
-class Plateau:
-    """ReduceLROnPlateau(patience=3) as configured upstream (src/optimization/train_methods.py:860-878), on the engine's lr."""
-
-    def __init__(self, eng, patience=3, factor=0.1):
-        self.eng, self.patience, self.factor = eng, patience, factor
-        self.best, self.bad = float("inf"), 0
-
-    def step(self, loss):
-        if loss < self.best * (1 - 1e-4):
-            self.best, self.bad = loss, 0
-        else:
-            self.bad += 1
-            if self.bad > self.patience:
-                self.eng.set_lr(float(self.eng.hyper[0].item()) * self.factor)
-                self.bad = 0
-
-    def state_dict(self):
-        return {"best": self.best, "num_bad_epochs": self.bad, "patience": self.patience, "factor": self.factor}
-
-    def load_state_dict(self, d):
-        self.best, self.bad = d["best"], d["num_bad_epochs"]
-
-
-def optimizer_state(eng):
-    ps = eng.student.ps
-    return {"exp_avg": ps.export_flat(eng.exp_avg), "exp_avg_sq": ps.export_flat(eng.exp_avg_sq),
-            "step_main": float(eng.adam_main[0].item()), "step_head": float(eng.adam_head[0].item()),
-            "head_active": int(eng.head_active.item()), "lr": float(eng.hyper[0].item())}
-
-
-def load_optimizer_state(eng, d):
-    ps = eng.student.ps
-    ps.import_flat(eng.exp_avg, d["exp_avg"]); ps.import_flat(eng.exp_avg_sq, d["exp_avg_sq"])
-    eng.adam_main[0] = d["step_main"]; eng.adam_head[0] = d["step_head"]
-    eng.head_active.fill_(d["head_active"]); eng.set_lr(d["lr"])
-
-
 def main(argv=None):
     cfg, args = parse_config(argv)
     rank, local = args.rank, args.local_rank
@@ -155,9 +133,11 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", "23457")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.manual_seed(cfg.getint("seed", 24))
+    scfg = step_config(cfg)                      # raises on an unsupported train_method / optimizer, like upstream
     sspec, sstate, tspecs, tstates = load_states(cfg, int(cfg.get("compound_coef", 2)))
-    eng = DistillEngine(sspec, tspecs, dev, step_config(cfg), world_size=world)
+    eng = DistillEngine(sspec, tspecs, dev, scfg, world_size=world)
     eng.load(sstate, tstates)
+    sched = TR.LrSchedule(eng, cfg)              # raises on an unsupported scheduler, like upstream
     if world > 1:
         import torch.distributed as dist
         dist.broadcast(eng.student.ps.flat, 0)
@@ -165,62 +145,99 @@ def main(argv=None):
     # input_pipeline = raw: samples arrive as decoded frames (uint8/uint16/float mel stacks) and Normalizer/Resizer/transposes
     # run on the GPU on a copy stream (mm_distillnet_amd.data.DeviceInputPipeline); default: ready-made tensors
     raw = cfg.get("input_pipeline", "tensor") == "raw"
-    train_set = RawSyntheticMultimodalDetection(cfg, "train") if raw else SyntheticMultimodalDetection(cfg, "train")
+    Set = RawSyntheticMultimodalDetection if raw else SyntheticMultimodalDetection
+    train_set, val_set = Set(cfg, "train"), Set(cfg, "val")
     pipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
+    vpipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
+    collate_fn = (lambda b: b) if raw else collate
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank) if world > 1 else None
     loader = torch.utils.data.DataLoader(train_set, batch_size=cfg.getint("batch_size"), shuffle=sampler is None,
-                                         drop_last=True, collate_fn=(lambda b: b) if raw else collate,
+                                         drop_last=True, collate_fn=collate_fn,
                                          num_workers=cfg.getint("num_workers", 0), sampler=sampler, pin_memory=not raw)
-    sched = Plateau(eng)
-    start_epoch, best_loss, best_epoch = 0, 1e10, 0
-    ckpt = f"{cfg['exp_name']}/checkpoint.{rank}.pth.tar"
-    if cfg.getboolean("resume", False) and os.path.exists(ckpt):
-        c = torch.load(ckpt, map_location="cpu", weights_only=False)
-        start_epoch, best_loss, best_epoch = c["epoch"], c["best_loss"], c["best_epoch"]
-        eng.student.load_state(c["state_dict"]); load_optimizer_state(eng, c["optimizer"]); sched.load_state_dict(c["scheduler"])
-        logger.info("resumed from %s at epoch %d", ckpt, start_epoch)
-    steps, captured, loss = 0, False, float("nan")
-    for epoch in range(start_epoch, cfg.getint("num_epoches", 1)):
+
+    def to_batch(item):
+        if raw:
+            return vpipe.submit(item).wait()
+        rgb, thermal, depth, audio, label, ids = item
+        return {"rgb": rgb.to(dev, non_blocking=True), "thermal": thermal.to(dev, non_blocking=True),
+                "depth": depth.to(dev, non_blocking=True), "audio": audio.to(dev, non_blocking=True)}
+
+    start_epoch, best_loss, best_epoch = TR.resume_from_checkpoint(cfg, eng, sched)
+    writer = TR.ScalarLog(cfg["exp_name"])
+    w_main, w_kd = cfg.getfloat("w_main", 1.0), cfg.getfloat("w_kd", 0.005)
+    n_epochs = cfg.getint("num_epoches", 1)
+    no_validation = cfg.getboolean("no_validation", False)
+    steps, captured, loss, val_loss = 0, False, float("nan"), float("nan")
+    stop = False
+    for epoch in range(start_epoch, n_epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
-        t0, n_img = time.time(), 0
-        for item in loader:
-            if raw:
-                batch = pipe.submit(item).wait()
-                audio = batch["audio"]
-            else:
-                rgb, thermal, depth, audio, label, ids = item
-                batch = {"rgb": rgb.to(dev, non_blocking=True), "thermal": thermal.to(dev, non_blocking=True),
-                         "depth": depth.to(dev, non_blocking=True), "audio": audio.to(dev, non_blocking=True)}
+        t0, n_img, out = time.time(), 0, None
+        it = iter(loader)
+        # one batch of look-ahead: the raw pipeline transforms batch n+1 on its copy stream while the step of batch n runs
+        nxt = next(it, None)
+        staged = pipe.submit(nxt) if (raw and nxt is not None) else None
+        num_iter = len(loader)
+        i_iter = 0
+        while nxt is not None:
+            item = nxt
+            batch = staged.wait() if raw else to_batch(item)
+            nxt = next(it, None)
             if not captured:
                 eng.capture(batch); captured = True
             out = eng.replay(batch)
-            n_img += audio.shape[0]; steps += 1
+            if raw and nxt is not None:
+                staged = pipe.submit(nxt)        # after replay(): the static inputs were copied out of `batch` on the compute stream
+            n_img += batch["audio"].shape[0]; steps += 1
             if steps % 10 == 0 or steps == 1:
-                loss = cfg.getfloat("w_main", 1.0) * (out["reg"].item() + out["cls"].item()) + cfg.getfloat("w_kd", 0.005) * out["kd"].sum().item()
-                logger.info("Epoch: %d/%d Iteration: %d Lr: %g Loss:%.5f Regression:%.5f Cls:%.5f KD:%.5f", epoch + 1,
-                            cfg.getint("num_epoches", 1), steps, eng.hyper[0].item(), loss, out["reg"].item(), out["cls"].item(),
-                            out["kd"].sum().item())
+                reg, cls, kd = out["reg"].item(), out["cls"].item(), out["kd"].sum().item()
+                eng.check_overflow()             # sticky device flag; checked where the host syncs anyway
+                loss = w_main * (reg + cls) + w_kd * kd
+                logger.info("Epoch: %d/%d Iteration: %d/%d Lr: %g Loss:%.5f Regression:%.5f Cls:%.5f KLDiv:0 KD:%.5f", epoch + 1,
+                            n_epochs, i_iter + 1, num_iter, eng.hyper[0].item(), loss, reg, cls, kd)
+                gstep = epoch * num_iter + i_iter
+                writer.add_scalar("Train/Total_loss", loss, gstep); writer.add_scalar("Train_/Regression_loss", reg, gstep)
+                writer.add_scalar("Train/Class_loss", cls, gstep); writer.add_scalar("Train/KLDiv", 0.0, gstep)
+                writer.add_scalar("Train/KD", kd, gstep)
+            i_iter += 1
             if 0 < args.max_steps <= steps:
+                stop = True
                 break
         torch.cuda.synchronize()
         eng.check_overflow()
-        loss = cfg.getfloat("w_main", 1.0) * (out["reg"].item() + out["cls"].item()) + cfg.getfloat("w_kd", 0.005) * out["kd"].sum().item()
+        if out is None:
+            logger.warning("epoch %d: the loader yielded no batch (dataset smaller than batch_size with drop_last)", epoch + 1)
+            break
+        # train_traditional returns the LAST iteration's loss (traditional.py:238); averaged over the ranks so that every rank
+        # feeds its scheduler the same number
+        loss = w_main * (out["reg"].item() + out["cls"].item()) + w_kd * out["kd"].sum().item()
+        loss = TR.allreduce_mean(loss, world, dev)
         logger.info("epoch %d: %.1f images/sec on this rank, last loss %.5f", epoch + 1, n_img / (time.time() - t0), loss)
         sched.step(loss)
-        is_best = loss < best_loss
-        if is_best:
-            best_loss, best_epoch = loss, epoch
-        torch.save({"epoch": epoch + 1, "state_dict": eng.student.ps.export_state(), "best_loss": best_loss, "best_epoch": best_epoch,
-                    "optimizer": optimizer_state(eng), "scheduler": sched.state_dict()}, ckpt)
-        if is_best:
-            shutil.copyfile(ckpt, f"{cfg['exp_name']}/best.{rank}.pth.tar")
-        if epoch - best_epoch > cfg.getint("es_patience", 5) > 0 or 0 < args.max_steps <= steps:
+        if no_validation:
+            continue
+        is_best = False
+        if epoch % cfg.getint("val_interval", 1) == 0:
+            val_loss = TR.validate(eng, val_set, cfg, epoch, writer, to_batch, collate_fn, world)
+            is_best = val_loss < best_loss
+            if is_best:
+                torch.save(eng.student.ps.export_state(), f"{cfg['exp_name']}/only_parameters_student_best.{rank}")
+                best_loss, best_epoch = val_loss, epoch + 1
+            if epoch - best_epoch > cfg.getint("es_patience", 5) > 0:
+                logger.info(f"ES Epoch{epoch}. Lowest loss is {val_loss}")
+                break
+        if cfg.getboolean("fast_run", False) and not is_best:
+            continue
+        TR.save_checkpoint(TR.checkpoint_state(eng, sched, epoch, best_loss, best_epoch), is_best, cfg)
+        if stop:
             break
+    writer.export_scalars_to_json(f"{cfg['exp_name']}/all_logs.{rank}.json")
+    if no_validation and captured:
+        val_loss = TR.validate(eng, val_set, cfg, n_epochs, writer, to_batch, collate_fn, world)
     if world > 1:
         import torch.distributed as dist
         dist.barrier(); dist.destroy_process_group()
-    return loss
+    return val_loss if val_loss == val_loss else loss
 
 
 if __name__ == "__main__":
