@@ -210,6 +210,10 @@ int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int 
 // reduced-precision path ("no AMP anywhere"); this is what torch.autocast(bf16) would make of its nn.Conv2d(k=1).
 int mmd_pwconv_fwd_bf16(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, hipStream_t stream);
 
+// Kernel selection of mmd_pwconv_fwd / _bwd_data for K <= 128 (csrc/pw_rows.hip, the thin-K row-slab kernel): 0 = the measured shape
+// filter decides (default), 1 = every supported launch takes it, 2 = none does.  Process-wide; for tests and A/B timing.
+int mmd_pwconv_rows_mode(int mode);
+
 int mmd_pwconv_fwd_pyr_bf16(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
 
 int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);

@@ -14,67 +14,8 @@
 // [row][k] with k contiguous and a 4-float row pad (stride 36 floats -> conflict-free ds_read_b128);
 // each lane reads 4 consecutive k for its row, lanes 32..63 take the next 4 k, which feeds 4 MFMAs.
 #include "common.h"
+#include "pw_args.h"
 #include <cstdlib>
-
-// BatchNorm(+swish, +drop-connect row scale) backward as a GEMM operand prologue: instead of a separate pass that writes
-//   dz[m,c] = scale_c * ( g'[m,c] - m1_c - (z[m,c] - mean_c) * invstd_c * m2_c ),   g' = g * mul_b[image(m)] * swish'(z*scale_c + shift_c)
-// (scale = gamma*invstd, shift = beta - mean*scale; m1 = sum(g')/count, m2 = sum(g'*xhat)/count from the reduce pass), the
-// input-gradient and weight-gradient GEMMs of the conv in front of the BatchNorm read (g, z) and evaluate dz while staging
-// their tile.  Removes one launch and one [M, C] write + two reads per BatchNorm from the backward's main chain.
-// Reference: autograd of nn.BatchNorm2d in train mode, call sites src/YetAnotherEfficientNet.py:428,447,477.
-struct BnBwdOp {
-  const float* z; const float* scale; const float* shift; const float* mean; const float* invstd;
-  const double* sums; double inv_count; int C; int act; const float* mul_b; int rows_per_image;
-  // input-gradient launch only: the evaluated dz is also stored once ([M, C], by the blocks of the first column panel), so the
-  // weight-gradient GEMM reads ONE plain tensor instead of re-evaluating the BatchNorm backward from (g, z) (+18-31 % on
-  // that kernel); dgamma / dbeta (+)= the reduce pass' sums
-  float* dz_out; float* dgamma; float* dbeta;
-};
-// per-channel coefficients: dz = a1*g' + a2*(z - mu) + a3
-__device__ __forceinline__ void bn_bwd_coef(const BnBwdOp& b, int c, float& a1, float& a2, float& a3, float& mu, float& sh) {
-  const float m1 = (float)(b.sums[c] * b.inv_count), m2 = (float)(b.sums[b.C + c] * b.inv_count);
-  const float is = b.invstd[c];
-  a1 = b.scale[c]; mu = b.mean[c]; sh = b.shift[c];
-  a2 = -a1 * is * m2; a3 = -a1 * m1;
-}
-struct BnBwdCoef4 { float4 a1, a2, a3, mu, sh; };
-__device__ __forceinline__ void bn_bwd_coef4(const BnBwdOp& b, int c, BnBwdCoef4& o) {
-  bn_bwd_coef(b, c, o.a1.x, o.a2.x, o.a3.x, o.mu.x, o.sh.x); bn_bwd_coef(b, c + 1, o.a1.y, o.a2.y, o.a3.y, o.mu.y, o.sh.y);
-  bn_bwd_coef(b, c + 2, o.a1.z, o.a2.z, o.a3.z, o.mu.z, o.sh.z); bn_bwd_coef(b, c + 3, o.a1.w, o.a2.w, o.a3.w, o.mu.w, o.sh.w);
-}
-__device__ __forceinline__ float bn_bwd_eval(float g, float z, float rs, int act, float a1, float a2, float a3, float mu, float sh) {
-  g *= rs;
-  if (act == MMD_ACT_SWISH) g *= mmd_swish_grad(z * a1 + sh);
-  return a1 * g + a2 * (z - mu) + a3;
-}
-__device__ __forceinline__ float4 bn_bwd_eval4(float4 g, float4 z, float rs, int act, const BnBwdCoef4& q) {
-  return make_float4(bn_bwd_eval(g.x, z.x, rs, act, q.a1.x, q.a2.x, q.a3.x, q.mu.x, q.sh.x),
-                     bn_bwd_eval(g.y, z.y, rs, act, q.a1.y, q.a2.y, q.a3.y, q.mu.y, q.sh.y),
-                     bn_bwd_eval(g.z, z.z, rs, act, q.a1.z, q.a2.z, q.a3.z, q.mu.z, q.sh.z),
-                     bn_bwd_eval(g.w, z.w, rs, act, q.a1.w, q.a2.w, q.a3.w, q.mu.w, q.sh.w));
-}
-
-// Stem 3x3 / stride-2 TF-SAME convolution as an implicit GEMM: row m = output pixel (b, oh, ow), k = ci*9 + i*3 + j, the A
-// element is x[b, ci, 2*oh + i - pad_t, 2*ow + j - pad_l] (zero outside the image), gathered from the NCHW image while staging;
-// the weight is the stem's native [Cout, Kp] matrix (mmd_stem_im2col's column order).  Replaces the direct VALU kernel
-// (one thread per pixel x all output channels: 188 us for the 8-channel student stem).
-struct StemOp { int Cin, H, W, OH, OW, pad_t, pad_l; };
-
-struct PwArgs {
-  const float* x; const float* w; float* y;
-  int M, K, N;
-  const float* in_scale; const float* in_shift; int in_act; BnLive in_bn;
-  const float* gate; int rows_per_image;
-  const float* bias; const float* out_scale; const float* out_shift; int out_act;
-  const float* residual; double* stats;
-  double* stats_ws; int ws_slots;            // slotted sums (common.h), tiled kernel only
-  long long y_batch_stride; long long y_offset;
-  int ntn; int nblk;
-  Pyr pyr; long long yoff_lev[MMD_MAX_LEV]; long long lev_stride;
-  int bf16;                                  // host-side: operands rounded to bf16 at the MFMA input (mixed-precision mode)
-  BnBwdOp bb;                                // PRO == 1: the A operand is a BatchNorm backward evaluated on the fly
-  StemOp st;                                 // PRO == 2: the A operand is the im2col of an NCHW image, gathered on the fly
-};
 
 // ---- bf16 mixed precision (BASELINE config 5): the SAME kernels with the inner product on v_mfma_f32_32x32x16_bf16.
 // Activations and weights stay fp32 in HBM and LDS; each lane converts its 8 consecutive k (RNE, v_cvt_pk_bf16_f32) right
@@ -923,7 +864,9 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   // 64x64 tiles (2x2 waves) for layers with sq_min <= big_tiles < sq_tiles
   static const int sq_tiles = getenv("MMD_SQ_TILES") ? atoi(getenv("MMD_SQ_TILES")) : 800;
   static const int sq_min = getenv("MMD_SQ_MIN") ? atoi(getenv("MMD_SQ_MIN")) : 160;
-  if (use_stream && K <= 128 && big_tiles >= 160) {
+  if (pw_rows_try(a, stream) == 1) {
+    // thin-K row-slab kernel (pw_rows.hip) took the launch
+  } else if (use_stream && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
     else pw_stream_launch<2, 2>(a, stream);

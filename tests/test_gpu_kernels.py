@@ -70,6 +70,71 @@ def test_pwconv_fwd_full(M, K, N):
     close(y2, x @ w.t(), 2e-4, 1e-5, "pw plain")
 
 
+@pytest.mark.parametrize("M,K,N,B,flags", [
+    (8192, 88, 528, 8, "gate aff swish stats res osc bias"),     # MBConv expand/project-like, 4 column panels
+    (8192, 120, 720, 8, "gate stats"),                          # gate-only prologue (frozen project conv), 8 panels
+    (32768, 112, 112, 8, "aff swish stats ws bias"),            # BiFPN / head layer, one 7-tile chunk, slotted statistics
+    (20008, 112, 112, 1, "live swish stats ws"),                # M % 16 != 0, live-BatchNorm prologue
+    (131072, 24, 144, 8, "osc act"),                            # thin expand conv with folded BN + swish epilogue
+    (65536, 16, 96, 4, "live swish stats ws"),
+    (40960, 32, 16, 4, "res bias"),                             # N = one tile
+    (2048, 112, 112, 8, "bias stats osc"),                      # small M: columns spread over panels (C = 1)
+    (48, 112, 36, 1, "bias"), (512, 112, 180, 2, "bias act"), (1000, 48, 288, 1, "aff"), (4096, 96, 24, 4, "gate res"),
+    (2048, 128, 352, 8, ""), (777, 16, 16, 1, "stats")])
+def test_pwconv_rows_kernel(M, K, N, B, flags):
+    """The thin-K row-slab kernel (csrc/pw_rows.hip, K <= 128) behind mmd_pwconv_fwd: every prologue / epilogue combination,
+    column panels, partial slabs and tiles, slotted and direct statistics, against fp32 torch; and bit-equality with the LDS-tiled
+    kernels is NOT expected (different summation order), only the fp32 tolerance."""
+    torch.manual_seed(M + 3 * K + 7 * N)
+    f = set(flags.split())
+    rpi = M // B
+    x = torch.randn(M, K); w = torch.randn(N, K) / math.sqrt(K)
+    isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+    a = x
+    args_in = [None, None, 0, None, None, None, 0]
+    if "aff" in f:
+        a = a * isc + ish
+        args_in = [g(isc), g(ish), 0, None, None, None, 0]
+    if "live" in f:      # coefficients derived in-kernel from raw batch sums (train-mode forward)
+        gamma, beta = torch.rand(K) + 0.5, torch.randn(K) * 0.2
+        st_in = torch.cat([x.double().sum(0), (x.double() ** 2).sum(0)])
+        mean = st_in[:K] / M; var = st_in[K:] / M - mean * mean
+        sc = gamma.double() / torch.sqrt(var + 1e-3)
+        a = (x.double() * sc + (beta.double() - mean * sc)).float()
+        args_in = [None, None, 0, g(st_in), g(gamma), g(beta), M]
+    if "swish" in f:
+        a = swish(a); args_in[2] = 1
+    gate = torch.rand(B, K) if "gate" in f else None
+    if gate is not None:
+        a = a * gate.repeat_interleave(rpi, 0)
+    bias = torch.randn(N) * 0.1 if "bias" in f else None
+    raw = a @ w.t() + (bias if bias is not None else 0)
+    osc, osh = (torch.rand(N) + 0.5, torch.randn(N) * 0.1) if "osc" in f else (None, None)
+    ref = raw * osc + osh if osc is not None else raw
+    act = 1 if ("act" in f or "osc" in f and "swish" in f) else 0
+    if act:
+        ref = swish(ref)
+    res = torch.randn(M, N) if "res" in f else None
+    if res is not None:
+        ref = ref + res
+    y = torch.full((M, N), float("nan"), device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV) if "stats" in f else None
+    ws = torch.zeros(64 * 2 * N, dtype=torch.float64, device=DEV) if "ws" in f else None
+    _lib.LIB.load().mmd_pwconv_rows_mode(1)          # every supported launch on the row-slab kernel (default: a measured shape filter)
+    try:
+        call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, *args_in, g(gate) if gate is not None else None, rpi,
+             g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
+             g(res) if res is not None else None, stats, 0, 0, ws, 64 if ws is not None else 0)
+    finally:
+        _lib.LIB.load().mmd_pwconv_rows_mode(0)
+    close(y, ref, 2e-4, 1e-5, "rows fwd")
+    if stats is not None:
+        close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
+        close(stats[N:], (raw.double() ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
+        if ws is not None:
+            assert ws.abs().max().item() == 0          # the slots are left zeroed for the next producer
+
+
 def test_pwconv_fwd_remap():
     torch.manual_seed(1)
     B, HW, K, N, A_total_rows = 2, 48, 112, 36, 600
@@ -739,7 +804,8 @@ def test_slotted_bn_sums_match_direct():
     st0.zero_(); st1.zero_()
     call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, st0, 0, 0, None, 0)
     call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, st1, 0, 0, ws, SL)
-    close(st1, st0, 1e-12, 1e-12, "pw slotted sums"); assert float(ws.abs().max()) == 0.0
+    # (the row-slab kernel folds a block's slabs in fp32 in LDS, in arrival order, before the f64 atomics: equal to fp32 rounding)
+    close(st1, st0, 1e-6, 1e-6, "pw slotted sums"); assert float(ws.abs().max()) == 0.0
     close(st0[:N], y.double().sum(0), 1e-6, 1e-7)
     # BN backward pass 1: 270000 rows -> 1055 row blocks per address
     M, C = 270000, 16
