@@ -201,6 +201,22 @@ int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, cons
 // dW[N,K] += dY^T * pro(X) (autograd of the 1x1 conv weight; reference: loss.backward(), src/optimization/traditional.py:182).
 int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);
 
+// All 1x1-conv weight gradients of a backward segment in ONE persistent launch + one deterministic fold (csrc/pw_wgrad_grouped.hip;
+// reference: autograd of every nn.Conv2d(k=1) weight of the student, src/YetAnotherEfficientNet.py:427,446, src/YetAnotherEfficientDet.py:171,238-265).
+// The caller fills dy / x / dw / in_scale / in_shift / gate / M / K / N / in_act / rows_per_image of each layer (same operand meaning as
+// mmd_pwconv_bwd_weight), mmd_wgrad_plan (host) fills the rest and returns the item / tile counts and the workspace size; the planned
+// table is then copied to device memory once and mmd_wgrad_grouped launched every step.  dW is WRITTEN (not accumulated), sums are
+// bit-reproducible run to run (no atomics).
+typedef struct MmdWgradLayer {
+  const float* dy; const float* x; float* dw;
+  const float* in_scale; const float* in_shift; const float* gate;
+  int M, K, N; int in_act; int rows_per_image;
+  int mchunk; int nsplit; int ntn, ntk; int item0; int tile0; int pad_;
+  long long ws_off;
+} MmdWgradLayer;
+int mmd_wgrad_plan(MmdWgradLayer* layers_host, int n, int rows_per_item, int* n_items, int* n_tiles, long long* ws_floats);
+int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks, double flops, double bytes, hipStream_t stream);
+
 // dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
 int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);
 

@@ -29,6 +29,22 @@ NONE, SWISH, SIGMOID = 0, 1, 2
 call = _lib.call
 
 
+class WgLayer(ctypes.Structure):
+    """MmdWgradLayer of include/mmdistill.h: one 1x1-conv weight gradient of the grouped launch (csrc/pw_wgrad_grouped.hip)."""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("in_scale", ctypes.c_void_p),
+                ("in_shift", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("M", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int),
+                ("in_act", ctypes.c_int), ("rows_per_image", ctypes.c_int), ("mchunk", ctypes.c_int), ("nsplit", ctypes.c_int),
+                ("ntn", ctypes.c_int), ("ntk", ctypes.c_int), ("item0", ctypes.c_int), ("tile0", ctypes.c_int), ("pad_", ctypes.c_int),
+                ("ws_off", ctypes.c_longlong)]
+
+
+# 1x1-conv weight gradients: deferred to the end of their backward segment and run as ONE persistent launch + a deterministic fold
+# (MMD_NO_WG_GROUP=1: one launch per layer on the weight-gradient stream, fp32 atomics - the round-1 schedule)
+WG_GROUP = not os.environ.get("MMD_NO_WG_GROUP")
+WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "512"))
+WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "1024"))
+
+
 @dataclass
 class Feat:
     """rows [B*H*W, C] plus the pending per-channel transform consumers must apply."""
@@ -117,6 +133,9 @@ class Net:
         self._anchors: Dict[int, torch.Tensor] = {}
         self._side = None
         self._wg = None           # weight-gradient stream: nothing downstream of a wgrad until the optimizer
+        self._wg_pending: list = []          # deferred 1x1-conv weight gradients of the current backward segment
+        self._wg_plans: Dict[int, dict] = {}  # segment index -> planned table (built once: arena addresses repeat every step)
+        self._wg_segment = 0
 
     # ------------------------------------------------------------------ parameters
     def load_state(self, state):
@@ -546,6 +565,49 @@ class Net:
                 return
             yield
 
+    def _pw_wgrad(self, dy: torch.Tensor, xz: torch.Tensor, dw: torch.Tensor, M: int, K: int, N: int, in_scale=None, in_shift=None,
+                  in_act: int = NONE, gate=None, rpi: int = 1):
+        """dW[N,K] (+)= dY^T pro(X).  Grouped mode: recorded, computed by _wg_flush() at the end of the backward segment."""
+        if not WG_GROUP or self.precision != "fp32" or not self.ps.flat.is_cuda:
+            with self._wgrad_stream():
+                call("mmd_pwconv_bwd_weight" + self._sfx, dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi)
+            return
+        self._wg_pending.append((dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi))
+
+    def _wg_flush(self):
+        """Launch the deferred weight gradients of this backward segment: one persistent grid over all (layer, tile, split) items
+        and one fold, on the weight-gradient stream behind everything issued so far."""
+        pend, self._wg_pending = self._wg_pending, []
+        seg = self._wg_segment
+        self._wg_segment += 1
+        if not pend:
+            return
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        sig = tuple((ptr(d), ptr(x), ptr(w), M, K, N, ptr(a), ptr(b), act, ptr(gt), rpi) for d, x, w, M, K, N, a, b, act, gt, rpi in pend)
+        plan = self._wg_plans.get(seg)
+        if plan is None or plan["sig"] != sig:
+            if self.arena.frozen and plan is not None:
+                raise RuntimeError("weight-gradient operands moved after graph capture")
+            n = len(pend)
+            arr = (WgLayer * n)()
+            for i, (d, x, w, M, K, N, a, b, act, gt, rpi) in enumerate(pend):
+                arr[i].dy, arr[i].x, arr[i].dw = ptr(d), ptr(x), ptr(w)
+                arr[i].in_scale, arr[i].in_shift, arr[i].gate = ptr(a) or None, ptr(b) or None, ptr(gt) or None
+                arr[i].M, arr[i].K, arr[i].N, arr[i].in_act, arr[i].rows_per_image = M, K, N, act, max(int(rpi), 1)
+            ni, nt, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+            rc = _lib.LIB.load().mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), n, WG_ROWS, ctypes.cast(ctypes.pointer(ni), ctypes.c_void_p),
+                                                ctypes.cast(ctypes.pointer(nt), ctypes.c_void_p), ctypes.cast(ctypes.pointer(wsf), ctypes.c_void_p))
+            if rc != 0:
+                raise RuntimeError(f"mmd_wgrad_plan failed with status {rc}")
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            plan = {"sig": sig, "table": table, "n": n, "items": ni.value, "tiles": nt.value, "ws": wsf.value,
+                    "flops": float(sum(2.0 * M * K * N for _, _, _, M, K, N, *_ in pend)),
+                    "bytes": float(sum(4.0 * (M * K + M * N + N * K) for _, _, _, M, K, N, *_ in pend))}
+            self._wg_plans[seg] = plan
+        ws = self._alloc(plan["ws"])
+        with self._wgrad_stream():
+            call("mmd_wgrad_grouped", plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS, plan["flops"], plan["bytes"])
+
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
                 mul_bc=None, mul_b=None, add_bc=None, sums=None, lazy: bool = False):
         """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated.
@@ -584,14 +646,13 @@ class Net:
             dx = self._alloc(M, K)
             dzm = self._alloc(M, N)
             call("mmd_pwconv_bwd_data_bn" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"])
-            with self._wgrad_stream():
-                call("mmd_pwconv_bwd_weight" + self._sfx, dzm, x.z, ps.g(wkey), M, K, N, *xargs)
+            self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
             return dx
-        with self._wgrad_stream():
-            if bias_key:
+        if bias_key:
+            with self._wgrad_stream():
                 call("mmd_colsum", dz, ps.g(bias_key), M, N)
-            call("mmd_pwconv_bwd_weight" + self._sfx, dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale,
-                 None if plain_in else x.shift, NONE if plain_in else x.act, gate, x.H * x.W)
+        self._pw_wgrad(dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale, None if plain_in else x.shift,
+                       NONE if plain_in else x.act, gate, x.H * x.W)
         if not want_dx:
             return None
         dx = self._alloc(M, K)
@@ -628,7 +689,7 @@ class Net:
         hw_key = f"{hname}.header.pointwise_conv.conv.weight"
         with self._wgrad_stream():
             call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
-            call("mmd_pwconv_bwd_weight" + self._sfx, dy, rec["hzd"], ps.g(hw_key), Mt, C, nout, None, None, NONE, None, 1)
+        self._pw_wgrad(dy, rec["hzd"], ps.g(hw_key), Mt, C, nout)
         dzd = self._alloc_pyr(pyr, C)
         call("mmd_pwconv_bwd_data" + self._sfx, dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
@@ -652,8 +713,7 @@ class Net:
                  desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C, self.t_scale[o:], self.t_shift[o:],
                  SWISH)
             wkey = f"{cname}.pointwise_conv.conv.weight"
-            with self._wgrad_stream():
-                call("mmd_pwconv_bwd_weight" + self._sfx, dz, L["zd"], ps.g(wkey), Mt, C, C, None, None, NONE, None, 1)
+            self._pw_wgrad(dz, L["zd"], ps.g(wkey), Mt, C, C)
             dzd = self._alloc_pyr(pyr, C)
             call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
@@ -677,6 +737,7 @@ class Net:
         A = tape["A"]
         slots: Dict[int, GradSlot] = {}
         self._bw = {"slots": slots, "stem_sums": None}
+        self._wg_pending, self._wg_segment = [], 0
 
         def slot(f: Feat) -> GradSlot:
             return slots.setdefault(f.z.data_ptr(), GradSlot())
@@ -792,8 +853,10 @@ class Net:
         self._backward_blocks([b for b in spec.blocks if stop_before is None or b.idx >= stop_before])
         if stop_before is None:
             self.backward_finish(0)
-        elif self._wg is not None:
-            torch.cuda.current_stream().wait_stream(self._wg)
+        else:
+            self._wg_flush()
+            if self._wg is not None:
+                torch.cuda.current_stream().wait_stream(self._wg)
 
     def backward_finish(self, stop_before: int):
         """Second part of a split backward: backbone blocks < stop_before, then the stem."""
@@ -879,7 +942,7 @@ class Net:
         with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
             col = self._alloc(stem.M, ps.stem_kp)
             call("mmd_stem_im2col", ximg, col, ximg.shape[0], ximg.shape[1], ximg.shape[2], ximg.shape[3], ps.stem_kp)
-            call("mmd_pwconv_bwd_weight", dz, col, ps.g(f"{P}._conv_stem.conv.weight"), stem.M, ps.stem_kp, stem.C, None, None,
-                 NONE, None, 1)
+        self._pw_wgrad(dz, col, ps.g(f"{P}._conv_stem.conv.weight"), stem.M, ps.stem_kp, stem.C)
+        self._wg_flush()
         if self._wg is not None:
             torch.cuda.current_stream().wait_stream(self._wg)

@@ -148,6 +148,54 @@ def test_pwconv_fwd_remap():
     assert out[:, :off].abs().max().item() == 0 and out[:, off + HW * N:].abs().max().item() == 0
 
 
+def test_wgrad_grouped_matches_torch_and_is_deterministic():
+    """All 1x1-conv weight gradients of a backward segment in one persistent launch + fold (csrc/pw_wgrad_grouped.hip): layers of
+    very different shapes and operand prologues (BN scale/shift + swish, squeeze-excite gate, plain) share one item table; the result
+    equals torch's autograd and - no atomics - is bit-identical run to run; dW is written, not accumulated."""
+    import ctypes
+    from mm_distillnet_amd.engine import WgLayer
+    torch.manual_seed(3)
+    shapes = [(4096, 16, 96, "aff"), (3000, 528, 88, "gate"), (130, 112, 180, ""), (8192, 112, 112, ""), (40000, 24, 144, "aff gate"),
+              (64, 1248, 208, ""), (1000, 72, 32, "")]
+    keep, refs, arr = [], [], (WgLayer * len(shapes))()
+    for i, (M, K, N, fl) in enumerate(shapes):
+        B = 2
+        rpi = M // B
+        x = torch.randn(M, K); dy = torch.randn(M, N)
+        isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+        gate = torch.rand(B, K)
+        a = x
+        if "aff" in fl:
+            a = swish(a * isc + ish)
+        if "gate" in fl:
+            a = a * gate.repeat_interleave(rpi, 0)
+        refs.append(dy.double().t() @ a.double())
+        dx, dd, dw = g(x), g(dy), torch.full((N, K), 7.0, device=DEV)
+        dsc, dsh, dg = (g(isc), g(ish)) if "aff" in fl else (None, None), None, g(gate) if "gate" in fl else None
+        dsc, dsh = dsc if "aff" in fl else (None, None)
+        keep.append((dx, dd, dw, dsc, dsh, dg))
+        arr[i].dy, arr[i].x, arr[i].dw = dd.data_ptr(), dx.data_ptr(), dw.data_ptr()
+        arr[i].in_scale = dsc.data_ptr() if dsc is not None else None
+        arr[i].in_shift = dsh.data_ptr() if dsh is not None else None
+        arr[i].gate = dg.data_ptr() if dg is not None else None
+        arr[i].M, arr[i].K, arr[i].N, arr[i].in_act, arr[i].rows_per_image = M, K, N, (1 if "aff" in fl else 0), rpi
+    ni, nt, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+    dll = _lib.LIB.load()
+    cv = lambda o: ctypes.cast(ctypes.pointer(o), ctypes.c_void_p)
+    assert dll.mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), len(shapes), 256, cv(ni), cv(nt), cv(wsf)) == 0
+    assert nt.value == sum(-(-N // 64) * -(-K // 64) for _, K, N, _ in shapes) and ni.value >= nt.value
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    ws = torch.full((wsf.value,), float("nan"), device=DEV)
+    outs = []
+    for rep in range(2):
+        call("mmd_wgrad_grouped", table, len(shapes), ni.value, nt.value, ws, 0 if rep else 300, 0.0, 0.0)
+        torch.cuda.synchronize()
+        outs.append([k[2].clone() for k in keep])
+    for (M, K, N, fl), ref, o0, o1 in zip(shapes, refs, outs[0], outs[1]):
+        close(o0, ref, 3e-4, 1e-5, f"grouped dW M{M} K{K} N{N} {fl}")
+        assert torch.equal(o0, o1), (M, K, N)          # different grid sizes, same bits: the fold order is fixed
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 24, 40), (4096, 16, 96), (1000, 528, 88), (130, 112, 180)])
 def test_pwconv_bwd(M, K, N):
     torch.manual_seed(M)
