@@ -41,8 +41,8 @@ class WgLayer(ctypes.Structure):
 # 1x1-conv weight gradients: deferred to the end of their backward segment and run as ONE persistent launch + a deterministic fold
 # (MMD_NO_WG_GROUP=1: one launch per layer on the weight-gradient stream, fp32 atomics - the round-1 schedule)
 WG_GROUP = not os.environ.get("MMD_NO_WG_GROUP")
-WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "512"))
-WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "1024"))
+WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "4096"))      # rows per item: 4096 x (64x64 tile) measured best (1.33 ms per step vs 2.58 at 256)
+WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "4096"))
 
 
 @dataclass
