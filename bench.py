@@ -198,6 +198,8 @@ def main():
         eng.force_ar = True
         eng.ar_split = eng._default_split()
     eng.load(sstate, tstates)
+    if os.environ.get("MMD_COMM") == "rccl" and (world > 1 or eng.force_ar):
+        eng.init_comm(rank)      # gradient exchange through the C ABI's own RCCL communicator (csrc/comm.hip) instead of torch.distributed
     if world > 1:   # identical initial student on every rank (DDP broadcasts parameters at construction)
         import torch.distributed as dist
         dist.broadcast(eng.student.ps.flat, 0)

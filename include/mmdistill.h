@@ -281,6 +281,17 @@ int mmd_image_letterbox(const void* src, int dtype, int H, int W, int C, float s
 // Resizer's audio branch: cv2.resize(INTER_CUBIC) of an [h,w,C] spectrogram stack to [C,S,S] (transformations.py:435-441).
 int mmd_resize_cubic(const float* src, int h, int w, int C, int common_size, float* dst, hipStream_t stream);
 
+
+// ---- data-parallel exchange (RCCL over xGMI), SURVEY.md section 8b.  Replaces DistributedDataParallel's gradient reduction
+// (src/optimization/train_methods.py:944-961): student gradients only, sum (the 1/N average rides in the optimizer pass), plus the
+// MAX-reduce of head_active.  librccl is opened lazily: -38 when it is not installed.
+// mmd_comm_unique_id: 128-byte rendezvous token made on rank 0 and handed to every rank by the host.
+int mmd_comm_unique_id(void* out128);
+int mmd_comm_init(void** comm_out, int rank, int world, const void* unique_id128);
+// In place, asynchronous on `stream`; dtype 0 = float32, 1 = int32; op 0 = sum, 1 = max.
+int mmd_comm_allreduce_bucket(void* comm, void* buf, long long count, int dtype, int op, hipStream_t stream);
+int mmd_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,10 @@ class DistillEngine:
             self.ar_split = None if env in ("", "none", "-1") else int(env)
         self._ar_work = None
         self.force_ar = False        # dev aid: issue the collectives on a one-rank group (bench.py MMD_FORCE_DP)
+        # MMD_COMM=rccl: the exchange goes through the C ABI's own RCCL communicator (mmd_comm_*: csrc/comm.hip) on a side HIP stream
+        # instead of torch.distributed's ProcessGroupNCCL (same library underneath); default: torch.distributed
+        self.comm = None
+        self.comm_stream = None
         self.keep = torch.tensor([1.0 - b.drop_rate for b in student_spec.blocks if b.skip], device=device).view(-1, 1)
 
     # ------------------------------------------------------------------
@@ -327,6 +331,56 @@ class DistillEngine:
         if self.ar_split is not None:
             self.student.backward_finish(self.ar_split)
 
+    def init_comm(self, rank: int):
+        """Create the C-ABI RCCL communicator (MMD_COMM=rccl).  The 128-byte rendezvous token is made on rank 0 and handed out through
+        the already-initialised torch.distributed group (any backend: it only carries these 128 bytes)."""
+        import torch.distributed as dist
+        dll = _lib.LIB.load()
+        tok = (ctypes.c_char * 128)()
+        if rank == 0:
+            rc = dll.mmd_comm_unique_id(ctypes.cast(tok, ctypes.c_void_p))
+            if rc != 0:
+                raise RuntimeError(f"mmd_comm_unique_id failed with status {rc}")
+        box = [bytes(tok)]
+        if self.world_size > 1:
+            dist.broadcast_object_list(box, src=0, group=self.pg)
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(box[0], 128)
+        rc = dll.mmd_comm_init(ctypes.cast(ctypes.pointer(h), ctypes.c_void_p), rank, self.world_size, ctypes.cast(buf, ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"mmd_comm_init failed with status {rc}")
+        self.comm = h
+        self.comm_stream = torch.cuda.Stream()
+
+    def close_comm(self):
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            _lib.LIB.load().mmd_comm_destroy(self.comm)
+            self.comm = None
+
+    def _comm_allreduce(self, phase):
+        """C-ABI path: buckets of `phase` on the communicator's stream, ordered after everything enqueued on the compute stream so
+        far; phase 1 also makes the compute stream wait for the whole exchange."""
+        dll = _lib.LIB.load()
+        g = self.student.ps.grad
+        buckets = self.grad_buckets()
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_event(cur.record_event())
+        sp = self.comm_stream.cuda_stream
+
+        def red(t, n, dtype, op):
+            rc = dll.mmd_comm_allreduce_bucket(self.comm, ctypes.c_void_p(t.data_ptr()), n, dtype, op, ctypes.c_void_p(sp))
+            if rc != 0:
+                raise RuntimeError(f"mmd_comm_allreduce_bucket failed with status {rc}")
+        if phase in (0, None):
+            for b, e in buckets[0]:
+                red(g[b:e], e - b, 0, 0)
+            red(self.head_active, 1, 1, 1)
+        if phase in (1, None):
+            for b, e in buckets[1]:
+                red(g[b:e], e - b, 0, 0)
+            cur.wait_event(self.comm_stream.record_event())
+
     def allreduce_grads(self, phase: Optional[int] = None):
         """RCCL all-reduce(sum) of the flat student gradient buffer (teachers are frozen: nothing else is
         exchanged).  The 1/world average is folded into the optimizer's grad_scale.  head_active is reduced
@@ -338,6 +392,8 @@ class DistillEngine:
         remaining ranges after the backward's end; it also makes the current stream wait for phase 0.  phase None: both."""
         if self.world_size <= 1 and not self.force_ar:
             return
+        if self.comm is not None:
+            return self._comm_allreduce(phase)
         import torch.distributed as dist
         g = self.student.ps.grad
         buckets = self.grad_buckets()

@@ -1,0 +1,138 @@
+"""Two data-parallel ranks on ONE GPU (both processes on cuda:0, gloo carrying the collectives): the N > 1 step path end to end -
+split backward, phased all-reduce of the flat student gradient buffer, head_active MAX-reduce, 1/N folded into Adam, per-rank
+BatchNorm statistics - against single-rank runs of the same two shards.  (RCCL itself needs two devices; the driver's 8-GPU run
+covers it.  Reference: DDP wrap + DistributedSampler, src/optimization/train_methods.py:944-961, src/optimization/traditional.py:58-71.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+S, B = 128, 2
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build(world, pg=None):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from test_gpu_step import build
+    eng, spec = build("pairwise", S)
+    eng.world_size = world
+    eng.pg = pg
+    if world > 1:
+        eng.ar_split = eng._default_split()
+    return eng, spec
+
+
+def _shard(rank):
+    from mm_distillnet_amd.synth import synth_inputs
+    return {k: v.to("cuda") for k, v in synth_inputs(B, S, seed=40 + rank).items()}
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng, spec = _build(world)
+    batch = _shard(rank)
+    ds = eng.make_drop_scale(B, torch.Generator(device="cuda").manual_seed(3))      # same masks as the single-rank runs
+    # eager data-parallel step, phase by phase (what DistillEngine.step does), keeping the local gradient for the check
+    eng.step_body(batch, ds)
+    g = eng.student.ps.grad
+    (p0,), tail = eng.grad_buckets()
+    seg1 = g[p0[0]:p0[1]].clone()
+    assert g[:p0[0]].abs().max().item() == 0.0            # the early blocks' gradients do not exist yet
+    eng.allreduce_grads(0)                                 # overlaps the second backward segment
+    eng.backward_tail()
+    torch.cuda.synchronize()
+    local = g.clone(); local[p0[0]:p0[1]] = seg1           # this rank's own gradient, before any reduction
+    eng.allreduce_grads(1)
+    torch.cuda.synchronize()
+    both = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    summed_ok = bool(torch.equal(g, both[0] + both[1]))
+    ha = int(eng.head_active.item())
+    eng.optimizer_body()
+    torch.cuda.synchronize()
+    flats = [torch.empty_like(eng.student.ps.flat) for _ in range(world)]
+    dist.all_gather(flats, eng.student.ps.flat)
+    same_params = bool(torch.equal(flats[0], flats[1]))
+    rms = [torch.empty_like(eng.student.ps.rmean) for _ in range(world)]
+    dist.all_gather(rms, eng.student.ps.rmean)
+    bn_per_rank = not bool(torch.equal(rms[0], rms[1]))    # plain BatchNorm2d: running statistics stay per rank
+    # captured path: three graphs + the collectives issued between them
+    eng2, _ = _build(world)
+    eng2.capture(batch)
+    eng2.replay(batch, ds)
+    torch.cuda.synchronize()
+    f2 = [torch.empty_like(eng2.student.ps.flat) for _ in range(world)]
+    dist.all_gather(f2, eng2.student.ps.flat)
+    graph_ok = bool(torch.equal(f2[0], f2[1])) and (eng2.student.ps.flat - eng.student.ps.flat).abs().max().item() <= 2.5e-4
+    q.put((rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, local.cpu(), eng.student.ps.flat.cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_rank_runs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, _, _ in res:
+        assert summed_ok, "all-reduced buffer != sum of the ranks' gradients"
+        assert same_params and bn_per_rank and graph_ok, (rank, same_params, bn_per_rank, graph_ok)
+    assert res[0][2] == res[1][2]                          # head_active agreed (MAX-reduced)
+    # single-rank runs of the two shards: same gradients (up to the atomics' summation order), and Adam on (gA + gB) / 2
+    grads = []
+    for rank in range(2):
+        eng, _ = _build(1)
+        ds = eng.make_drop_scale(B, torch.Generator(device="cuda").manual_seed(3))
+        eng.step_body(_shard(rank), ds)
+        torch.cuda.synchronize()
+        grads.append(eng.student.ps.grad.clone())
+        tol = 2e-3 * grads[rank].abs().max().item()
+        assert (grads[rank].cpu() - res[rank][6]).abs().max().item() <= tol
+    eng, _ = _build(1)
+    eng.world_size = 2                                      # 1/N folded into the optimizer
+    eng.student.ps.grad.copy_(grads[0] + grads[1])
+    eng.head_active.fill_(res[0][2])
+    eng.optimizer_body()
+    torch.cuda.synchronize()
+    assert (eng.student.ps.flat.cpu() - res[0][7]).abs().max().item() <= 2.5e-4      # one Adam step moves a weight by <= lr
+
+
+def test_c_abi_rccl_communicator_one_rank():
+    """mmd_comm_* (csrc/comm.hip): a one-rank RCCL communicator through the C ABI - rendezvous token, init, in-place
+    all-reduce of a gradient range (sum) and of the head_active flag (max) on a side stream, destroy.  With one rank the collective
+    is the identity; what is exercised is the binding, the dtype / op mapping and the stream ordering."""
+    import ctypes
+    from mm_distillnet_amd import _lib
+    dll = _lib.LIB.load()
+    tok = (ctypes.c_char * 128)()
+    assert dll.mmd_comm_unique_id(ctypes.cast(tok, ctypes.c_void_p)) == 0
+    h = ctypes.c_void_p()
+    assert dll.mmd_comm_init(ctypes.cast(ctypes.pointer(h), ctypes.c_void_p), 0, 1, ctypes.cast(tok, ctypes.c_void_p)) == 0
+    g = torch.randn(1 << 20, device="cuda"); ref = g.clone()
+    flag = torch.tensor([1], dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_event(torch.cuda.current_stream().record_event())
+    assert dll.mmd_comm_allreduce_bucket(h, ctypes.c_void_p(g[1024:].data_ptr()), g.numel() - 1024, 0, 0, ctypes.c_void_p(side.cuda_stream)) == 0
+    assert dll.mmd_comm_allreduce_bucket(h, ctypes.c_void_p(flag.data_ptr()), 1, 1, 1, ctypes.c_void_p(side.cuda_stream)) == 0
+    torch.cuda.current_stream().wait_event(side.record_event())
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref) and int(flag.item()) == 1
+    assert dll.mmd_comm_allreduce_bucket(h, None, 4, 0, 0, None) == -22
+    assert dll.mmd_comm_destroy(h) == 0

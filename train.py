@@ -142,6 +142,8 @@ def main(argv=None):
         import torch.distributed as dist
         dist.broadcast(eng.student.ps.flat, 0)
         eng.student.refresh()
+        if os.environ.get("MMD_COMM") == "rccl":
+            eng.init_comm(rank)      # exchange through the C ABI's RCCL communicator (csrc/comm.hip) instead of torch.distributed
     # input_pipeline = raw: samples arrive as decoded frames (uint8/uint16/float mel stacks) and Normalizer/Resizer/transposes
     # run on the GPU on a copy stream (mm_distillnet_amd.data.DeviceInputPipeline); default: ready-made tensors
     raw = cfg.get("input_pipeline", "tensor") == "raw"
