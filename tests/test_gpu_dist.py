@@ -75,7 +75,7 @@ def _worker(rank, world, port, q):
     f2 = [torch.empty_like(eng2.student.ps.flat) for _ in range(world)]
     dist.all_gather(f2, eng2.student.ps.flat)
     graph_ok = bool(torch.equal(f2[0], f2[1])) and (eng2.student.ps.flat - eng.student.ps.flat).abs().max().item() <= 2.5e-4
-    q.put((rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, local.cpu(), eng.student.ps.flat.cpu()))
+    q.put((rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, local.cpu().numpy(), eng.student.ps.flat.cpu().numpy()))      # numpy: pickled by value (torch tensors travel as shared-memory handles that die with the child)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -104,14 +104,14 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
         torch.cuda.synchronize()
         grads.append(eng.student.ps.grad.clone())
         tol = 2e-3 * grads[rank].abs().max().item()
-        assert (grads[rank].cpu() - res[rank][6]).abs().max().item() <= tol
+        assert (grads[rank].cpu() - torch.from_numpy(res[rank][6])).abs().max().item() <= tol
     eng, _ = _build(1)
     eng.world_size = 2                                      # 1/N folded into the optimizer
     eng.student.ps.grad.copy_(grads[0] + grads[1])
     eng.head_active.fill_(res[0][2])
     eng.optimizer_body()
     torch.cuda.synchronize()
-    assert (eng.student.ps.flat.cpu() - res[0][7]).abs().max().item() <= 2.5e-4      # one Adam step moves a weight by <= lr
+    assert (eng.student.ps.flat.cpu() - torch.from_numpy(res[0][7])).abs().max().item() <= 2.5e-4      # one Adam step moves a weight by <= lr
 
 
 def test_c_abi_rccl_communicator_one_rank():
