@@ -41,6 +41,10 @@ class WgLayer(ctypes.Structure):
 # 1x1-conv weight gradients: deferred to the end of their backward segment and run as ONE persistent launch + a deterministic fold
 # (MMD_NO_WG_GROUP=1: one launch per layer on the weight-gradient stream, fp32 atomics - the round-1 schedule)
 WG_GROUP = not os.environ.get("MMD_NO_WG_GROUP")
+# the OTHER leaves (depthwise / squeeze-excite / fusion-weight / bias gradients) stay forked off the main chain where they arise: small and
+# latency-bound, they fill the main chain's gaps - deferring them to the segment end as well measured 20.8-22.1 ms/step against 20.5
+WG_DEFER = WG_GROUP and bool(os.environ.get("MMD_WG_DEFER"))
+WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "60"))     # flush the grouped launch every WG_CHUNK recorded layers (two launches per D2 backward: 19.66 vs 19.8-20.2 ms/step for one, 20.5+ for four)
 WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "4096"))      # rows per item: 4096 x (64x64 tile) measured best (1.33 ms per step vs 2.58 at 256)
 WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "4096"))
 
@@ -134,6 +138,7 @@ class Net:
         self._side = None
         self._wg = None           # weight-gradient stream: nothing downstream of a wgrad until the optimizer
         self._wg_pending: list = []          # deferred 1x1-conv weight gradients of the current backward segment
+        self._leaf_pending: list = []        # other deferred leaves (closures), issued by _wg_flush
         self._wg_plans: Dict[int, dict] = {}  # segment index -> planned table (built once: arena addresses repeat every step)
         self._wg_segment = 0
 
@@ -573,13 +578,30 @@ class Net:
                 call("mmd_pwconv_bwd_weight" + self._sfx, dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi)
             return
         self._wg_pending.append((dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi))
+        if WG_CHUNK > 0 and len(self._wg_pending) >= WG_CHUNK:
+            self._wg_flush()
+
+    def _leaf(self, fn):
+        """A leaf of the backward graph other than a 1x1-conv weight gradient (depthwise / squeeze-excite / fusion-weight / bias
+        gradients): in grouped mode it is issued by _wg_flush() with the rest, behind ONE cross-stream dependency, instead of forking
+        off the main chain at ~160 points of the step (every fork is an event record + wait = a cross-branch edge of the graph)."""
+        if WG_DEFER and self.ps.flat.is_cuda:
+            self._leaf_pending.append(fn)
+        else:
+            with self._wgrad_stream():
+                fn()
 
     def _wg_flush(self):
         """Launch the deferred weight gradients of this backward segment: one persistent grid over all (layer, tile, split) items
         and one fold, on the weight-gradient stream behind everything issued so far."""
         pend, self._wg_pending = self._wg_pending, []
+        leaves, self._leaf_pending = self._leaf_pending, []
         seg = self._wg_segment
         self._wg_segment += 1
+        if leaves:
+            with self._wgrad_stream():
+                for fn in leaves:
+                    fn()
         if not pend:
             return
         ptr = lambda t: 0 if t is None else t.data_ptr()
@@ -649,8 +671,7 @@ class Net:
             self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
             return dx
         if bias_key:
-            with self._wgrad_stream():
-                call("mmd_colsum", dz, ps.g(bias_key), M, N)
+            self._leaf(lambda dz=dz, gb=ps.g(bias_key): call("mmd_colsum", dz, gb, M, N))
         self._pw_wgrad(dz, x.z, ps.g(wkey), M, K, N, None if plain_in else x.scale, None if plain_in else x.shift,
                        NONE if plain_in else x.act, gate, x.H * x.W)
         if not want_dx:
@@ -663,8 +684,8 @@ class Net:
         """-> dx, or (dx, sums) when `bn_aff` = (scale, shift, mean, invstd) of the BatchNorm(+swish) that produced x: the
         stride-1 input-gradient launch then also accumulates that BN's backward sums (no separate reduce pass)."""
         ps = self.ps
-        with self._wgrad_stream():
-            call("mmd_dwconv_bwd_weight", x.z, dzd, ps.g(wkey), x.B, x.H, x.W, x.C, k, s, x.scale, x.shift, x.act)
+        self._leaf(lambda x=x, dzd=dzd, gw=ps.g(wkey): call("mmd_dwconv_bwd_weight", x.z, dzd, gw, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift,
+                                                             x.act))
         if not want_dx:
             return None
         dx = self._alloc(x.M, x.C)
@@ -687,15 +708,13 @@ class Net:
         for lvl, (h, w) in enumerate(pyr["sizes"]):
             call("mmd_slice_rows", dout, dy[pyr["row0"][lvl]:], pyr["B"], h * w, nout, A * per_anchor, rec["yoff"][lvl])
         hw_key = f"{hname}.header.pointwise_conv.conv.weight"
-        with self._wgrad_stream():
-            call("mmd_colsum", dy, ps.g(f"{hname}.header.pointwise_conv.conv.bias"), Mt, nout)
+        self._leaf(lambda dy=dy, gb=ps.g(f"{hname}.header.pointwise_conv.conv.bias"): call("mmd_colsum", dy, gb, Mt, nout))
         self._pw_wgrad(dy, rec["hzd"], ps.g(hw_key), Mt, C, nout)
         dzd = self._alloc_pyr(pyr, C)
         call("mmd_pwconv_bwd_data" + self._sfx, dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
-        with self._wgrad_stream():
-            call("mmd_dwconv3_pyr_bwd_weight", rec["hx"], dzd, ps.g(f"{hname}.header.depthwise_conv.conv.weight"), desc, C,
-                 self.t_scale[xo:], self.t_shift[xo:], SWISH, ls)
+        self._leaf(lambda hx=rec["hx"], dzd=dzd, gw=ps.g(f"{hname}.header.depthwise_conv.conv.weight"), sc=self.t_scale[xo:], sh=self.t_shift[xo:]:
+                   call("mmd_dwconv3_pyr_bwd_weight", hx, dzd, gw, desc, C, sc, sh, SWISH, ls))
         g = self._alloc_pyr(pyr, C)
         call("mmd_dwconv3_pyr", dzd, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
              None, None, None, 0)
@@ -717,10 +736,9 @@ class Net:
             dzd = self._alloc_pyr(pyr, C)
             call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
-            with self._wgrad_stream():
-                call("mmd_dwconv3_pyr_bwd_weight", L["x"], dzd, ps.g(f"{cname}.depthwise_conv.conv.weight"), desc, C,
-                     None if xo is None else self.t_scale[xo:], None if xo is None else self.t_shift[xo:],
-                     NONE if xo is None else SWISH, ls)
+            self._leaf(lambda lx=L["x"], dzd=dzd, gw=ps.g(f"{cname}.depthwise_conv.conv.weight"), sc=None if xo is None else self.t_scale[xo:],
+                       sh=None if xo is None else self.t_shift[xo:], act=NONE if xo is None else SWISH:
+                       call("mmd_dwconv3_pyr_bwd_weight", lx, dzd, gw, desc, C, sc, sh, act, ls))
             g = self._alloc_pyr(pyr, C)
             call("mmd_dwconv3_pyr", dzd, ps.w(f"{cname}.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
                  None, None, None, 0)
@@ -737,7 +755,7 @@ class Net:
         A = tape["A"]
         slots: Dict[int, GradSlot] = {}
         self._bw = {"slots": slots, "stem_sums": None}
-        self._wg_pending, self._wg_segment = [], 0
+        self._wg_pending, self._leaf_pending, self._wg_segment = [], [], 0
 
         def slot(f: Feat) -> GradSlot:
             return slots.setdefault(f.z.data_ptr(), GradSlot())
@@ -809,8 +827,7 @@ class Net:
                 wdot = self._zalloc((4,))
                 call("mmd_bifpn_node_dw_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
                      ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs)
-                with self._wgrad_stream():
-                    call("mmd_bifpn_theta_bwd", th, wdot, ps.g(f"{cell}.{rec['theta']}"), nth)
+                self._leaf(lambda th=th, wdot=wdot, gt=ps.g(f"{cell}.{rec['theta']}"), nth=nth: call("mmd_bifpn_theta_bwd", th, wdot, gt, nth))
                 wi = 1 + (1 if in1 is not None else 0)
                 for operand, kind in ((up, "up"), (pl, "pool")):
                     if operand is None:
@@ -905,10 +922,9 @@ class Net:
             call("mmd_se_fc_bwd", pool5[0], rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
                  ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, None, None, None, None,
                  f1.B, blk.cmid, blk.se, pool5, sums1)
-            with self._wgrad_stream():
-                call("mmd_se_fc_wgrad", dpe, dpr, rec["hpre"], rec["pooled"], ps.g(f"{q}._se_reduce.conv.weight"),
-                     ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"), ps.g(f"{q}._se_expand.conv.bias"),
-                     f1.B, blk.cmid, blk.se)
+            self._leaf(lambda dpe=dpe, dpr=dpr, hp=rec["hpre"], po=rec["pooled"], g1_=ps.g(f"{q}._se_reduce.conv.weight"),
+                       g2_=ps.g(f"{q}._se_reduce.conv.bias"), g3_=ps.g(f"{q}._se_expand.conv.weight"), g4_=ps.g(f"{q}._se_expand.conv.bias"),
+                       nb=f1.B, cm=blk.cmid, se=blk.se: call("mmd_se_fc_wgrad", dpe, dpr, hp, po, g1_, g2_, g3_, g4_, nb, cm, se))
             dz1 = self._bn_bwd(g1, f1.z, a1, f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
                                add_bc=dpooled, sums=sums1)
             f0: Feat = rec.get("f0", inp)
