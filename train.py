@@ -124,7 +124,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", ngpu * args.nodes if cfg.get("engine") == "DistributedDataParallel" else 1))
     os.makedirs(cfg["exp_name"], exist_ok=True)
     logging.basicConfig(level=logging.INFO, handlers=[logging.StreamHandler(),
-                                                      logging.FileHandler(f"{cfg['exp_name']}/{cfg['exp_name']}.{rank}.log")])
+                                                      logging.FileHandler(f"{cfg['exp_name']}/{os.path.basename(cfg['exp_name'].rstrip('/'))}.{rank}.log")])
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
