@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const MmdWgradLayer*
   const int c4 = (tid & 15) * 4;         // column offset inside the 64-wide tile
   const int lrow = tid >> 4;             // 0..15
   int li = 0;
+  // (an XCD-aware walk - consecutive items, i.e. the tiles that re-read one M slab, on one XCD - measured SLOWER: family 1.33-1.45 ->
+  // 1.72-1.79 ms per step; the plain stride spreads every layer over all XCDs and balances better than the L2 reuse is worth)
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     while (sItem0[li + 1] <= item) ++li;              // items are visited in increasing order: amortised O(1)
     li = __builtin_amdgcn_readfirstlane(li);          // block-uniform: the layer record comes in through scalar loads
