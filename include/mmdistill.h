@@ -164,6 +164,10 @@ int mmd_nms_teacher(const float* cand, const int* n_keep, const float* over_scor
 // merge01 != 0: image 1 also takes image 0's rows, in front of its own, when both have rows (augment=True, :379-387).
 int mmd_nms_merge(const float* t0, const int* c0, const float* t1, const int* c1, const float* t2, const int* c2, int nteachers, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, int cap, float* big_ws, hipStream_t stream);
 
+// The same merge over 1..4 sources (host arrays of device pointers, teacher order); the 4th source is the "augmentation" pass of
+// ModelWithNMSKDListLossAugmented (src/optimization/train_methods.py:73-110).  big_ws: B * mmd_nms_ws_floats(nsrc * cap * (merge01 ? 2 : 1)).
+int mmd_nms_merge_n(const float* const* srcs, const int* const* cnts, int nsrc, float iou_threshold, int inclusive, int B, float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, int cap, float* big_ws, hipStream_t stream);
+
 // Floats per image of `big_ws` for NMS lists of up to nmax rows (0 when nmax <= 1024).  mmd_nms_merge: nmax = nteachers * cap * (merge01 ? 2 : 1).
 int mmd_nms_ws_floats(int nmax);
 

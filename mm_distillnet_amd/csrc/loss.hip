@@ -50,17 +50,18 @@ __device__ __forceinline__ float block_max(float v, float* sm, int tid) {
 // If da_s != null: da_s[b,j] (+)= dL/d a_s[b,j] * gscale   (student side only; teachers are constants).
 // accumulate: 0 = store, 1 = read-modify-write (sequential launches), 2 = atomic (concurrent blocks write the same da_s)
 __device__ __forceinline__ void mta_kl_body(const float* __restrict__ a_s, const float* __restrict__ t0,
-                                            const float* __restrict__ t1, const float* __restrict__ t2, int nt,
+                                            const float* __restrict__ t1, const float* __restrict__ t2, const float* __restrict__ t3, int nt,
                                             int HW, int B, float T, float* loss, float* da_s, float gscale,
                                             int accumulate, int b, float* sm) {
   const int tid = threadIdx.x;
   const float* as = a_s + (size_t)b * HW;
-  const float* tp[3] = {t0 + (size_t)b * HW, t1 ? t1 + (size_t)b * HW : nullptr, t2 ? t2 + (size_t)b * HW : nullptr};
+  const float* tp[4] = {t0 + (size_t)b * HW, t1 ? t1 + (size_t)b * HW : nullptr, t2 ? t2 + (size_t)b * HW : nullptr,
+                        t3 ? t3 + (size_t)b * HW : nullptr};
   // L2 norms
   float acc = 0.f;
   for (int j = tid; j < HW; j += 256) acc += as[j] * as[j];
   const float ns = fmaxf(sqrtf(block_sum(acc, sm, tid)), 1e-12f);
-  float nk[3] = {1.f, 1.f, 1.f};
+  float nk[4] = {1.f, 1.f, 1.f, 1.f};
   for (int k = 0; k < nt; ++k) {
     acc = 0.f;
     for (int j = tid; j < HW; j += 256) acc += tp[k][j] * tp[k][j];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a
                                                      int HW, int B, float T, float* loss, float* da_s, float gscale,
                                                      int accumulate) {
   __shared__ float sm[8];
-  mta_kl_body(a_s, t0, t1, t2, nt, HW, B, T, loss, da_s, gscale, accumulate, blockIdx.x, sm);
+  mta_kl_body(a_s, t0, t1, t2, nullptr, nt, HW, B, T, loss, da_s, gscale, accumulate, blockIdx.x, sm);
 }
 
 // Every (level, teacher) pair of a step in ONE launch: grid (B, levels, pairs).  The per-pair launches are 8-block kernels
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a
 //   pairwise mode (ModelWithNMSLoss): pairs = teachers, loss[t*nlev + l]; da_s[l] accumulates over teachers with atomics (zero on entry)
 //   list mode (ModelWithNMSKDListLoss): pairs = 1, each block multiplies the nt teacher maps, loss[l]
 #define MTA_MAX_LEV 5
-#define MTA_MAX_T 3
+#define MTA_MAX_T 4      // 3 teachers + the "augmentation" pass of ModelWithNMSKDListLossAugmented (src/optimization/train_methods.py:73-110)
 struct MtaMulti {
   const float* a_s[MTA_MAX_LEV]; const float* a_t[MTA_MAX_T][MTA_MAX_LEV]; float* da[MTA_MAX_LEV]; int HW[MTA_MAX_LEV];
   int nt, list_mode, B; float T, gscale; float* loss;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(256) void mta_kl_multi_kernel(MtaMulti m) {
   __shared__ float sm[8];
   const int l = blockIdx.y, t = blockIdx.z, nlev = gridDim.y;
   if (m.list_mode)
-    mta_kl_body(m.a_s[l], m.a_t[0][l], m.nt > 1 ? m.a_t[1][l] : nullptr, m.nt > 2 ? m.a_t[2][l] : nullptr, m.nt, m.HW[l], m.B, m.T,
-                m.loss + l, m.da[l], m.gscale, 0, blockIdx.x, sm);
+    mta_kl_body(m.a_s[l], m.a_t[0][l], m.nt > 1 ? m.a_t[1][l] : nullptr, m.nt > 2 ? m.a_t[2][l] : nullptr,
+                m.nt > 3 ? m.a_t[3][l] : nullptr, m.nt, m.HW[l], m.B, m.T, m.loss + l, m.da[l], m.gscale, 0, blockIdx.x, sm);
   else
-    mta_kl_body(m.a_s[l], m.a_t[t][l], nullptr, nullptr, 1, m.HW[l], m.B, m.T, m.loss + t * nlev + l, m.da[l], m.gscale,
+    mta_kl_body(m.a_s[l], m.a_t[t][l], nullptr, nullptr, nullptr, 1, m.HW[l], m.B, m.T, m.loss + t * nlev + l, m.da[l], m.gscale,
                 m.nt > 1 ? 2 : 0, blockIdx.x, sm);
 }
 extern "C" int mmd_mta_kl_multi(const float* const* a_s, const float* const* a_t, float* const* da_s, const int* HW, int nlev,

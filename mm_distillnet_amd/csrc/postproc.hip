@@ -126,7 +126,7 @@ extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float
 // kept so far, then resolved internally with the bitmask - with the sorted order, the kept list and the chunk bitmask in a global
 // workspace.  Greedy NMS only ever compares a candidate with EARLIER KEPT boxes, so the chunked result is the sequential one, bit for bit.
 struct NmsArgs {
-  const float* src[3]; const int* cnt[3]; int nsrc;
+  const float* src[4]; const int* cnt[4]; int nsrc;
   int mode; float thr; int inclusive;
   const float* over_scores; const int* label_map; float image_size;
   float* out; int* out_cnt; int out_cols; int out_cap;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
   __shared__ int s_n, s_nk;
   const int b = blockIdx.x, tid = threadIdx.x;
   // gather source rows (concatenation order = source order)
-  int cnts[3] = {0, 0, 0}, cnts0[3] = {0, 0, 0}, n = 0, n0 = 0;
+  int cnts[4] = {0, 0, 0, 0}, cnts0[4] = {0, 0, 0, 0}, n = 0, n0 = 0;
   for (int s = 0; s < a.nsrc; ++s) { cnts[s] = min(a.cnt[s][b], a.in_cap); n += cnts[s]; }
   if (a.merge01 && b == 1 && n > 0) {
     for (int s = 0; s < a.nsrc; ++s) { cnts0[s] = min(a.cnt[s][0], a.in_cap); n0 += cnts0[s]; }
@@ -394,6 +394,22 @@ extern "C" int mmd_nms_merge(const float* t0, const int* c0, const float* t1, co
   a.mode = 1; a.thr = iou_threshold; a.inclusive = inclusive; a.merge01 = (merge01 && B >= 2) ? 1 : 0;
   a.out = boxes; a.out_cnt = nbox; a.out_cols = 5; a.out_cap = maxg; a.mask_ws = mask_ws; a.overflow = overflow;
   a.in_cap = cap; a.nmax = nteachers * cap * (a.merge01 ? 2 : 1); a.big_ws = big_ws; a.P = pp_pow2(a.nmax);
+  a.big_stride = mmd_nms_ws_floats(a.nmax);
+  hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
+  return mmd_check_launch();
+}
+
+// Same merge over up to 4 sources given as host arrays of device pointers (the 4th: the "augmentation" pass of
+// ModelWithNMSKDListLossAugmented, src/optimization/train_methods.py:73-110, whose labels are concatenated after the teachers').
+extern "C" int mmd_nms_merge_n(const float* const* srcs, const int* const* cnts, int nsrc, float iou_threshold, int inclusive, int B,
+                               float* boxes, int* nbox, int maxg, unsigned long long* mask_ws, int* overflow, int merge01, int cap,
+                               float* big_ws, hipStream_t stream) {
+  if (!srcs || !cnts || !boxes || !nbox || !mask_ws || !overflow || B <= 0 || nsrc < 1 || nsrc > 4 || maxg <= 0 || cap <= 0) return MMD_EINVAL;
+  NmsArgs a{};
+  for (int i = 0; i < nsrc; ++i) { if (!srcs[i] || !cnts[i]) return MMD_EINVAL; a.src[i] = srcs[i]; a.cnt[i] = cnts[i]; }
+  a.nsrc = nsrc; a.mode = 1; a.thr = iou_threshold; a.inclusive = inclusive; a.merge01 = (merge01 && B >= 2) ? 1 : 0;
+  a.out = boxes; a.out_cnt = nbox; a.out_cols = 5; a.out_cap = maxg; a.mask_ws = mask_ws; a.overflow = overflow;
+  a.in_cap = cap; a.nmax = nsrc * cap * (a.merge01 ? 2 : 1); a.big_ws = big_ws; a.P = pp_pow2(a.nmax);
   a.big_stride = mmd_nms_ws_floats(a.nmax);
   hipLaunchKernelGGL(pp_nms_kernel, dim3(B), dim3(1024), 0, stream, a);
   return mmd_check_launch();

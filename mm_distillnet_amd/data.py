@@ -45,6 +45,28 @@ class SyntheticMultimodalDetection(Dataset):
         audio = torch.nn.functional.interpolate(raw, size=(S, S), mode="bicubic", align_corners=False)[0]
         return rgb, thermal, depth, audio, None, i
 
+    def yield_batch(self, batch_size, ids):
+        return _yield_batch(self, batch_size, ids)
+
+
+def _yield_batch(ds, batch_size, ids):
+    """`MultimodalDetection.yield_batch` (src/datasets/MultimodalDetection.py:352-367): for every sample of the batch draw ANOTHER recording
+    (numpy's global RNG, like upstream), return its RGB frame and the spectrograms of the two recordings' MIXED audio.  Upstream mixes
+    the waveforms with librosa (`merge_audios`, :329-350: (a1 + a2) / 2 -> mel spectrogram -> cv2 resize); the synthetic dataset has no
+    waveforms, so it mixes the dB-scale spectrograms as incoherent sources at half amplitude each: 10 log10(10^(a/10) + 10^(b/10)) - 6 dB.
+    -> (rgb [B,3,S,S], audio [B,8,S,S])"""
+    import numpy as np
+    mine = set(int(i) for i in ids)
+    pool = [i for i in range(len(ds)) if i not in mine]
+    picks = np.random.choice(pool, size=batch_size)
+    rgbs, audios = [], []
+    for k in range(batch_size):
+        rgb2, _, _, a2, _, _ = ds[int(picks[k])]
+        a1 = ds[int(ids[k])][3]
+        mix = 10.0 * torch.log10(torch.pow(10.0, a1 / 10.0) + torch.pow(10.0, a2 / 10.0)) - 6.0206
+        rgbs.append(rgb2); audios.append(mix)
+    return torch.stack(rgbs), torch.stack(audios)
+
 
 def collate(batch):
     items = list(zip(*batch))

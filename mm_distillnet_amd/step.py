@@ -91,6 +91,7 @@ class DistillEngine:
             self.valid_mask |= 1 << int(i)
         self.cap = int(cfg.cand_cap)     # 0: set to the anchor count at the first step
         self.graph = None
+        self._graphs: Dict[str, tuple] = {}       # step variant ("plain" / "aug") -> (static inputs, g_main, g_tail, g_opt, outputs)
         self.concurrent_teachers = True
         self.side_streams: List = []
         self.fork_stream = True if torch.cuda.is_available() and str(device).startswith("cuda") else None
@@ -179,15 +180,16 @@ class DistillEngine:
         return self.ws.alloc((B * n,)) if n else None
 
     def _merge(self, rows_t, cnt_t, B: int, augment: bool):
-        """cross-teacher concat + NMS -> (boxes [B,G,5], nbox [B], G)"""
+        """cross-teacher concat + NMS -> (boxes [B,G,5], nbox [B], G).  Up to 4 sources: the teachers in ModuleDict order, then the
+        "augmentation" pass of ModelWithNMSKDListLossAugmented."""
         nt, cap = len(rows_t), self.cap
         nmax = nt * cap * (2 if (augment and B >= 2) else 1)
         G = self.cfg.max_boxes if self.cfg.max_boxes > 0 else nmax
         boxes = self.ws.alloc((B, G, 5)); nbox = self.ws.alloc((B,), torch.int32)
-        call("mmd_nms_merge", rows_t[0], cnt_t[0], rows_t[1] if nt > 1 else None, cnt_t[1] if nt > 1 else None,
-             rows_t[2] if nt > 2 else None, cnt_t[2] if nt > 2 else None, nt, float(self.cfg.merge_iou),
-             1 if self.cfg.inclusive_nms else 0, B, boxes, nbox, G, self.mask_ws, self.overflow, 1 if augment else 0, cap,
-             self._nms_ws(B, nmax))
+        vp = ctypes.c_void_p
+        srcs = (vp * nt)(*[t.data_ptr() for t in rows_t]); cnts = (vp * nt)(*[t.data_ptr() for t in cnt_t])
+        call("mmd_nms_merge_n", srcs, cnts, nt, float(self.cfg.merge_iou), 1 if self.cfg.inclusive_nms else 0, B, boxes, nbox, G,
+             self.mask_ws, self.overflow, 1 if augment else 0, cap, self._nms_ws(B, nmax))
         return boxes, nbox, G
 
     def _pseudo_labels(self, net: Net, cls, reg, B: int, A: int, S: int):
@@ -268,7 +270,7 @@ class DistillEngine:
         da_all = self.ws.alloc((st._pyr["total"],))
         call("mmd_memset_async", da_all, 0, da_all.numel() * 4)
         da = [da_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
-        nt = len(self.teachers)
+        nt = len(self.teachers) + (1 if (cfg.kd_mode == "list" and batch.get("aug_rgb") is not None) else 0)
         kd = self.ws.alloc((nt if cfg.kd_mode == "pairwise" else 1, nlv))
         call("mmd_memset_async", kd, 0, kd.numel() * 4)
         # the three frozen teachers are independent of each other and of the student forward: issue them on
@@ -278,13 +280,23 @@ class DistillEngine:
         concurrent = self.concurrent_teachers and torch.cuda.is_available()
         if concurrent and not self.side_streams:
             self.side_streams = [torch.cuda.Stream() for _ in self.teachers]
-        for ti, (mod, net) in enumerate(self.teachers.items()):
-            side = self.side_streams[ti] if concurrent else main_stream
-            if concurrent:
+        passes = [(mod, net, ti, None) for ti, (mod, net) in enumerate(self.teachers.items())]
+        if cfg.kd_mode == "list" and batch.get("aug_rgb") is not None:
+            # ModelWithNMSKDListLossAugmented.forward(augment=True) (src/optimization/train_methods.py:73-110): the RGB teacher once more,
+            # on `label` = RGB frames of the recordings whose audio was mixed into this batch; its pseudo-labels are concatenated after
+            # the teachers' and its features join the MTA list.  Same net object, same side stream: the second pass starts after the
+            # first one's labels / attention maps have been taken (stream order), so it may reuse the net's arena.
+            if "rgb" not in self.teachers:
+                raise ValueError("the augmentation pass runs the RGB teacher")
+            passes.append(("augmentation", self.teachers["rgb"], list(self.teachers).index("rgb"), batch["aug_rgb"]))
+        for pi, (mod, net, si, xin) in enumerate(passes):
+            ti = pi
+            side = self.side_streams[si] if concurrent else main_stream
+            if concurrent and xin is None:
                 side.wait_event(fork_event)
             with torch.cuda.stream(side):
                 net.begin_step()
-                cls_t, reg_t, feats_t = net.forward(audio if mod == "audio" else batch[mod], train=False)
+                cls_t, reg_t, feats_t = net.forward(xin if xin is not None else (audio if mod == "audio" else batch[mod]), train=False)
                 if cfg.augment and B >= 2:      # average_batch_0_1 on the (already consumed by the heads) feature maps
                     for f in feats_t:
                         call("mmd_avg_image01", f.z, f.H * f.W * f.C)
@@ -439,12 +451,21 @@ class DistillEngine:
         self.optimizer_body()
         return out
 
+    @staticmethod
+    def _variant(batch) -> str:
+        return "aug" if (batch is not None and batch.get("aug_rgb") is not None) else "plain"
+
     def capture(self, batch: Dict[str, torch.Tensor]):
         """Warm up eagerly (sizes the arenas), then capture forward+loss+backward and the optimizer as
         hipGraphs (the backward in two segments when world_size > 1); the gradient all-reduce is launched eagerly between
-        them (RCCL is not captured) and overlaps with the second backward segment."""
+        them (RCCL is not captured) and overlaps with the second backward segment.
+        One set of graphs per step variant: "plain", and "aug" when the batch carries `aug_rgb` (the extra RGB-teacher pass of
+        ModelWithNMSKDListLossAugmented); replay() picks by the batch's keys and captures a missing variant on first use."""
         B = batch["audio"].shape[0]
-        self.static = {k: v.clone() for k, v in batch.items()}
+        arenas = [self.ws, self.student.arena, self.student.zarena] + [a for n in self.teachers.values() for a in (n.arena, n.zarena)]
+        for arena in arenas:
+            arena.frozen = False             # a later variant may need more workspace: chunks are only ever appended
+        self.static = {k: v.clone() for k, v in batch.items() if v is not None}
         self.static["drop_scale"] = self.make_drop_scale(B)
         torch.cuda.synchronize()
         # snapshot so the warm-up steps do not change the training trajectory
@@ -460,13 +481,14 @@ class DistillEngine:
                 self.optimizer_body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for arena in [self.ws, self.student.arena, self.student.zarena] + [a for n in self.teachers.values() for a in (n.arena, n.zarena)]:
+        for arena in arenas:
             arena.frozen = True
         # thread_local: with a process group alive, the RCCL watchdog thread polls its own events; under the default
         # "global" mode such a call from another thread would invalidate the capture
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.step_body(self.static, self.static["drop_scale"])
+        out = self.out
         self.g_tail = None
         if self.ar_split is not None:
             self.g_tail = torch.cuda.CUDAGraph()
@@ -481,11 +503,17 @@ class DistillEngine:
         self.student.refresh()
         torch.cuda.synchronize()
         self.graph = True
+        self._graphs[self._variant(batch)] = (self.static, self.g_main, self.g_tail, self.g_opt, out)
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, drop_scale: Optional[torch.Tensor] = None):
         if batch is not None:
+            key = self._variant(batch)
+            if key not in self._graphs:
+                self.capture(batch)
+            self.static, self.g_main, self.g_tail, self.g_opt, self.out = self._graphs[key]
             for k, v in batch.items():
-                self.static[k].copy_(v, non_blocking=True)
+                if v is not None:
+                    self.static[k].copy_(v, non_blocking=True)
         B = self.static["audio"].shape[0]
         self.static["drop_scale"].copy_(drop_scale if drop_scale is not None else self.make_drop_scale(B))
         self.g_main.replay()

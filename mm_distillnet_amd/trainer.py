@@ -26,7 +26,14 @@ from .layout import param_rows
 
 logger = logging.getLogger("train")
 
-SUPPORTED_METHODS = ("traditional_nms", "traditional_nms_augmented", "traditional_nms_kdlist")
+SUPPORTED_METHODS = ("traditional_nms", "traditional_nms_augmented", "traditional_nms_kdlist", "traditional_nms_kdlist_augmented")
+
+
+def kdlist_augment_now(epoch: int) -> bool:
+    """train_traditional's draw for `traditional_nms_kdlist_augmented` (src/optimization/traditional.py:121-124):
+    random.random() > max(0.5, 0.5 + 0.5 * (1 - epoch / 50)) - never in epoch 0, half of the iterations from epoch 50 on."""
+    import random
+    return random.random() > max(0.5, 0.5 + 0.5 * (1 - epoch / 50))
 
 
 # ------------------------------------------------------------------------------------------------ optimizer

@@ -26,7 +26,8 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
                     batch: Dict[str, torch.Tensor], image_size: int, coef: int = 2,
                     drop_masks: Optional[Dict[int, torch.Tensor]] = None, conf_threshold: float = 0.3,
                     nms_threshold: float = 0.5, T: float = 9.0, p: float = 2.0, training: bool = True,
-                    kd_mode: str = "pairwise", inclusive_nms: bool = False, augment: bool = False):
+                    kd_mode: str = "pairwise", inclusive_nms: bool = False, augment: bool = False,
+                    aug_rgb: Optional[torch.Tensor] = None):
     """-> dict(reg[1], cls[1], kd: list of Tensor[5] per teacher (pairwise) or [Tensor[5]] (list),
                labels: merged [m,5] per image, logits_s, features_s)"""
     audio = batch["audio"]
@@ -38,11 +39,15 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
     logits_s, feats_s = net.forward(student, audio, coef, training, drop_masks)
     per_teacher, kd, feats_all = [], [], []
     B = batch["audio"].shape[0]
-    for mod in TEACHER_ORDER:
-        if mod not in teachers:
-            continue
+    # ModelWithNMSKDListLossAugmented.forward(augment=True) (src/optimization/train_methods.py:73-110): one more pass, the RGB teacher on
+    # `label` = RGB frames of OTHER recordings whose audio was mixed into this batch's audio; its labels and features join the lists
+    order = [m for m in TEACHER_ORDER if m in teachers] + (["augmentation"] if aug_rgb is not None else [])
+    for mod in order:
         with torch.no_grad():
-            logits_t, feats_t = net.forward(teachers[mod], batch[mod], coef, False)
+            if mod == "augmentation":
+                logits_t, feats_t = net.forward(teachers["rgb"], aug_rgb, coef, False)
+            else:
+                logits_t, feats_t = net.forward(teachers[mod], batch[mod], coef, False)
             feats_t = [f.detach() for f in feats_t]
             if augment:      # average_batch_0_1 (:279-289)
                 feats_t = [f.clone() for f in feats_t]

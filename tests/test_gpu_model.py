@@ -123,9 +123,14 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     c2 = torch.load(ck, map_location="cpu", weights_only=False)
     assert c2["epoch"] == 2 and c2["optimizer"]["state"][0]["step"] == 5
     # unsupported cfg values raise like upstream instead of silently training something else
-    for bad in ('"optimizer": "RMSprop"', '"scheduler": "OneCycle"', '"train_method": "traditional_nms_kdlist_augmented"'):
+    for bad in ('"optimizer": "RMSprop"', '"scheduler": "OneCycle"', '"train_method": "adversarial"'):
         with pytest.raises(Exception, match="Unsupported"):
             train.main(["--config_file", cfgf, "--overwrite", ov[:-1] + ", " + bad + "}", "--max_steps", "1"])
+    # traditional_nms_kdlist_augmented: from epoch 1 on some iterations mix in other recordings (4th list entry); both graph variants get used
+    draws = iter([False, True, True, False])
+    monkeypatch.setattr(train.TR, "kdlist_augment_now", lambda epoch: next(draws))
+    ov_k = ov[:-1] + ', "train_method": "traditional_nms_kdlist_augmented", "exp_name": "exp_kd"}'
+    assert np.isfinite(train.main(["--config_file", cfgf, "--overwrite", ov_k, "--max_steps", "4"]))
     # SGD / StepLR run through the same flat optimizer pass
     ov_s = ov[:-1] + ', "optimizer": "SGD", "momentum": 0.9, "weight_decay": 1e-4, "scheduler": "StepLR", "step_size": 1, "gamma": 0.5, "exp_name": "exp_sgd"}'
     assert np.isfinite(train.main(["--config_file", cfgf, "--overwrite", ov_s, "--max_steps", "3"]))

@@ -41,7 +41,7 @@ def build(variant, S=256, precision="fp32", coef=2):
     mods = {"rgb": MODS["rgb"]} if variant == "rgb1" else MODS      # "rgb1" = BASELINE configs[1]: one RGB teacher
     teachers = teacher_states(coef, mods)
     spec_s, st_s = make_state(coef, 8, 24, "audio")
-    cfg = StepConfig(image_size=S, kd_mode="list" if variant == "list" else "pairwise", augment=variant == "augmented",
+    cfg = StepConfig(image_size=S, kd_mode="list" if variant in ("list", "listaug") else "pairwise", augment=variant == "augmented",
                      precision=precision)
     eng = DistillEngine(spec_s, {k: v[0] for k, v in teachers.items()}, DEV, cfg)
     eng.load(st_s, {k: v[1] for k, v in teachers.items()})
@@ -66,7 +66,14 @@ def grad_checks(gold, grads, norm_tol, head_rtol, head_atol):
             check_summary(gold, "grad." + name, grads[name], head_rtol, head_atol)
 
 
-@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented", "rgb1"])
+def step_batch(variant, B, S):
+    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=31).items()}
+    if variant == "listaug":      # ModelWithNMSKDListLossAugmented: `label` = RGB frames of other recordings, a 4th list entry
+        batch["aug_rgb"] = synth_inputs(B, S, seed=57)["rgb"].to(DEV)
+    return batch
+
+
+@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented", "rgb1", "listaug"])
 def test_step_golden_reference_labels(golden_dir, variant):
     """Whole-step parity with the teacher-side integer noise removed: the teachers' pseudo-labels come from the reference run
     (the golden's per-teacher [n,6] rows) instead of the GPU teachers' decode + NMS, so no int() truncation of a last-bit-different
@@ -76,8 +83,8 @@ def test_step_golden_reference_labels(golden_dir, variant):
     gold = np.load(os.path.join(golden_dir, f"step_d2_256_{variant}.npz"))
     S, B = 256, 2
     eng, spec = build(variant, S)
-    nt = len(eng.teachers)
-    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=31).items()}
+    nt = len(eng.teachers) + (1 if variant == "listaug" else 0)
+    batch = step_batch(variant, B, S)
     ds = drop_scale_from(gold, spec)
     A = eng.student.anchors(S).shape[0]
     labels = eng.labels_from_rows([[gold[f"teacher{ti}_img{i}"] for i in range(B)] for ti in range(nt)], A)
@@ -101,13 +108,13 @@ def test_step_golden_reference_labels(golden_dir, variant):
             check_summary(gold, "adam." + name, params[name], 1e-5, 1e-4)
 
 
-@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented", "rgb1"])
+@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented", "rgb1", "listaug"])
 def test_step_golden(golden_dir, variant):
     gold = np.load(os.path.join(golden_dir, f"step_d2_256_{variant}.npz"))
     S, B = 256, 2
     eng, spec = build(variant, S)
-    nt = len(eng.teachers)
-    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=31).items()}
+    nt = len(eng.teachers) + (1 if variant == "listaug" else 0)
+    batch = step_batch(variant, B, S)
     ds = drop_scale_from(gold, spec)
     out = eng.step_body(batch, ds)
     torch.cuda.synchronize()
@@ -222,6 +229,26 @@ def test_d4_768_step_vs_oracle():
     # train-mode BatchNorm over ONE image decorrelates part of the gradient (measured cos 0.70, norm ratio 1.001); a layout / indexing
     # bug gives cos ~ 0
     assert cos_b > 0.5 and 0.8 < ratio_b < 1.25, (cos_b, ratio_b)
+
+
+def test_graph_variants_plain_and_list_augmented():
+    """traditional_nms_kdlist_augmented alternates, iteration by iteration, between the plain KD-list step and the one with the extra
+    RGB-teacher pass: one set of hipGraphs per variant, picked by the batch's keys; each replays its own eager step."""
+    S, B = 128, 2
+    eng, spec = build("list", S)
+    ref, _ = build("list", S)
+    plain = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
+    aug = dict(plain, aug_rgb=synth_inputs(B, S, seed=6)["rgb"].to(DEV))
+    ds = eng.make_drop_scale(B, torch.Generator(device=DEV).manual_seed(1))
+    for batch in (plain, aug, plain, aug):
+        o = eng.replay(batch, ds)
+        r = ref.step(batch, ds)
+        torch.cuda.synchronize()
+        assert o["nbox"].tolist() == r["nbox"].tolist()
+        np.testing.assert_allclose(o["kd"].cpu().numpy(), r["kd"].cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(o["cls"].cpu().numpy(), r["cls"].cpu().numpy(), rtol=1e-3)
+        assert (eng.student.ps.flat - ref.student.ps.flat).abs().max().item() <= 1e-3      # 4 Adam steps of <= lr each
+    assert set(eng._graphs) == {"plain", "aug"}
 
 
 def test_graph_replay_matches_eager():

@@ -131,7 +131,7 @@ def test_postproc(golden_dir):
         np.testing.assert_array_equal(gt.reshape(-1, 6), g[f"gt{i}"])
 
 
-@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented", "rgb1"])
+@pytest.mark.parametrize("variant", ["pairwise", "list", "augmented", "rgb1", "listaug"])
 def test_step(golden_dir, variant):
     g = np.load(os.path.join(golden_dir, f"step_d2_256_{variant}.npz"))
     S, B = 256, 2
@@ -145,9 +145,11 @@ def test_step(golden_dir, variant):
     batch = synth_inputs(B, S, seed=31)
     masks = {int(b): torch.from_numpy(m) for b, m in zip(g["drop_blocks"], g["drop_masks"])}
     # "augmented" = ModelWithNMSLossAugmented.forward(..., augment=True): pairwise KD + audio merge / feature averaging / label merge
-    out = ST.distill_forward(st, teachers, batch, S, 2, masks, kd_mode="list" if variant == "list" else "pairwise",
-                             augment=variant == "augmented")
-    for ti in range(len(mods)):
+    # "listaug" = ModelWithNMSKDListLossAugmented.forward(label=<RGB frames of other recordings>, augment=True)
+    aug_rgb = synth_inputs(B, S, seed=57)["rgb"] if variant == "listaug" else None
+    out = ST.distill_forward(st, teachers, batch, S, 2, masks, kd_mode="list" if variant in ("list", "listaug") else "pairwise",
+                             augment=variant == "augmented", aug_rgb=aug_rgb)
+    for ti in range(len(mods) + (1 if variant == "listaug" else 0)):
         for i in range(B):
             np.testing.assert_array_equal(out["per_teacher"][ti][i].reshape(-1, 6), g[f"teacher{ti}_img{i}"])
     np.testing.assert_allclose(out["reg"].detach().numpy(), g["reg"], rtol=1e-4)

@@ -259,9 +259,10 @@ def golden_step():
     states = {k: make_state(2, cin, seed, k, cls_bias=bias[k])[1] for k, (cin, seed) in mods.items()}
     spec, st_s = make_state(2, 8, 24, "audio")
     batch = synth_inputs(B, S, seed=31)
-    only = os.environ.get("GOLDEN_STEP_VARIANTS", "pairwise,list,augmented,rgb1").split(",")
+    only = os.environ.get("GOLDEN_STEP_VARIANTS", "pairwise,list,augmented,rgb1,listaug").split(",")
     for variant, cls_name in [("pairwise", "ModelWithNMSLoss"), ("list", "ModelWithNMSKDListLoss"),
-                              ("augmented", "ModelWithNMSLossAugmented"), ("rgb1", "ModelWithNMSLoss")]:
+                              ("augmented", "ModelWithNMSLossAugmented"), ("rgb1", "ModelWithNMSLoss"),
+                              ("listaug", "ModelWithNMSKDListLossAugmented")]:
         if variant not in only:
             continue
         # "rgb1" = BASELINE configs[1]: use_thermal = use_depth = False -> the ModuleDict holds the RGB teacher only
@@ -280,7 +281,10 @@ def golden_step():
                                        cfg(S), VALID)
         opt = torch.optim.Adam(student.parameters(), lr=1e-4, betas=(0.9, 0.999))
         opt.zero_grad()
-        if variant == "augmented":      # augment=True: audio merge, teacher feature averaging, labels of image 0 -> image 1
+        if variant == "listaug":        # `label` = RGB frames of other recordings (train_set.yield_batch), augment=True: a 4th list entry
+            aug_rgb = synth_inputs(B, S, seed=57)["rgb"]
+            res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"], aug_rgb, augment=True)
+        elif variant == "augmented":      # augment=True: audio merge, teacher feature averaging, labels of image 0 -> image 1
             res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"].clone(), None, augment=True)
         else:
             res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"], None)
@@ -318,12 +322,16 @@ def golden_step():
             for k in tmods:
                 pred, _ = teachers[k](batch[k])
                 per.append(RU.logits_to_ground_truth(pred, None, VALID, cfg(S), include_scores=True))
+        if variant == "listaug":
+            with torch.no_grad():
+                pred, _ = teachers["rgb"](aug_rgb)
+                per.append(RU.logits_to_ground_truth(pred, None, VALID, cfg(S), include_scores=True))
         for ti, lab in enumerate(per):
             for i in range(B):
                 d[f"teacher{ti}_img{i}"] = np.asarray(lab[i], dtype=np.float32).reshape(-1, 6)
         np.savez_compressed(os.path.join(OUT, f"step_d2_256_{variant}.npz"), **d)
         print("step", variant, d["reg"], d["cls"], d["kd"].reshape(-1)[:5], d["loss"],
-              [d[f"teacher{t}_img{i}"].shape[0] for t in range(len(tmods)) for i in range(B)])
+              [d[f"teacher{t}_img{i}"].shape[0] for t in range(len(per)) for i in range(B)])
 
 
 def synth_detections(seed=41, n_batches=5, bs=4, S=512):

@@ -73,9 +73,8 @@ def parse_config(argv=None):
 def step_config(cfg) -> StepConfig:
     method = cfg.get("train_method", "traditional_nms_augmented")
     if method not in TR.SUPPORTED_METHODS:
-        # traditional_nms_kdlist_augmented (src/optimization/train_methods.py:50-162) needs the dataset's yield_batch / merge_audios
-        # (librosa re-synthesis of two recordings, src/datasets/MultimodalDetection.py:329-367); the adversarial / generator / BOHB
-        # methods are outside the hot path.  Upstream: raise Exception(f"Unsupported train method ...") (:1000)
+        # the adversarial / generator / BOHB methods are outside the hot path.
+        # Upstream: raise Exception(f"Unsupported train method ...") (src/optimization/train_methods.py:1000)
         raise Exception(f"Unsupported train method {method} provided")
     # valid_labels -> VOC ids of the classes a teacher prediction must have (src/datasets/BaseDataset.py:141-165, utils.py:285-323)
     vl = cfg.get("valid_labels", "car")
@@ -168,6 +167,9 @@ def main(argv=None):
     writer = TR.ScalarLog(cfg["exp_name"])
     w_main, w_kd = cfg.getfloat("w_main", 1.0), cfg.getfloat("w_kd", 0.005)
     n_epochs = cfg.getint("num_epoches", 1)
+    kdlist_aug = cfg.get("train_method", "") == "traditional_nms_kdlist_augmented"
+    if kdlist_aug and raw:
+        raise Exception("traditional_nms_kdlist_augmented needs the dataset's yield_batch: not available with input_pipeline = raw")
     no_validation = cfg.getboolean("no_validation", False)
     steps, captured, loss, val_loss = 0, False, float("nan"), float("nan")
     stop = False
@@ -184,6 +186,12 @@ def main(argv=None):
         while nxt is not None:
             item = nxt
             batch = staged.wait() if raw else to_batch(item)
+            if kdlist_aug and TR.kdlist_augment_now(epoch):
+                # traditional_nms_kdlist_augmented (traditional.py:121-124, train_methods.py:50-162): the batch's audio is replaced by
+                # its mix with other recordings' audio, and those recordings' RGB frames go through the RGB teacher as a 4th list entry.
+                # (Upstream hands the model augment=cfg audio_augmentation_merge instead of this draw, which only works when both agree.)
+                aug_rgb, mixed = train_set.yield_batch(batch["audio"].shape[0], item[5])
+                batch = dict(batch, audio=mixed.to(dev, non_blocking=True), aug_rgb=aug_rgb.to(dev, non_blocking=True))
             nxt = next(it, None)
             if not captured:
                 eng.capture(batch); captured = True
