@@ -233,6 +233,8 @@ int mmd_pwconv_fwd_bf16(const float* x, const float* w, float* y, int M, int K, 
 // Kernel selection of mmd_pwconv_fwd / _bwd_data for K <= 128 (csrc/pw_rows.hip, the thin-K row-slab kernel): 0 = the measured shape
 // filter decides (default), 1 = every supported launch takes it, 2 = none does.  Process-wide; for tests and A/B timing.
 int mmd_pwconv_rows_mode(int mode);
+// Same switch for the long-K small-M kernel with the LDS-DMA pipelined K loop (csrc/pw_longk.hip: K >= 384, about one block per CU).
+int mmd_pwconv_longk_mode(int mode);
 
 int mmd_pwconv_fwd_pyr_bf16(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
 

@@ -66,3 +66,5 @@ struct PwArgs {
 // pw_rows.hip: thin-K (K <= 128) launches on the row-slab kernel; returns 1 when it took the launch, 0 when the shape / operand mode is
 // not covered (the caller then uses the LDS-tiled kernels), < 0 on error.
 int pw_rows_try(PwArgs& a, hipStream_t stream);
+// pw_longk.hip: long-K small-M launches (plain / gate-only A operand) on the LDS-DMA pipelined kernel; same return convention.
+int pw_longk_try(PwArgs& a, hipStream_t stream);

@@ -866,6 +866,8 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   static const int sq_min = getenv("MMD_SQ_MIN") ? atoi(getenv("MMD_SQ_MIN")) : 160;
   if (pw_rows_try(a, stream) == 1) {
     // thin-K row-slab kernel (pw_rows.hip) took the launch
+  } else if (pw_longk_try(a, stream) == 1) {
+    // long-K small-M kernel with the LDS-DMA pipelined K loop (pw_longk.hip)
   } else if (use_stream && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);

@@ -135,6 +135,67 @@ def test_pwconv_rows_kernel(M, K, N, B, flags):
             assert ws.abs().max().item() == 0          # the slots are left zeroed for the next producer
 
 
+@pytest.mark.parametrize("M,K,N,B,flags", [
+    (2048, 1248, 208, 8, "gate osc res"),        # teacher project conv at 16x16 (10 K steps)
+    (2048, 2112, 352, 8, "gate osc"),            # 17 steps
+    (8192, 528, 88, 8, "gate osc res"),          # 32x32 stage, K tail of 16
+    (8192, 720, 120, 8, "gate"),                 # K tail of 80, N tail
+    (2048, 1248, 208, 8, "acc"),                 # plain input-gradient GEMM, accumulating into the output
+    (2048, 720, 208, 1, "stats bias"),           # statistics, bias
+    (100, 260, 36, 1, ""), (2048, 256, 64, 8, "gate"), (96, 388, 4, 1, "bias act")])
+def test_pwconv_longk_kernel(M, K, N, B, flags):
+    """The long-K small-M kernel (csrc/pw_longk.hip): LDS-DMA ring three K steps deep, swizzled tiles, counted waits, asm fragment
+    reads - against fp32 torch for every supported operand / epilogue form, K tails that are not a multiple of the 128-wide step and
+    of the 16-byte chunk grid, repeated launches (a race in the ring would show as run-to-run differences)."""
+    torch.manual_seed(M + 3 * K + 7 * N)
+    f = set(flags.split())
+    rpi = M // B
+    x = torch.randn(M, K); w = torch.randn(N, K) / math.sqrt(K)
+    gate = torch.rand(B, K) if "gate" in f else None
+    a = x * gate.repeat_interleave(rpi, 0) if gate is not None else x
+    bias = torch.randn(N) * 0.1 if "bias" in f else None
+    raw = a @ w.t() + (bias if bias is not None else 0)
+    osc, osh = (torch.rand(N) + 0.5, torch.randn(N) * 0.1) if "osc" in f else (None, None)
+    ref = raw * osc + osh if osc is not None else raw
+    act = 1 if "act" in f else 0
+    if act:
+        ref = swish(ref)
+    res = torch.randn(M, N) if ("res" in f or "acc" in f) else None
+    if res is not None:
+        ref = ref + res
+    stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV) if "stats" in f else None
+    dll = _lib.LIB.load()
+    dll.mmd_pwconv_longk_mode(1)
+    outs = []
+    try:
+        for rep in range(3):
+            y = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
+            if stats is not None:
+                stats.zero_()
+            call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
+                 g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
+                 y if "acc" in f else (g(res) if res is not None else None), stats, 0, 0, None, 0)
+            torch.cuda.synchronize()
+            outs.append(y.clone())
+    finally:
+        dll.mmd_pwconv_longk_mode(0)
+    close(outs[0], ref, 2e-4, 1e-5, "longk fwd")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if stats is not None:
+        close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
+        close(stats[N:], (raw.double() ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
+    # and the LDS-tiled kernels on the same launch agree
+    dll.mmd_pwconv_longk_mode(2)
+    try:
+        y2 = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
+        call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
+             g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
+             y2 if "acc" in f else (g(res) if res is not None else None), None, 0, 0, None, 0)
+    finally:
+        dll.mmd_pwconv_longk_mode(0)
+    close(y2, ref, 2e-4, 1e-5, "tiled fwd")
+
+
 def test_pwconv_fwd_remap():
     torch.manual_seed(1)
     B, HW, K, N, A_total_rows = 2, 48, 112, 36, 600
