@@ -30,11 +30,6 @@
 #define RW_ABL_NOSTORE 256
 #define RW_ABL_NOFETCH 512
 #define RW_ABL_NOMFMA 1024
-#define RW_ABL_NOSTAGE 2048
-#define RW_ABL_NOROT 4096
-#define RW_ABL_EXIT0 8192
-#define RW_ABL_EXIT1 16384
-#define RW_ABL_EXIT2 32768
 
 struct RowsArgs {
   int LDB;          // LDS row stride of the weight panel (K + 4 floats)
@@ -65,7 +60,6 @@ __global__ __launch_bounds__(512, 2) void pw_rows_kernel(PwArgs a, RowsArgs ra) 
   const int panel = blockIdx.x / ra.bpp, bi = blockIdx.x - panel * ra.bpp;
   const int n0p = panel * pcols;
 
-  if (ra.mode & RW_ABL_EXIT0) return;
   // 8 waves per block = 2 per SIMD (waves w and w + 4 share a SIMD): the slabs are dealt evenly over the panel's SIMD slots
   // (consecutive slabs per slot), and a slot's two waves split its run, so while one wave is in its epilogue / fragment transform the
   // other keeps the MFMA pipe busy
@@ -102,12 +96,7 @@ __global__ __launch_bounds__(512, 2) void pw_rows_kernel(PwArgs a, RowsArgs ra) 
     // stored or summed.  (A register-staged loop - load, wait, ds_write - cost ~7 us per block: 7 dependent L2 round trips.)
     const int f4 = K >> 2, spr = f4 + 1, total = pcols * spr;
     const int nI = (total + 63) >> 6;
-    // every block wants the SAME panel at the same moment: each starts at a different piece (rotation by block index), so that
-    // the CUs of an XCD do not queue up on one L2 line / channel after the other
-    const int rot = (ra.mode & RW_ABL_NOROT) ? 0 : (int)((bi * 37u) % (unsigned)nI);
-    for (int i0 = wave; i0 < nI; i0 += 8) {
-      if (ra.mode & RW_ABL_NOSTAGE) break;
-      int ii = i0 + rot; if (ii >= nI) ii -= nI;
+    for (int ii = wave; ii < nI; ii += 8) {
       const int slot = ii * 64 + lane;
       const int n = slot / spr, k4 = slot - n * spr;
       const float* src = a.w + (size_t)min(n0p + n, N - 1) * K + min(k4, f4 - 1) * 4;
@@ -132,7 +121,6 @@ __global__ __launch_bounds__(512, 2) void pw_rows_kernel(PwArgs a, RowsArgs ra) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the panel pieces (LDS-DMA counts on vmcnt) have landed ...
   __syncthreads();                                       // ... in every wave
-  if (ra.mode & RW_ABL_EXIT1) return;
 
   if (s_beg < s_end) {
     for (int s = s_beg; s < s_end; ++s) {
@@ -158,7 +146,6 @@ __global__ __launch_bounds__(512, 2) void pw_rows_kernel(PwArgs a, RowsArgs ra) 
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) { ac[kk].x *= gn[kk].x; ac[kk].y *= gn[kk].y; }
       }
-      if (ra.mode & RW_ABL_EXIT2) { if (ac[0].x == 123.f) a.y[0] = ac[NKK - 1].y; return; }
       if (s + 1 < s_end && !(ra.mode & RW_ABL_NOFETCH)) fetch(s + 1);                  // in flight during this slab's MFMAs
       // ---- output row bookkeeping: lane (r, g) owns rows row0 + 4g + i, i = 0..3, of column (tile*16 + r).
       // Everything below is phrased as whole-chunk passes behind wave-uniform branches: a wave64 VALU instruction costs 4 cycles, so a
