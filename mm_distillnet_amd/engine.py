@@ -137,6 +137,7 @@ class Net:
         self._anchors: Dict[int, torch.Tensor] = {}
         self._side = None
         self._wg = None           # weight-gradient stream: nothing downstream of a wgrad until the optimizer
+        self.mark_block, self.mark_event = -1, None
         self._wg_pending: list = []          # deferred 1x1-conv weight gradients of the current backward segment
         self._leaf_pending: list = []        # other deferred leaves (closures), issued by _wg_flush
         self._wg_plans: Dict[int, dict] = {}  # segment index -> planned table (built once: arena addresses repeat every step)
@@ -342,6 +343,8 @@ class Net:
                              out_aff=(b2["fscale"], b2["fshift"]), residual=res)
             if blk.skip:
                 skip_i += 1
+            if blk.idx == self.mark_block and self.ps.flat.is_cuda:
+                self.mark_event = torch.cuda.current_stream().record_event()      # "this net is past block k" (step.py staggers the teachers on it)
             cur = Feat(y, B, H1, W1, blk.cout)
             rec["out"] = cur
             if train:

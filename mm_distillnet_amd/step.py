@@ -289,11 +289,23 @@ class DistillEngine:
             if "rgb" not in self.teachers:
                 raise ValueError("the augmentation pass runs the RGB teacher")
             passes.append(("augmentation", self.teachers["rgb"], list(self.teachers).index("rgb"), batch["aug_rgb"]))
+        # Staggered teachers: the frozen nets have the same layer sequence, so three streams started together run in lockstep - three
+        # MFMA-bound GEMMs at once, then three HBM-bound depthwise convs at once.  Teacher i+1 therefore starts once teacher i is past
+        # the high-resolution stages (its second stride-2 block: D2 block 5): 20.3-20.7 -> 19.9-20.1 ms/step in alternating runs
+        # (profiles/r02_notes.md).  MMD_STAGGER=<block> overrides, -1 disables.  Holding teacher 0 behind the student as well measured
+        # slower (20.3-20.5).
+        s2 = [b.idx for b in next(iter(self.teachers.values())).spec.blocks if b.stride == 2]
+        stagger = int(os.environ.get("MMD_STAGGER", str(s2[1] if len(s2) > 1 else -1)))
+        prev_net = None
         for pi, (mod, net, si, xin) in enumerate(passes):
             ti = pi
             side = self.side_streams[si] if concurrent else main_stream
             if concurrent and xin is None:
                 side.wait_event(fork_event)
+                if stagger >= 0 and prev_net is not None and prev_net.mark_event is not None:
+                    side.wait_event(prev_net.mark_event)
+                net.mark_block, net.mark_event = stagger, None
+                prev_net = net
             with torch.cuda.stream(side):
                 net.begin_step()
                 cls_t, reg_t, feats_t = net.forward(xin if xin is not None else (audio if mod == "audio" else batch[mod]), train=False)
