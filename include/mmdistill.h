@@ -56,6 +56,15 @@ int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, co
 // Replaces Conv2dStaticSamePadding(groups=C) (src/YetAnotherEfficientNet.py:433-435, src/YetAnotherEfficientDet.py:169-170) incl. F.pad (:51-65).
 int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream);
 
+// Frozen-net MBConv front half in one kernel: expand 1x1 conv + folded BN0 + swish -> depthwise kxk/stride (TF-SAME) + folded BN1 + swish
+// + squeeze-excite average pool (pool[B,Cmid] +=, nullable).  The 6x expanded tensor stays in LDS (MFMA -> LDS -> depthwise).
+// w_expand [Cmid, Cin] as stored by the reference, w_dw tap-major [k*k, Cmid].  -22 for a geometry without a kernel: ask
+// mmd_mbconv_expand_dw_supported (Cin in {16,24,32,48,56}, Cmid % 48 == 0, k in {3,5}, stride in {1,2}) and keep mmd_pwconv_fwd +
+// mmd_dwconv_fwd otherwise.  Replaces MBConvBlock.forward's `_expand_conv`/`_bn0`/swish/`_depthwise_conv`/`_bn1`/swish/avg-pool
+// in eval mode (src/YetAnotherEfficientNet.py:450-470).
+int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stride);
+int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream);
+
 // Input gradient of the depthwise conv.  With bn_sums (stride 1 only) the launch also accumulates the sums of the BatchNorm(+swish)
 // backward that consumes dx: bn_sums[c] += sum dx*swish'(u), bn_sums[C+c] += sum dx*swish'(u)*xhat, u = bn_z*bn_scale+bn_shift,
 // xhat = (bn_z-bn_mean)*bn_invstd (bn_z = that BN's forward input, same shape as dx); stats_ws/ws_slots as in mmd_dwconv_fwd.

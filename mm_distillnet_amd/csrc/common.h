@@ -143,4 +143,5 @@ void mmd_prof_tag(int family, const char* fmt, long long a, long long b, long lo
 #define MMD_FAM_DW 2
 #define MMD_FAM_DW_BWD 3
 #define MMD_FAM_ELT 4
+#define MMD_FAM_MBX 5
 #define MMD_FAM_COUNT 8

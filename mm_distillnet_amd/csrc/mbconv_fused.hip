@@ -1,0 +1,241 @@
+// Frozen-net MBConv front half in ONE kernel — CDNA4 / gfx950:
+//   e  = swish(BN0(x · W0ᵀ))            expand 1x1 conv, folded BatchNorm, swish      [B,H,W,Cin] -> [B,H,W,C]   (never leaves the CU)
+//   y  = swish(BN1(dwconv_kxk/s(e)))     depthwise conv (TF "SAME" zero padding), folded BatchNorm, swish  -> [B,OH,OW,C]
+//   pool[b,c] += mean_hw y               squeeze-excite average pool
+//
+// Reference ops: MBConvBlock.forward, src/YetAnotherEfficientNet.py:450-485 (`_expand_conv` -> `_bn0` -> swish -> `_depthwise_conv`
+// -> `_bn1` -> swish -> adaptive_avg_pool2d), for the three frozen teachers (eval-mode BatchNorm: running statistics, foldable).
+// The unfused path writes the 6x expanded tensor, reads it back for the depthwise conv and writes the depthwise output; here the
+// expanded tile (+halo) is produced by MFMA straight into LDS and consumed from there, so HBM sees x once (Cin channels) and y once.
+//
+// Block (4 waves) = one image, one 48-channel chunk (every EfficientNet expanded width is a multiple of 48 = 6 x 8), one TH x TW output
+// tile; the chunk is walked as three 16-channel sub-chunks through ONE LDS tile of [pixels incl. halo][16 (+4 pad)] floats (23-32 KB, so
+// four blocks share a CU and one block's MFMA phase runs beside another's VALU phase); the x fragments are loaded once, before the loop.
+//  phase 1 (MFMA, v_mfma_f32_16x16x4_f32, exact fp32): D[channel][pixel] = W0[channel][:] · x[pixel][:].  A = W0 rows (16 channels),
+//    B = x rows (16 pixels of the flattened input tile incl. halo); k is split so that lane group g = lane>>4 owns the contiguous
+//    run k in [g*NK, (g+1)*NK) of BOTH operands (any consistent k permutation is a valid GEMM), i.e. NK = Cin/4 MFMAs per tile and
+//    each lane's operand run is NK contiguous floats in memory.  A lane ends up with 4 consecutive channels of one pixel = one
+//    float4 of the NHWC LDS image; BN0 + swish are applied once per element, pixels outside the image are written as 0 (the
+//    reference zero-pads the ACTIVATED tensor).
+//  phase 2 (VALU): threads = (channel quad, pixel group); each group owns a strip of R outputs along W, as in dwconv.hip.
+// LDS pixel stride 20 floats: 16 consecutive pixels x one 16-B quad land on 64 distinct banks in phase 1's ds_write_b128.
+#include "common.h"
+#include <cstdlib>
+
+struct MbxArgs {
+  const float* x; const float* w0; const float* sc0; const float* sh0;
+  const float* wd; const float* sc1; const float* sh1;
+  float* y; float* pool; float pool_scale;
+  int B, H, W, Cin, C, OH, OW, pad_t, pad_l, tiles_h, tiles_w, cchunks;
+  int abl;
+};
+
+template <int K, int S> struct MbxCfg;
+template <> struct MbxCfg<3, 1> { static constexpr int TH = 16, TW = 16, R = 4; };
+template <> struct MbxCfg<5, 1> { static constexpr int TH = 16, TW = 16, R = 4; };
+template <> struct MbxCfg<3, 2> { static constexpr int TH = 8, TW = 8, R = 1; };
+template <> struct MbxCfg<5, 2> { static constexpr int TH = 8, TW = 8, R = 1; };
+
+constexpr int MBX_CC = 48;      // channels per block = 3 sub-chunks of 16 (one MFMA row tile each)
+constexpr int MBX_LD = 20;      // LDS floats per pixel (16 channels + 4 pad)
+constexpr int MBX_NW = 4;       // waves per block
+
+template <int NK, int K, int S>
+__global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
+  using Cf = MbxCfg<K, S>;
+  constexpr int TH = Cf::TH, TW = Cf::TW, R = Cf::R, NW = MBX_NW;
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, P = IH * IW;
+  constexpr int PT = (P + 15) / 16, TPW = (PT + NW - 1) / NW;
+  constexpr int NT = NW * 64, NG = NT / 4, CC = MBX_CC, LD = MBX_LD;
+  constexpr int SEG = (R - 1) * S + K, NSTRIP = TH * (TW / R);
+  extern __shared__ float smem[];                             // ONE array: expanded tile [P][LD] | depthwise weights [K*K][CC] | pool sums [CC]
+  float* const sE = smem;
+  float* const sW = smem + P * LD;
+  float* const sPool = sW + K * K * CC;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int cc = bid % a.cchunks; bid /= a.cchunks;
+  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
+  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  const int b = bid, c0 = cc * CC;
+  const int oh0 = th * TH, ow0 = tw * TW, ih0 = oh0 * S - a.pad_t, iw0 = ow0 * S - a.pad_l;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+
+  // operands of phase 1, all issued before the first use: the wave's x fragments (kept for the three channel sub-chunks) ...
+  float bx[TPW][NK];
+  bool in[TPW];
+  {
+    const float* xb = a.x + (size_t)b * H * W * Cin + g * NK;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int p = (wave + t * NW) * 16 + r;
+      const int pr = p / IW, pc = p - pr * IW;
+      const int ih = ih0 + pr, iw = iw0 + pc;
+      in[t] = p < P && ih >= 0 && ih < H && iw >= 0 && iw < W;
+      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);      // unconditional load, masked after the epilogue
+      const float* xp = xb + ((size_t)ihc * W + iwc) * Cin;
+#pragma unroll
+      for (int j = 0; j < NK; j += 2) {
+        const float2 v = *reinterpret_cast<const float2*>(xp + j);
+        bx[t][j] = v.x; bx[t][j + 1] = v.y;
+      }
+    }
+  }
+  for (int i = tid; i < K * K * 12; i += NT) {
+    const int tap = i / 12, q = (i % 12) * 4;
+    *reinterpret_cast<float4*>(&sW[tap * CC + q]) = mmd_ld4(a.wd + (size_t)tap * a.C + c0 + q);
+  }
+  if (tid < CC) sPool[tid] = 0.f;
+
+  const int qd = tid & 3, grp = tid >> 2, c4 = qd * 4;          // phase 2: 4 channel quads x 64 pixel groups
+#pragma unroll 1
+  for (int ct = 0; ct < 3; ++ct) {
+    // ---- phase 1: 16 expanded channels of the whole input tile -> LDS
+    {
+      float aw[NK];
+      const float* wp = a.w0 + (size_t)(c0 + ct * 16 + r) * Cin + g * NK;
+#pragma unroll
+      for (int j = 0; j < NK; j += 2) {
+        const float2 v = *reinterpret_cast<const float2*>(wp + j);
+        aw[j] = v.x; aw[j + 1] = v.y;
+      }
+      const float4 s0 = mmd_ld4(a.sc0 + c0 + ct * 16 + 4 * g), h0 = mmd_ld4(a.sh0 + c0 + ct * 16 + 4 * g);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + t * NW;
+        if (tile >= PT) break;                                 // wave-uniform
+        if (a.abl & 1) break;
+        const int p = tile * 16 + r;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NK; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[j], bx[t][j], acc, 0, 0, 0);
+        float4 v;
+        v.x = mmd_swish(acc[0] * s0.x + h0.x); v.y = mmd_swish(acc[1] * s0.y + h0.y);
+        v.z = mmd_swish(acc[2] * s0.z + h0.z); v.w = mmd_swish(acc[3] * s0.w + h0.w);
+        if (!in[t]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < P) *reinterpret_cast<float4*>(&sE[p * LD + 4 * g]) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: depthwise conv of the 16 channels from LDS, BN1 + swish, pool partial sums
+    float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(a.abl & 2)) {
+      const int cb = c0 + ct * 16 + c4;
+      const float4 osc = mmd_ld4(a.sc1 + cb), osh = mmd_ld4(a.sh1 + cb);
+      const float* const sWc = sW + ct * 16 + c4;
+      for (int s = grp; s < NSTRIP; s += NG) {
+        const int orow = s / (TW / R), ocol0 = (s % (TW / R)) * R;
+        float4 acc[R];
+#pragma unroll
+        for (int o = 0; o < R; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll(K == 3 ? 3 : 1)
+        for (int i = 0; i < K; ++i) {
+          float4 in4[SEG];
+          const float* prow = &sE[((orow * S + i) * IW + ocol0 * S) * LD + c4];
+#pragma unroll
+          for (int q = 0; q < SEG; ++q) in4[q] = *reinterpret_cast<const float4*>(prow + q * LD);
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(&sWc[(i * K + j) * CC]);
+#pragma unroll
+            for (int o = 0; o < R; ++o) {
+              acc[o].x += in4[o * S + j].x * wv.x; acc[o].y += in4[o * S + j].y * wv.y;
+              acc[o].z += in4[o * S + j].z * wv.z; acc[o].w += in4[o * S + j].w * wv.w;
+            }
+          }
+        }
+        const int oh = oh0 + orow;
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+          const int ow = ow0 + ocol0 + o;
+          if (oh < a.OH && ow < a.OW) {
+            float4 t;
+            t.x = mmd_swish(acc[o].x * osc.x + osh.x); t.y = mmd_swish(acc[o].y * osc.y + osh.y);
+            t.z = mmd_swish(acc[o].z * osc.z + osh.z); t.w = mmd_swish(acc[o].w * osc.w + osh.w);
+            pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
+            mmd_st4(a.y + (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + cb, t);
+          }
+        }
+      }
+    }
+    if (a.pool) {                                              // lanes l, l^4, l^8, ... of a wave share the channel quad
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) {
+        pl.x += __shfl_xor(pl.x, o, 64); pl.y += __shfl_xor(pl.y, o, 64); pl.z += __shfl_xor(pl.z, o, 64); pl.w += __shfl_xor(pl.w, o, 64);
+      }
+      if (lane < 4) {
+        float* sp = sPool + ct * 16 + c4;
+        atomicAdd(sp, pl.x); atomicAdd(sp + 1, pl.y); atomicAdd(sp + 2, pl.z); atomicAdd(sp + 3, pl.w);
+      }
+    }
+    __syncthreads();                                           // sE is rewritten by the next sub-chunk
+  }
+  if (a.pool && tid < CC) atomicAdd(&a.pool[(size_t)b * a.C + c0 + tid], sPool[tid] * a.pool_scale);
+}
+
+static int mbx_same_pad_lo(int n, int k, int s, int* out) {
+  int o = (n + s - 1) / s;
+  int extra = (o - 1) * s - n + k;
+  if (extra < 0) extra = 0;
+  *out = o;
+  return extra / 2;
+}
+
+template <int NK, int K, int S>
+static int mbx_launch(MbxArgs& a, hipStream_t st) {
+  using Cf = MbxCfg<K, S>;
+  a.tiles_h = cdiv(a.OH, Cf::TH); a.tiles_w = cdiv(a.OW, Cf::TW); a.cchunks = a.C / MBX_CC;
+  const long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
+  if (nb > 0x7fffffffLL) return MMD_EINVAL;
+  constexpr int IH = (Cf::TH - 1) * S + K, IW = (Cf::TW - 1) * S + K;
+  constexpr size_t lds = (size_t)(IH * IW * MBX_LD + K * K * MBX_CC + MBX_CC) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
+  static const int abl = getenv("MMD_MBX_ABL") ? atoi(getenv("MMD_MBX_ABL")) : 0;
+  a.abl = abl;
+  hipLaunchKernelGGL((mbx_kernel<NK, K, S>), dim3((unsigned)nb), dim3(MBX_NW * 64), lds, st, a);
+  return mmd_check_launch();
+}
+
+template <int NK>
+static int mbx_launch_ks(MbxArgs& a, int k, int s, hipStream_t st) {
+  if (k == 3 && s == 1) return mbx_launch<NK, 3, 1>(a, st);
+  if (k == 3 && s == 2) return mbx_launch<NK, 3, 2>(a, st);
+  if (k == 5 && s == 1) return mbx_launch<NK, 5, 1>(a, st);
+  return mbx_launch<NK, 5, 2>(a, st);
+}
+
+// 1 when mmd_mbconv_expand_dw_fwd has a kernel for this block geometry (the caller keeps the two-kernel path otherwise)
+extern "C" int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stride) {
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return 0;
+  if (Cmid <= 0 || Cmid % MBX_CC) return 0;
+  return Cin == 16 || Cin == 24 || Cin == 32 || Cin == 48 || Cin == 56;
+}
+
+// y[B,OH,OW,Cmid] = swish(dwconv_same(swish(x[B,H,W,Cin] · w_expand[Cmid,Cin]ᵀ * scale0 + shift0), w_dw[k*k,Cmid]) * scale1 + shift1);
+// pool[B,Cmid] += mean over OH x OW of y (pool may be null).  OH = ceil(H / stride).
+extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+                                        const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                        int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
+  if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y || B <= 0 || H <= 0 || W <= 0) return MMD_EINVAL;
+  if (!mmd_mbconv_expand_dw_supported(Cin, Cmid, k, stride)) return MMD_EINVAL;
+  MbxArgs a{};
+  a.x = x; a.w0 = w_expand; a.sc0 = scale0; a.sh0 = shift0; a.wd = w_dw; a.sc1 = scale1; a.sh1 = shift1; a.y = y; a.pool = pool;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.C = Cmid;
+  a.pad_t = mbx_same_pad_lo(H, k, stride, &a.OH); a.pad_l = mbx_same_pad_lo(W, k, stride, &a.OW);
+  a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
+  mmd_prof_tag(MMD_FAM_MBX, "mbx H%lld K%lld N%lld k%lld", H, Cin, Cmid, k * 10 + stride);
+  mmd_prof_begin(MMD_FAM_MBX, stream);
+  int rc;
+  switch (Cin) {
+    case 16: rc = mbx_launch_ks<4>(a, k, stride, stream); break;
+    case 24: rc = mbx_launch_ks<6>(a, k, stride, stream); break;
+    case 32: rc = mbx_launch_ks<8>(a, k, stride, stream); break;
+    case 48: rc = mbx_launch_ks<12>(a, k, stride, stream); break;
+    default: rc = mbx_launch_ks<14>(a, k, stride, stream); break;
+  }
+  mmd_prof_end(MMD_FAM_MBX, stream, 2.0 * B * H * W * (double)Cin * Cmid + 2.0 * B * a.OH * a.OW * (double)Cmid * k * k,
+               4.0 * ((double)B * H * W * Cin + (double)B * a.OH * a.OW * Cmid));
+  return rc;
+}

@@ -207,6 +207,7 @@ class Net:
         return (x.scale, x.shift, x.act, None, None, None, 0)
 
     STATS_SLOTS = 0 if os.environ.get("MMD_NO_SLOTS") else 64
+    FUSE_FRONT = not os.environ.get("MMD_NO_MBX")       # frozen nets: expand + depthwise of the thin-input blocks in one kernel
 
     def _stats_ws(self, stats, M: int, C: int):
         """(workspace, slots) for a BatchNorm-sum producer over M rows: the thin full-resolution layers would send
@@ -293,7 +294,11 @@ class Net:
             q = f"{P}._blocks.{blk.idx}"
             inp = cur
             rec = {"inp": inp}
-            if blk.expand != 1:
+            fused_front = (not train and blk.expand != 1 and self.FUSE_FRONT and ps.flat.is_cuda
+                           and _lib.LIB.load().mmd_mbconv_expand_dw_supported(inp.C, blk.cmid, blk.kernel, blk.stride) == 1)
+            if fused_front:
+                f0 = None           # frozen net, thin input: expand + depthwise in one kernel below, the expanded tensor stays in LDS
+            elif blk.expand != 1:
                 st0 = self._bn_stats(f"{q}._bn0", train)
                 a0 = self._bn_aff(f"{q}._bn0", train, st0, inp.M)
                 if train:
@@ -306,7 +311,7 @@ class Net:
             else:
                 f0 = inp
             res = inp.z if blk.skip else None
-            H1, W1 = -(-f0.H // blk.stride), -(-f0.W // blk.stride)
+            H1, W1 = -(-inp.H // blk.stride), -(-inp.W // blk.stride)
             M1 = B * H1 * W1
             pooled = self._zalloc((B, blk.cmid))
             hpre = self._alloc(B, blk.se)
@@ -334,8 +339,15 @@ class Net:
             else:
                 # frozen net: BN1+swish and the SE average pool ride in the depthwise epilogue (no separate pool pass)
                 b1 = ps.bn(f"{q}._bn1")
-                a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
-                                     out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled)
+                if fused_front:
+                    b0 = ps.bn(f"{q}._bn0")
+                    a1v = self._alloc(M1, blk.cmid)
+                    call("mmd_mbconv_expand_dw_fwd", inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
+                         ps.w(f"{q}._depthwise_conv.conv.weight"), b1["fscale"], b1["fshift"], a1v, pooled, B, inp.H, inp.W, inp.C,
+                         blk.cmid, blk.kernel, blk.stride)
+                else:
+                    a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
+                                         out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled)
                 f1 = Feat(a1v, B, H1, W1, blk.cmid)
                 call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 b2 = ps.bn(f"{q}._bn2")

@@ -330,6 +330,46 @@ def test_dwconv(k, s, H, W, C):
     close(dwo, w.grad.reshape(C, k * k).t(), 3e-4, 1e-5, "dw bwd weight")
 
 
+@pytest.mark.parametrize("cin,cmid,k,s,H,W", [(16, 96, 3, 2, 32, 32), (24, 144, 3, 1, 32, 32), (24, 144, 5, 2, 40, 24),
+                                               (48, 288, 5, 1, 24, 16), (48, 288, 3, 2, 16, 16), (16, 96, 3, 1, 13, 21),
+                                               (24, 48, 5, 2, 17, 9), (32, 192, 3, 2, 19, 35), (56, 336, 5, 1, 7, 5),
+                                               (32, 192, 5, 2, 8, 8), (16, 48, 3, 1, 3, 2)])
+def test_mbconv_expand_dw_fused(cin, cmid, k, s, H, W):
+    """Frozen-net MBConv front half in one kernel (expand 1x1 + BN0 + swish -> depthwise + BN1 + swish + SE pool; MBConvBlock.forward,
+    src/YetAnotherEfficientNet.py:450-470 in eval mode) against torch fp32 and against the two-kernel HIP path it replaces."""
+    torch.manual_seed(cin * 7 + cmid + k * 10 + s + H)
+    B = 3
+    x = torch.randn(B, cin, H, W)
+    w0 = torch.randn(cmid, cin) / math.sqrt(cin)
+    sc0, sh0 = torch.rand(cmid) + 0.5, torch.randn(cmid) * 0.2
+    wd = torch.randn(cmid, 1, k, k) / k
+    sc1, sh1 = torch.rand(cmid) + 0.5, torch.randn(cmid) * 0.2
+    e = swish(F.conv2d(x, w0.view(cmid, cin, 1, 1)) * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1))
+    y = swish(F.conv2d(same_pad(e, k, s), wd, stride=s, groups=cmid) * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1))
+    OH, OW = y.shape[-2:]
+    dll = _lib.LIB.load()
+    assert dll.mmd_mbconv_expand_dw_supported(cin, cmid, k, s) == 1
+    xn, w0n, wdn = g(nhwc(x)), g(w0), g(wd.reshape(cmid, k * k).t())
+    yo = torch.full((B * OH * OW, cmid), float("nan"), device=DEV)
+    pool = torch.zeros(B, cmid, device=DEV)
+    call("mmd_mbconv_expand_dw_fwd", xn, w0n, g(sc0), g(sh0), wdn, g(sc1), g(sh1), yo, pool, B, H, W, cin, cmid, k, s)
+    close(yo.view(B, OH, OW, cmid), nhwc(y), 2e-4, 1e-5, "fused expand+dw")
+    close(pool, y.mean((2, 3)), 2e-4, 1e-5, "fused pool")
+    # the two-kernel path of the same block
+    ez = torch.empty(B * H * W, cmid, device=DEV)
+    call("mmd_pwconv_fwd", xn, w0n, ez, B * H * W, cin, cmid, None, None, 0, None, None, None, 0, None, H * W, None, g(sc0), g(sh0), 1,
+         None, None, 0, 0, None, 0)
+    y2 = torch.empty(B * OH * OW, cmid, device=DEV)
+    call("mmd_dwconv_fwd", ez, wdn, y2, B, H, W, cmid, k, s, None, None, 0, None, None, None, 0, g(sc1), g(sh1), 1, None, None, None, 0)
+    close(yo, y2, 2e-5, 1e-6, "fused vs two-kernel path")
+    # null pool, and a geometry without a kernel is refused
+    call("mmd_mbconv_expand_dw_fwd", xn, w0n, g(sc0), g(sh0), wdn, g(sc1), g(sh1), y2, None, B, H, W, cin, cmid, k, s)
+    assert torch.equal(y2, yo)
+    assert dll.mmd_mbconv_expand_dw_supported(88, 528, 3, 1) == 0 and dll.mmd_mbconv_expand_dw_supported(16, 100, 3, 1) == 0
+    with pytest.raises(RuntimeError):
+        call("mmd_mbconv_expand_dw_fwd", xn, w0n, g(sc0), g(sh0), wdn, g(sc1), g(sh1), y2, None, B, H, W, 88, cmid, k, s)
+
+
 @pytest.mark.parametrize("M,C,act", [(500, 48, 1), (64, 112, 0), (2048, 528, 1)])
 def test_bn_train_fwd_bwd(M, C, act):
     torch.manual_seed(C)
