@@ -27,7 +27,6 @@ struct MbxArgs {
   const float* wd; const float* sc1; const float* sh1;
   float* y; float* pool; float pool_scale;
   int B, H, W, Cin, C, OH, OW, pad_t, pad_l, tiles_h, tiles_w, cchunks;
-  int abl;
 };
 
 template <int K, int S> struct MbxCfg;
@@ -40,6 +39,11 @@ constexpr int MBX_CC = 48;      // channels per block = 3 sub-chunks of 16 (one 
 constexpr int MBX_LD = 20;      // LDS floats per pixel (16 channels + 4 pad)
 constexpr int MBX_NW = 4;       // waves per block
 
+// value of the lane `ctrl` selects (0x120 + n = row_ror:n, rotation within each 16-lane row)
+template <int CTRL> __device__ __forceinline__ float mbx_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 template <int NK, int K, int S>
 __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
   using Cf = MbxCfg<K, S>;
@@ -48,10 +52,12 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
   constexpr int PT = (P + 15) / 16, TPW = (PT + NW - 1) / NW;
   constexpr int NT = NW * 64, NG = NT / 4, CC = MBX_CC, LD = MBX_LD;
   constexpr int SEG = (R - 1) * S + K, NSTRIP = TH * (TW / R);
-  extern __shared__ float smem[];                             // ONE array: expanded tile [P][LD] | depthwise weights [K*K][CC] | pool sums [CC]
+  extern __shared__ float smem[];      // ONE array: expanded tile [16 PT][LD] | depthwise weights [K*K][CC] | pool sums [CC] | sc0 sh0 sc1 sh1 [4][CC] | W0 chunk [CC][Cin]
   float* const sE = smem;
-  float* const sW = smem + P * LD;
+  float* const sW = smem + PT * 16 * LD;
   float* const sPool = sW + K * K * CC;
+  float* const sAff = sPool + CC;
+  float* const sW0 = sAff + 4 * CC;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);
@@ -75,18 +81,33 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
       in[t] = p < P && ih >= 0 && ih < H && iw >= 0 && iw < W;
       const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);      // unconditional load, masked after the epilogue
       const float* xp = xb + ((size_t)ihc * W + iwc) * Cin;
+      if (NK % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NK; j += 4) {
+          const float4 v = mmd_ld4(xp + j);
+          bx[t][j] = v.x; bx[t][j + 1] = v.y; bx[t][j + 2] = v.z; bx[t][j + 3] = v.w;
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < NK; j += 2) {
         const float2 v = *reinterpret_cast<const float2*>(xp + j);
         bx[t][j] = v.x; bx[t][j + 1] = v.y;
       }
+      }
     }
   }
+  // ... and the block's parameters, staged in LDS once (a global load per sub-chunk would put its latency on the critical path 3 x 2 times)
   for (int i = tid; i < K * K * 12; i += NT) {
     const int tap = i / 12, q = (i % 12) * 4;
     *reinterpret_cast<float4*>(&sW[tap * CC + q]) = mmd_ld4(a.wd + (size_t)tap * a.C + c0 + q);
   }
-  if (tid < CC) sPool[tid] = 0.f;
+  for (int i = tid; i < CC * NK; i += NT)                       // [CC][Cin] is contiguous in the [Cmid][Cin] weight
+    *reinterpret_cast<float4*>(&sW0[i * 4]) = mmd_ld4(a.w0 + (size_t)c0 * Cin + i * 4);
+  if (tid < CC) {
+    sPool[tid] = 0.f;
+    sAff[tid] = a.sc0[c0 + tid]; sAff[CC + tid] = a.sh0[c0 + tid]; sAff[2 * CC + tid] = a.sc1[c0 + tid]; sAff[3 * CC + tid] = a.sh1[c0 + tid];
+  }
+  __syncthreads();
 
   const int qd = tid & 3, grp = tid >> 2, c4 = qd * 4;          // phase 2: 4 channel quads x 64 pixel groups
 #pragma unroll 1
@@ -94,19 +115,17 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
     // ---- phase 1: 16 expanded channels of the whole input tile -> LDS
     {
       float aw[NK];
-      const float* wp = a.w0 + (size_t)(c0 + ct * 16 + r) * Cin + g * NK;
+      const float* wp = sW0 + (ct * 16 + r) * (4 * NK) + g * NK;
 #pragma unroll
       for (int j = 0; j < NK; j += 2) {
         const float2 v = *reinterpret_cast<const float2*>(wp + j);
         aw[j] = v.x; aw[j + 1] = v.y;
       }
-      const float4 s0 = mmd_ld4(a.sc0 + c0 + ct * 16 + 4 * g), h0 = mmd_ld4(a.sh0 + c0 + ct * 16 + 4 * g);
+      const float4 s0 = *reinterpret_cast<const float4*>(&sAff[ct * 16 + 4 * g]), h0 = *reinterpret_cast<const float4*>(&sAff[CC + ct * 16 + 4 * g]);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         const int tile = wave + t * NW;
-        if (tile >= PT) break;                                 // wave-uniform
-        if (a.abl & 1) break;
-        const int p = tile * 16 + r;
+        if (tile >= PT) break;                                  // wave-uniform (only the last t can miss)
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NK; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[j], bx[t][j], acc, 0, 0, 0);
@@ -114,16 +133,16 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
         v.x = mmd_swish(acc[0] * s0.x + h0.x); v.y = mmd_swish(acc[1] * s0.y + h0.y);
         v.z = mmd_swish(acc[2] * s0.z + h0.z); v.w = mmd_swish(acc[3] * s0.w + h0.w);
         if (!in[t]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < P) *reinterpret_cast<float4*>(&sE[p * LD + 4 * g]) = v;
+        *reinterpret_cast<float4*>(&sE[(tile * 16 + r) * LD + 4 * g]) = v;      // rows P .. 16 PT - 1 of sE are padding
       }
     }
     __syncthreads();
 
     // ---- phase 2: depthwise conv of the 16 channels from LDS, BN1 + swish, pool partial sums
     float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!(a.abl & 2)) {
+    {
       const int cb = c0 + ct * 16 + c4;
-      const float4 osc = mmd_ld4(a.sc1 + cb), osh = mmd_ld4(a.sh1 + cb);
+      const float4 osc = *reinterpret_cast<const float4*>(&sAff[2 * CC + ct * 16 + c4]), osh = *reinterpret_cast<const float4*>(&sAff[3 * CC + ct * 16 + c4]);
       const float* const sWc = sW + ct * 16 + c4;
       for (int s = grp; s < NSTRIP; s += NG) {
         const int orow = s / (TW / R), ocol0 = (s % (TW / R)) * R;
@@ -160,12 +179,10 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
         }
       }
     }
-    if (a.pool) {                                              // lanes l, l^4, l^8, ... of a wave share the channel quad
-#pragma unroll
-      for (int o = 4; o < 64; o <<= 1) {
-        pl.x += __shfl_xor(pl.x, o, 64); pl.y += __shfl_xor(pl.y, o, 64); pl.z += __shfl_xor(pl.z, o, 64); pl.w += __shfl_xor(pl.w, o, 64);
-      }
-      if (lane < 4) {
+    if (a.pool) {                  // lanes l, l+4, l+8, l+12 of a 16-lane row share the channel quad: two DPP row rotations, then 16 lanes add to LDS
+      pl.x += mbx_dpp<0x124>(pl.x); pl.y += mbx_dpp<0x124>(pl.y); pl.z += mbx_dpp<0x124>(pl.z); pl.w += mbx_dpp<0x124>(pl.w);
+      pl.x += mbx_dpp<0x128>(pl.x); pl.y += mbx_dpp<0x128>(pl.y); pl.z += mbx_dpp<0x128>(pl.z); pl.w += mbx_dpp<0x128>(pl.w);
+      if ((lane & 12) == 0) {
         float* sp = sPool + ct * 16 + c4;
         atomicAdd(sp, pl.x); atomicAdd(sp + 1, pl.y); atomicAdd(sp + 2, pl.z); atomicAdd(sp + 3, pl.w);
       }
@@ -190,10 +207,8 @@ static int mbx_launch(MbxArgs& a, hipStream_t st) {
   const long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
   if (nb > 0x7fffffffLL) return MMD_EINVAL;
   constexpr int IH = (Cf::TH - 1) * S + K, IW = (Cf::TW - 1) * S + K;
-  constexpr size_t lds = (size_t)(IH * IW * MBX_LD + K * K * MBX_CC + MBX_CC) * sizeof(float);
+  constexpr size_t lds = (size_t)((IH * IW + 15) / 16 * 16 * MBX_LD + K * K * MBX_CC + 5 * MBX_CC + MBX_CC * 4 * NK) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
-  static const int abl = getenv("MMD_MBX_ABL") ? atoi(getenv("MMD_MBX_ABL")) : 0;
-  a.abl = abl;
   hipLaunchKernelGGL((mbx_kernel<NK, K, S>), dim3((unsigned)nb), dim3(MBX_NW * 64), lds, st, a);
   return mmd_check_launch();
 }
