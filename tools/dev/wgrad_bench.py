@@ -48,7 +48,7 @@ Mt = sum((B * h * w + 127) // 128 * 128 for h, w in sizes)
 x = torch.randn(Mt, 112, device=DEV); dy = torch.randn(Mt, 112, device=DEV); dw = torch.zeros(9, 112, device=DEV)
 t = timeit(lambda: call("mmd_dwconv3_pyr_bwd_weight", x, dy, dw, desc, 112, None, None, 0, 0))
 rows.append(("dwpyr C112", 8, t, 8.0 * x.numel()))
-for line in open(os.path.join(ROOT, "tools/dev/pw_shapes.csv")):
+for line in ([] if os.environ.get("WG_DW_ONLY") else open(os.path.join(ROOT, "tools/dev/pw_shapes.csv"))):
     if line.startswith("#"):
         continue
     M, K, N, f, cnt = (int(v) for v in line.split(","))
