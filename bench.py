@@ -40,7 +40,8 @@ FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
             1: ("pw_wgrad_kernel (1x1 conv weight-grad MFMA GEMM)", "mfma"),
             2: ("dw_fwd_kernel (depthwise conv forward)", "hbm"),
             3: ("dw_bwd kernels (depthwise conv backward)", "hbm"),
-            4: ("row-streaming kernels (BN backward / affine / pools)", "hbm")}
+            4: ("row-streaming kernels (BN backward / affine / pools)", "hbm"),
+            5: ("mbx_kernel (frozen nets: expand 1x1 + depthwise in one kernel)", "hbm")}
 PEAK = {"mfma": 157.3, "hbm": 8000.0}      # TFLOP/s fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
 
 
@@ -294,7 +295,7 @@ def main():
             achieved = by / (tms * 1e-3) / 1e9
             unit = "GB/s"
         traffic = None
-        fam_key = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd"}[fam]
+        fam_key = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd", 5: "mbx"}[fam]
         try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["families"][fam_key]
             # the committed PMC passes are of the default workload only
