@@ -14,7 +14,7 @@ from typing import Dict
 import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libmmdistill_hip.so")
+LIB_PATH = os.environ.get("MMD_LIB") or os.path.join(PKG, "libmmdistill_hip.so")      # MMD_LIB: another build of the same library (A/B timing)
 HEADER = os.path.join(os.path.dirname(PKG), "include", "mmdistill.h")
 
 _CT = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
