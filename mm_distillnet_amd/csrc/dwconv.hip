@@ -257,6 +257,191 @@ static int dw_fwd_launch_31(DwArgs& a, hipStream_t st) {
   return dw_fwd_launch<3, 1, 16>(a, st);
 }
 
+// ---- 3x3 / stride 1 as a row-streaming register window -------------------------------------------------------------------
+// The tile kernel above spends ~70 % of a launch in its per-tile skeleton (tile index math, LDS staging writes, two barriers, epilogue
+// address math: profiles/r02_notes.md).  Here a thread owns 4 channels x R output columns and walks down `rh` output rows keeping the
+// three input rows it needs in registers: per output row it loads the next input row (R + 2 float4, producer transform applied as
+// they arrive), does the 9 x R float4 FMAs against register-resident taps and runs the epilogue.  No LDS tile and no barrier in the
+// loop; neighbouring threads re-load the two shared columns from L1.  Same prologue / epilogue contract as dw_fwd_kernel (producer
+// BN(+swish) incl. live batch statistics, flipped taps for the input gradient, raw BatchNorm sums or folded BN + swish + pool, the
+// `bz` sums of a BatchNorm backward).  LW = float4 lanes per pixel (16 / 8 / 4 -> 64- / 32- / 16-channel chunks).
+// Stand-alone, frozen-net epilogue, B = 8: 128^2 x 144 47.8 -> 36.7 us, 256^2 x 64 66.1 -> 50.4, 32^2 x 528 13.8 -> 10.9.
+struct DwRowsGeom { int colblocks, rowblocks, rh; };
+
+// PRO: producer transform on the input; EPI: 0 raw output, 1 raw + BatchNorm sums, 2 raw + the `bz` sums of a BatchNorm backward,
+// 3 folded BN / activation / pool.  Compile-time: the union of all modes needs 244 VGPRs and ran 1.5x slower than the specialised bodies.
+template <int R, int LW, bool PRO, int EPI>
+__global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) {
+  constexpr int CC = 4 * LW;
+  __shared__ float sRed[2 * 4 * CC];
+  const int tid = threadIdx.x, c4 = (tid & (LW - 1)) * 4, strip = tid / LW;
+  int bid = a.noswz ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int cc = bid % a.cchunks; bid /= a.cchunks;
+  const int cb = bid % gm.colblocks; bid /= gm.colblocks;
+  const int rb = bid % gm.rowblocks; bid /= gm.rowblocks;
+  const int b = bid, c0 = cc * CC, c = c0 + c4;
+  const bool cok = c < a.C;
+  const int H = a.H, W = a.W, C = a.C;
+  const int ow0 = (cb * (256 / LW) + strip) * R, oh0 = rb * gm.rh, oh1 = min(oh0 + gm.rh, H);
+  float4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = cok ? mmd_ld4(a.w + (size_t)(a.flip ? 8 - t : t) * C + c) : make_float4(0, 0, 0, 0);
+  DwView v;
+  v.act = a.in_act;
+  if (PRO) dw_in_coef(a.in_scale, a.in_shift, a.in_bn, c, cok, v);
+  float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
+  if (EPI == 3 && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
+  float4 bsc, bsh, bmu, bis;
+  if (EPI == 2 && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
+  const float* const xb = a.x + (size_t)b * H * W * C + (cok ? c : 0);
+  const size_t ob = (size_t)b * H * W * C + c;
+  bool colok[R + 2];
+#pragma unroll
+  for (int q = 0; q < R + 2; ++q) { const int iw = ow0 - 1 + q; colok[q] = cok && iw >= 0 && iw < W; }
+
+  auto load_row = [&](int ih, float4 (&dst)[R + 2]) {
+    const bool rok = ih >= 0 && ih < H;
+    const float* p = xb + ((long long)min(max(ih, 0), H - 1) * W + (ow0 - 1)) * C;
+#pragma unroll
+    for (int q = 0; q < R + 2; ++q) {
+      float4 u = make_float4(0, 0, 0, 0);
+      if (rok && colok[q]) {
+        u = mmd_ld4(p + q * C);
+        if (PRO) {
+          if (v.xf) { u.x = u.x * v.sc.x + v.sh.x; u.y = u.y * v.sc.y + v.sh.y; u.z = u.z * v.sc.z + v.sh.z; u.w = u.w * v.sc.w + v.sh.w; }
+          if (v.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
+        }
+      }
+      dst[q] = u;
+    }
+  };
+  float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
+  auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2]) {
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+      float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {      // explicit FMAs in one fixed order: every instantiation rounds alike (dx with and without the sums is bit-identical)
+        const float4 x0 = r0[o + j], x1 = r1[o + j], x2 = r2[o + j], k0 = wt[j], k1 = wt[3 + j], k2 = wt[6 + j];
+        acc.x = __fmaf_rn(x2.x, k2.x, __fmaf_rn(x1.x, k1.x, __fmaf_rn(x0.x, k0.x, acc.x)));
+        acc.y = __fmaf_rn(x2.y, k2.y, __fmaf_rn(x1.y, k1.y, __fmaf_rn(x0.y, k0.y, acc.y)));
+        acc.z = __fmaf_rn(x2.z, k2.z, __fmaf_rn(x1.z, k1.z, __fmaf_rn(x0.z, k0.z, acc.z)));
+        acc.w = __fmaf_rn(x2.w, k2.w, __fmaf_rn(x1.w, k1.w, __fmaf_rn(x0.w, k0.w, acc.w)));
+      }
+      const int ow = ow0 + o;
+      if (cok && ow < W) {
+        const size_t off = ob + ((size_t)oh * W + ow) * C;
+        if (EPI == 2) {
+          const float4 zz = mmd_ld4(a.bz + off);
+          float4 gg;
+          gg.x = acc.x * mmd_swish_grad(zz.x * bsc.x + bsh.x); gg.y = acc.y * mmd_swish_grad(zz.y * bsc.y + bsh.y);
+          gg.z = acc.z * mmd_swish_grad(zz.z * bsc.z + bsh.z); gg.w = acc.w * mmd_swish_grad(zz.w * bsc.w + bsh.w);
+          s.x += gg.x; s.y += gg.y; s.z += gg.z; s.w += gg.w;
+          ss.x += gg.x * (zz.x - bmu.x) * bis.x; ss.y += gg.y * (zz.y - bmu.y) * bis.y;
+          ss.z += gg.z * (zz.z - bmu.z) * bis.z; ss.w += gg.w * (zz.w - bmu.w) * bis.w;
+        } else if (EPI == 1) {
+          s.x += acc.x; s.y += acc.y; s.z += acc.z; s.w += acc.w;
+          ss.x += acc.x * acc.x; ss.y += acc.y * acc.y; ss.z += acc.z * acc.z; ss.w += acc.w * acc.w;
+        }
+        float4 t = acc;
+        if (EPI == 3) {
+          if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
+          if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
+          pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
+        }
+        mmd_st4(a.y + off, t);
+      }
+    }
+  };
+
+  float4 w0[R + 2], w1[R + 2], w2[R + 2];
+  load_row(oh0 - 1, w0);
+  load_row(oh0, w1);
+  for (int oh = oh0; oh < oh1; oh += 3) {
+    load_row(oh + 1, w2);
+    out_row(oh, w0, w1, w2);
+    if (oh + 1 < oh1) { load_row(oh + 2, w0); out_row(oh + 1, w1, w2, w0); }
+    if (oh + 2 < oh1) { load_row(oh + 3, w1); out_row(oh + 2, w2, w0, w1); }
+  }
+  if ((EPI == 1 || EPI == 2) || (EPI == 3 && a.pool)) {      // lanes l, l^LW, l^2LW, ... of a wave share the channel quad; then the 4 waves through LDS
+    auto red = [](float4 x) {
+#pragma unroll
+      for (int o = LW; o < 64; o <<= 1) {
+        x.x += __shfl_xor(x.x, o, 64); x.y += __shfl_xor(x.y, o, 64); x.z += __shfl_xor(x.z, o, 64); x.w += __shfl_xor(x.w, o, 64);
+      }
+      return x;
+    };
+    const int wave = tid >> 6, lane = tid & 63;
+    if (EPI == 1 || EPI == 2) {
+      s = red(s); ss = red(ss);
+      if (lane < LW) {
+        *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = s;
+        *reinterpret_cast<float4*>(&sRed[4 * CC + wave * CC + c4]) = ss;
+      }
+      __syncthreads();
+      if (tid < CC && c0 + tid < C) {
+        const float vs = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
+        const float vq = sRed[4 * CC + tid] + sRed[5 * CC + tid] + sRed[6 * CC + tid] + sRed[7 * CC + tid];
+        double* st = a.stats_ws ? a.stats_ws + (size_t)((blockIdx.x / a.cchunks) % a.ws_slots) * 2 * C : a.stats;
+        atomicAdd(&st[c0 + tid], (double)vs);
+        atomicAdd(&st[C + c0 + tid], (double)vq);
+      }
+      __syncthreads();
+    }
+    if (EPI == 3 && a.pool) {
+      pl = red(pl);
+      if (lane < LW) *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = pl;
+      __syncthreads();
+      if (tid < CC && c0 + tid < C) {
+        const float vv = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
+        atomicAdd(&a.pool[(size_t)b * C + c0 + tid], vv * a.pool_scale);
+      }
+    }
+  }
+}
+
+template <int R, int LW>
+static int dw3_rows_go(DwArgs& a, hipStream_t st) {
+  DwRowsGeom gm;
+  a.cchunks = cdiv(a.C, 4 * LW);
+  gm.colblocks = cdiv(a.W, (256 / LW) * R);
+  // rows per block: as many as leave >= ~1024 blocks, at least 4 (every block re-reads two halo rows)
+  static const int force_rh = getenv("MMD_DW_ROWS_RH") ? atoi(getenv("MMD_DW_ROWS_RH")) : 0;
+  const long long per_row = (long long)a.B * a.cchunks * gm.colblocks;
+  int rh = force_rh > 0 ? force_rh : (int)((long long)a.H * per_row / 1024);
+  if (rh < 4) rh = 4; if (rh > a.H) rh = a.H;
+  gm.rh = rh; gm.rowblocks = cdiv(a.H, rh);
+  const long long nb = per_row * gm.rowblocks;
+  static const int noswz = getenv("MMD_DW_NOSWZ") ? 1 : 0;
+  a.noswz = noswz;
+  if (!a.stats || a.ws_slots < 2 || nb / a.cchunks <= MMD_STATS_DEPTH) a.stats_ws = nullptr;
+  const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
+  const int epi = a.bz ? 2 : (a.stats ? 1 : ((a.out_scale || a.out_act != MMD_ACT_NONE || a.pool) ? 3 : 0));
+  const dim3 grid((unsigned)nb), blk(256);
+#define MMD_DW3_ROWS(P, E) hipLaunchKernelGGL((dw3_rows_kernel<R, LW, P, E>), grid, blk, 0, st, a, gm)
+  if (pro) { if (epi == 0) MMD_DW3_ROWS(true, 0); else if (epi == 1) MMD_DW3_ROWS(true, 1); else if (epi == 2) MMD_DW3_ROWS(true, 2); else MMD_DW3_ROWS(true, 3); }
+  else { if (epi == 0) MMD_DW3_ROWS(false, 0); else if (epi == 1) MMD_DW3_ROWS(false, 1); else if (epi == 2) MMD_DW3_ROWS(false, 2); else MMD_DW3_ROWS(false, 3); }
+#undef MMD_DW3_ROWS
+  if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * a.C, st);
+  return mmd_check_launch();
+}
+
+// -> 1 when the geometry is left to the tile kernel.  A thread's strip of R columns needs W >= 16 R to fill a block row; with a
+// producer transform the R + 2 loaded columns per R outputs make narrow strips (R < 4) more expensive than the tile's 1.56x halo.
+static int dw3_rows_launch(DwArgs& a, hipStream_t st) {
+  static const int mode = getenv("MMD_DW_ROWS") ? atoi(getenv("MMD_DW_ROWS")) : 1;
+  if (!mode) return 1;
+  if (a.stats && (a.out_scale || a.out_act != MMD_ACT_NONE || a.pool)) return 1;      // sums + folded epilogue together: tile kernel only
+  const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
+  const int lw = a.C <= 16 ? 4 : (a.C <= 32 ? 8 : 16);
+  const int strips = 256 / lw;
+  if (a.W >= 4 * strips) { if (lw == 16) return dw3_rows_go<4, 16>(a, st); if (lw == 8) return dw3_rows_go<4, 8>(a, st); return dw3_rows_go<4, 4>(a, st); }
+  if (pro || lw != 16) return 1;
+  if (a.W >= 32) return dw3_rows_go<2, 16>(a, st);
+  if (a.W >= 16) return dw3_rows_go<1, 16>(a, st);
+  return 1;
+}
+
 static int same_pad_lo(int n, int k, int s, int* out) {
   int o = (n + s - 1) / s;
   int extra = (o - 1) * s - n + k;
@@ -285,8 +470,10 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   a.stats_ws = stats_ws; a.ws_slots = ws_slots;
   mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW, stream);
-  int rc;
-  if (k == 3 && stride == 1) rc = dw_fwd_launch_31(a, stream);
+  int rc = 1;
+  if (k == 3 && stride == 1) rc = dw3_rows_launch(a, stream);
+  if (rc != 1) {}
+  else if (k == 3 && stride == 1) rc = dw_fwd_launch_31(a, stream);
   else if (k == 3) rc = dw_fwd_launch<3, 2>(a, stream);
   else if (stride == 1) rc = dw_fwd_launch<5, 1>(a, stream);
   else rc = dw_fwd_launch<5, 2>(a, stream);
@@ -381,7 +568,8 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
       a.stats = bn_sums; a.stats_ws = stats_ws; a.ws_slots = ws_slots;
       a.bz = bn_z; a.bscale = bn_scale; a.bshift = bn_shift; a.bmean = bn_mean; a.binvstd = bn_invstd;
     }
-    rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch<5, 1>(a, stream);
+    rc = (k == 3) ? dw3_rows_launch(a, stream) : 1;
+    if (rc == 1) rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch<5, 1>(a, stream);
   } else {
     size_t total = (size_t)B * H * W * (C >> 2);
     if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_kernel<3>, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, 0);
