@@ -435,6 +435,9 @@ static int dw3_rows_launch(DwArgs& a, hipStream_t st) {
   const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
   const int lw = a.C <= 16 ? 4 : (a.C <= 32 ? 8 : 16);
   const int strips = 256 / lw;
+  // in the step (us per launch, tile -> rows): 256^2 x 16 37 -> 22, 256^2 x 32 53 -> 38, 32^2 x 528 17.8 -> 15.2, 16^2 x 2112 23.7 -> 16.2,
+  // input gradient 128^2 x 144 72 -> 56; the one loser is the student's 128^2 x 144 forward (producer BN + swish, sums: 60 -> 68)
+  if (pro && a.C > 64 && (a.C & 63)) return 1;
   if (a.W >= 4 * strips) { if (lw == 16) return dw3_rows_go<4, 16>(a, st); if (lw == 8) return dw3_rows_go<4, 8>(a, st); return dw3_rows_go<4, 4>(a, st); }
   if (pro || lw != 16) return 1;
   if (a.W >= 32) return dw3_rows_go<2, 16>(a, st);
@@ -683,6 +686,114 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
   }
 }
 
+// 3x3 / stride 1 weight gradient on the row-streaming window of dw3_rows_kernel: a thread keeps three (transformed) input rows of its
+// R + 2 columns and the 9 tap sums of its 4 channels in registers and walks down `rh` rows; per row it loads the next input row and
+// the dY row.  One shuffle + LDS reduction and 9 x CC atomics per block at the end, as in the tile kernel.
+template <int R, int LW, bool PRO>
+__global__ __launch_bounds__(256) void dw3_wgrad_rows_kernel(DwWgArgs a, DwRowsGeom gm) {
+  constexpr int CC = 4 * LW;
+  __shared__ float sRed[4 * 9 * CC];
+  const int tid = threadIdx.x, c4 = (tid & (LW - 1)) * 4, strip = tid / LW;
+  int bid = blockIdx.x;
+  const int cc = bid % a.cchunks; bid /= a.cchunks;
+  const int cb = bid % gm.colblocks; bid /= gm.colblocks;
+  const int rb = bid % gm.rowblocks; bid /= gm.rowblocks;
+  const int b = bid, c0 = cc * CC, c = c0 + c4;
+  const bool cok = c < a.C;
+  const int H = a.H, W = a.W, C = a.C;
+  const int ow0 = (cb * (256 / LW) + strip) * R, oh0 = rb * gm.rh, oh1 = min(oh0 + gm.rh, H);
+  DwView v;
+  v.act = a.in_act;
+  if (PRO) { BnLive none{}; dw_in_coef(a.in_scale, a.in_shift, none, c, cok, v); }
+  const float* const xb = a.x + (size_t)b * H * W * C + (cok ? c : 0);
+  const float* const gb = a.dy + (size_t)b * H * W * C + (cok ? c : 0);
+  bool colok[R + 2];
+#pragma unroll
+  for (int q = 0; q < R + 2; ++q) { const int iw = ow0 - 1 + q; colok[q] = cok && iw >= 0 && iw < W; }
+  auto load_row = [&](int ih, float4 (&dst)[R + 2]) {
+    const bool rok = ih >= 0 && ih < H;
+    const float* p = xb + ((long long)min(max(ih, 0), H - 1) * W + (ow0 - 1)) * C;
+#pragma unroll
+    for (int q = 0; q < R + 2; ++q) {
+      float4 u = make_float4(0, 0, 0, 0);
+      if (rok && colok[q]) {
+        u = mmd_ld4(p + q * C);
+        if (PRO) {
+          if (v.xf) { u.x = u.x * v.sc.x + v.sh.x; u.y = u.y * v.sc.y + v.sh.y; u.z = u.z * v.sc.z + v.sh.z; u.w = u.w * v.sc.w + v.sh.w; }
+          if (v.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
+        }
+      }
+      dst[q] = u;
+    }
+  };
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
+  auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2]) {
+    float4 g[R];
+    const float* p = gb + ((long long)oh * W + ow0) * C;
+#pragma unroll
+    for (int o = 0; o < R; ++o) g[o] = colok[o + 1] ? mmd_ld4(p + o * C) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int o = 0; o < R; ++o) {
+        acc[j].x += g[o].x * r0[o + j].x; acc[j].y += g[o].y * r0[o + j].y; acc[j].z += g[o].z * r0[o + j].z; acc[j].w += g[o].w * r0[o + j].w;
+        acc[3 + j].x += g[o].x * r1[o + j].x; acc[3 + j].y += g[o].y * r1[o + j].y; acc[3 + j].z += g[o].z * r1[o + j].z; acc[3 + j].w += g[o].w * r1[o + j].w;
+        acc[6 + j].x += g[o].x * r2[o + j].x; acc[6 + j].y += g[o].y * r2[o + j].y; acc[6 + j].z += g[o].z * r2[o + j].z; acc[6 + j].w += g[o].w * r2[o + j].w;
+      }
+  };
+  float4 w0[R + 2], w1[R + 2], w2[R + 2];
+  load_row(oh0 - 1, w0);
+  load_row(oh0, w1);
+  for (int oh = oh0; oh < oh1; oh += 3) {
+    load_row(oh + 1, w2);
+    out_row(oh, w0, w1, w2);
+    if (oh + 1 < oh1) { load_row(oh + 2, w0); out_row(oh + 1, w1, w2, w0); }
+    if (oh + 2 < oh1) { load_row(oh + 3, w1); out_row(oh + 2, w2, w0, w1); }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float4 x = acc[t];
+#pragma unroll
+    for (int o = LW; o < 64; o <<= 1) {
+      x.x += __shfl_xor(x.x, o, 64); x.y += __shfl_xor(x.y, o, 64); x.z += __shfl_xor(x.z, o, 64); x.w += __shfl_xor(x.w, o, 64);
+    }
+    if (lane < LW) *reinterpret_cast<float4*>(&sRed[(wave * 9 + t) * CC + c4]) = x;
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * CC; i += 256) {
+    const int t = i / CC, q = i - t * CC;
+    if (c0 + q < C)
+      atomicAdd(&a.dw[(size_t)t * C + c0 + q], sRed[(0 * 9 + t) * CC + q] + sRed[(1 * 9 + t) * CC + q] + sRed[(2 * 9 + t) * CC + q] + sRed[(3 * 9 + t) * CC + q]);
+  }
+}
+
+template <int R, int LW>
+static int dw3_wgrad_rows_go(DwWgArgs& a, bool pro, hipStream_t st) {
+  DwRowsGeom gm;
+  a.cchunks = cdiv(a.C, 4 * LW);
+  gm.colblocks = cdiv(a.W, (256 / LW) * R);
+  const long long per_row = (long long)a.B * a.cchunks * gm.colblocks;
+  int rh = (int)((long long)a.H * per_row / 1024);
+  if (rh < 4) rh = 4; if (rh > a.H) rh = a.H;
+  gm.rh = rh; gm.rowblocks = cdiv(a.H, rh);
+  const dim3 grid((unsigned)(per_row * gm.rowblocks)), blk(256);
+  if (pro) hipLaunchKernelGGL((dw3_wgrad_rows_kernel<R, LW, true>), grid, blk, 0, st, a, gm);
+  else hipLaunchKernelGGL((dw3_wgrad_rows_kernel<R, LW, false>), grid, blk, 0, st, a, gm);
+  return mmd_check_launch();
+}
+
+// -> 1 when the geometry is left to the tile kernel.  Stand-alone (B = 8, producer BN + swish on x): 256^2 x 16 67.3 -> 31.9 us, but
+// 128^2 x 144 45.2 -> 57.5 and 64^2 x 112 21.0 -> 22.7 (the tile kernel already streams these at 3.3 / 1.4 TB/s; its 64-channel chunk
+// is what wastes the thin layer), so only the 16-channel-chunk form is used.
+static int dw3_wgrad_rows_launch(DwWgArgs& a, hipStream_t st) {
+  static const int mode = getenv("MMD_DW_ROWS") ? atoi(getenv("MMD_DW_ROWS")) : 1;
+  if (!mode || a.C > 16 || a.W < 256) return 1;
+  return dw3_wgrad_rows_go<4, 4>(a, a.in_scale || a.in_act != MMD_ACT_NONE, st);
+}
+
 template <int K, int S>
 static int dw_wgrad_launch(DwWgArgs& a, hipStream_t st) {
   using Cf = DwCfg<K, S>;
@@ -707,8 +818,10 @@ extern "C" int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw,
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwwg H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
-  int rc;
-  if (k == 3 && stride == 1) rc = dw_wgrad_launch<3, 1>(a, stream);
+  int rc = 1;
+  if (k == 3 && stride == 1) rc = dw3_wgrad_rows_launch(a, stream);
+  if (rc != 1) {}
+  else if (k == 3 && stride == 1) rc = dw_wgrad_launch<3, 1>(a, stream);
   else if (k == 3) rc = dw_wgrad_launch<3, 2>(a, stream);
   else if (stride == 1) rc = dw_wgrad_launch<5, 1>(a, stream);
   else rc = dw_wgrad_launch<5, 2>(a, stream);

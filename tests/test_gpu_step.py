@@ -240,16 +240,25 @@ def test_graph_variants_plain_and_list_augmented():
     plain = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
     aug = dict(plain, aug_rgb=synth_inputs(B, S, seed=6)["rgb"].to(DEV))
     ds = eng.make_drop_scale(B, torch.Generator(device=DEV).manual_seed(1))
+    def sync_state():      # both engines start every step from the same parameters / running statistics / optimizer state, so a step is
+        # compared like a first step (two free-running engines drift apart by up to 2 lr per weight and step - Adam's first steps are
+        # sign-like - and train-mode BatchNorm over 2 x 128^2 amplifies that to a few % of the classification loss)
+        for dst, src in ((eng.student.ps, ref.student.ps),):
+            for name in ("flat", "rmean", "rvar", "nbt"):
+                getattr(dst, name).copy_(getattr(src, name))
+        for name in ("exp_avg", "exp_avg_sq", "adam_main", "adam_head", "head_active"):
+            getattr(eng, name).copy_(getattr(ref, name))
+        eng.student.refresh()
+
     for batch in (plain, aug, plain, aug):
+        sync_state()
         o = eng.replay(batch, ds)
         r = ref.step(batch, ds)
         torch.cuda.synchronize()
         assert o["nbox"].tolist() == r["nbox"].tolist()
-        # (the two engines drift apart by up to 2 lr per weight and step - Adam's first steps are sign-like - and train-mode BatchNorm
-        # over 2 x 128^2 amplifies it: loose on the scalars after the first step, exact on the structure)
-        np.testing.assert_allclose(o["kd"].cpu().numpy(), r["kd"].cpu().numpy(), rtol=5e-3, atol=1e-5)
-        np.testing.assert_allclose(o["cls"].cpu().numpy(), r["cls"].cpu().numpy(), rtol=2e-2)
-        assert (eng.student.ps.flat - ref.student.ps.flat).abs().max().item() <= 1e-3      # 4 Adam steps of <= lr each
+        np.testing.assert_allclose(o["kd"].cpu().numpy(), r["kd"].cpu().numpy(), rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(o["cls"].cpu().numpy(), r["cls"].cpu().numpy(), rtol=2e-3)
+        assert (eng.student.ps.flat - ref.student.ps.flat).abs().max().item() <= 2.5e-4      # one Adam step of <= lr each, from equal states
     assert set(eng._graphs) == {"plain", "aug"}
 
 
