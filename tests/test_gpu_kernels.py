@@ -777,6 +777,57 @@ def _pyr(B, sizes):
     return (ctypes.c_int * len(flat))(*flat), row0, rows
 
 
+def test_pyramid_dw_rows_kernel_wide_levels():
+    """mmd_dwconv3_pyr on a pyramid whose first level is >= 64 wide: the flipped launch without a producer transform takes the
+    row-streaming kernel on EVERY level (narrow levels leave strips idle), the others the tile kernel: against the per-level launches
+    and torch, with a per-level producer transform, with live-BatchNorm coefficients, and flipped."""
+    torch.manual_seed(33)
+    B, C = 2, 112
+    sizes = [(64, 64), (32, 32), (16, 16), (7, 5)]
+    desc, row0, rows = _pyr(B, sizes)
+    Mt, nl, ls = row0[-1], len(sizes), 2 * C
+    x = torch.zeros(Mt, C); dy = torch.zeros(Mt, C)
+    for l in range(nl):
+        x[row0[l]:row0[l] + rows[l]] = torch.randn(rows[l], C)
+        dy[row0[l]:row0[l] + rows[l]] = torch.randn(rows[l], C)
+    wd = torch.randn(9, C) / 3
+    sc = torch.rand(nl * ls) + 0.5; sh = torch.randn(nl * ls) * 0.1
+    o = C
+    y = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls)
+    yf = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0)
+    wt = wd.t().reshape(C, 1, 3, 3)
+    for l, (h, w) in enumerate(sizes):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        a = swish(x[sl] * sc[ol:ol + C] + sh[ol:ol + C]).view(B, h, w, C).permute(0, 3, 1, 2)
+        ref = F.conv2d(a, wt, padding=1, groups=C).permute(0, 2, 3, 1).reshape(-1, C)
+        close(y[sl], ref, 2e-4, 1e-5, f"pyr rows fwd level {l}")
+        yr = torch.empty(rows[l], C, device=DEV)
+        call("mmd_dwconv_fwd", g(x[sl]), g(wd), yr, B, h, w, C, 3, 1, g(sc[ol:ol + C]), g(sh[ol:ol + C]), 1, None, None, None, 0,
+             None, None, 0, None, None, None, 0)
+        close(y[sl], yr, 1e-6, 1e-7, f"pyr rows vs per-level launch, level {l}")
+        refb = F.conv2d(dy[sl].view(B, h, w, C).permute(0, 3, 1, 2), wt.flip(2, 3), padding=1, groups=C).permute(0, 2, 3, 1).reshape(-1, C)
+        close(yf[sl], refb, 2e-4, 1e-5, f"pyr rows flipped level {l}")
+    # padding rows between the levels are not written
+    for l in range(nl - 1):
+        assert float(y[row0[l] + rows[l]:row0[l + 1]].abs().sum()) == 0.0
+    # live-BatchNorm prologue: per-level coefficients derived from raw sums with the level's own element count
+    stats = torch.zeros(2 * nl * ls, dtype=torch.float64)
+    gam, bet = torch.rand(nl * ls) + 0.5, torch.randn(nl * ls) * 0.1
+    for l in range(nl):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        stats[2 * ol:2 * ol + C] = x[sl].double().sum(0); stats[2 * ol + C:2 * ol + 2 * C] = (x[sl].double() ** 2).sum(0)
+    yl = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls)
+    for l, (h, w) in enumerate(sizes):
+        sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
+        yr = torch.empty(rows[l], C, device=DEV)
+        call("mmd_dwconv_fwd", g(x[sl]), g(wd), yr, B, h, w, C, 3, 1, None, None, 1, g(stats[2 * ol:2 * ol + 2 * C]),
+             g(gam[ol:ol + C]), g(bet[ol:ol + C]), rows[l], None, None, 0, None, None, None, 0)
+        close(yl[sl], yr, 1e-6, 1e-7, f"pyr rows live BN level {l}")
+
+
 def test_pyramid_launches_match_per_level():
     """One-launch-per-pyramid kernels (heads) against the per-level kernels they replace, on a padded pyramid."""
     import ctypes
