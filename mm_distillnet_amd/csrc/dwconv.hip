@@ -61,7 +61,7 @@ __device__ __forceinline__ void dw_in_coef(const float* in_scale, const float* i
   }
 }
 
-template <int K, int S, int LANES = 16>
+template <int K, int S, int LANES = 16, bool PRO = true>
 __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
   using Cf = DwCfg<K, S, LANES>;
   constexpr int NPIX = Cf::IH * Cf::IW;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
   for (int it = 0; it < NIT; ++it) {
     const int p = tid / LANES + it * Cf::G;
     float4 u = ok[it] ? v[it] : make_float4(0, 0, 0, 0);
-    if (ok[it]) {
+    if (PRO && ok[it]) {
       if (a.xf) { u.x = u.x * sc.x + sh.x; u.y = u.y * sc.y + sh.y; u.z = u.z * sc.z + sh.z; u.w = u.w * sc.w + sh.w; }
       if (a.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
     }
@@ -93,7 +93,10 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
   }
 }
 
-template <int K, int S, int LANES = 16>
+// PRO / EPI: the launch's prologue and epilogue mode as compile-time parameters (PRO: producer transform; EPI 0 raw, 1 raw + BatchNorm
+// sums, 2 raw + `bz` sums, 3 folded BN / activation / pool, 4 any combination at run time) - as for dw3_rows_kernel, the union of all
+// modes costs registers and branches on every launch.
+template <int K, int S, int LANES = 16, bool PRO = true, int EPI = 4>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   using Cf = DwCfg<K, S, LANES>;
   constexpr int CC = Cf::CC;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     float4 wv = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
     *reinterpret_cast<float4*>(&sW[tap * CC + q]) = wv;
   }
-  dw_stage_input<K, S, LANES>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+  dw_stage_input<K, S, LANES, PRO>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
   __syncthreads();
 
   const int p = tid / LANES;
@@ -166,18 +169,19 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       }
     }
   }
+  constexpr bool E_BZ = EPI == 2 || EPI == 4, E_ST = EPI == 1 || EPI == 4, E_OUT = EPI == 3 || EPI == 4;
   float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
-  if (a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
+  if (E_OUT && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
   float4 bsc, bsh, bmu, bis;
-  if (a.bz && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
+  if (E_BZ && a.bz && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
   const int oh = oh0 + orow;
 #pragma unroll
   for (int o = 0; o < Cf::R; ++o) {
     int ow = ow0 + ocol0 + o;
     if (cok && oh < OH && ow < OW) {
       float4 v = acc[o];
-      if (a.bz) {
+      if (E_BZ && a.bz) {
         const float4 zz = mmd_ld4(a.bz + (((size_t)b * OH + oh) * OW + ow) * a.C + c);
         float4 gg;
         gg.x = v.x * mmd_swish_grad(zz.x * bsc.x + bsh.x); gg.y = v.y * mmd_swish_grad(zz.y * bsc.y + bsh.y);
@@ -185,18 +189,20 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
         s.x += gg.x; s.y += gg.y; s.z += gg.z; s.w += gg.w;
         ss.x += gg.x * (zz.x - bmu.x) * bis.x; ss.y += gg.y * (zz.y - bmu.y) * bis.y;
         ss.z += gg.z * (zz.z - bmu.z) * bis.z; ss.w += gg.w * (zz.w - bmu.w) * bis.w;
-      } else {
+      } else if (E_ST) {
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
       }
       float4 t = v;
-      if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
-      if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
-      pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
+      if (E_OUT) {
+        if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
+        if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
+        pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
+      }
       mmd_st4(yout + (((size_t)b * OH + oh) * OW + ow) * a.C + c, t);
     }
   }
-  if (a.stats || a.pool) {
+  if (((E_ST || E_BZ) && a.stats) || (E_OUT && a.pool)) {
     // reduce over the 4 pixel-groups of a wave (lanes l, l^16, l^32, l^48 share c4), then over 4 waves in LDS
     auto red4 = [](float4 v) {       // lanes l, l^LANES, l^2LANES, ... of a wave share the channel group
 #pragma unroll
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       return v;
     };
     const int wave = tid >> 6, lane = tid & 63;
-    if (a.stats) {
+    if ((E_ST || E_BZ) && a.stats) {
       s = red4(s); ss = red4(ss);
       if (lane < LANES) {
         *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = s;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       }
       __syncthreads();
     }
-    if (a.pool) {
+    if (E_OUT && a.pool) {
       pl = red4(pl);
       if (lane < LANES) *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = pl;
       __syncthreads();
@@ -242,7 +248,15 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   static const int noswz = getenv("MMD_DW_NOSWZ") ? 1 : 0;
   a.noswz = noswz;
   if (!a.stats || a.ws_slots < 2 || nb / a.cchunks <= MMD_STATS_DEPTH) a.stats_ws = nullptr;
-  hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES>), dim3((unsigned)nb), dim3(256), 0, st, a);
+  const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
+  const bool out = a.out_scale || a.out_act != MMD_ACT_NONE || a.pool;
+  const int epi = (a.stats && out) ? 4 : (a.bz ? 2 : (a.stats ? 1 : (out ? 3 : 0)));
+  const dim3 grid((unsigned)nb), blk(256);
+#define MMD_DW_TILE(P, E) hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, P, E>), grid, blk, 0, st, a)
+  if (epi == 4) MMD_DW_TILE(true, 4);
+  else if (pro) { if (epi == 0) MMD_DW_TILE(true, 0); else if (epi == 1) MMD_DW_TILE(true, 1); else if (epi == 2) MMD_DW_TILE(true, 2); else MMD_DW_TILE(true, 3); }
+  else { if (epi == 0) MMD_DW_TILE(false, 0); else if (epi == 1) MMD_DW_TILE(false, 1); else if (epi == 2) MMD_DW_TILE(false, 2); else MMD_DW_TILE(false, 3); }
+#undef MMD_DW_TILE
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * a.C, st);
   return mmd_check_launch();
 }
@@ -542,7 +556,8 @@ extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const i
     for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nr;
     hipLaunchKernelGGL((dw3_rows_kernel<4, 16, false, 0>), dim3(nr), dim3(256), 0, stream, a, gm);
   } else {
-    hipLaunchKernelGGL((dw_fwd_kernel<3, 1>), dim3(nb), dim3(256), 0, stream, a);
+    if (pro) hipLaunchKernelGGL((dw_fwd_kernel<3, 1, 16, true, 0>), dim3(nb), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((dw_fwd_kernel<3, 1, 16, false, 0>), dim3(nb), dim3(256), 0, stream, a);
   }
   double rows = a.pyr.row0[a.pyr.n];
   mmd_prof_end(MMD_FAM_DW, stream, 2.0 * rows * C * 9, 8.0 * rows * C);
