@@ -645,7 +645,7 @@ struct DwWgArgs {
   Pyr pyr; long long lev_stride; int nsplit_lev[MMD_MAX_LEV];
 };
 
-template <int K, int S>
+template <int K, int S, bool PRO>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
   using Cf = DwCfg<K, S>;
   static_assert(Cf::IH * Cf::IW >= 4 * K * K, "reduction scratch aliases the input tile");
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
     const int th = tile / tiles_w, tw = tile % tiles_w;
     const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
     __syncthreads();
-    dw_stage_input<K, S>(fa, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+    dw_stage_input<K, S, 16, PRO>(fa, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
     __syncthreads();
     float4 g[Cf::R];
     const int oh = oh0 + orow;
@@ -853,7 +853,8 @@ static int dw_wgrad_launch(DwWgArgs& a, hipStream_t st) {
   int base = a.B * a.cchunks;
   int ns = cdiv(2048, base); if (ns > ntiles) ns = ntiles; if (ns < 1) ns = 1;
   a.nsplit = ns;
-  hipLaunchKernelGGL((dw_wgrad_kernel<K, S>), dim3((unsigned)(base * ns)), dim3(256), 0, st, a);
+  if (a.in_scale || a.in_act != MMD_ACT_NONE) hipLaunchKernelGGL((dw_wgrad_kernel<K, S, true>), dim3((unsigned)(base * ns)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((dw_wgrad_kernel<K, S, false>), dim3((unsigned)(base * ns)), dim3(256), 0, st, a);
   return mmd_check_launch();
 }
 
@@ -903,7 +904,8 @@ extern "C" int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float
   for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nb;
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwwgpyr C%lld", C, 0, 0, 0);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
-  hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(nb), dim3(256), 0, stream, a);
+  if (in_scale || in_act != MMD_ACT_NONE) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, true>), dim3(nb), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, false>), dim3(nb), dim3(256), 0, stream, a);
   double rows = a.pyr.row0[a.pyr.n];
   mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * rows * C * 9, 8.0 * rows * C);
   return mmd_check_launch();
