@@ -41,7 +41,7 @@ FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
             2: ("dw_fwd_kernel (depthwise conv forward)", "hbm"),
             3: ("dw_bwd kernels (depthwise conv backward)", "hbm"),
             4: ("row-streaming kernels (BN backward / affine / pools)", "hbm"),
-            5: ("mbx_kernel (frozen nets: expand 1x1 + depthwise in one kernel)", "hbm")}
+            5: ("mbx_kernel / bifpn_node_fused_kernel (frozen nets: expand + depthwise, whole BiFPN node, one kernel each)", "hbm")}
 PEAK = {"mfma": 157.3, "hbm": 8000.0}      # TFLOP/s fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
 
 

@@ -27,6 +27,12 @@ int mmd_bifpn_fuse_fwd(const float* in0, const float* in1, const float* up, cons
 // activation for the backward.
 int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* f_out, float* zd, int B, int H, int W, int C, hipStream_t stream);
 
+// Whole BiFPN node of a frozen net in one kernel: fusion + swish + depthwise 3x3 + 1x1 conv (w_pw [C, C] as stored upstream) + bias + folded
+// BatchNorm (SeparableConvBlock(norm=True) after BiFPN._forward_fast_attention's weighted sum, src/YetAnotherEfficientDet.py:150-185,338-390,
+// eval mode).  -22 for a width without a kernel: ask mmd_bifpn_node_fused_supported (C = 112) and keep mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd.
+int mmd_bifpn_node_fused_supported(int C);
+int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* w_pw, const float* bias, const float* scale, const float* shift, float* y, int B, int H, int W, int C, hipStream_t stream);
+
 // Backward of the fusion node, part 1: dx = df*swish'(x), wdot[i] += <dx, operand_i>.
 int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream);
 

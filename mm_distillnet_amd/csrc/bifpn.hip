@@ -177,6 +177,196 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
   return mmd_check_launch();
 }
 
+// ---- whole BiFPN node of a FROZEN net in one kernel ---------------------------------------------------------------------------
+//   y = BN_folded( pw( dw3x3( swish( sum_i w_i * operand_i ) ) ) + bias )      SeparableConvBlock(norm=True, activation=False) after the
+// fast-attention fusion (src/YetAnotherEfficientDet.py:150-185, 338-390), eval mode.  The two-kernel path writes the depthwise output,
+// reads it back in a 1x1-conv GEMM launch and pays two launches on the net's serial chain per node (40 nodes per net).  Here a block of
+// 8 waves owns an 8x8 pixel tile and all C = 112 channels:
+//   phase 0  fused + activated input tile with halo (10x10 px) -> LDS            (VALU; 28 channel quads x 100 px over 512 threads)
+//   phase 1  depthwise 3x3 from LDS -> zd tile [64 px][C] in LDS                  (VALU)
+//   phase 2  zd · Wpwᵀ on v_mfma_f32_16x16x4_f32: A = zd rows (16 px), B = Wpw rows (16 output channels), k split so that lane group g owns
+//            the contiguous run [28 g, 28 g + 28) of both; Wpw is fetched into registers before phase 0 and parked in the LDS region the
+//            input tile no longer needs (B fragments straight from L2 instead - 78 KB, two blocks per CU - measured slower: 16.5 -> 18.2 us
+//            per launch); 28 (row, column) tiles over 8 waves
+//   epilogue (acc + bias) * scale + shift straight from the accumulators (16 lanes = 64 contiguous bytes of one pixel).
+// 86 KB of LDS (one block per CU).
+constexpr int FN_C = 112, FN_Q = FN_C / 4, FN_FS = FN_C, FN_ZS = FN_C + 4, FN_WS = FN_C + 4, FN_NT = 512;
+constexpr int FN_U = (100 * FN_FS > FN_C * FN_WS) ? 100 * FN_FS : FN_C * FN_WS;      // input tile, later the 1x1 weights
+
+__global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, const float* __restrict__ wdw, const float* __restrict__ wpw,
+                                                                const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float* __restrict__ y,
+                                                                int tiles_h, int tiles_w) {
+  extern __shared__ float smem[];
+  float* const sU = smem;                       // [100][FS] fused input tile | [C][WS] pointwise weights
+  float* const sZ = smem + FN_U;                // [64][ZS] depthwise output tile
+  float* const sWd = sZ + 64 * FN_ZS;           // [9][C] depthwise taps
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h; bid /= tiles_h;
+  const int b = bid, oh0 = th * 8, ow0 = tw * 8;
+  // the 1x1 weights of the whole node, in flight while phases 0 and 1 run
+  constexpr int NW4 = FN_C * FN_Q, WPT = (NW4 + FN_NT - 1) / FN_NT;
+  float4 wreg[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int idx = tid + i * FN_NT;
+    wreg[i] = idx < NW4 ? mmd_ld4(wpw + (size_t)idx * 4) : make_float4(0, 0, 0, 0);
+  }
+  for (int i = tid; i < 9 * FN_Q; i += FN_NT) *reinterpret_cast<float4*>(&sWd[i * 4]) = mmd_ld4(wdw + (size_t)i * 4);
+  // ---- phase 0: every global load of the thread's (pixel, quad) items is issued before the first use (one block per CU: nothing else
+  // would hide six dependent load latencies); the pooled operand's 3x3 window is gathered in the second pass
+  {
+    constexpr int NI = (100 * FN_Q + FN_NT - 1) / FN_NT;
+    float4 v0[NI], v1[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int it = tid + i * FN_NT;
+      const int p = it / FN_Q, q = it - p * FN_Q;
+      const int ih = oh0 - 1 + p / 10, iw = ow0 - 1 + p % 10;
+      ok[i] = it < 100 * FN_Q && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      v0[i] = make_float4(0, 0, 0, 0); v1[i] = make_float4(0, 0, 0, 0);
+      if (ok[i]) {
+        const size_t off = (((size_t)b * a.H + ih) * a.W + iw) * a.C + q * 4;
+        v0[i] = mmd_ld4(a.in0 + off);
+        if (a.in1) v1[i] = mmd_ld4(a.in1 + off);
+        else if (a.up) v1[i] = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (ih >> 1)) * (a.W >> 1) + (iw >> 1)) * a.C + q * 4);
+      }
+    }
+    const int n2 = (a.in1 || a.up) ? 1 : 0;            // operand order (in0, in1, up, pool): in1 and up never occur together
+    const float wp_ = a.pl ? w[1 + n2] : 0.f;
+#pragma unroll
+    for (int i0 = 0; i0 < NI; i0 += 3) {               // the pooled operand's 3x3 windows of three items are gathered together (27 loads in flight)
+      float4 m[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = i0 + u;
+        m[u] = make_float4(0, 0, 0, 0);
+        if (i < NI && a.pl && ok[i]) {
+          const int it = tid + i * FN_NT;
+          const int p = it / FN_Q, q = it - p * FN_Q;
+          m[u] = pool_window(a.pl, b, oh0 - 1 + p / 10, ow0 - 1 + p % 10, q * 4, a.PH, a.PW, a.C, a.pad_t, a.pad_l);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = i0 + u;
+        if (i >= NI) break;
+        const int it = tid + i * FN_NT;
+        if (it >= 100 * FN_Q) break;
+        const int p = it / FN_Q, q = it - p * FN_Q;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (ok[i]) {
+          v.x = w[0] * v0[i].x; v.y = w[0] * v0[i].y; v.z = w[0] * v0[i].z; v.w = w[0] * v0[i].w;
+          if (n2) { v.x += w[1] * v1[i].x; v.y += w[1] * v1[i].y; v.z += w[1] * v1[i].z; v.w += w[1] * v1[i].w; }
+          if (a.pl) { v.x += wp_ * m[u].x; v.y += wp_ * m[u].y; v.z += wp_ * m[u].z; v.w += wp_ * m[u].w; }
+          v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w);
+        }
+        *reinterpret_cast<float4*>(&sU[p * FN_FS + q * 4]) = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 1
+  for (int it = tid; it < 64 * FN_Q; it += FN_NT) {
+    const int p = it / FN_Q, q = it - p * FN_Q;
+    const int orow = p >> 3, ocol = p & 7;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float4 x = *reinterpret_cast<const float4*>(&sU[((orow + i) * 10 + ocol + j) * FN_FS + q * 4]);
+        const float4 k = *reinterpret_cast<const float4*>(&sWd[(i * 3 + j) * FN_C + q * 4]);
+        acc.x += x.x * k.x; acc.y += x.y * k.y; acc.z += x.z * k.z; acc.w += x.w * k.w;
+      }
+    *reinterpret_cast<float4*>(&sZ[p * FN_ZS + q * 4]) = acc;
+  }
+  __syncthreads();                                   // every read of the input tile is done: park the 1x1 weights in its place
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int idx = tid + i * FN_NT;
+    if (idx < NW4) { const int n = idx / FN_Q, k4 = idx - n * FN_Q; *reinterpret_cast<float4*>(&sU[n * FN_WS + k4 * 4]) = wreg[i]; }
+  }
+  __syncthreads();
+  // ---- phase 2
+  const int lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave & 3;
+  float ebi[4], esc[4], esh[4];                  // epilogue coefficients of the wave's column tiles (ct = (wave >> 2) + 2 j)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = min(((wave >> 2) + 2 * j) * 16 + r, FN_C - 1);
+    ebi[j] = bias ? bias[n] : 0.f; esc[j] = scale[n]; esh[j] = shift[n];
+  }
+  float af[28];
+  {
+    const float* ap = &sZ[(rt * 16 + r) * FN_ZS + g * 28];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(ap + 4 * j);
+      af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4) {
+    const int ct = (wave >> 2) + 2 * j4;
+    if (ct >= 7) break;                                  // wave-uniform
+    float bf[28];
+    const float* bp = &sU[(ct * 16 + r) * FN_WS + g * 28];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(bp + 4 * j);
+      bf[4 * j] = v.x; bf[4 * j + 1] = v.y; bf[4 * j + 2] = v.z; bf[4 * j + 3] = v.w;
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};      // two chains: a dependent MFMA waits ~8 passes for its accumulator
+#pragma unroll
+    for (int k = 0; k < 28; k += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bf[k], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k + 1], bf[k + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
+    const int n = ct * 16 + r;
+    const float bi = ebi[j4], sc = esc[j4], sh = esh[j4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = rt * 16 + 4 * g + i;
+      const int oh = oh0 + (p >> 3), ow = ow0 + (p & 7);
+      if (oh < a.H && ow < a.W) y[(((size_t)b * a.H + oh) * a.W + ow) * FN_C + n] = (acc[i] + bi) * sc + sh;
+    }
+  }
+}
+
+// 1 when mmd_bifpn_node_fwd_fused has a kernel for this width (the caller keeps mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd otherwise)
+extern "C" int mmd_bifpn_node_fused_supported(int C) { return C == FN_C ? 1 : 0; }
+
+// Whole frozen-net BiFPN node: y[B*H*W, C] = ((dw3x3(swish(fuse(operands))) · w_pw[C,C]ᵀ) + bias) * scale + shift.
+extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
+                                        const float* w_dw, const float* w_pw, const float* bias, const float* scale, const float* shift,
+                                        float* y, int B, int H, int W, int C, hipStream_t stream) {
+  FuseArgs a{};
+  int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (rc || !w_dw || !w_pw || !scale || !shift || !y || C != FN_C || (in1 && up)) return MMD_EINVAL;      // (no BiFPN node fuses in1 AND up)
+  const int th = cdiv(H, 8), tw = cdiv(W, 8);
+  constexpr size_t lds = (size_t)(FN_U + 64 * FN_ZS + 9 * FN_C) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  mmd_prof_tag(MMD_FAM_MBX, "node H%lld C%lld ops%lld", H, C, a.ntheta, 0);
+  mmd_prof_begin(MMD_FAM_MBX, stream);
+  hipLaunchKernelGGL(bifpn_node_fused_kernel, dim3((unsigned)(B * th * tw)), dim3(FN_NT), lds, stream, a, w_dw, w_pw, bias, scale, shift,
+                     y, th, tw);
+  const double rows = (double)B * H * W;
+  mmd_prof_end(MMD_FAM_MBX, stream, rows * C * (2.0 * 9 + 2.0 * C), 4.0 * rows * C * (a.ntheta + 1 + (pool ? 3 : 0)));
+  return mmd_check_launch();
+}
+
 // backward part 1: dx = df * swish'(x) (x recomputed from the operands); wdot[i] += <dx, operand_i>
 // The gradients of the same-resolution operands (in0, in1) are w_i * dx: written / accumulated here (d0, d1 nullable) instead
 // of by a scale_acc launch each; dx itself is stored only when an upsampled or pooled operand still needs it.

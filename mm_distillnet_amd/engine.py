@@ -207,6 +207,7 @@ class Net:
         return (x.scale, x.shift, x.act, None, None, None, 0)
 
     STATS_SLOTS = 0 if os.environ.get("MMD_NO_SLOTS") else 64
+    FUSE_NODE = not os.environ.get("MMD_NO_NODE_FUSE")  # frozen nets: a BiFPN node (fusion, depthwise, 1x1 conv, BN) in one kernel
     FUSE_FRONT = not os.environ.get("MMD_NO_MBX")       # frozen nets: expand + depthwise of the thin-input blocks in one kernel
 
     def _stats_ws(self, stats, M: int, C: int):
@@ -439,9 +440,20 @@ class Net:
 
     def _node(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
               pl: Optional[Feat], train: bool, tape: dict, y=None) -> Feat:
+        th = self.ps.w(f"{cell}.{theta}")
+        if (not train and self.FUSE_NODE and self.ps.flat.is_cuda
+                and _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) == 1):
+            # frozen net: fusion + depthwise + 1x1 conv + folded BN in one launch, the depthwise output never leaves the CU
+            name = f"{cell}.{conv}"
+            b = self.ps.bn(f"{name}.bn")
+            if y is None:
+                y = self._alloc(in0.M, in0.C)
+            call("mmd_bifpn_node_fwd_fused", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                 self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
+                 self.ps.w(f"{name}.pointwise_conv.conv.bias"), b["fscale"], b["fshift"], y, in0.B, in0.H, in0.W, in0.C)
+            return Feat(y, in0.B, in0.H, in0.W, in0.C)
         f = self._alloc(in0.M, in0.C) if train else None      # the fused activation is only kept for the backward
         zd = self._alloc(in0.M, in0.C)
-        th = self.ps.w(f"{cell}.{theta}")
         call("mmd_bifpn_node_dw_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
              self.ps.w(f"{cell}.{conv}.depthwise_conv.conv.weight"), f, zd, in0.B, in0.H, in0.W, in0.C)
         ff = Feat(f if f is not None else zd, in0.B, in0.H, in0.W, in0.C)

@@ -983,6 +983,37 @@ def test_bifpn_node_dw_fused(mode, H, W, C):
     assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("mode,H,W", [("td", 8, 8), ("bu", 16, 12), ("p7", 4, 4), ("td", 64, 64), ("bu", 32, 32), ("bu", 6, 10), ("p7", 2, 2)])
+def test_bifpn_node_whole_fused(mode, H, W):
+    """Whole frozen-net BiFPN node in one kernel (fusion + swish + depthwise 3x3 + 1x1 conv + bias + folded BN; BiFPN._forward_fast_attention
+    + SeparableConvBlock(norm=True), src/YetAnotherEfficientDet.py:150-185,338-390) against the two launches it replaces and torch."""
+    torch.manual_seed(11)
+    B, C = 2, 112
+    in0 = torch.randn(B * H * W, C)
+    in1 = torch.randn(B * H * W, C) if mode == "bu" else None
+    up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
+    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7") else None
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    wd = torch.randn(9, C) / 3
+    wp = torch.randn(C, C) / math.sqrt(C); bias = torch.randn(C) * 0.1
+    sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    gp = lambda t: g(t) if t is not None else None
+    dll = _lib.LIB.load()
+    assert dll.mmd_bifpn_node_fused_supported(C) == 1 and dll.mmd_bifpn_node_fused_supported(224) == 0
+    z = torch.zeros(B * H * W, C, device=DEV)
+    call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), None, z, B, H, W, C)
+    y_ref = torch.empty(B * H * W, C, device=DEV)
+    call("mmd_pwconv_fwd", z, g(wp), y_ref, B * H * W, C, C, None, None, 0, None, None, None, 0, None, H * W, g(bias), g(sc), g(sh), 0,
+         None, None, 0, 0, None, 0)
+    y = torch.full((B * H * W, C), float("nan"), device=DEV)
+    call("mmd_bifpn_node_fwd_fused", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(wp), g(bias), g(sc), g(sh), y, B, H, W, C)
+    close(y, y_ref, 2e-5, 1e-6, "whole node vs two launches")
+    ref = (z.cpu().double() @ wp.double().t() + bias.double()) * sc.double() + sh.double()
+    close(y, ref, 2e-4, 1e-5, "whole node vs fp64 GEMM of the depthwise output")
+    with pytest.raises(RuntimeError):
+        call("mmd_bifpn_node_fwd_fused", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(wp), g(bias), g(sc), g(sh), y, B, H, W, 64)
+
+
 def test_slotted_bn_sums_match_direct():
     """Thin full-resolution layers: the producers spread their BatchNorm-sum atomics over workspace slots and fold
     them (common.h MMD_STATS_DEPTH); the folded sums equal the direct ones and the workspace is left zero."""
