@@ -225,6 +225,25 @@ def test_d4_eval_vs_oracle():
         assert relerr(feat_nchw(u), v) < 2e-3
 
 
+@pytest.mark.parametrize("coef,size", [(0, 256), (1, 384), (3, 256)])      # input sizes are multiples of 128, as upstream (nn.Upsample x2 between levels)
+def test_other_compound_coefficients_eval_vs_oracle(coef, size):
+    """EfficientDet-D0 / D1 / D3 frozen nets against the oracle: widths for which the fused frozen-net kernels have no instantiation
+    (BiFPN width 64 / 88 / 160: two-kernel node path; backbone inputs of 40 channels: expand GEMM + depthwise) next to blocks that do use
+    them, and the row-streaming depthwise kernel at other channel counts."""
+    spec, st = make_state(coef, 3, 40 + coef, "rgb")
+    net = Net(spec, DEV, trainable=False)
+    net.load_state(st)
+    x = synth_inputs(2, size, seed=9)["rgb"]
+    net.begin_step()
+    cls, reg, feats = net.forward(x.to(DEV), train=False)
+    with torch.no_grad():
+        (c, r, a), f = O.forward(st, x, coef, False)
+    assert cls.shape == c.shape and reg.shape == r.shape
+    assert relerr(cls, c) < 2e-3 and relerr(reg, r) < 2e-3
+    for u, v in zip(feats, f):
+        assert relerr(feat_nchw(u), v) < 2e-3
+
+
 def test_d4_train_fwd_bwd_vs_oracle():
     """BASELINE config-5 architecture (D4, 8-channel student) through the TRAIN forward and the hand-scheduled backward in
     fp32 against the oracle's autograd: 7 BiFPN cells of width 224, 4-layer heads, 48-channel stem, 32 MBConv blocks."""
