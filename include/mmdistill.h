@@ -65,7 +65,7 @@ int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W
 // Frozen-net MBConv front half in one kernel: expand 1x1 conv + folded BN0 + swish -> depthwise kxk/stride (TF-SAME) + folded BN1 + swish
 // + squeeze-excite average pool (pool[B,Cmid] +=, nullable).  The 6x expanded tensor stays in LDS (MFMA -> LDS -> depthwise).
 // w_expand [Cmid, Cin] as stored by the reference, w_dw tap-major [k*k, Cmid].  -22 for a geometry without a kernel: ask
-// mmd_mbconv_expand_dw_supported (Cin in {16,24,32,48,56}, Cmid % 48 == 0, k in {3,5}, stride in {1,2}) and keep mmd_pwconv_fwd +
+// mmd_mbconv_expand_dw_supported (Cin in {16,24,32,40,48,56}, Cmid % 48 == 0, k in {3,5}, stride in {1,2}) and keep mmd_pwconv_fwd +
 // mmd_dwconv_fwd otherwise.  Replaces MBConvBlock.forward's `_expand_conv`/`_bn0`/swish/`_depthwise_conv`/`_bn1`/swish/avg-pool
 // in eval mode (src/YetAnotherEfficientNet.py:450-470).
 int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stride);

@@ -225,7 +225,7 @@ static int mbx_launch_ks(MbxArgs& a, int k, int s, hipStream_t st) {
 extern "C" int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stride) {
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return 0;
   if (Cmid <= 0 || Cmid % MBX_CC) return 0;
-  return Cin == 16 || Cin == 24 || Cin == 32 || Cin == 48 || Cin == 56;
+  return Cin == 16 || Cin == 24 || Cin == 32 || Cin == 40 || Cin == 48 || Cin == 56;
 }
 
 // y[B,OH,OW,Cmid] = swish(dwconv_same(swish(x[B,H,W,Cin] · w_expand[Cmid,Cin]ᵀ * scale0 + shift0), w_dw[k*k,Cmid]) * scale1 + shift1);
@@ -247,6 +247,7 @@ extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, c
     case 16: rc = mbx_launch_ks<4>(a, k, stride, stream); break;
     case 24: rc = mbx_launch_ks<6>(a, k, stride, stream); break;
     case 32: rc = mbx_launch_ks<8>(a, k, stride, stream); break;
+    case 40: rc = mbx_launch_ks<10>(a, k, stride, stream); break;
     case 48: rc = mbx_launch_ks<12>(a, k, stride, stream); break;
     default: rc = mbx_launch_ks<14>(a, k, stride, stream); break;
   }

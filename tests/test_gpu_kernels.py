@@ -336,7 +336,7 @@ def test_dwconv(k, s, H, W, C):
 @pytest.mark.parametrize("cin,cmid,k,s,H,W", [(16, 96, 3, 2, 32, 32), (24, 144, 3, 1, 32, 32), (24, 144, 5, 2, 40, 24),
                                                (48, 288, 5, 1, 24, 16), (48, 288, 3, 2, 16, 16), (16, 96, 3, 1, 13, 21),
                                                (24, 48, 5, 2, 17, 9), (32, 192, 3, 2, 19, 35), (56, 336, 5, 1, 7, 5),
-                                               (32, 192, 5, 2, 8, 8), (16, 48, 3, 1, 3, 2)])
+                                               (32, 192, 5, 2, 8, 8), (16, 48, 3, 1, 3, 2), (40, 240, 5, 2, 20, 12), (40, 240, 3, 1, 9, 17)])
 def test_mbconv_expand_dw_fused(cin, cmid, k, s, H, W):
     """Frozen-net MBConv front half in one kernel (expand 1x1 + BN0 + swish -> depthwise + BN1 + swish + SE pool; MBConvBlock.forward,
     src/YetAnotherEfficientNet.py:450-470 in eval mode) against torch fp32 and against the two-kernel HIP path it replaces."""

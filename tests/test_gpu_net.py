@@ -228,7 +228,7 @@ def test_d4_eval_vs_oracle():
 @pytest.mark.parametrize("coef,size", [(0, 256), (1, 384), (3, 256)])      # input sizes are multiples of 128, as upstream (nn.Upsample x2 between levels)
 def test_other_compound_coefficients_eval_vs_oracle(coef, size):
     """EfficientDet-D0 / D1 / D3 frozen nets against the oracle: widths for which the fused frozen-net kernels have no instantiation
-    (BiFPN width 64 / 88 / 160: two-kernel node path; backbone inputs of 40 channels: expand GEMM + depthwise) next to blocks that do use
+    (BiFPN width 64 / 88 / 160: two-kernel node path) next to blocks that do use
     them, and the row-streaming depthwise kernel at other channel counts."""
     spec, st = make_state(coef, 3, 40 + coef, "rgb")
     net = Net(spec, DEV, trainable=False)
