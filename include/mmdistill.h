@@ -39,8 +39,10 @@ int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, cons
 // Backward of w = relu(theta)/(sum+1e-4).
 // Node backward in one launch: depthwise 3x3 input gradient (from an LDS tile of dzd, the gradient w.r.t. the depthwise output)
 // + fusion backward (same outputs as mmd_bifpn_fuse_bwd fed with df = dwconv^T(dzd, w_dw)); dup (nullable, needs `up`): the gradient of
-// the nearest-upsampled operand [B, H/2, W/2, C] (=|+=) w_up * 2x2 block sums, written here instead of by mmd_upsample2_bwd_acc.
-int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, hipStream_t stream);
+// the nearest-upsampled operand [B, H/2, W/2, C] (=|+=) w_up * 2x2 block sums, written here instead of by mmd_upsample2_bwd_acc;
+// dw_grad (nullable): the node's depthwise weight gradient [9, C] += , from the recomputed fused activation and the dzd tile this launch
+// already holds (instead of a mmd_dwconv_bwd_weight launch over a materialised f).
+int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, hipStream_t stream);
 
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
 

@@ -430,12 +430,13 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
-                                                         float* __restrict__ dup, int acc_up,
+                                                         float* __restrict__ dup, int acc_up, float* __restrict__ dwg,
                                                          int tiles_h, int tiles_w, int cchunks) {
   constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
   __shared__ float sIn[IH * IW * 64];
   __shared__ float sW[9 * 64];
   __shared__ float sred[4 * 3];
+  static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
@@ -483,15 +484,16 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
   float d[3] = {0.f, 0.f, 0.f};
   const int oh = oh0 + orow;
-  float4 gq[R];
+  float4 gq[R], fq[R];
 #pragma unroll
   for (int o = 0; o < R; ++o) {
     const int ow = ow0 + ocol0 + o;
-    gq[o] = make_float4(0, 0, 0, 0);
+    gq[o] = make_float4(0, 0, 0, 0); fq[o] = make_float4(0, 0, 0, 0);
     if (cok && oh < a.H && ow < a.W) {
       float4 t[4];
       float4 sv = fuse_presum(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3]);
       const size_t off = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
+      if (dwg) fq[o] = make_float4(mmd_swish(sv.x), mmd_swish(sv.y), mmd_swish(sv.z), mmd_swish(sv.w));      // the node's fused activation
       float4 g = acc[o];
       g.x *= mmd_swish_grad(sv.x); g.y *= mmd_swish_grad(sv.y); g.z *= mmd_swish_grad(sv.z); g.w *= mmd_swish_grad(sv.w);
       gq[o] = g;
@@ -535,19 +537,57 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { float v = wave_sum(d[i]); if (lane == 0) sred[wave * 3 + i] = v; }
-  __syncthreads();
+  // depthwise weight gradient of the node, from what this launch already holds: dw[i][j] += sum_q f[q] * dzd[q - (i-1, j-1)], f recomputed
+  // above and the dzd neighbourhood still in the LDS tile (it is the flipped-tap window of the input gradient: tap' = 8 - tap).
+  // Replaces a mmd_dwconv_bwd_weight launch per node and the materialised f it read.
+  float4 dwa[9];
+  if (dwg) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwa[t] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float4 in[SEG];
+      const float* prow = &sIn[((orow + i) * IW + ocol0) * 64 + c4];
+#pragma unroll
+      for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+          dwa[i * 3 + j].x += fq[o].x * in[o + j].x; dwa[i * 3 + j].y += fq[o].y * in[o + j].y;
+          dwa[i * 3 + j].z += fq[o].z * in[o + j].z; dwa[i * 3 + j].w += fq[o].w * in[o + j].w;
+        }
+    }
+  }
+  __syncthreads();                                  // sred complete; every read of the dzd tile done
   if (tid < a.ntheta) atomicAdd(&wdot[tid], sred[tid] + sred[3 + tid] + sred[6 + tid] + sred[9 + tid]);
+  if (dwg) {
+    float* sRedW = sIn;                             // [4 waves][9][64]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float4 v = dwa[t];
+      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      if (lane < 16) *reinterpret_cast<float4*>(&sRedW[(wave * 9 + t) * 64 + c4]) = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * 64; i += 256) {
+      const int t = i >> 6, q = i & 63;
+      if (c0 + q < a.C)
+        atomicAdd(&dwg[(size_t)(8 - t) * a.C + c0 + q], sRedW[(0 * 9 + t) * 64 + q] + sRedW[(1 * 9 + t) * 64 + q] + sRedW[(2 * 9 + t) * 64 + q] + sRedW[(3 * 9 + t) * 64 + q]);
+    }
+  }
 }
 extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool,
                                      const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
                                      int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
-                                     hipStream_t stream) {
+                                     float* dw_grad, hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   hipLaunchKernelGGL(fuse_dw_bwd_kernel, dim3((unsigned)(B * th * tw * cc)), dim3(256), 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0,
-                     d1, acc1, dup, acc_up, th, tw, cc);
+                     d1, acc1, dup, acc_up, dw_grad, th, tw, cc);
   return mmd_check_launch();
 }
 

@@ -207,6 +207,7 @@ class Net:
         return (x.scale, x.shift, x.act, None, None, None, 0)
 
     STATS_SLOTS = 0 if os.environ.get("MMD_NO_SLOTS") else 64
+    NODE_WG = not os.environ.get("MMD_NO_NODE_WG")      # BiFPN nodes: depthwise weight gradient inside the node's backward launch
     FUSE_NODE = not os.environ.get("MMD_NO_NODE_FUSE")  # frozen nets: a BiFPN node (fusion, depthwise, 1x1 conv, BN) in one kernel
     FUSE_FRONT = not os.environ.get("MMD_NO_MBX")       # frozen nets: expand + depthwise of the thin-input blocks in one kernel
 
@@ -452,7 +453,9 @@ class Net:
                  self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
                  self.ps.w(f"{name}.pointwise_conv.conv.bias"), b["fscale"], b["fshift"], y, in0.B, in0.H, in0.W, in0.C)
             return Feat(y, in0.B, in0.H, in0.W, in0.C)
-        f = self._alloc(in0.M, in0.C) if train else None      # the fused activation is only kept for the backward
+        # the fused activation is not materialised: the node's backward launch recomputes it, also for the depthwise weight gradient
+        # (MMD_NO_NODE_WG=1: the earlier form - f written here, weight gradient by its own launch on the side stream - for A/B timing)
+        f = self._alloc(in0.M, in0.C) if (train and not self.NODE_WG) else None
         zd = self._alloc(in0.M, in0.C)
         call("mmd_bifpn_node_dw_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
              self.ps.w(f"{cell}.{conv}.depthwise_conv.conv.weight"), f, zd, in0.B, in0.H, in0.W, in0.C)
@@ -825,8 +828,9 @@ class Net:
                 W = out.C
                 dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W, lazy=True)
                 dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
-                # depthwise weight gradient on the side stream; its input gradient is computed inside the fusion-backward launch
-                self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1, want_dx=False)
+                # the depthwise weight gradient and the depthwise input gradient both come out of the fusion-backward launch below
+                if not self.NODE_WG:
+                    self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1, want_dx=False)
                 in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
                 th = ps.w(f"{cell}.{rec['theta']}")
                 nth = th.numel()
@@ -853,7 +857,8 @@ class Net:
                     su.t = upargs[0]
                 wdot = self._zalloc((4,))
                 call("mmd_bifpn_node_dw_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-                     ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs)
+                     ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
+                     ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None)
                 self._leaf(lambda th=th, wdot=wdot, gt=ps.g(f"{cell}.{rec['theta']}"), nth=nth: call("mmd_bifpn_theta_bwd", th, wdot, gt, nth))
                 wi = 1 + (1 if in1 is not None else 0)
                 for operand, kind in ((up, "up"), (pl, "pool")):

@@ -1208,12 +1208,19 @@ def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
                 call("mmd_upsample2_bwd_acc", dx, dup_w, g(theta), nth, 1, 0, B, H, W, C)
                 call("mmd_upsample2_bwd_acc", dx, dup_a, g(theta), nth, 1, 1, B, H, W, C)
         else:
+            dwg = torch.zeros(9, C, device=DEV)
             call("mmd_bifpn_node_dw_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(dzd), dx, wdot, B, H, W, C, d0, 1,
-                 d1, 0, dup_w, 0)
+                 d1, 0, dup_w, 0, dwg)
+            # the node's depthwise weight gradient from the same launch == mmd_dwconv_bwd_weight over the materialised fused activation
+            f_ref = torch.empty(B * H * W, C, device=DEV)
+            call("mmd_bifpn_fuse_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), f_ref, B, H, W, C)
+            dw_ref = torch.zeros(9, C, device=DEV)
+            call("mmd_dwconv_bwd_weight", f_ref, g(dzd), dw_ref, B, H, W, C, 3, 1, None, None, 0)
+            close(dwg, dw_ref, 1e-4, 1e-5, "depthwise weight gradient out of the node backward")
             if up is not None:       # second launch: accumulate form, dx not materialised (the top-down nodes' configuration)
                 wd2 = torch.zeros(4, device=DEV)
                 call("mmd_bifpn_node_dw_bwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(dzd), None, wd2, B, H, W, C,
-                     g(base0.clone()), 1, None, 0, dup_a, 1)
+                     g(base0.clone()), 1, None, 0, dup_a, 1, None)
         outs[name] = (dx, wdot, d0, d1, dup_w, dup_a)
     for a, b, what in zip(outs["ref"], outs["fused"], ("dx", "wdot", "d0", "d1", "dup (write)", "dup (accumulate)")):
         if a is not None:
