@@ -76,7 +76,9 @@ int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float*
 // Input gradient of the depthwise conv.  With bn_sums (stride 1 only) the launch also accumulates the sums of the BatchNorm(+swish)
 // backward that consumes dx: bn_sums[c] += sum dx*swish'(u), bn_sums[C+c] += sum dx*swish'(u)*xhat, u = bn_z*bn_scale+bn_shift,
 // xhat = (bn_z-bn_mean)*bn_invstd (bn_z = that BN's forward input, same shape as dx); stats_ws/ws_slots as in mmd_dwconv_fwd.
-int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, hipStream_t stream);
+// dw_grad (nullable; needs bn_sums, C >= 64): the conv's weight gradient [k*k, C] += out of the same launch, with the forward input taken as
+// swish(bn_z*bn_scale+bn_shift) - what mmd_dwconv_bwd_weight computes from x = bn_z with that producer transform.
+int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad, hipStream_t stream);
 
 // Weight gradient of the depthwise conv, tap-major dw[k*k, C] (+=).
 int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, hipStream_t stream);

@@ -26,6 +26,7 @@ struct DwArgs {
   // input-gradient launch feeding a BatchNorm(+swish) backward: stats become (sum g, sum g*xhat) with g = y * swish'(u),
   // u = bz*bscale + bshift, xhat = (bz - bmean)*binvstd, bz = the BN's forward input at the output position (y itself is stored)
   const float* bz; const float* bscale; const float* bshift; const float* bmean; const float* binvstd;
+  float* dwg;        // input-gradient launch with `bz`: also the depthwise WEIGHT gradient [k*k, C] += sum_q swish(u)[q] * x[q + tap] (x = the launch's input = dY)
   int noswz;
   int tiles_h, tiles_w, cchunks;
   Pyr pyr; long long lev_stride;
@@ -96,7 +97,10 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
 // PRO / EPI: the launch's prologue and epilogue mode as compile-time parameters (PRO: producer transform; EPI 0 raw, 1 raw + BatchNorm
 // sums, 2 raw + `bz` sums, 3 folded BN / activation / pool, 4 any combination at run time) - as for dw3_rows_kernel, the union of all
 // modes costs registers and branches on every launch.
-template <int K, int S, int LANES = 16, bool PRO = true, int EPI = 4>
+// WG (with EPI 2): the weight gradient of the forward conv out of the same launch - the dY tile is in LDS, the forward input a0 = swish(u)
+// is recomputed for the BatchNorm sums anyway; k*k float4 sums per thread, one block reduction, k*k*CC atomics per block.  A depthwise
+// weight-gradient launch is a leaf whose kernel time the saturated chip pays in full (profiles/r02_notes.md).
+template <int K, int S, int LANES = 16, bool PRO = true, int EPI = 4, bool WG = false>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   using Cf = DwCfg<K, S, LANES>;
   constexpr int CC = Cf::CC;
@@ -176,6 +180,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   float4 bsc, bsh, bmu, bis;
   if (E_BZ && a.bz && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
   const int oh = oh0 + orow;
+  float4 fq[WG ? Cf::R : 1];
+  if (WG) {
+#pragma unroll
+    for (int o = 0; o < Cf::R; ++o) fq[o] = make_float4(0, 0, 0, 0);
+  }
 #pragma unroll
   for (int o = 0; o < Cf::R; ++o) {
     int ow = ow0 + ocol0 + o;
@@ -183,6 +192,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       float4 v = acc[o];
       if (E_BZ && a.bz) {
         const float4 zz = mmd_ld4(a.bz + (((size_t)b * OH + oh) * OW + ow) * a.C + c);
+        if (WG) fq[o] = make_float4(mmd_swish(zz.x * bsc.x + bsh.x), mmd_swish(zz.y * bsc.y + bsh.y), mmd_swish(zz.z * bsc.z + bsh.z),
+                                    mmd_swish(zz.w * bsc.w + bsh.w));
         float4 gg;
         gg.x = v.x * mmd_swish_grad(zz.x * bsc.x + bsh.x); gg.y = v.y * mmd_swish_grad(zz.y * bsc.y + bsh.y);
         gg.z = v.z * mmd_swish_grad(zz.z * bsc.z + bsh.z); gg.w = v.w * mmd_swish_grad(zz.w * bsc.w + bsh.w);
@@ -238,6 +249,44 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       }
     }
   }
+  if constexpr (WG) {
+    static_assert(S == 1 && LANES == 16 && Cf::IH * Cf::IW >= 4 * K * K, "weight-gradient reduction aliases the input tile");
+    // dw[i][j] += sum_q a0[q] * dY[q - (i - p, j - p)]: the launch's (flipped-tap) window of dY around q, read once more from the LDS tile
+    float4 dwa[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) dwa[t] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      float4 in[Cf::SEG];
+      const float* prow = &sIn[((orow + i) * Cf::IW + ocol0) * CC + c4];
+#pragma unroll
+      for (int q = 0; q < Cf::SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * CC);
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int o = 0; o < Cf::R; ++o) {
+          dwa[i * K + j].x += fq[o].x * in[o + j].x; dwa[i * K + j].y += fq[o].y * in[o + j].y;
+          dwa[i * K + j].z += fq[o].z * in[o + j].z; dwa[i * K + j].w += fq[o].w * in[o + j].w;
+        }
+    }
+    __syncthreads();                                  // every read of the tile is done: reduce in its place
+    float* sRedW = sIn;                               // [4 waves][K*K][CC]
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      float4 v = dwa[t];
+      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      if (lane < 16) *reinterpret_cast<float4*>(&sRedW[(wave * K * K + t) * CC + c4]) = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * K * CC; i += 256) {
+      const int t = i / CC, q = i - t * CC;
+      if (c0 + q < a.C)
+        atomicAdd(&a.dwg[(size_t)(K * K - 1 - t) * a.C + c0 + q], sRedW[(0 * K * K + t) * CC + q] + sRedW[(1 * K * K + t) * CC + q] +
+                                                                    sRedW[(2 * K * K + t) * CC + q] + sRedW[(3 * K * K + t) * CC + q]);
+    }
+  }
 }
 
 template <int K, int S, int LANES = 16>
@@ -253,10 +302,15 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   const int epi = (a.stats && out) ? 4 : (a.bz ? 2 : (a.stats ? 1 : (out ? 3 : 0)));
   const dim3 grid((unsigned)nb), blk(256);
 #define MMD_DW_TILE(P, E) hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, P, E>), grid, blk, 0, st, a)
+  if constexpr (S == 1 && LANES == 16) {
+    if (a.dwg && epi == 2 && !pro) { hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, false, 2, true>), grid, blk, 0, st, a); goto launched; }
+  }
+  if (a.dwg) return MMD_EINVAL;
   if (epi == 4) MMD_DW_TILE(true, 4);
   else if (pro) { if (epi == 0) MMD_DW_TILE(true, 0); else if (epi == 1) MMD_DW_TILE(true, 1); else if (epi == 2) MMD_DW_TILE(true, 2); else MMD_DW_TILE(true, 3); }
   else { if (epi == 0) MMD_DW_TILE(false, 0); else if (epi == 1) MMD_DW_TILE(false, 1); else if (epi == 2) MMD_DW_TILE(false, 2); else MMD_DW_TILE(false, 3); }
 #undef MMD_DW_TILE
+launched:
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * a.C, st);
   return mmd_check_launch();
 }
@@ -605,10 +659,11 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
 extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k,
                                    int stride, const float* bn_z, const float* bn_scale, const float* bn_shift,
                                    const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws,
-                                   int ws_slots, hipStream_t stream) {
+                                   int ws_slots, float* dw_grad, hipStream_t stream) {
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if (bn_sums && (stride != 1 || !bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
+  if (dw_grad && (!bn_sums || C < 64)) return MMD_EINVAL;        // the weight gradient rides on the BatchNorm-sum form (it needs a0 = swish(u))
   int OH, OW;
   int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd H%lld C%lld k%lld s%lld", H, C, k, stride);
@@ -622,7 +677,8 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
       a.stats = bn_sums; a.stats_ws = stats_ws; a.ws_slots = ws_slots;
       a.bz = bn_z; a.bscale = bn_scale; a.bshift = bn_shift; a.bmean = bn_mean; a.binvstd = bn_invstd;
     }
-    rc = (k == 3) ? dw3_rows_launch(a, stream) : 1;
+    a.dwg = dw_grad;
+    rc = (k == 3 && !dw_grad) ? dw3_rows_launch(a, stream) : 1;      // (the row-streaming kernel has no weight-gradient form)
     if (rc == 1) rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch<5, 1>(a, stream);
   } else {
     size_t total = (size_t)B * H * W * (C >> 2);

@@ -207,6 +207,7 @@ class Net:
         return (x.scale, x.shift, x.act, None, None, None, 0)
 
     STATS_SLOTS = 0 if os.environ.get("MMD_NO_SLOTS") else 64
+    DW_WG = not os.environ.get("MMD_NO_DW_WG")          # stride-1 backbone layers: depthwise weight gradient inside the input-gradient launch
     NODE_WG = not os.environ.get("MMD_NO_NODE_WG")      # BiFPN nodes: depthwise weight gradient inside the node's backward launch
     FUSE_NODE = not os.environ.get("MMD_NO_NODE_FUSE")  # frozen nets: a BiFPN node (fusion, depthwise, 1x1 conv, BN) in one kernel
     FUSE_FRONT = not os.environ.get("MMD_NO_MBX")       # frozen nets: expand + depthwise of the thin-input blocks in one kernel
@@ -712,19 +713,23 @@ class Net:
 
     def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True, bn_aff=None):
         """-> dx, or (dx, sums) when `bn_aff` = (scale, shift, mean, invstd) of the BatchNorm(+swish) that produced x: the
-        stride-1 input-gradient launch then also accumulates that BN's backward sums (no separate reduce pass)."""
+        stride-1 input-gradient launch then also accumulates that BN's backward sums (no separate reduce pass) and the conv's weight
+        gradient (tile kernel; for the 3x3 layers that gives up the faster row-streaming input-gradient kernel and still wins: a
+        weight-gradient leaf costs its full kernel time on the saturated chip - 18.44 -> 18.27 ms/step)."""
         ps = self.ps
-        self._leaf(lambda x=x, dzd=dzd, gw=ps.g(wkey): call("mmd_dwconv_bwd_weight", x.z, dzd, gw, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift,
-                                                             x.act))
+        wg_inside = self.DW_WG and want_dx and bn_aff is not None and s == 1 and x.C >= 64
+        if not wg_inside:
+            self._leaf(lambda x=x, dzd=dzd, gw=ps.g(wkey): call("mmd_dwconv_bwd_weight", x.z, dzd, gw, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift,
+                                                                 x.act))
         if not want_dx:
             return None
         dx = self._alloc(x.M, x.C)
         if bn_aff is not None and s == 1:
             sums = self._zalloc((2 * x.C,), torch.float64)
             call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, x.z, bn_aff[0], bn_aff[1], bn_aff[2],
-                 bn_aff[3], sums, *self._stats_ws(sums, x.M, x.C))
+                 bn_aff[3], sums, *self._stats_ws(sums, x.M, x.C), ps.g(wkey) if wg_inside else None)
             return dx, sums
-        call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, None, None, None, None, None, None, None, 0)
+        call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, None, None, None, None, None, None, None, 0, None)
         return (dx, None) if bn_aff is not None else dx
 
     def _head_bwd(self, hname: str, per_anchor: int, dout: torch.Tensor, tape: dict, pyr: dict, A: int, C: int):

@@ -316,7 +316,7 @@ def test_dwconv(k, s, H, W, C):
     close(pool, ye.mean((2, 3)), 2e-4, 1e-5, "pool")
     # backward
     dxo = torch.empty(B * H * W, C, device=DEV)
-    call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dxo, B, H, W, C, k, s, None, None, None, None, None, None, None, 0)
+    call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dxo, B, H, W, C, k, s, None, None, None, None, None, None, None, 0, None)
     close(dxo.view(B, H, W, C), nhwc(a.grad), 2e-4, 1e-5, "dw bwd data")
     if s == 1:      # fused sums of the BatchNorm(+swish) backward that consumes dx == the stand-alone reduce pass
         mu, istd = torch.randn(C) * 0.2, torch.rand(C) + 0.5
@@ -325,9 +325,16 @@ def test_dwconv(k, s, H, W, C):
              None, 0)
         got = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
         dx2 = torch.empty_like(dxo)
-        call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx2, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got, None, 0)
+        call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx2, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got, None, 0, None)
         assert torch.equal(dx2, dxo)
         close(got, ref, 1e-5, 1e-5, "BN sums fused into dw bwd-data")
+        if C >= 64:      # ... and the conv's weight gradient out of the same launch (x = swish(BN(z)) recomputed from z)
+            got2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+            dx3 = torch.empty_like(dxo); dwg = torch.zeros(k * k, C, device=DEV)
+            call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx3, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got2, None, 0, dwg)
+            close(dx3, dxo, 1e-6, 1e-7, "dx with the weight gradient riding along")
+            close(got2, ref, 1e-5, 1e-5, "BN sums with the weight gradient riding along")
+            close(dwg, w.grad.reshape(C, k * k).t(), 3e-4, 1e-5, "dw weight gradient out of the input-gradient launch")
     dwo = torch.zeros(k * k, C, device=DEV)
     call("mmd_dwconv_bwd_weight", g(nhwc(x)), g(nhwc(dy)), dwo, B, H, W, C, k, s, g(isc), g(ish), 1)
     close(dwo, w.grad.reshape(C, k * k).t(), 3e-4, 1e-5, "dw bwd weight")
@@ -860,7 +867,7 @@ def test_pyramid_launches_match_per_level():
              None, None, 0, None, None, None, 0)
         assert torch.equal(y[sl], yr), l
         dxr = torch.empty(rows[l], C, device=DEV)
-        call("mmd_dwconv_bwd_data", g(dy[sl]), g(wd), dxr, B, h, w, C, 3, 1, None, None, None, None, None, None, None, 0)
+        call("mmd_dwconv_bwd_data", g(dy[sl]), g(wd), dxr, B, h, w, C, 3, 1, None, None, None, None, None, None, None, 0, None)
         assert torch.equal(yf[sl], dxr), l
         call("mmd_dwconv_bwd_weight", g(x[sl]), g(dy[sl]), dwr, B, h, w, C, 3, 1, g(sc[ol:ol + C]), g(sh[ol:ol + C]), 1)
     close(dwp, dwr, 1e-4, 1e-5, "pyr dw wgrad")
@@ -1191,7 +1198,7 @@ def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
     dzd = torch.randn(B * H * W, C)
     gp = lambda t: g(t) if t is not None else None
     df = torch.empty(B * H * W, C, device=DEV)
-    call("mmd_dwconv_bwd_data", g(dzd), g(wd), df, B, H, W, C, 3, 1, None, None, None, None, None, None, None, 0)
+    call("mmd_dwconv_bwd_data", g(dzd), g(wd), df, B, H, W, C, 3, 1, None, None, None, None, None, None, None, 0, None)
     base0 = torch.randn(B * H * W, C)
     outs = {}
     for name in ("ref", "fused"):
