@@ -76,7 +76,7 @@ int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float*
 // Input gradient of the depthwise conv.  With bn_sums (stride 1 only) the launch also accumulates the sums of the BatchNorm(+swish)
 // backward that consumes dx: bn_sums[c] += sum dx*swish'(u), bn_sums[C+c] += sum dx*swish'(u)*xhat, u = bn_z*bn_scale+bn_shift,
 // xhat = (bn_z-bn_mean)*bn_invstd (bn_z = that BN's forward input, same shape as dx); stats_ws/ws_slots as in mmd_dwconv_fwd.
-// dw_grad (nullable; needs bn_sums, C >= 64): the conv's weight gradient [k*k, C] += out of the same launch, with the forward input taken as
+// dw_grad (nullable; needs bn_sums): the conv's weight gradient [k*k, C] += out of the same launch, with the forward input taken as
 // swish(bn_z*bn_scale+bn_shift) - what mmd_dwconv_bwd_weight computes from x = bn_z with that producer transform.
 int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad, hipStream_t stream);
 
@@ -213,7 +213,9 @@ int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N
 // (Regressor/Classifier.forward, src/YetAnotherEfficientDet.py:463-532: conv_list shared across levels, bn_list per level.)
 int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
 
-int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long lev_stride, hipStream_t stream);
+// dw_grad (nullable; flip = 1 launches): the conv's weight gradient [9, C] += from the same launch, x operand = act(wg_x * wg_scale + wg_shift)
+// with per-level coefficients lev_stride apart (what mmd_dwconv3_pyr_bwd_weight(wg_x, x, ...) computes).
+int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long lev_stride, const float* wg_x, const float* wg_scale, const float* wg_shift, int wg_act, float* dw_grad, hipStream_t stream);
 
 int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const int* pyr_desc, int C, const float* in_scale, const float* in_shift, int in_act, long long lev_stride, hipStream_t stream);
 

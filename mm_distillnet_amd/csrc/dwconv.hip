@@ -26,6 +26,7 @@ struct DwArgs {
   // input-gradient launch feeding a BatchNorm(+swish) backward: stats become (sum g, sum g*xhat) with g = y * swish'(u),
   // u = bz*bscale + bshift, xhat = (bz - bmean)*binvstd, bz = the BN's forward input at the output position (y itself is stored)
   const float* bz; const float* bscale; const float* bshift; const float* bmean; const float* binvstd;
+  int wg_act;        // dw3_rows_kernel<WG>: activation of the weight gradient's x operand (bz = x, bscale / bshift = its producer affine)
   float* dwg;        // input-gradient launch with `bz`: also the depthwise WEIGHT gradient [k*k, C] += sum_q swish(u)[q] * x[q + tap] (x = the launch's input = dY)
   int noswz;
   int tiles_h, tiles_w, cchunks;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
   }
   if constexpr (WG) {
-    static_assert(S == 1 && LANES == 16 && Cf::IH * Cf::IW >= 4 * K * K, "weight-gradient reduction aliases the input tile");
+    static_assert(S == 1 && Cf::IH * Cf::IW >= 4 * K * K, "weight-gradient reduction aliases the input tile");
     // dw[i][j] += sum_q a0[q] * dY[q - (i - p, j - p)]: the launch's (flipped-tap) window of dY around q, read once more from the LDS tile
     float4 dwa[K * K];
 #pragma unroll
@@ -275,9 +276,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
 #pragma unroll
     for (int t = 0; t < K * K; ++t) {
       float4 v = dwa[t];
-      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
-      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
-      if (lane < 16) *reinterpret_cast<float4*>(&sRedW[(wave * K * K + t) * CC + c4]) = v;
+#pragma unroll
+      for (int o = LANES; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+      }
+      if (lane < LANES) *reinterpret_cast<float4*>(&sRedW[(wave * K * K + t) * CC + c4]) = v;
     }
     __syncthreads();
     for (int i = tid; i < K * K * CC; i += 256) {
@@ -302,7 +305,7 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   const int epi = (a.stats && out) ? 4 : (a.bz ? 2 : (a.stats ? 1 : (out ? 3 : 0)));
   const dim3 grid((unsigned)nb), blk(256);
 #define MMD_DW_TILE(P, E) hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, P, E>), grid, blk, 0, st, a)
-  if constexpr (S == 1 && LANES == 16) {
+  if constexpr (S == 1) {
     if (a.dwg && epi == 2 && !pro) { hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, false, 2, true>), grid, blk, 0, st, a); goto launched; }
   }
   if (a.dwg) return MMD_EINVAL;
@@ -338,10 +341,14 @@ struct DwRowsGeom { int colblocks, rowblocks, rh; };
 
 // PRO: producer transform on the input; EPI: 0 raw output, 1 raw + BatchNorm sums, 2 raw + the `bz` sums of a BatchNorm backward,
 // 3 folded BN / activation / pool.  Compile-time: the union of all modes needs 244 VGPRs and ran 1.5x slower than the specialised bodies.
-template <int R, int LW, bool PRO, int EPI>
+// WG (flipped input-gradient launches without a producer transform): the conv's weight gradient out of the same launch,
+// dw[8 - tap'] += sum_q f[q] * dY[q + tap' offset] with f = act(x * scale + shift) loaded at the output pixel (a.bz = x) and the dY
+// neighbourhood = the register window; one block reduction + 9 x CC atomics per block.
+template <int R, int LW, bool PRO, int EPI, bool WG = false>
 __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) {
   constexpr int CC = 4 * LW;
   __shared__ float sRed[2 * 4 * CC];
+  __shared__ float sRedW[WG ? 4 * 9 * CC : 1];
   const int tid = threadIdx.x, c4 = (tid & (LW - 1)) * 4, strip = tid / LW;
   int bid = (a.noswz || a.pyr.n) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   // pyramid launch: this block's level (unrolled selects, as in dw_fwd_kernel); every level uses the same R and rows per block, a
@@ -402,7 +409,32 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
     }
   };
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
+  float4 dwa[WG ? 9 : 1];
+  float4 gsc = make_float4(1, 1, 1, 1), gsh = make_float4(0, 0, 0, 0);
+  if (WG) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwa[t] = make_float4(0, 0, 0, 0);
+    const long long lo = (long long)lev * a.lev_stride;
+    if (a.bscale && cok) { gsc = mmd_ld4(a.bscale + lo + c); gsh = mmd_ld4(a.bshift + lo + c); }
+  }
   auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2]) {
+    if constexpr (WG) {
+#pragma unroll
+      for (int o = 0; o < R; ++o) {
+        const int ow = ow0 + o;
+        if (cok && ow < W) {
+          float4 f = mmd_ld4(a.bz + ob + ((size_t)oh * W + ow) * C);
+          if (a.bscale) { f.x = f.x * gsc.x + gsh.x; f.y = f.y * gsc.y + gsh.y; f.z = f.z * gsc.z + gsh.z; f.w = f.w * gsc.w + gsh.w; }
+          if (a.wg_act == MMD_ACT_SWISH) { f.x = mmd_swish(f.x); f.y = mmd_swish(f.y); f.z = mmd_swish(f.z); f.w = mmd_swish(f.w); }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            dwa[j].x += f.x * r0[o + j].x; dwa[j].y += f.y * r0[o + j].y; dwa[j].z += f.z * r0[o + j].z; dwa[j].w += f.w * r0[o + j].w;
+            dwa[3 + j].x += f.x * r1[o + j].x; dwa[3 + j].y += f.y * r1[o + j].y; dwa[3 + j].z += f.z * r1[o + j].z; dwa[3 + j].w += f.w * r1[o + j].w;
+            dwa[6 + j].x += f.x * r2[o + j].x; dwa[6 + j].y += f.y * r2[o + j].y; dwa[6 + j].z += f.z * r2[o + j].z; dwa[6 + j].w += f.w * r2[o + j].w;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int o = 0; o < R; ++o) {
       float4 acc = make_float4(0, 0, 0, 0);
@@ -484,6 +516,25 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
         const float vv = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
         atomicAdd(&a.pool[(size_t)b * C + c0 + tid], vv * a.pool_scale);
       }
+    }
+  }
+  if constexpr (WG) {
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float4 x = dwa[t];
+#pragma unroll
+      for (int o = LW; o < 64; o <<= 1) {
+        x.x += __shfl_xor(x.x, o, 64); x.y += __shfl_xor(x.y, o, 64); x.z += __shfl_xor(x.z, o, 64); x.w += __shfl_xor(x.w, o, 64);
+      }
+      if (lane < LW) *reinterpret_cast<float4*>(&sRedW[(wave * 9 + t) * CC + c4]) = x;
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * CC; i += 256) {
+      const int t = i / CC, q = i - t * CC;
+      if (c0 + q < C)
+        atomicAdd(&a.dwg[(size_t)(8 - t) * C + c0 + q],
+                  sRedW[(0 * 9 + t) * CC + q] + sRedW[(1 * 9 + t) * CC + q] + sRedW[(2 * 9 + t) * CC + q] + sRedW[(3 * 9 + t) * CC + q]);
     }
   }
 }
@@ -573,12 +624,18 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   return rc;
 }
 
+extern "C" int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const int* pyr_desc, int C, const float* in_scale,
+                                          const float* in_shift, int in_act, long long lev_stride, hipStream_t stream);
+
 // Depthwise 3x3/s1 over a whole feature pyramid in ONE launch (shared weights; per-level producer BN via lev_stride).
 // flip=1 gives the input gradient.  x, y: pyramid row buffers [row0[n], C].
 extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip,
                                const float* in_scale, const float* in_shift, int in_act, const double* in_stats,
-                               const float* in_gamma, const float* in_beta, long long lev_stride, hipStream_t stream) {
+                               const float* in_gamma, const float* in_beta, long long lev_stride,
+                               const float* wg_x, const float* wg_scale, const float* wg_shift, int wg_act, float* dw_grad,
+                               hipStream_t stream) {
   if (!x || !w || !y || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if (dw_grad && (!wg_x || !flip || (wg_scale == nullptr) != (wg_shift == nullptr))) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
   if (in_stats && (in_scale || !in_gamma || !in_beta)) return MMD_EINVAL;
   DwArgs a{};
@@ -608,14 +665,23 @@ extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const i
       nr += a.B * a.cchunks * cdiv(a.pyr.W[l], 64) * cdiv(a.pyr.H[l], gm.rh);
     }
     for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nr;
-    hipLaunchKernelGGL((dw3_rows_kernel<4, 16, false, 0>), dim3(nr), dim3(256), 0, stream, a, gm);
+    if (dw_grad) {
+      a.bz = wg_x; a.bscale = wg_scale; a.bshift = wg_shift; a.wg_act = wg_act; a.dwg = dw_grad;
+      hipLaunchKernelGGL((dw3_rows_kernel<4, 16, false, 0, true>), dim3(nr), dim3(256), 0, stream, a, gm);
+      dw_grad = nullptr;                                  // done
+    } else {
+      hipLaunchKernelGGL((dw3_rows_kernel<4, 16, false, 0>), dim3(nr), dim3(256), 0, stream, a, gm);
+    }
   } else {
     if (pro) hipLaunchKernelGGL((dw_fwd_kernel<3, 1, 16, true, 0>), dim3(nb), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((dw_fwd_kernel<3, 1, 16, false, 0>), dim3(nb), dim3(256), 0, stream, a);
   }
   double rows = a.pyr.row0[a.pyr.n];
   mmd_prof_end(MMD_FAM_DW, stream, 2.0 * rows * C * 9, 8.0 * rows * C);
-  return mmd_check_launch();
+  int rc = mmd_check_launch();
+  if (rc == MMD_OK && dw_grad)      // geometry without the fused form: the weight gradient by its own launch, same stream
+    rc = mmd_dwconv3_pyr_bwd_weight(wg_x, x, dw_grad, pyr_desc, C, wg_scale, wg_shift, wg_act, lev_stride, stream);
+  return rc;
 }
 
 // ---- input gradient -------------------------------------------------------------------
@@ -663,7 +729,7 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if (bn_sums && (stride != 1 || !bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
-  if (dw_grad && (!bn_sums || C < 64)) return MMD_EINVAL;        // the weight gradient rides on the BatchNorm-sum form (it needs a0 = swish(u))
+  if (dw_grad && !bn_sums) return MMD_EINVAL;        // the weight gradient rides on the BatchNorm-sum form (it needs a0 = swish(u))
   int OH, OW;
   int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd H%lld C%lld k%lld s%lld", H, C, k, stride);

@@ -543,7 +543,8 @@ class Net:
             cname = f"{hname}.conv_list.{i}"
             o = off0 + i * C
             zd = self._alloc_pyr(pyr, C)
-            call("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride)
+            call("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
+                 None, None, None, NONE, None)
             z = self._alloc_pyr(pyr, C)
             st = self.stats_flat[2 * o:] if train else None
             call("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
@@ -558,7 +559,8 @@ class Net:
             layers.append({"x": cur, "x_off": None if i == 0 else off0 + (i - 1) * C, "zd": zd, "z": z, "off": o})
             cur, cur_xf = z, nxt_xf
         zd = self._alloc_pyr(pyr, C)
-        call("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride)
+        call("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
+             None, None, None, NONE, None)
         aoff, yoff = 0, []
         for (h, w) in pyr["sizes"]:
             yoff.append(aoff * per_anchor)
@@ -717,7 +719,7 @@ class Net:
         gradient (tile kernel; for the 3x3 layers that gives up the faster row-streaming input-gradient kernel and still wins: a
         weight-gradient leaf costs its full kernel time on the saturated chip - 18.44 -> 18.27 ms/step)."""
         ps = self.ps
-        wg_inside = self.DW_WG and want_dx and bn_aff is not None and s == 1 and x.C >= 64
+        wg_inside = self.DW_WG and want_dx and bn_aff is not None and s == 1
         if not wg_inside:
             self._leaf(lambda x=x, dzd=dzd, gw=ps.g(wkey): call("mmd_dwconv_bwd_weight", x.z, dzd, gw, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift,
                                                                  x.act))
@@ -731,6 +733,18 @@ class Net:
             return dx, sums
         call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, None, None, None, None, None, None, None, 0, None)
         return (dx, None) if bn_aff is not None else dx
+
+    PYR_WG = not os.environ.get("MMD_NO_PYR_WG")
+
+    def _pyr_dw_bwd(self, dzd, wkey: str, g, desc, C: int, ls: int, x, sc, sh, act: int):
+        """Input gradient of a shared-weight pyramid depthwise conv; its weight gradient rides in the same launch (MMD_NO_PYR_WG=1:
+        by its own launch on the weight-gradient stream, the earlier form, for A/B timing)."""
+        ps = self.ps
+        if self.PYR_WG:
+            call("mmd_dwconv3_pyr", dzd, ps.w(wkey), g, desc, C, 1, None, None, NONE, None, None, None, ls, x, sc, sh, act, ps.g(wkey))
+            return
+        self._leaf(lambda: call("mmd_dwconv3_pyr_bwd_weight", x, dzd, ps.g(wkey), desc, C, sc, sh, act, ls))
+        call("mmd_dwconv3_pyr", dzd, ps.w(wkey), g, desc, C, 1, None, None, NONE, None, None, None, 0, None, None, None, NONE, None)
 
     def _head_bwd(self, hname: str, per_anchor: int, dout: torch.Tensor, tape: dict, pyr: dict, A: int, C: int):
         """Backward of one head over the whole pyramid; returns the gradient w.r.t. the pyramid feature buffer."""
@@ -748,11 +762,9 @@ class Net:
         dzd = self._alloc_pyr(pyr, C)
         call("mmd_pwconv_bwd_data" + self._sfx, dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
-        self._leaf(lambda hx=rec["hx"], dzd=dzd, gw=ps.g(f"{hname}.header.depthwise_conv.conv.weight"), sc=self.t_scale[xo:], sh=self.t_shift[xo:]:
-                   call("mmd_dwconv3_pyr_bwd_weight", hx, dzd, gw, desc, C, sc, sh, SWISH, ls))
+        # the depthwise weight gradient rides in the (flipped) input-gradient launch: a leaf launch's kernel time is paid in full
         g = self._alloc_pyr(pyr, C)
-        call("mmd_dwconv3_pyr", dzd, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
-             None, None, None, 0)
+        self._pyr_dw_bwd(dzd, f"{hname}.header.depthwise_conv.conv.weight", g, desc, C, ls, rec["hx"], self.t_scale[xo:], self.t_shift[xo:], SWISH)
         bsums = self._zalloc((2 * 5 * ls,), torch.float64)
         off0 = rec["layers"][0]["off"]
         for i in reversed(range(spec.head_layers)):
@@ -771,12 +783,9 @@ class Net:
             dzd = self._alloc_pyr(pyr, C)
             call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
-            self._leaf(lambda lx=L["x"], dzd=dzd, gw=ps.g(f"{cname}.depthwise_conv.conv.weight"), sc=None if xo is None else self.t_scale[xo:],
-                       sh=None if xo is None else self.t_shift[xo:], act=NONE if xo is None else SWISH:
-                       call("mmd_dwconv3_pyr_bwd_weight", lx, dzd, gw, desc, C, sc, sh, act, ls))
             g = self._alloc_pyr(pyr, C)
-            call("mmd_dwconv3_pyr", dzd, ps.w(f"{cname}.depthwise_conv.conv.weight"), g, desc, C, 1, None, None, NONE,
-                 None, None, None, 0)
+            self._pyr_dw_bwd(dzd, f"{cname}.depthwise_conv.conv.weight", g, desc, C, ls, L["x"], None if xo is None else self.t_scale[xo:],
+                             None if xo is None else self.t_shift[xo:], NONE if xo is None else SWISH)
         return g
 
     def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]],

@@ -328,7 +328,7 @@ def test_dwconv(k, s, H, W, C):
         call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx2, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got, None, 0, None)
         assert torch.equal(dx2, dxo)
         close(got, ref, 1e-5, 1e-5, "BN sums fused into dw bwd-data")
-        if C >= 64:      # ... and the conv's weight gradient out of the same launch (x = swish(BN(z)) recomputed from z)
+        if True:         # ... and the conv's weight gradient out of the same launch (x = swish(BN(z)) recomputed from z)
             got2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
             dx3 = torch.empty_like(dxo); dwg = torch.zeros(k * k, C, device=DEV)
             call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx3, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got2, None, 0, dwg)
@@ -801,9 +801,9 @@ def test_pyramid_dw_rows_kernel_wide_levels():
     sc = torch.rand(nl * ls) + 0.5; sh = torch.randn(nl * ls) * 0.1
     o = C
     y = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls)
+    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls, None, None, None, 0, None)
     yf = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0, None, None, None, 0, None)
     wt = wd.t().reshape(C, 1, 3, 3)
     for l, (h, w) in enumerate(sizes):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
@@ -819,6 +819,17 @@ def test_pyramid_dw_rows_kernel_wide_levels():
     # padding rows between the levels are not written
     for l in range(nl - 1):
         assert float(y[row0[l] + rows[l]:row0[l + 1]].abs().sum()) == 0.0
+    # the weight gradient riding in the flipped launch == the stand-alone pyramid weight-gradient launch (x with per-level BN + swish)
+    dw_ref = torch.zeros(9, C, device=DEV)
+    call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dw_ref, desc, C, g(sc)[o:], g(sh)[o:], 1, ls)
+    dwg = torch.zeros(9, C, device=DEV); yf2 = torch.zeros(Mt, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, ls, g(x), g(sc)[o:], g(sh)[o:], 1, dwg)
+    assert torch.equal(yf2, yf)
+    close(dwg, dw_ref, 1e-4, 1e-5, "pyramid weight gradient out of the flipped launch")
+    dwg0 = torch.zeros(9, C, device=DEV); dw_ref0 = torch.zeros(9, C, device=DEV)
+    call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dw_ref0, desc, C, None, None, 0, 0)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, 0, g(x), None, None, 0, dwg0)
+    close(dwg0, dw_ref0, 1e-4, 1e-5, "pyramid weight gradient, plain x")
     # live-BatchNorm prologue: per-level coefficients derived from raw sums with the level's own element count
     stats = torch.zeros(2 * nl * ls, dtype=torch.float64)
     gam, bet = torch.rand(nl * ls) + 0.5, torch.randn(nl * ls) * 0.1
@@ -826,7 +837,7 @@ def test_pyramid_dw_rows_kernel_wide_levels():
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         stats[2 * ol:2 * ol + C] = x[sl].double().sum(0); stats[2 * ol + C:2 * ol + 2 * C] = (x[sl].double() ** 2).sum(0)
     yl = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls)
+    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls, None, None, None, 0, None)
     for l, (h, w) in enumerate(sizes):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         yr = torch.empty(rows[l], C, device=DEV)
@@ -853,9 +864,9 @@ def test_pyramid_launches_match_per_level():
     o = C                                         # use "layer 1" of each level
     # ---- depthwise forward with per-level prologue, and its flipped form
     y = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls)
+    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls, None, None, None, 0, None)
     yf = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0, None, None, None, 0, None)
     dwp = torch.zeros(9, C, device=DEV)
     call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dwp, desc, C, g(sc)[o:], g(sh)[o:], 1, ls)
     dwr = torch.zeros(9, C, device=DEV)
@@ -878,7 +889,7 @@ def test_pyramid_launches_match_per_level():
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         stats[2 * ol:2 * ol + C] = x[sl].double().sum(0); stats[2 * ol + C:2 * ol + 2 * C] = (x[sl].double() ** 2).sum(0)
     yl = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls)
+    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls, None, None, None, 0, None)
     for l, (h, w) in enumerate(sizes):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         yr = torch.empty(rows[l], C, device=DEV)
