@@ -19,6 +19,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 // Public ABI (include/mmdistill.h repeats this struct).
 struct MmdWgradLayer {
@@ -27,20 +28,31 @@ struct MmdWgradLayer {
   int M, K, N; int in_act; int rows_per_image;
   int mchunk;      // rows per split (multiple of 32)
   int nsplit;      // cdiv(M, mchunk)
-  int ntn, ntk;    // 64-wide tiles over N and K
+  int ntn, ntk;    // T-wide tiles over N and K
   int item0;       // first work item: item = item0 + (split * ntn + tn) * ntk + tk
   int tile0;       // first output tile (fold): tile = tile0 + tn * ntk + tk
   int pad_;
-  long long ws_off;   // floats: partial of item i at ws + ws_off + (i - item0) * 4096
+  long long ws_off;   // floats: partial of item i at ws + ws_off + (i - item0) * T * T  (T = pad_: the planner's tile edge, 64 or 128)
 };
 
-#define GW_LD 68
 #define GW_BR 32
 #define GW_MAXL 512
 
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
-  __shared__ float sD[GW_BR * GW_LD];
-  __shared__ float sX[GW_BR * GW_LD];
+// Output tile edge: 64 (a wave owns one 32x32 sub-tile; default) or 128 (a wave owns 2x2 of them; MMD_WG_TILE=128).  An item reads
+// rows x (T + T) floats for a T x T output: with 64-wide tiles the step's weight gradients move 5.4 GB for 2.5 GB of operands (every dY
+// slab is re-read per K tile, every X slab per N tile; 6.3 GB measured), 128-wide tiles would move 3.4 GB and make the 112-wide BiFPN /
+// head layers single-tile - and measured SLOWER all the same: step 18.5 -> 20.2-20.7 ms at the same MFMA time per item, 19.2 with 4x the
+// rows per item (232 VGPRs, two waves per SIMD, a quarter of the items to balance over the chip).  The launch is not HBM-bound.
+static int wg_tile() {
+  static const int t = getenv("MMD_WG_TILE") ? atoi(getenv("MMD_WG_TILE")) : 64;
+  return t == 128 ? 128 : 64;
+}
+
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void wgrad_grouped_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
+  constexpr int LD = T + 4, NTH = T / 4, RPP = 256 / NTH, NL = GW_BR / RPP, S = T / 64;
+  __shared__ float sD[GW_BR * LD];
+  __shared__ float sX[GW_BR * LD];
   __shared__ int sItem0[GW_MAXL + 1];
   const int tid = threadIdx.x;
   for (int i = tid; i < nl; i += 256) sItem0[i] = L[i].item0;
@@ -48,8 +60,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const MmdWgradLayer*
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wn = wave >> 1, wk = wave & 1;
-  const int c4 = (tid & 15) * 4;         // column offset inside the 64-wide tile
-  const int lrow = tid >> 4;             // 0..15
+  const int c4 = (tid & (NTH - 1)) * 4;  // column offset inside the T-wide tile
+  const int lrow = tid / NTH;            // 0 .. RPP-1
   int li = 0;
   // (an XCD-aware walk - consecutive items, i.e. the tiles that re-read one M slab, on one XCD - measured SLOWER: family 1.33-1.45 ->
   // 1.72-1.79 ms per step; the plain stride spreads every layer over all XCDs and balances better than the L2 reuse is worth)
@@ -62,19 +74,22 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const MmdWgradLayer*
     const int tn = b % a.ntn; b /= a.ntn;
     const int mbeg = b * a.mchunk;
     const int mend = min(a.M, mbeg + a.mchunk);
-    const int n0 = tn * 64, k0 = tk * 64;
+    const int n0 = tn * T, k0 = tk * T;
     const bool nok = (n0 + c4) < a.N, kok = (k0 + c4) < a.K;
     float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
     if (a.in_scale && kok) { xsc = mmd_ld4(a.in_scale + k0 + c4); xsh = mmd_ld4(a.in_shift + k0 + c4); }
-    f32x16 acc;
+    f32x16 acc[S][S];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    constexpr int NL = GW_BR / 16;
+    for (int u = 0; u < S; ++u)
+#pragma unroll
+      for (int v = 0; v < S; ++v)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[u][v][q] = 0.f;
     float4 rd[NL], rx[NL], rg[NL]; bool rok[NL];
     auto gload = [&](int mb) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const int row = mb + lrow + i * 16;
+        const int row = mb + lrow + i * RPP;
         rok[i] = row < mend;
         const int rc = rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
         rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
@@ -90,37 +105,67 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const MmdWgradLayer*
         if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
         if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
         if (!(rok[i] && kok)) v = make_float4(0, 0, 0, 0);
-        *reinterpret_cast<float4*>(&sX[(lrow + i * 16) * GW_LD + c4]) = v;
-        *reinterpret_cast<float4*>(&sD[(lrow + i * 16) * GW_LD + c4]) = (rok[i] && nok) ? rd[i] : make_float4(0, 0, 0, 0);
+        *reinterpret_cast<float4*>(&sX[(lrow + i * RPP) * LD + c4]) = v;
+        *reinterpret_cast<float4*>(&sD[(lrow + i * RPP) * LD + c4]) = (rok[i] && nok) ? rd[i] : make_float4(0, 0, 0, 0);
       }
     };
-    const bool idle = n0 + wn * 32 >= a.N || k0 + wk * 32 >= a.K;      // this wave's 32x32 sub-tile is all N / K padding
+    // 32x32 sub-tiles of this wave that are all N / K padding are skipped: the live ones are a prefix in each dimension (padding sits at
+    // the end), so the MFMA loop is instantiated per (live n sub-tiles, live k sub-tiles) - no per-MFMA branch
+    int nu = 0, nv = 0;
+#pragma unroll
+    for (int u = 0; u < S; ++u) { nu += (n0 + (wn * S + u) * 32 < a.N) ? 1 : 0; nv += (k0 + (wk * S + u) * 32 < a.K) ? 1 : 0; }
+    nu = __builtin_amdgcn_readfirstlane(nu); nv = __builtin_amdgcn_readfirstlane(nv);
+    const float* const pd = &sD[h * LD + wn * S * 32 + r];
+    const float* const px = &sX[h * LD + wk * S * 32 + r];
+    auto mma = [&](auto nu_c, auto nv_c) {
+      constexpr int NU = decltype(nu_c)::value, NV = decltype(nv_c)::value;
+#pragma unroll
+      for (int tt = 0; tt < GW_BR / 2; ++tt) {
+        float dv[NU], xv[NV];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) dv[u] = pd[tt * 2 * LD + u * 32];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[v] = px[tt * 2 * LD + v * 32];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], xv[v], acc[u][v], 0, 0, 0);
+      }
+    };
     gload(mbeg);
     for (int mb = mbeg; mb < mend; mb += GW_BR) {
       lstore();
       __syncthreads();
       if (mb + GW_BR < mend) gload(mb + GW_BR);
-      if (!idle) {
-        const float* pd = &sD[h * GW_LD + wn * 32 + r];
-        const float* px = &sX[h * GW_LD + wk * 32 + r];
-#pragma unroll
-        for (int tt = 0; tt < GW_BR / 2; ++tt)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[tt * 2 * GW_LD], px[tt * 2 * GW_LD], acc, 0, 0, 0);
+      if (nu && nv) {
+        if constexpr (S == 1) mma(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        else {
+          if (nu == 2 && nv == 2) mma(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+          else if (nu == 2) mma(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+          else if (nv == 2) mma(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+          else mma(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        }
       }
       __syncthreads();
     }
-    // partial tile [64 n][64 k] -> this item's workspace slot (128-B row segments per wave instruction)
-    float* out = ws + a.ws_off + (size_t)(item - a.item0) * 4096;
+    // partial tile [T n][T k] -> this item's workspace slot (128-B row segments per wave instruction)
+    float* out = ws + a.ws_off + (size_t)(item - a.item0) * (T * T);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int n = wn * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      out[n * 64 + wk * 32 + r] = acc[q];
-    }
+    for (int u = 0; u < S; ++u)
+#pragma unroll
+      for (int v = 0; v < S; ++v)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n = (wn * S + u) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          out[n * T + (wk * S + v) * 32 + r] = acc[u][v][q];
+        }
   }
 }
 
 // one block per output tile: dW[n0.., k0..] = sum over the splits (in split order) of the partial tiles
+template <int T>
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const MmdWgradLayer* __restrict__ L, int nl, int ntiles, const float* __restrict__ ws) {
+  constexpr int TT = T * T, NU = TT / 1024;
   __shared__ int s_li;
   const int tile = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
@@ -133,21 +178,21 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const MmdWgradLayer* __
   const int t = tile - a.tile0;
   const int tn = t / a.ntk, tk = t - tn * a.ntk;
   const int tiles = a.ntn * a.ntk;
-  const float* p = ws + a.ws_off + (size_t)t * 4096 + tid * 4;
-  float4 s[4];
+  const float* p = ws + a.ws_off + (size_t)t * TT + tid * 4;
+  float4 s[NU];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < NU; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int sp = 0; sp < a.nsplit; ++sp) {
-    const float* q = p + (size_t)sp * tiles * 4096;
+    const float* q = p + (size_t)sp * tiles * TT;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const float4 v = mmd_ld4(q + u * 1024);
       s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
     }
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = u * 1024 + tid * 4, n = tn * 64 + (e >> 6), k = tk * 64 + (e & 63);
+  for (int u = 0; u < NU; ++u) {
+    const int e = u * 1024 + tid * 4, n = tn * T + e / T, k = tk * T + e % T;
     if (n < a.N && k < a.K) mmd_st4(a.dw + (size_t)n * a.K + k, s[u]);       // K % 4 == 0: a float4 is all-valid or all-out
   }
 }
@@ -164,14 +209,15 @@ extern "C" int mmd_wgrad_plan(MmdWgradLayer* layers, int n, int rows_per_item, i
     if (a.gate && a.rows_per_image <= 0) return MMD_EINVAL;
     if ((a.in_scale == nullptr) != (a.in_shift == nullptr)) return MMD_EINVAL;
     if (a.rows_per_image <= 0) a.rows_per_image = 1;
-    a.ntn = cdiv(a.N, 64); a.ntk = cdiv(a.K, 64);
-    int splits = cdiv(a.M, rows_per_item);
+    const int T = wg_tile();
+    a.ntn = cdiv(a.N, T); a.ntk = cdiv(a.K, T);
+    int splits = cdiv(a.M, T == 128 ? max(rows_per_item / 4, GW_BR) : rows_per_item);      // same MFMA time per item for either tile
     a.mchunk = cdiv(cdiv(a.M, splits), GW_BR) * GW_BR;
     a.nsplit = cdiv(a.M, a.mchunk);
-    a.item0 = items; a.tile0 = tiles; a.ws_off = ws; a.pad_ = 0;
+    a.item0 = items; a.tile0 = tiles; a.ws_off = ws; a.pad_ = T;
     items += a.nsplit * a.ntn * a.ntk;
     tiles += a.ntn * a.ntk;
-    ws += (long long)a.nsplit * a.ntn * a.ntk * 4096;
+    ws += (long long)a.nsplit * a.ntn * a.ntk * T * T;
   }
   *n_items = items; *n_tiles = tiles; *ws_floats = ws;
   return MMD_OK;
@@ -185,8 +231,13 @@ extern "C" int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, 
   if (blocks > n_items) blocks = n_items;
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wgrouped L%lld items%lld tiles%lld b%lld", n_layers, n_items, n_tiles, blocks);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
-  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
+  if (wg_tile() == 128) {
+    hipLaunchKernelGGL(wgrad_grouped_kernel<128>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    hipLaunchKernelGGL(wgrad_fold_kernel<128>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
+  } else {
+    hipLaunchKernelGGL(wgrad_grouped_kernel<64>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    hipLaunchKernelGGL(wgrad_fold_kernel<64>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
+  }
   mmd_prof_end(MMD_FAM_PW_WGRAD, stream, flops, bytes);
   return mmd_check_launch();
 }

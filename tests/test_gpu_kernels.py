@@ -244,7 +244,8 @@ def test_wgrad_grouped_matches_torch_and_is_deterministic():
     dll = _lib.LIB.load()
     cv = lambda o: ctypes.cast(ctypes.pointer(o), ctypes.c_void_p)
     assert dll.mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), len(shapes), 256, cv(ni), cv(nt), cv(wsf)) == 0
-    assert nt.value == sum(-(-N // 64) * -(-K // 64) for _, K, N, _ in shapes) and ni.value >= nt.value
+    T = arr[0].pad_        # the planner's output-tile edge (64 or 128)
+    assert T in (64, 128) and nt.value == sum(-(-N // T) * -(-K // T) for _, K, N, _ in shapes) and ni.value >= nt.value
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
     ws = torch.full((wsf.value,), float("nan"), device=DEV)
     outs = []
