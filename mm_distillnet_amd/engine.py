@@ -719,7 +719,7 @@ class Net:
         gradient (tile kernel; for the 3x3 layers that gives up the faster row-streaming input-gradient kernel and still wins: a
         weight-gradient leaf costs its full kernel time on the saturated chip - 18.44 -> 18.27 ms/step)."""
         ps = self.ps
-        wg_inside = self.DW_WG and want_dx and bn_aff is not None and s == 1
+        wg_inside = self.DW_WG and want_dx and bn_aff is not None and s == 1 and x.C >= 64      # (block 0, 32 channels at 256^2: 221 us inside vs 47 + 67)
         if not wg_inside:
             self._leaf(lambda x=x, dzd=dzd, gw=ps.g(wkey): call("mmd_dwconv_bwd_weight", x.z, dzd, gw, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift,
                                                                  x.act))
