@@ -214,8 +214,9 @@ int mmd_pwconv_fwd(const float* x, const float* w, float* y, int M, int K, int N
 int mmd_pwconv_fwd_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
 
 // dw_grad (nullable; flip = 1 launches): the conv's weight gradient [9, C] += from the same launch, x operand = act(wg_x * wg_scale + wg_shift)
-// with per-level coefficients lev_stride apart (what mmd_dwconv3_pyr_bwd_weight(wg_x, x, ...) computes).
-int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long lev_stride, const float* wg_x, const float* wg_scale, const float* wg_shift, int wg_act, float* dw_grad, hipStream_t stream);
+// with per-level coefficients lev_stride apart (what mmd_dwconv3_pyr_bwd_weight(wg_x, x, ...) computes); bn_sums (nullable, needs dw_grad
+// and a swish producer): the sums of the BatchNorm(+swish) backward that consumes y - what mmd_bn_bwd_reduce_pyr(y, wg_x, ...) computes.
+int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const int* pyr_desc, int C, int flip, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long lev_stride, const float* wg_x, const float* wg_scale, const float* wg_shift, int wg_act, float* dw_grad, const float* wg_mean, const float* wg_invstd, double* bn_sums, hipStream_t stream);
 
 int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const int* pyr_desc, int C, const float* in_scale, const float* in_shift, int in_act, long long lev_stride, hipStream_t stream);
 

@@ -411,11 +411,13 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
   float4 dwa[WG ? 9 : 1];
   float4 gsc = make_float4(1, 1, 1, 1), gsh = make_float4(0, 0, 0, 0);
+  float4 gmu = make_float4(0, 0, 0, 0), gis = make_float4(0, 0, 0, 0);
   if (WG) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) dwa[t] = make_float4(0, 0, 0, 0);
     const long long lo = (long long)lev * a.lev_stride;
     if (a.bscale && cok) { gsc = mmd_ld4(a.bscale + lo + c); gsh = mmd_ld4(a.bshift + lo + c); }
+    if (a.stats && cok) { gmu = mmd_ld4(a.bmean + lo + c); gis = mmd_ld4(a.binvstd + lo + c); }
   }
   auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2]) {
     if constexpr (WG) {
@@ -463,6 +465,15 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
           s.x += acc.x; s.y += acc.y; s.z += acc.z; s.w += acc.w;
           ss.x += acc.x * acc.x; ss.y += acc.y * acc.y; ss.z += acc.z * acc.z; ss.w += acc.w * acc.w;
         }
+        if (WG && a.stats) {      // sums of the BatchNorm(+swish) backward that consumes this launch's output (x's producer BN): x is re-read from L1
+          const float4 zz = mmd_ld4(a.bz + off);
+          float4 gg;
+          gg.x = acc.x * mmd_swish_grad(zz.x * gsc.x + gsh.x); gg.y = acc.y * mmd_swish_grad(zz.y * gsc.y + gsh.y);
+          gg.z = acc.z * mmd_swish_grad(zz.z * gsc.z + gsh.z); gg.w = acc.w * mmd_swish_grad(zz.w * gsc.w + gsh.w);
+          s.x += gg.x; s.y += gg.y; s.z += gg.z; s.w += gg.w;
+          ss.x += gg.x * (zz.x - gmu.x) * gis.x; ss.y += gg.y * (zz.y - gmu.y) * gis.y;
+          ss.z += gg.z * (zz.z - gmu.z) * gis.z; ss.w += gg.w * (zz.w - gmu.w) * gis.w;
+        }
         float4 t = acc;
         if (EPI == 3) {
           if (a.out_scale) { t.x = t.x * osc.x + osh.x; t.y = t.y * osc.y + osh.y; t.z = t.z * osc.z + osh.z; t.w = t.w * osc.w + osh.w; }
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
     if (oh + 1 < oh1) { load_row(oh + 2, w0); out_row(oh + 1, w1, w2, w0); }
     if (oh + 2 < oh1) { load_row(oh + 3, w1); out_row(oh + 2, w2, w0, w1); }
   }
-  if ((EPI == 1 || EPI == 2) || (EPI == 3 && a.pool)) {      // lanes l, l^LW, l^2LW, ... of a wave share the channel quad; then the 4 waves through LDS
+  if ((EPI == 1 || EPI == 2) || (WG && a.stats) || (EPI == 3 && a.pool)) {      // lanes l, l^LW, l^2LW, ... of a wave share the channel quad; then the 4 waves through LDS
     auto red = [](float4 x) {
 #pragma unroll
       for (int o = LW; o < 64; o <<= 1) {
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
       return x;
     };
     const int wave = tid >> 6, lane = tid & 63;
-    if (EPI == 1 || EPI == 2) {
+    if (EPI == 1 || EPI == 2 || (WG && a.stats)) {
       s = red(s); ss = red(ss);
       if (lane < LW) {
         *reinterpret_cast<float4*>(&sRed[wave * CC + c4]) = s;
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
       if (tid < CC && c0 + tid < C) {
         const float vs = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
         const float vq = sRed[4 * CC + tid] + sRed[5 * CC + tid] + sRed[6 * CC + tid] + sRed[7 * CC + tid];
-        double* st = a.stats_ws ? a.stats_ws + (size_t)((blockIdx.x / a.cchunks) % a.ws_slots) * 2 * C : a.stats;
+        double* st = (a.stats_ws ? a.stats_ws + (size_t)((blockIdx.x / a.cchunks) % a.ws_slots) * 2 * C : a.stats) + 2 * (long long)lev * a.lev_stride;
         atomicAdd(&st[c0 + tid], (double)vs);
         atomicAdd(&st[C + c0 + tid], (double)vq);
       }
@@ -626,6 +637,9 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
 
 extern "C" int mmd_dwconv3_pyr_bwd_weight(const float* x, const float* dy, float* dw, const int* pyr_desc, int C, const float* in_scale,
                                           const float* in_shift, int in_act, long long lev_stride, hipStream_t stream);
+extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, int act, const int* pyr_desc, long long lev_stride, float* g_out, double* sums,
+                                     int C, hipStream_t stream);      // elt.hip
 
 // Depthwise 3x3/s1 over a whole feature pyramid in ONE launch (shared weights; per-level producer BN via lev_stride).
 // flip=1 gives the input gradient.  x, y: pyramid row buffers [row0[n], C].
@@ -633,9 +647,10 @@ extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const i
                                const float* in_scale, const float* in_shift, int in_act, const double* in_stats,
                                const float* in_gamma, const float* in_beta, long long lev_stride,
                                const float* wg_x, const float* wg_scale, const float* wg_shift, int wg_act, float* dw_grad,
-                               hipStream_t stream) {
+                               const float* wg_mean, const float* wg_invstd, double* bn_sums, hipStream_t stream) {
   if (!x || !w || !y || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
   if (dw_grad && (!wg_x || !flip || (wg_scale == nullptr) != (wg_shift == nullptr))) return MMD_EINVAL;
+  if (bn_sums && (!dw_grad || !wg_scale || !wg_mean || !wg_invstd || wg_act != MMD_ACT_SWISH)) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
   if (in_stats && (in_scale || !in_gamma || !in_beta)) return MMD_EINVAL;
   DwArgs a{};
@@ -667,8 +682,9 @@ extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const i
     for (int l = a.pyr.n; l <= MMD_MAX_LEV; ++l) a.pyr.blk0[l] = nr;
     if (dw_grad) {
       a.bz = wg_x; a.bscale = wg_scale; a.bshift = wg_shift; a.wg_act = wg_act; a.dwg = dw_grad;
+      a.bmean = wg_mean; a.binvstd = wg_invstd; a.stats = bn_sums;
       hipLaunchKernelGGL((dw3_rows_kernel<4, 16, false, 0, true>), dim3(nr), dim3(256), 0, stream, a, gm);
-      dw_grad = nullptr;                                  // done
+      dw_grad = nullptr; bn_sums = nullptr;               // done
     } else {
       hipLaunchKernelGGL((dw3_rows_kernel<4, 16, false, 0>), dim3(nr), dim3(256), 0, stream, a, gm);
     }
@@ -681,6 +697,8 @@ extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const i
   int rc = mmd_check_launch();
   if (rc == MMD_OK && dw_grad)      // geometry without the fused form: the weight gradient by its own launch, same stream
     rc = mmd_dwconv3_pyr_bwd_weight(wg_x, x, dw_grad, pyr_desc, C, wg_scale, wg_shift, wg_act, lev_stride, stream);
+  if (rc == MMD_OK && bn_sums)      // ... and the BatchNorm backward sums by theirs
+    rc = mmd_bn_bwd_reduce_pyr(y, wg_x, wg_scale, wg_shift, wg_mean, wg_invstd, wg_act, pyr_desc, lev_stride, nullptr, bn_sums, C, stream);
   return rc;
 }
 

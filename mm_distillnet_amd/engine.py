@@ -544,7 +544,7 @@ class Net:
             o = off0 + i * C
             zd = self._alloc_pyr(pyr, C)
             call("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
-                 None, None, None, NONE, None)
+                 None, None, None, NONE, None, None, None, None)
             z = self._alloc_pyr(pyr, C)
             st = self.stats_flat[2 * o:] if train else None
             call("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
@@ -560,7 +560,7 @@ class Net:
             cur, cur_xf = z, nxt_xf
         zd = self._alloc_pyr(pyr, C)
         call("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
-             None, None, None, NONE, None)
+             None, None, None, NONE, None, None, None, None)
         aoff, yoff = 0, []
         for (h, w) in pyr["sizes"]:
             yoff.append(aoff * per_anchor)
@@ -736,15 +736,20 @@ class Net:
 
     PYR_WG = not os.environ.get("MMD_NO_PYR_WG")
 
-    def _pyr_dw_bwd(self, dzd, wkey: str, g, desc, C: int, ls: int, x, sc, sh, act: int):
-        """Input gradient of a shared-weight pyramid depthwise conv; its weight gradient rides in the same launch (MMD_NO_PYR_WG=1:
-        by its own launch on the weight-gradient stream, the earlier form, for A/B timing)."""
+    def _pyr_dw_bwd(self, dzd, wkey: str, g, desc, C: int, ls: int, x, sc, sh, act: int, bn=None) -> bool:
+        """Input gradient of a shared-weight pyramid depthwise conv; its weight gradient rides in the same launch, and so do the sums of
+        the BatchNorm(+swish) backward that consumes g when `bn` = (mean, invstd, sums) of x's producer is given (-> True: the caller
+        skips that reduce pass).  MMD_NO_PYR_WG=1: weight gradient by its own launch on the weight-gradient stream (earlier form, A/B)."""
         ps = self.ps
         if self.PYR_WG:
-            call("mmd_dwconv3_pyr", dzd, ps.w(wkey), g, desc, C, 1, None, None, NONE, None, None, None, ls, x, sc, sh, act, ps.g(wkey))
-            return
+            mu, istd, sums = bn if bn is not None else (None, None, None)
+            call("mmd_dwconv3_pyr", dzd, ps.w(wkey), g, desc, C, 1, None, None, NONE, None, None, None, ls, x, sc, sh, act, ps.g(wkey),
+                 mu, istd, sums)
+            return bn is not None
         self._leaf(lambda: call("mmd_dwconv3_pyr_bwd_weight", x, dzd, ps.g(wkey), desc, C, sc, sh, act, ls))
-        call("mmd_dwconv3_pyr", dzd, ps.w(wkey), g, desc, C, 1, None, None, NONE, None, None, None, 0, None, None, None, NONE, None)
+        call("mmd_dwconv3_pyr", dzd, ps.w(wkey), g, desc, C, 1, None, None, NONE, None, None, None, 0, None, None, None, NONE, None,
+             None, None, None)
+        return False
 
     def _head_bwd(self, hname: str, per_anchor: int, dout: torch.Tensor, tape: dict, pyr: dict, A: int, C: int):
         """Backward of one head over the whole pyramid; returns the gradient w.r.t. the pyramid feature buffer."""
@@ -762,18 +767,21 @@ class Net:
         dzd = self._alloc_pyr(pyr, C)
         call("mmd_pwconv_bwd_data" + self._sfx, dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
-        # the depthwise weight gradient rides in the (flipped) input-gradient launch: a leaf launch's kernel time is paid in full
-        g = self._alloc_pyr(pyr, C)
-        self._pyr_dw_bwd(dzd, f"{hname}.header.depthwise_conv.conv.weight", g, desc, C, ls, rec["hx"], self.t_scale[xo:], self.t_shift[xo:], SWISH)
+        # the depthwise weight gradient rides in the (flipped) input-gradient launch: a leaf launch's kernel time is paid in full; so do
+        # the sums of the BatchNorm backward that consumes g (x's producer), instead of a reduce pass over (g, z)
         bsums = self._zalloc((2 * 5 * ls,), torch.float64)
         off0 = rec["layers"][0]["off"]
+        g = self._alloc_pyr(pyr, C)
+        have_sums = self._pyr_dw_bwd(dzd, f"{hname}.header.depthwise_conv.conv.weight", g, desc, C, ls, rec["hx"], self.t_scale[xo:], self.t_shift[xo:],
+                                     SWISH, bn=(self.t_mean[xo:], self.t_invstd[xo:], bsums[2 * (xo - off0):]))
         for i in reversed(range(spec.head_layers)):
             L = rec["layers"][i]
             cname = f"{hname}.conv_list.{i}"
             o = L["off"]
             sums = bsums[2 * (o - off0):]
-            call("mmd_bn_bwd_reduce_pyr", g, L["z"], self.t_scale[o:], self.t_shift[o:], self.t_mean[o:], self.t_invstd[o:],
-                 SWISH, desc, ls, None, sums, C)
+            if not have_sums:
+                call("mmd_bn_bwd_reduce_pyr", g, L["z"], self.t_scale[o:], self.t_shift[o:], self.t_mean[o:], self.t_invstd[o:],
+                     SWISH, desc, ls, None, sums, C)
             dz = self._alloc_pyr(pyr, C)
             call("mmd_bn_bwd_apply_pyr", g, L["z"], self.t_mean[o:], self.t_invstd[o:], ps.flat[ps.gamma_off + o:], sums,
                  desc, ls, dz, ps.grad[ps.gamma_off + o:], ps.grad[ps.beta_off + o:], C, self.t_scale[o:], self.t_shift[o:],
@@ -784,8 +792,9 @@ class Net:
             call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
             g = self._alloc_pyr(pyr, C)
-            self._pyr_dw_bwd(dzd, f"{cname}.depthwise_conv.conv.weight", g, desc, C, ls, L["x"], None if xo is None else self.t_scale[xo:],
-                             None if xo is None else self.t_shift[xo:], NONE if xo is None else SWISH)
+            have_sums = self._pyr_dw_bwd(dzd, f"{cname}.depthwise_conv.conv.weight", g, desc, C, ls, L["x"], None if xo is None else self.t_scale[xo:],
+                                         None if xo is None else self.t_shift[xo:], NONE if xo is None else SWISH,
+                                         bn=None if xo is None else (self.t_mean[xo:], self.t_invstd[xo:], bsums[2 * (xo - off0):]))
         return g
 
     def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]],

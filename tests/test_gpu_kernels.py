@@ -802,9 +802,9 @@ def test_pyramid_dw_rows_kernel_wide_levels():
     sc = torch.rand(nl * ls) + 0.5; sh = torch.randn(nl * ls) * 0.1
     o = C
     y = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls, None, None, None, 0, None)
+    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls, None, None, None, 0, None, None, None, None)
     yf = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0, None, None, None, 0, None)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0, None, None, None, 0, None, None, None, None)
     wt = wd.t().reshape(C, 1, 3, 3)
     for l, (h, w) in enumerate(sizes):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
@@ -824,12 +824,24 @@ def test_pyramid_dw_rows_kernel_wide_levels():
     dw_ref = torch.zeros(9, C, device=DEV)
     call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dw_ref, desc, C, g(sc)[o:], g(sh)[o:], 1, ls)
     dwg = torch.zeros(9, C, device=DEV); yf2 = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, ls, g(x), g(sc)[o:], g(sh)[o:], 1, dwg)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, ls, g(x), g(sc)[o:], g(sh)[o:], 1, dwg,
+         None, None, None)
     assert torch.equal(yf2, yf)
     close(dwg, dw_ref, 1e-4, 1e-5, "pyramid weight gradient out of the flipped launch")
+    # ... and the sums of the BatchNorm(+swish) backward that consumes the launch's output (x's producer BN, per level)
+    mu = torch.randn(nl * ls) * 0.2; istd = torch.rand(nl * ls) + 0.5
+    s_ref = torch.zeros(2 * nl * ls, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce_pyr", yf, g(x), g(sc)[o:], g(sh)[o:], g(mu)[o:], g(istd)[o:], 1, desc, ls, None, s_ref[2 * o:], C)
+    s_got = torch.zeros(2 * nl * ls, dtype=torch.float64, device=DEV)
+    dwg2 = torch.zeros(9, C, device=DEV)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, ls, g(x), g(sc)[o:], g(sh)[o:], 1, dwg2,
+         g(mu)[o:], g(istd)[o:], s_got[2 * o:])
+    assert torch.equal(yf2, yf)
+    close(dwg2, dw_ref, 1e-4, 1e-5, "pyramid weight gradient (with the BN sums riding along)")
+    close(s_got, s_ref, 1e-5, 1e-6, "BN backward sums out of the flipped pyramid launch")
     dwg0 = torch.zeros(9, C, device=DEV); dw_ref0 = torch.zeros(9, C, device=DEV)
     call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dw_ref0, desc, C, None, None, 0, 0)
-    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, 0, g(x), None, None, 0, dwg0)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf2, desc, C, 1, None, None, 0, None, None, None, 0, g(x), None, None, 0, dwg0, None, None, None)
     close(dwg0, dw_ref0, 1e-4, 1e-5, "pyramid weight gradient, plain x")
     # live-BatchNorm prologue: per-level coefficients derived from raw sums with the level's own element count
     stats = torch.zeros(2 * nl * ls, dtype=torch.float64)
@@ -838,7 +850,7 @@ def test_pyramid_dw_rows_kernel_wide_levels():
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         stats[2 * ol:2 * ol + C] = x[sl].double().sum(0); stats[2 * ol + C:2 * ol + 2 * C] = (x[sl].double() ** 2).sum(0)
     yl = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls, None, None, None, 0, None)
+    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls, None, None, None, 0, None, None, None, None)
     for l, (h, w) in enumerate(sizes):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         yr = torch.empty(rows[l], C, device=DEV)
@@ -865,9 +877,9 @@ def test_pyramid_launches_match_per_level():
     o = C                                         # use "layer 1" of each level
     # ---- depthwise forward with per-level prologue, and its flipped form
     y = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls, None, None, None, 0, None)
+    call("mmd_dwconv3_pyr", g(x), g(wd), y, desc, C, 0, g(sc)[o:], g(sh)[o:], 1, None, None, None, ls, None, None, None, 0, None, None, None, None)
     yf = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0, None, None, None, 0, None)
+    call("mmd_dwconv3_pyr", g(dy), g(wd), yf, desc, C, 1, None, None, 0, None, None, None, 0, None, None, None, 0, None, None, None, None)
     dwp = torch.zeros(9, C, device=DEV)
     call("mmd_dwconv3_pyr_bwd_weight", g(x), g(dy), dwp, desc, C, g(sc)[o:], g(sh)[o:], 1, ls)
     dwr = torch.zeros(9, C, device=DEV)
@@ -890,7 +902,7 @@ def test_pyramid_launches_match_per_level():
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         stats[2 * ol:2 * ol + C] = x[sl].double().sum(0); stats[2 * ol + C:2 * ol + 2 * C] = (x[sl].double() ** 2).sum(0)
     yl = torch.zeros(Mt, C, device=DEV)
-    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls, None, None, None, 0, None)
+    call("mmd_dwconv3_pyr", g(x), g(wd), yl, desc, C, 0, None, None, 1, g(stats)[2 * o:], g(gam)[o:], g(bet)[o:], ls, None, None, None, 0, None, None, None, None)
     for l, (h, w) in enumerate(sizes):
         sl = slice(row0[l], row0[l] + rows[l]); ol = o + l * ls
         yr = torch.empty(rows[l], C, device=DEV)
