@@ -203,9 +203,17 @@ def test_net_train_512_full_size_vs_oracle():
     print("512^2 train gradient check: cos %.7f norm ratio %.5f per-tensor max rel err p50 %.2e p95 %.2e max %.2e (%s)" % (
         cos, ratio, errs[len(errs) // 2][0], errs[int(0.95 * len(errs))][0], errs[-1][0], errs[-1][1]))
     assert cos > 0.9999 and abs(ratio - 1.0) < 2e-3, (cos, ratio)
-    fuse = [e for e in errs if e[1].split(".")[-1] in ("p6_w1", "p5_w1", "p4_w1", "p3_w1", "p4_w2", "p5_w2", "p6_w2", "p7_w2")]
-    rest = [e for e in errs if e not in fuse]
-    assert errs[int(0.95 * len(errs))][0] < 2e-2 and rest[-1][0] < 6e-2 and fuse[-1][0] < 0.25, errs[-8:]
+    is_fuse = lambda k: k.split(".")[-1] in ("p6_w1", "p5_w1", "p4_w1", "p3_w1", "p4_w2", "p5_w2", "p6_w2", "p7_w2")
+    rest = [e for e in errs if not is_fuse(e[1])]
+    assert errs[int(0.95 * len(errs))][0] < 2e-2 and rest[-1][0] < 6e-2, errs[-8:]
+    # the 2- / 3-element fast-attention weights: d theta_k = sum_i wdot_i (delta_ik S - r_i) / S^2 is a difference of large dot products,
+    # so one weight's gradient can be tiny next to its own rounding noise (per-tensor relative error 0.15-0.26 run to run, fp32 atomics
+    # in the dot products); measured against the largest fusion-weight gradient of the net the error is stable
+    fk = [k for k, v in so.items() if v.requires_grad and is_fuse(k)]
+    fmax = max(so[k].grad.abs().max().item() for k in fk)
+    ferr = max((grads[k].double() - so[k].grad.double()).abs().max().item() for k in fk) / fmax
+    print("fusion weights: max abs err / largest fusion-weight gradient %.3e" % ferr)
+    assert ferr < 5e-3, ferr          # measured 1.0-1.1e-3 in every run
 
 
 def test_d4_eval_vs_oracle():
