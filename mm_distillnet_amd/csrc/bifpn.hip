@@ -39,19 +39,25 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
   return m;
 }
 
+// MODE: -1 = operand set read from the arguments at run time; otherwise bit 0 = in1, bit 1 = up, bit 2 = pool present (compile time: the node
+// backward kernel is instantiated per operand set - the run-time form keeps every operand's registers and branches alive)
+template <int MODE = -1>
 __device__ __forceinline__ float4 fuse_presum(const FuseArgs& a, const float* w, int b, int h, int x, int c, float4* o0,
                                               float4* o1, float4* o2, float4* o3) {
+  const bool has1 = MODE < 0 ? a.in1 != nullptr : (MODE & 1) != 0;
+  const bool hasu = MODE < 0 ? a.up != nullptr : (MODE & 2) != 0;
+  const bool hasp = MODE < 0 ? a.pl != nullptr : (MODE & 4) != 0;
   size_t off = (((size_t)b * a.H + h) * a.W + x) * a.C + c;
   int wi = 0;
   float4 s = make_float4(0, 0, 0, 0);
   float4 v = mmd_ld4(a.in0 + off); *o0 = v;
   s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
-  if (a.in1) { v = mmd_ld4(a.in1 + off); *o1 = v; s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi; }
-  if (a.up) {
+  if (has1) { v = mmd_ld4(a.in1 + off); *o1 = v; s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi; }
+  if (hasu) {
     v = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (h >> 1)) * (a.W >> 1) + (x >> 1)) * a.C + c); *o2 = v;
     s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
   }
-  if (a.pl) {
+  if (hasp) {
     v = pool_window(a.pl, b, h, x, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l); *o3 = v;
     s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
   }
@@ -427,6 +433,7 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 // Fused node backward: the depthwise 3x3 input gradient  df = dwconv^T(dzd, w)  is computed from an LDS tile of dzd (8x8
 // pixels + halo, 64-channel chunk) and fed straight into the fusion backward above - one launch instead of two and no df
 // round trip through HBM (mirror of fuse_dw_fwd_kernel; 40 launches on the backward's serial chain).
+template <int MODE>
 __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     gq[o] = make_float4(0, 0, 0, 0); fq[o] = make_float4(0, 0, 0, 0);
     if (cok && oh < a.H && ow < a.W) {
       float4 t[4];
-      float4 sv = fuse_presum(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3]);
+      float4 sv = fuse_presum<MODE>(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3]);
       const size_t off = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
       if (dwg) fq[o] = make_float4(mmd_swish(sv.x), mmd_swish(sv.y), mmd_swish(sv.z), mmd_swish(sv.w));      // the node's fused activation
       float4 g = acc[o];
@@ -510,17 +517,17 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       }
       int wi = 0;
       d[wi++] += g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
-      if (a.in1) d[wi++] += g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
-      if (a.up) d[wi++] += g.x * t[2].x + g.y * t[2].y + g.z * t[2].z + g.w * t[2].w;
-      if (a.pl) d[wi++] += g.x * t[3].x + g.y * t[3].y + g.z * t[3].z + g.w * t[3].w;
+      if (MODE & 1) d[wi++] += g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
+      if (MODE & 2) d[wi++] += g.x * t[2].x + g.y * t[2].y + g.z * t[2].z + g.w * t[2].w;
+      if (MODE & 4) d[wi++] += g.x * t[3].x + g.y * t[3].y + g.z * t[3].z + g.w * t[3].w;
     }
   }
   const int wave = tid >> 6, lane = tid & 63;
-  if (dup) {
+  if ((MODE & 2) && dup) {
     // gradient of the nearest-upsampled operand: w_up * (sum over the 2x2 block).  A thread holds 4 pixels of one row (two
     // horizontal pairs); the row below belongs to lane ^ 32 of the same wave (pixel groups 4w..4w+3 = rows 2w, 2w, 2w+1, 2w+1),
     // tiles start on even rows / columns, so every 2x2 block is complete inside one wave: no atomics
-    const float wu = w[1 + (a.in1 ? 1 : 0)];
+    const float wu = w[1 + ((MODE & 1) ? 1 : 0)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float4 sv = make_float4(gq[2 * q].x + gq[2 * q + 1].x, gq[2 * q].y + gq[2 * q + 1].y, gq[2 * q].z + gq[2 * q + 1].z,
@@ -586,8 +593,19 @@ extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const f
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
-  hipLaunchKernelGGL(fuse_dw_bwd_kernel, dim3((unsigned)(B * th * tw * cc)), dim3(256), 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0,
-                     d1, acc1, dup, acc_up, dw_grad, th, tw, cc);
+  const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
+  const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
+#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc)
+  switch (mode) {          // the operand sets of BiFPN._forward_fast_attention: (in, up), (in, td, pool), (in, pool); others through the generic forms
+    case 2: MMD_NODE_BWD(2); break;
+    case 5: MMD_NODE_BWD(5); break;
+    case 4: MMD_NODE_BWD(4); break;
+    case 1: MMD_NODE_BWD(1); break;
+    case 3: MMD_NODE_BWD(3); break;
+    case 6: MMD_NODE_BWD(6); break;
+    default: MMD_NODE_BWD(7); break;
+  }
+#undef MMD_NODE_BWD
   return mmd_check_launch();
 }
 
