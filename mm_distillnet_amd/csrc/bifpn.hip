@@ -199,6 +199,7 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
 constexpr int FN_C = 112, FN_Q = FN_C / 4, FN_FS = FN_C, FN_ZS = FN_C + 4, FN_WS = FN_C + 4, FN_NT = 512;
 constexpr int FN_U = (100 * FN_FS > FN_C * FN_WS) ? 100 * FN_FS : FN_C * FN_WS;      // input tile, later the 1x1 weights
 
+template <int MODE>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
 __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ y,
@@ -239,12 +240,12 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
       if (ok[i]) {
         const size_t off = (((size_t)b * a.H + ih) * a.W + iw) * a.C + q * 4;
         v0[i] = mmd_ld4(a.in0 + off);
-        if (a.in1) v1[i] = mmd_ld4(a.in1 + off);
-        else if (a.up) v1[i] = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (ih >> 1)) * (a.W >> 1) + (iw >> 1)) * a.C + q * 4);
+        if (MODE & 1) v1[i] = mmd_ld4(a.in1 + off);
+        else if (MODE & 2) v1[i] = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (ih >> 1)) * (a.W >> 1) + (iw >> 1)) * a.C + q * 4);
       }
     }
-    const int n2 = (a.in1 || a.up) ? 1 : 0;            // operand order (in0, in1, up, pool): in1 and up never occur together
-    const float wp_ = a.pl ? w[1 + n2] : 0.f;
+    constexpr int n2 = (MODE & 3) ? 1 : 0;             // operand order (in0, in1, up, pool): in1 and up never occur together
+    const float wp_ = (MODE & 4) ? w[1 + n2] : 0.f;
 #pragma unroll
     for (int i0 = 0; i0 < NI; i0 += 3) {               // the pooled operand's 3x3 windows of three items are gathered together (27 loads in flight)
       float4 m[3];
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
       for (int u = 0; u < 3; ++u) {
         const int i = i0 + u;
         m[u] = make_float4(0, 0, 0, 0);
-        if (i < NI && a.pl && ok[i]) {
+        if (i < NI && (MODE & 4) && ok[i]) {
           const int it = tid + i * FN_NT;
           const int p = it / FN_Q, q = it - p * FN_Q;
           m[u] = pool_window(a.pl, b, oh0 - 1 + p / 10, ow0 - 1 + p % 10, q * 4, a.PH, a.PW, a.C, a.pad_t, a.pad_l);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
         if (ok[i]) {
           v.x = w[0] * v0[i].x; v.y = w[0] * v0[i].y; v.z = w[0] * v0[i].z; v.w = w[0] * v0[i].w;
           if (n2) { v.x += w[1] * v1[i].x; v.y += w[1] * v1[i].y; v.z += w[1] * v1[i].z; v.w += w[1] * v1[i].w; }
-          if (a.pl) { v.x += wp_ * m[u].x; v.y += wp_ * m[u].y; v.z += wp_ * m[u].z; v.w += wp_ * m[u].w; }
+          if (MODE & 4) { v.x += wp_ * m[u].x; v.y += wp_ * m[u].y; v.z += wp_ * m[u].z; v.w += wp_ * m[u].w; }
           v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w);
         }
         *reinterpret_cast<float4*>(&sU[p * FN_FS + q * 4]) = v;
@@ -361,13 +362,23 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
   constexpr size_t lds = (size_t)(FN_U + 64 * FN_ZS + 9 * FN_C) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   mmd_prof_tag(MMD_FAM_MBX, "node H%lld C%lld ops%lld", H, C, a.ntheta, 0);
   mmd_prof_begin(MMD_FAM_MBX, stream);
-  hipLaunchKernelGGL(bifpn_node_fused_kernel, dim3((unsigned)(B * th * tw)), dim3(FN_NT), lds, stream, a, w_dw, w_pw, bias, scale, shift,
-                     y, th, tw);
+  const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
+  const dim3 grid((unsigned)(B * th * tw)), blk(FN_NT);
+#define MMD_NODE_FWD(M) hipLaunchKernelGGL(bifpn_node_fused_kernel<M>, grid, blk, lds, stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw)
+  if (mode == 2) MMD_NODE_FWD(2);             // (in, up): top-down nodes
+  else if (mode == 5) MMD_NODE_FWD(5);        // (in, td, pool): bottom-up nodes
+  else if (mode == 4) MMD_NODE_FWD(4);        // (in, pool): p7_out
+  else if (mode == 1) MMD_NODE_FWD(1);
+  else return MMD_EINVAL;
+#undef MMD_NODE_FWD
   const double rows = (double)B * H * W;
   mmd_prof_end(MMD_FAM_MBX, stream, rows * C * (2.0 * 9 + 2.0 * C), 4.0 * rows * C * (a.ntheta + 1 + (pool ? 3 : 0)));
   return mmd_check_launch();
