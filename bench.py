@@ -160,6 +160,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU baseline's batch (0 = the per-GPU batch)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON record: RCCL prints its version banner to stdout when a communicator comes up, so
+    # file descriptor 1 points at stderr for the whole run and the record goes out through a saved duplicate at the end
+    sys.stdout.flush()
+    real_out = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -334,7 +339,8 @@ def main():
                            "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                            "graph": use_graph, "pseudo_label_boxes_per_image": nbox},
                 "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_out, (json.dumps(line) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
