@@ -191,8 +191,12 @@ def main():
     sspec = make_spec(args.coef, 8)
     sstate = calibrated_state(sspec, 4, calib["audio"], dev)
     batch_cpu = synth_inputs(B, S, seed=24 + rank)
+    # the frozen teachers are REPLICAS: their classifier biases are tuned on rank 0's batch (seed 24) and every teacher tensor is
+    # broadcast from rank 0 below, so all ranks hold bit-identical teachers whatever their own batch is
+    tune_batch = batch_cpu if rank == 0 else synth_inputs(B, S, seed=24)
     for k in tstates:
-        tune_teacher_bias(specs[k], tstates[k], batch_cpu[k], dev)
+        tune_teacher_bias(specs[k], tstates[k], tune_batch[k], dev)
+    del tune_batch
     log("teacher biases tuned")
     eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S, precision=args.precision), world_size=world, process_group=pg)
     if world == 1 and os.environ.get("MMD_FORCE_DP"):
@@ -206,10 +210,12 @@ def main():
     eng.load(sstate, tstates)
     if os.environ.get("MMD_COMM") == "rccl" and (world > 1 or eng.force_ar):
         eng.init_comm(rank)      # gradient exchange through the C ABI's own RCCL communicator (csrc/comm.hip) instead of torch.distributed
-    if world > 1:   # identical initial student on every rank (DDP broadcasts parameters at construction)
+    if world > 1:   # identical initial student on every rank (DDP broadcasts parameters and buffers at construction) and identical teachers
         import torch.distributed as dist
-        dist.broadcast(eng.student.ps.flat, 0)
-        eng.student.refresh()
+        for net in [eng.student] + list(eng.teachers.values()):
+            for t in (net.ps.flat, net.ps.rmean, net.ps.rvar):
+                dist.broadcast(t, 0)
+            net.refresh()
     batch = {k: v.to(dev) for k, v in batch_cpu.items()}
 
     def barrier():
@@ -242,17 +248,22 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     log("timed %d steps: %.2f ms/step" % (args.steps, ms))
-    if os.environ.get("MMD_BENCH_PERSTEP"):      # dev aid: per-step distribution (A/B comparisons need the median/min)
-        per = []
-        for _ in range(int(os.environ["MMD_BENCH_PERSTEP"])):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            run()
-            torch.cuda.synchronize()
-            per.append((time.perf_counter() - t1) * 1e3)
-        per.sort()
-        log("per-step ms: min %.3f  p25 %.3f  median %.3f  p75 %.3f  max %.3f" % (
-            per[0], per[len(per) // 4], per[len(per) // 2], per[3 * len(per) // 4], per[-1]))
+    # Outside the timed region: the distribution of single synchronised steps over >= 100 more steps.  One build runs in a "fast" or a
+    # "slow" mode (~5 % apart) depending on the process / time window (profiles/r02_notes.md); the 20-step mean above cannot tell which
+    # one it landed in, the median and spread of 100 steps next to it can.
+    per = []
+    for _ in range(max(int(os.environ.get("MMD_BENCH_PERSTEP", "100")), 1)):
+        barrier() if world > 1 else torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t1) * 1e3)
+    per.sort()
+    per_step = {"n": len(per), "min_ms": round(per[0], 3), "p25_ms": round(per[len(per) // 4], 3), "median_ms": round(per[len(per) // 2], 3),
+                "p75_ms": round(per[3 * len(per) // 4], 3), "max_ms": round(per[-1], 3),
+                "note": "single steps, each followed by a device synchronise (adds the host's launch + sync latency to every sample)"}
+    log("per-step ms: min %.3f  p25 %.3f  median %.3f  p75 %.3f  max %.3f" % (
+        per[0], per[len(per) // 4], per[len(per) // 2], per[3 * len(per) // 4], per[-1]))
     if int(eng.overflow.item()):
         print("per-teacher candidate counts:", [c.cpu().tolist() for c in eng.out["cnt_t"]], file=sys.stderr)
     eng.check_overflow()
@@ -338,7 +349,7 @@ def main():
                                          "%dx%d, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % (args.coef, S, S, B),
                            "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
                            "graph": use_graph, "pseudo_label_boxes_per_image": nbox},
-                "roofline": roof, "cpu_baseline": cpu}
+                "per_step": per_step, "roofline": roof, "cpu_baseline": cpu}
         sys.stdout.flush()
         os.write(real_out, (json.dumps(line) + "\n").encode())
     if world > 1:

@@ -363,7 +363,9 @@ __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
 
 static int pp_pow2(int n) { int p = 2048; while (p < n) p <<= 1; return p; }
 // floats of chunked-path workspace per image for lists of up to nmax rows
-extern "C" int mmd_nms_ws_floats(int nmax) { return nmax <= PP_CAP ? 0 : (int)(2ll * pp_pow2(nmax) + 6ll * nmax); }
+// (rounded up to a multiple of 4 floats: kbox is read and written as float4, so every image's slice must start 16-byte aligned -
+// with an odd nmax, e.g. cap = 9 * 341 anchors at image_size 128, 6 * nmax alone leaves odd images 8-byte aligned)
+extern "C" int mmd_nms_ws_floats(int nmax) { return nmax <= PP_CAP ? 0 : (int)((2ll * pp_pow2(nmax) + 6ll * nmax + 3) / 4 * 4); }
 
 // per-teacher NMS: cand [B,cap,6] + n_keep -> out [B,cap,6] (truncated coords, quirk score, mapped label), out_cnt [B].
 // mask_ws: B * 1024 * 16 words.  big_ws (nullable when cap <= 1024): B * mmd_nms_ws_floats(cap) floats.

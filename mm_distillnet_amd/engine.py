@@ -140,7 +140,7 @@ class Net:
         self.mark_block, self.mark_event = -1, None
         self._wg_pending: list = []          # deferred 1x1-conv weight gradients of the current backward segment
         self._leaf_pending: list = []        # other deferred leaves (closures), issued by _wg_flush
-        self._wg_plans: Dict[int, dict] = {}  # segment index -> planned table (built once: arena addresses repeat every step)
+        self._wg_plans: Dict[tuple, dict] = {}  # (segment index, operand signature) -> planned table (built once: arena addresses repeat every step)
         self._wg_segment = 0
 
     # ------------------------------------------------------------------ parameters
@@ -639,9 +639,11 @@ class Net:
             return
         ptr = lambda t: 0 if t is None else t.data_ptr()
         sig = tuple((ptr(d), ptr(x), ptr(w), M, K, N, ptr(a), ptr(b), act, ptr(gt), rpi) for d, x, w, M, K, N, a, b, act, gt, rpi in pend)
-        plan = self._wg_plans.get(seg)
-        if plan is None or plan["sig"] != sig:
-            if self.arena.frozen and plan is not None:
+        # one plan per (segment, operand signature): a second step variant captured later ("aug") may lay its operands out
+        # differently, and the device tables of the variants captured before must stay alive - their graphs keep reading them
+        plan = self._wg_plans.get((seg, sig))
+        if plan is None:
+            if self.arena.frozen:
                 raise RuntimeError("weight-gradient operands moved after graph capture")
             n = len(pend)
             arr = (WgLayer * n)()
@@ -658,7 +660,7 @@ class Net:
             plan = {"sig": sig, "table": table, "n": n, "items": ni.value, "tiles": nt.value, "ws": wsf.value,
                     "flops": float(sum(2.0 * M * K * N for _, _, _, M, K, N, *_ in pend)),
                     "bytes": float(sum(4.0 * (M * K + M * N + N * K) for _, _, _, M, K, N, *_ in pend))}
-            self._wg_plans[seg] = plan
+            self._wg_plans[(seg, sig)] = plan
         ws = self._alloc(plan["ws"])
         with self._wgrad_stream():
             call("mmd_wgrad_grouped", plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS, plan["flops"], plan["bytes"])

@@ -91,38 +91,39 @@ def get_batch_central_distances(outputs: Sequence, targets: Sequence, width: flo
 
 
 def compute_ap(recall, precision):
-    mrec = np.concatenate(([0.0], recall, [1.0]))
-    mpre = np.concatenate(([0.0], precision, [0.0]))
-    for i in range(mpre.size - 1, 0, -1):
-        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
-    i = np.where(mrec[1:] != mrec[:-1])[0]
-    return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    """Area under the precision envelope over the recall steps (the py-faster-rcnn rule the reference uses,
+    src/utils/utils.py:1255-1280): precision is replaced by its running maximum from the right, and every change of recall
+    contributes (delta recall) x (envelope right of the step)."""
+    rec = np.r_[0.0, recall, 1.0]
+    env = np.maximum.accumulate(np.r_[0.0, precision, 0.0][::-1])[::-1]
+    width = np.diff(rec)
+    steps = np.flatnonzero(rec[1:] != rec[:-1])
+    return np.sum(width[steps] * env[steps + 1])
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls):
-    """-> (precision, recall, AP, F1, classes, total_predictions / total_ground_truth), one entry per ground-truth class."""
+    """-> (precision, recall, AP, F1, classes, total_predictions / total_ground_truth), one entry per ground-truth class
+    (src/utils/utils.py:1188-1252).  Classes come from the ground truth, so each has at least one object; a class nobody
+    predicted scores 0 on all three."""
     target_cls = np.asarray(target_cls)
-    i = np.argsort(-conf)
-    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
-    unique_classes = np.unique(target_cls)
-    ap, p, r = [], [], []
-    total_gt, total_p = 0.0, 0.0
-    for c in unique_classes:
-        i = pred_cls == c
-        n_gt, n_p = (target_cls == c).sum(), i.sum()
-        total_gt += n_gt; total_p += n_p
-        if n_p == 0 and n_gt == 0:
+    ranked = np.argsort(-conf)
+    hit, cls_ranked = tp[ranked], pred_cls[ranked]
+    classes, n_objects = np.unique(target_cls, return_counts=True)
+    prec, rec, ap = [], [], []
+    n_pred = 0.0
+    for c, n_gt in zip(classes, n_objects):
+        mine = hit[cls_ranked == c]
+        n_pred += mine.size
+        if mine.size == 0:
+            prec.append(0); rec.append(0); ap.append(0)
             continue
-        if n_p == 0 or n_gt == 0:
-            ap.append(0); r.append(0); p.append(0)
-            continue
-        fpc, tpc = (1 - tp[i]).cumsum(), tp[i].cumsum()
-        rc = tpc / (n_gt + 1e-16)
-        pc = tpc / (tpc + fpc)
-        r.append(rc[-1]); p.append(pc[-1]); ap.append(compute_ap(rc, pc))
-    p, r, ap = np.array(p), np.array(r), np.array(ap)
-    f1 = 2 * p * r / (p + r + 1e-16)
-    return p, r, ap, f1, unique_classes.astype("int32"), total_p / total_gt
+        hits, misses = np.cumsum(mine), np.cumsum(1 - mine)
+        r_curve = hits / (n_gt + 1e-16)
+        p_curve = hits / (hits + misses)
+        prec.append(p_curve[-1]); rec.append(r_curve[-1]); ap.append(compute_ap(r_curve, p_curve))
+    prec, rec, ap = np.array(prec), np.array(rec), np.array(ap)
+    f1 = 2 * prec * rec / (prec + rec + 1e-16)
+    return prec, rec, ap, f1, classes.astype("int32"), n_pred / float(n_objects.sum())
 
 
 def evaluate_table(all_predictions: List[List], all_labels: List[List], labels: Sequence, image_size: int) -> dict:

@@ -246,6 +246,9 @@ class DistillEngine:
         st = self.student
         S = cfg.image_size
         B = batch["audio"].shape[0]
+        # validate() upstream calls model(..., validate=True) with `augment` left at its default False
+        # (src/optimization/train_methods.py:1083-1185): the validation losses never see the audio merge / feature averaging / label merge
+        aug = bool(cfg.augment and train)
         self.ws.reset()
         self.mask_ws = self.ws.alloc((B * 1024 * 16,), torch.int64)
         if self.fork_stream is None:
@@ -256,7 +259,7 @@ class DistillEngine:
             fork_event = torch.cuda.current_stream().record_event()
         st.begin_step()
         audio = batch["audio"]
-        if cfg.augment and B >= 2:      # merge_batch_0_1: image 1 <- log10(a0^10 + a1^10), out of place
+        if aug and B >= 2:      # merge_batch_0_1: image 1 <- log10(a0^10 + a1^10), out of place
             merged = st._alloc(*audio.shape)
             call("mmd_audio_merge01", audio, merged, audio[0].numel(), B)
             audio = merged
@@ -309,7 +312,7 @@ class DistillEngine:
             with torch.cuda.stream(side):
                 net.begin_step()
                 cls_t, reg_t, feats_t = net.forward(xin if xin is not None else (audio if mod == "audio" else batch[mod]), train=False)
-                if cfg.augment and B >= 2:      # average_batch_0_1 on the (already consumed by the heads) feature maps
+                if aug and B >= 2:      # average_batch_0_1 on the (already consumed by the heads) feature maps
                     for f in feats_t:
                         call("mmd_avg_image01", f.z, f.H * f.W * f.C)
                 if teacher_labels is not None:
@@ -334,7 +337,7 @@ class DistillEngine:
             call("mmd_mta_attention_bwd", st._fcat, da_all, d_all, st._pyr["total"], feats_s[0].C, float(cfg.p), 0)
             dfe = [d_all[st._pyr["row0"][l]:st._pyr["row0"][l] + st._pyr["rows"][l]] for l in range(nlv)]
         # cross-teacher merge -> annotations
-        boxes, nbox, G = self._merge(rows_t, cnt_t, B, cfg.augment)
+        boxes, nbox, G = self._merge(rows_t, cnt_t, B, aug)
         # focal + smooth-L1 with gradients w.r.t. (pre-sigmoid) classifier logits and regression
         nc = st.spec.num_classes
         assign = self.ws.alloc((B * A,), torch.int32); npos = self.ws.alloc((B,), torch.int32)

@@ -129,8 +129,13 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     # traditional_nms_kdlist_augmented: from epoch 1 on some iterations mix in other recordings (4th list entry); both graph variants get used
     draws = iter([False, True, True, False])
     monkeypatch.setattr(train.TR, "kdlist_augment_now", lambda epoch: next(draws))
-    ov_k = ov[:-1] + ', "train_method": "traditional_nms_kdlist_augmented", "exp_name": "exp_kd"}'
+    # (upstream hands the model augment=cfg audio_augmentation_merge: the 4th RGB-teacher pass needs the flag, the draw alone only mixes audio)
+    ov_k = ov[:-1] + ', "train_method": "traditional_nms_kdlist_augmented", "audio_augmentation_merge": "True", "exp_name": "exp_kd"}'
     assert np.isfinite(train.main(["--config_file", cfgf, "--overwrite", ov_k, "--max_steps", "4"]))
+    # --max_steps ends the run on every path out of the epoch body (no_validation / fast_run `continue`s included)
+    ov_n = ov[:-1] + ', "no_validation": "True", "num_epoches": 3, "exp_name": "exp_nv"}'
+    train.main(["--config_file", cfgf, "--overwrite", ov_n, "--max_steps", "2"])
+    assert train.LAST_RUN_STEPS == 2
     # SGD / StepLR run through the same flat optimizer pass
     ov_s = ov[:-1] + ', "optimizer": "SGD", "momentum": 0.9, "weight_decay": 1e-4, "scheduler": "StepLR", "step_size": 1, "gamma": 0.5, "exp_name": "exp_sgd"}'
     assert np.isfinite(train.main(["--config_file", cfgf, "--overwrite", ov_s, "--max_steps", "3"]))

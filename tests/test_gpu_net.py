@@ -135,14 +135,14 @@ def test_net_eval_512_vs_oracle(B):
 
 
 def _full_size_batch():
-    """B = 8 (the benchmark's per-GPU batch) when the host has the memory for the oracle's autograd tape (~3 GB per image at
-    512^2), else 2."""
-    try:
-        import psutil
-        free_gb = psutil.virtual_memory().available / 2 ** 30
-    except Exception:
-        free_gb = 0.0
-    return 8 if free_gb >= 64 else 2
+    """B = 8, the benchmark's per-GPU batch.  The oracle's autograd tape needs ~3 GB of host memory per image at 512^2: a host
+    without it SKIPS (loudly) - the test never shrinks to a smaller batch on its own."""
+    import psutil
+    free_gb = psutil.virtual_memory().available / 2 ** 30
+    if free_gb < 48:
+        pytest.skip(f"full-size parity test needs >= 48 GB of free host memory for the oracle (have {free_gb:.0f} GB): NOT RUN at B = 8")
+    print(f"full-size parity test: B = 8 ({free_gb:.0f} GB of host memory free)")
+    return 8
 
 
 def test_net_train_512_full_size_vs_oracle():

@@ -70,6 +70,9 @@ def parse_config(argv=None):
     return cfg, args
 
 
+LAST_RUN_STEPS = 0        # optimizer steps of the most recent main() (read by the tests)
+
+
 def step_config(cfg) -> StepConfig:
     method = cfg.get("train_method", "traditional_nms_augmented")
     if method not in TR.SUPPORTED_METHODS:
@@ -168,6 +171,7 @@ def main(argv=None):
     w_main, w_kd = cfg.getfloat("w_main", 1.0), cfg.getfloat("w_kd", 0.005)
     n_epochs = cfg.getint("num_epoches", 1)
     kdlist_aug = cfg.get("train_method", "") == "traditional_nms_kdlist_augmented"
+    kdlist_pass = kdlist_aug and cfg.getboolean("audio_augmentation_merge", False)
     if kdlist_aug and raw:
         raise Exception("traditional_nms_kdlist_augmented needs the dataset's yield_batch: not available with input_pipeline = raw")
     no_validation = cfg.getboolean("no_validation", False)
@@ -188,10 +192,14 @@ def main(argv=None):
             batch = staged.wait() if raw else to_batch(item)
             if kdlist_aug and TR.kdlist_augment_now(epoch):
                 # traditional_nms_kdlist_augmented (traditional.py:121-124, train_methods.py:50-162): the batch's audio is replaced by
-                # its mix with other recordings' audio, and those recordings' RGB frames go through the RGB teacher as a 4th list entry.
-                # (Upstream hands the model augment=cfg audio_augmentation_merge instead of this draw, which only works when both agree.)
+                # its mix with other recordings' audio (`label, audio = train_set.yield_batch(...)`).  Whether those recordings' RGB frames
+                # then go through the RGB teacher as a 4th list entry is NOT decided by this draw: upstream hands the model
+                # augment=cfg audio_augmentation_merge (traditional.py:136), so with the flag off only the mixed audio is used.
+                # (Flag on and no draw: upstream would feed the dataset's `label` to the RGB teacher - not reproduced, see INTEGRATION.md.)
                 aug_rgb, mixed = train_set.yield_batch(batch["audio"].shape[0], item[5])
-                batch = dict(batch, audio=mixed.to(dev, non_blocking=True), aug_rgb=aug_rgb.to(dev, non_blocking=True))
+                batch = dict(batch, audio=mixed.to(dev, non_blocking=True))
+                if kdlist_pass:
+                    batch["aug_rgb"] = aug_rgb.to(dev, non_blocking=True)
             nxt = next(it, None)
             if not captured:
                 eng.capture(batch); captured = True
@@ -225,6 +233,8 @@ def main(argv=None):
         logger.info("epoch %d: %.1f images/sec on this rank, last loss %.5f", epoch + 1, n_img / (time.time() - t0), loss)
         sched.step(loss)
         if no_validation:
+            if stop:
+                break
             continue
         is_best = False
         if epoch % cfg.getint("val_interval", 1) == 0:
@@ -236,17 +246,21 @@ def main(argv=None):
             if epoch - best_epoch > cfg.getint("es_patience", 5) > 0:
                 logger.info(f"ES Epoch{epoch}. Lowest loss is {val_loss}")
                 break
-        if cfg.getboolean("fast_run", False) and not is_best:
-            continue
-        TR.save_checkpoint(TR.checkpoint_state(eng, sched, epoch, best_loss, best_epoch), is_best, cfg)
-        if stop:
+        if not (cfg.getboolean("fast_run", False) and not is_best):
+            TR.save_checkpoint(TR.checkpoint_state(eng, sched, epoch, best_loss, best_epoch), is_best, cfg)
+        if stop:           # --max_steps reached: checked on every path out of the epoch body
             break
+    global LAST_RUN_STEPS
+    LAST_RUN_STEPS = steps
     writer.export_scalars_to_json(f"{cfg['exp_name']}/all_logs.{rank}.json")
-    if no_validation and captured:
-        val_loss = TR.validate(eng, val_set, cfg, n_epochs, writer, to_batch, collate_fn, world)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier(); dist.destroy_process_group()
+    try:
+        if no_validation and captured:
+            val_loss = TR.validate(eng, val_set, cfg, n_epochs, writer, to_batch, collate_fn, world)
+    finally:
+        eng.close_comm()        # the C-ABI RCCL communicator (MMD_COMM=rccl) goes before the process group does
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(); dist.destroy_process_group()
     return val_loss if val_loss == val_loss else loss
 
 
