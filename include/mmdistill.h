@@ -44,7 +44,18 @@ int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, cons
 // already holds (instead of a mmd_dwconv_bwd_weight launch over a materialised f).
 int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, hipStream_t stream);
 
+// Round 3: "the writer of the last contribution to a gradient computes the BatchNorm-backward sums of the total".  Same launch as
+// mmd_bifpn_node_dw_bwd; for each operand gradient it writes (d0 / d1 / dup) an optional (z, mean, invstd, sums): when this launch
+// completes that gradient and the operand is the output y = BN(z) of a BatchNorm (a BiFPN node / down-channel output), sums [2C] (+)=
+// [sum g, sum g*xhat], xhat = (z - mean)*invstd, over the completed gradient g - what mmd_bn_bwd_reduce(act = NONE) would compute in a
+// launch of its own on the backward's serial chain (autograd of the BatchNorm in SeparableConvBlock, src/YetAnotherEfficientDet.py:171-176).
+int mmd_bifpn_node_dw_bwd2(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, hipStream_t stream);
+
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
+
+// d theta of every fusion node of a net in ONE launch: desc [nodes][2] = (offset of the node's theta in theta_base / dtheta_base, its
+// operand count); wdot_all [nodes][4] = the dot products the node backward launches accumulated.
+int mmd_bifpn_theta_bwd_batched(const float* theta_base, float* dtheta_base, const float* wdot_all, const long long* desc, int nodes, hipStream_t stream);
 
 // dst (+)= w_idx(theta) * src (same-resolution operand gradient).
 int mmd_scale_acc(const float* src, float* dst, const float* theta, int ntheta, int widx, int accumulate, long long numel, hipStream_t stream);
@@ -57,6 +68,10 @@ int mmd_maxpool_same_fwd(const float* src, float* out, int B, int PH, int PW, in
 
 // Backward of MaxPool2dStaticSamePadding(3,2) in gather form (first maximum in scan order wins).
 int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream);
+
+// + (z, mean, invstd, sums): the BatchNorm-backward sums of the completed gradient dst when this launch is its last contribution and
+// src = BN(z) (see mmd_bifpn_node_dw_bwd2).  C <= 512.
+int mmd_maxpool_same_bwd_acc2(const float* src, const float* dout, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int PH, int PW, int C, const float* z, const float* mean, const float* invstd, double* sums, hipStream_t stream);
 
 // Depthwise kxk TF-SAME conv, NHWC, fused producer BN+swish prologue, stats / eval-BN+swish / SE-pool epilogue.
 // stats_ws/ws_slots (nullable/0): zeroed workspace of ws_slots*2C doubles; launches that would send > 128 blocks to one
@@ -224,6 +239,12 @@ int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale,
 
 int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma, const double* sums, const int* pyr_desc, long long lev_stride, float* dz, float* dgamma, float* dbeta, int C, const float* scale, const float* shift, int act, hipStream_t stream);
 
+// out = a + b (+ c, nullable) over a pyramid row buffer [rows, C] (the two heads' input gradients + the MTA loss' feature gradient =
+// the gradient w.r.t. the last BiFPN cell's outputs), and per level l with z[l] != NULL (host arrays of n device pointers; that level's
+// feature map is BN(z[l]), z[l] its own [B*H*W, C] tensor) sums[l] [2C] (+)= [sum out, sum out*xhat]: the BatchNorm-backward reduce
+// passes of the five output nodes (src/YetAnotherEfficientDet.py:338-390) in the launch that completes their upstream gradient.
+int mmd_pyr_add_bnsums(const float* a, const float* b, const float* c, float* out, const int* pyr_desc, int C, const float* const* z, const float* const* mean, const float* const* invstd, double* const* sums, hipStream_t stream);
+
 // dW[N,K] += dY^T * pro(X) (autograd of the 1x1 conv weight; reference: loss.backward(), src/optimization/traditional.py:182).
 int mmd_pwconv_bwd_weight(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, hipStream_t stream);
 
@@ -272,6 +293,16 @@ int mmd_pwconv_bwd_data_bf16(const float* dy, const float* wt, float* dx, int M,
 // so that the weight gradient can be the plain mmd_pwconv_bwd_weight(dz_out, x); dgamma / dbeta (+)= [sum g'*xhat, sum g'].  Autograd of nn.BatchNorm2d (train) behind nn.Conv2d(k=1): src/YetAnotherEfficientNet.py:427-428,446-447,477;
 // src/YetAnotherEfficientDet.py:171-176.
 int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
+
+// mmd_pwconv_bwd_data_bn with two more (optional) jobs for its epilogue.  residual (may alias dx): dx = BnBwd(g, z) * W + residual - the
+// skip branch's / earlier consumers' contributions already sit in the gradient buffer.  xs_*: dx is then the COMPLETE gradient w.r.t. a
+// tensor y' = BN'(xs_z) * xs_mul_b[image] (+ skip) (an MBConv block output / a tap), and xs_sums [2K] (+)= [sum g', sum g'*xhat'],
+// g' = dx * xs_mul_b[image], xhat' = (xs_z - xs_mean)*xs_invstd: the reduce pass of that upstream BatchNorm's backward, without a launch of
+// its own and without the scale_acc launch that added the skip gradient (src/YetAnotherEfficientNet.py:477-485).  stats_ws / ws_slots
+// (nullable / 0) as in mmd_pwconv_fwd: slotted sums for launches with more than 128 row tiles.
+int mmd_pwconv_bwd_data_bn2(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, hipStream_t stream);
+
+int mmd_pwconv_bwd_data_bn2_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, hipStream_t stream);
 
 int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
 

@@ -29,9 +29,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
     procs = []
+    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))
     for s in srcs:
         o = os.path.join(PKG, "build", os.path.basename(s)[:-4] + ".o")
         objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
+            continue            # object newer than its source and every header
         procs.append((s, subprocess.Popen([hipcc, *FLAGS, "-c", s, "-o", o], stdout=subprocess.PIPE,
                                           stderr=subprocess.STDOUT)))
     for s, p in procs:

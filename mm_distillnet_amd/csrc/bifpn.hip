@@ -449,11 +449,12 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
                                                          float* __restrict__ dup, int acc_up, float* __restrict__ dwg,
-                                                         int tiles_h, int tiles_w, int cchunks) {
+                                                         int tiles_h, int tiles_w, int cchunks, BnSumDst x0, BnSumDst x1, BnSumDst xu) {
   constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
   __shared__ float sIn[IH * IW * 64];
   __shared__ float sW[9 * 64];
   __shared__ float sred[4 * 3];
+  __shared__ float sBn[3 * 2 * 4 * 64];            // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel]
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
@@ -503,6 +504,15 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   float d[3] = {0.f, 0.f, 0.f};
   const int oh = oh0 + orow;
   float4 gq[R], fq[R];
+  // BatchNorm-backward sums of the totals written below (x0 / x1 / xu.z != nullptr: this launch is the last contribution to that operand's
+  // gradient, the operand is a BatchNorm output; replaces the mmd_bn_bwd_reduce launch of the operand's node)
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  float4 bs0 = z4, bq0 = z4, bs1 = z4, bq1 = z4, bsu = z4, bqu = z4, mu0 = z4, is0 = z4, mu1 = z4, is1 = z4, muu = z4, isu = z4;
+  if (cok) {
+    if (x0.z) { mu0 = mmd_ld4(x0.mean + c); is0 = mmd_ld4(x0.invstd + c); }
+    if ((MODE & 1) && x1.z) { mu1 = mmd_ld4(x1.mean + c); is1 = mmd_ld4(x1.invstd + c); }
+    if ((MODE & 2) && xu.z) { muu = mmd_ld4(xu.mean + c); isu = mmd_ld4(xu.invstd + c); }
+  }
 #pragma unroll
   for (int o = 0; o < R; ++o) {
     const int ow = ow0 + ocol0 + o;
@@ -520,11 +530,13 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
         if (acc0) { float4 q = mmd_ld4(d0 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         mmd_st4(d0 + off, v);
+        if (x0.z) bnsum_acc4(x0, off, v, mu0, is0, bs0, bq0);
       }
       if (d1) {
         float4 v = make_float4(g.x * w[1], g.y * w[1], g.z * w[1], g.w * w[1]);
         if (acc1) { float4 q = mmd_ld4(d1 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         mmd_st4(d1 + off, v);
+        if ((MODE & 1) && x1.z) bnsum_acc4(x1, off, v, mu1, is1, bs1, bq1);
       }
       int wi = 0;
       d[wi++] += g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
@@ -550,8 +562,20 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         sv.x *= wu; sv.y *= wu; sv.z *= wu; sv.w *= wu;
         if (acc_up) { float4 pv = mmd_ld4(o); sv.x += pv.x; sv.y += pv.y; sv.z += pv.z; sv.w += pv.w; }
         mmd_st4(o, sv);
+        if (xu.z) bnsum_acc4(xu, (size_t)(o - dup), sv, muu, isu, bsu, bqu);
       }
     }
+  }
+  {
+    // per-channel block sums: lanes l, l^16, l^32, l^48 of a wave share the channel quad, then the 4 waves through LDS
+    auto put = [&](float4 v, int slot) {
+      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      if (lane < 16) *reinterpret_cast<float4*>(&sBn[(slot * 4 + wave) * 64 + c4]) = v;
+    };
+    if (x0.z) { put(bs0, 0); put(bq0, 1); }
+    if ((MODE & 1) && x1.z) { put(bs1, 2); put(bq1, 3); }
+    if ((MODE & 2) && xu.z) { put(bsu, 4); put(bqu, 5); }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { float v = wave_sum(d[i]); if (lane == 0) sred[wave * 3 + i] = v; }
@@ -577,8 +601,18 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         }
     }
   }
-  __syncthreads();                                  // sred complete; every read of the dzd tile done
+  __syncthreads();                                  // sred / sBn complete; every read of the dzd tile done
   if (tid < a.ntheta) atomicAdd(&wdot[tid], sred[tid] + sred[3 + tid] + sred[6 + tid] + sred[9 + tid]);
+  if (tid < 128 && c0 + (tid & 63) < a.C) {         // threads 0..63: sum g, 64..127: sum g*xhat
+    const int q = tid & 63, hq = tid >> 6;
+    auto flush = [&](const BnSumDst& x, int op) {
+      const float* r = &sBn[((op * 2 + hq) * 4) * 64 + q];
+      atomicAdd(&x.sums[hq * a.C + c0 + q], (double)(r[0] + r[64] + r[128] + r[192]));
+    };
+    if (x0.z) flush(x0, 0);
+    if ((MODE & 1) && x1.z) flush(x1, 1);
+    if ((MODE & 2) && xu.z) flush(xu, 2);
+  }
   if (dwg) {
     float* sRedW = sIn;                             // [4 waves][9][64]
 #pragma unroll
@@ -596,17 +630,20 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     }
   }
 }
-extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool,
-                                     const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
-                                     int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
-                                     float* dw_grad, hipStream_t stream) {
+static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up, const float* pool,
+                            const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
+                            int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                            float* dw_grad, BnSumDst x0, BnSumDst x1, BnSumDst xu, hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
+  if ((x0.z && (!d0 || !x0.mean || !x0.invstd || !x0.sums)) || (x1.z && (!d1 || !x1.mean || !x1.invstd || !x1.sums)) ||
+      (xu.z && (!dup || !xu.mean || !xu.invstd || !xu.sums)))
+    return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
-#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc)
+#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu)
   switch (mode) {          // the operand sets of BiFPN._forward_fast_attention: (in, up), (in, td, pool), (in, pool); others through the generic forms
     case 2: MMD_NODE_BWD(2); break;
     case 5: MMD_NODE_BWD(5); break;
@@ -618,6 +655,25 @@ extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const f
   }
 #undef MMD_NODE_BWD
   return mmd_check_launch();
+}
+extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool,
+                                     const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
+                                     int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                     float* dw_grad, hipStream_t stream) {
+  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
+                          BnSumDst{}, BnSumDst{}, BnSumDst{}, stream);
+}
+// Same launch; for each operand gradient it writes (d0, d1, dup) an optional (z, mean, invstd, sums): when this launch is the LAST
+// contribution to that gradient and the operand is the output of a BatchNorm, sums [2C] (+)= [sum g, sum g*xhat] of the completed
+// gradient - the reduce pass of the operand node's BatchNorm backward without a launch of its own (common.h BnSumDst).
+extern "C" int mmd_bifpn_node_dw_bwd2(const float* in0, const float* in1, const float* up, const float* pool,
+                                      const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
+                                      int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                      float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0,
+                                      const float* z1, const float* mean1, const float* invstd1, double* sums1,
+                                      const float* zu, const float* meanu, const float* invstdu, double* sumsu, hipStream_t stream) {
+  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
+                          BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream);
 }
 
 // d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   
@@ -727,14 +783,24 @@ extern "C" int mmd_maxpool_same_fwd(const float* src, float* out, int B, int PH,
 // max-pool backward in gather form: every source pixel looks at the (<=4) windows that contain it and takes the
 // window's gradient iff it is the FIRST maximum of that window in row-major scan order (torch semantics; a
 // zero-padding element that wins swallows the gradient).
-__global__ void maxpool_bwd_acc_kernel(const float* __restrict__ src, const float* __restrict__ dout, float* __restrict__ dst,
+// xs.z != nullptr: this launch completes the gradient of `src` = BN(xs.z); it then also accumulates that BatchNorm's backward sums
+// (LDS float atomics per block, one double atomic per channel and block; `iters` items per thread keep the block count - the depth of
+// the same-address atomics - in the hundreds).  C <= MP_MAXC in that mode.
+#define MP_MAXC 512
+__global__ __launch_bounds__(256) void maxpool_bwd_acc_kernel(const float* __restrict__ src, const float* __restrict__ dout, float* __restrict__ dst,
                                        const float* theta, int n, int widx, int accumulate, int B, int PH, int PW, int C,
-                                       int OH, int OW, int pad_t, int pad_l) {
+                                       int OH, int OW, int pad_t, int pad_l, BnSumDst xs, int iters) {
+  __shared__ float sS[2 * MP_MAXC];
+  if (xs.z) {
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sS[i] = 0.f;
+    __syncthreads();
+  }
   float w = theta_weight(theta, n, widx);
   const int c4n = C >> 2;
-  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  size_t total = (size_t)B * PH * PW * c4n;
-  if (idx >= total) return;
+  const size_t total = (size_t)B * PH * PW * c4n;
+  for (int it = 0; it < iters; ++it) {
+  size_t idx = ((size_t)blockIdx.x * iters + it) * 256 + threadIdx.x;
+  if (idx >= total) break;
   int c = (int)(idx % c4n) * 4; size_t pix = idx / c4n;
   int x = (int)(pix % PW); pix /= PW;
   int y = (int)(pix % PH); int b = (int)(pix / PH);
@@ -769,18 +835,67 @@ __global__ void maxpool_bwd_acc_kernel(const float* __restrict__ src, const floa
         if (by[q] == y && bx[q] == x) acc[q] += gg[q];
     }
   float4 o = make_float4(acc[0] * w, acc[1] * w, acc[2] * w, acc[3] * w);
-  float* d = dst + (((size_t)b * PH + y) * PW + x) * C + c;
+  const size_t doff = (((size_t)b * PH + y) * PW + x) * C + c;
+  float* d = dst + doff;
   if (accumulate) { float4 p = mmd_ld4(d); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
   mmd_st4(d, o);
+  if (xs.z) {
+    const float4 zz = mmd_ld4(xs.z + doff), mu = mmd_ld4(xs.mean + c), is = mmd_ld4(xs.invstd + c);
+    atomicAdd(&sS[c], o.x); atomicAdd(&sS[c + 1], o.y); atomicAdd(&sS[c + 2], o.z); atomicAdd(&sS[c + 3], o.w);
+    atomicAdd(&sS[C + c], o.x * (zz.x - mu.x) * is.x); atomicAdd(&sS[C + c + 1], o.y * (zz.y - mu.y) * is.y);
+    atomicAdd(&sS[C + c + 2], o.z * (zz.z - mu.z) * is.z); atomicAdd(&sS[C + c + 3], o.w * (zz.w - mu.w) * is.w);
+  }
+  }
+  if (xs.z) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&xs.sums[i], (double)sS[i]);
+  }
 }
-extern "C" int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta,
-                                        int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream) {
+static int maxpool_bwd_impl(const float* src, const float* dout, float* dst, const float* theta, int ntheta,
+                            int widx, int accumulate, int B, int PH, int PW, int C, BnSumDst xs, hipStream_t stream) {
   if (!src || !dout || !dst || B <= 0 || PH <= 0 || PW <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if (theta && (widx < 0 || widx >= ntheta || ntheta > 3)) return MMD_EINVAL;
+  if (xs.z && (!xs.mean || !xs.invstd || !xs.sums || C > MP_MAXC)) return MMD_EINVAL;
   int OH, OW, pt, pl;
   pool_geom(PH, &OH, &pt); pool_geom(PW, &OW, &pl);
   size_t total = (size_t)B * PH * PW * (C >> 2);
-  hipLaunchKernelGGL(maxpool_bwd_acc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, src, dout, dst, theta, ntheta, widx,
-                     accumulate, B, PH, PW, C, OH, OW, pt, pl);
+  int iters = 1;
+  if (xs.z) { iters = cdiv(total, 256 * 512); if (iters > 16) iters = 16; if (iters < 1) iters = 1; }
+  hipLaunchKernelGGL(maxpool_bwd_acc_kernel, dim3(cdiv(total, 256 * (size_t)iters)), dim3(256), 0, stream, src, dout, dst, theta, ntheta, widx,
+                     accumulate, B, PH, PW, C, OH, OW, pt, pl, xs, iters);
+  return mmd_check_launch();
+}
+extern "C" int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta,
+                                        int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream) {
+  return maxpool_bwd_impl(src, dout, dst, theta, ntheta, widx, accumulate, B, PH, PW, C, BnSumDst{}, stream);
+}
+// + the BatchNorm-backward sums of the completed gradient when this launch is its last contribution and src = BN(z) (common.h BnSumDst)
+extern "C" int mmd_maxpool_same_bwd_acc2(const float* src, const float* dout, float* dst, const float* theta, int ntheta,
+                                         int widx, int accumulate, int B, int PH, int PW, int C, const float* z, const float* mean,
+                                         const float* invstd, double* sums, hipStream_t stream) {
+  return maxpool_bwd_impl(src, dout, dst, theta, ntheta, widx, accumulate, B, PH, PW, C, BnSumDst{z, mean, invstd, sums}, stream);
+}
+
+// d theta of EVERY fusion node of a net in one launch (the per-node launch above is a leaf that forks off the backward's main chain 40
+// times per step): node i has its fusion weights at theta_base + off[i] (n[i] of them), their gradient at dtheta_base + off[i] and its
+// dot products at wdot_all + 4*i.
+__global__ void fuse_theta_bwd_batched_kernel(const float* theta_base, float* dtheta_base, const float* wdot_all, const long long* desc, int nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nodes) return;
+  const long long off = desc[2 * i]; const int n = (int)desc[2 * i + 1];
+  const float* theta = theta_base + off; float* dtheta = dtheta_base + off; const float* wdot = wdot_all + 4 * i;
+  float r[3], S = FUSE_EPS;
+  for (int k = 0; k < n; ++k) { r[k] = fmaxf(theta[k], 0.f); S += r[k]; }
+  for (int k = 0; k < n; ++k) {
+    if (!(theta[k] > 0.f)) continue;
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc += wdot[j] * ((j == k ? S : 0.f) - r[j]) / (S * S);
+    dtheta[k] += acc;
+  }
+}
+extern "C" int mmd_bifpn_theta_bwd_batched(const float* theta_base, float* dtheta_base, const float* wdot_all, const long long* desc,
+                                           int nodes, hipStream_t stream) {
+  if (!theta_base || !dtheta_base || !wdot_all || !desc || nodes <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(fuse_theta_bwd_batched_kernel, dim3(cdiv(nodes, 64)), dim3(64), 0, stream, theta_base, dtheta_base, wdot_all, desc, nodes);
   return mmd_check_launch();
 }

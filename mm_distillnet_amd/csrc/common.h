@@ -74,6 +74,16 @@ static inline BnLive mmd_make_bn(const double* stats, const float* gamma, const 
   b.eps = 1e-3f; return b;
 }
 
+// "The writer of the last contribution to a gradient computes the BatchNorm-backward sums of the total": destination descriptor for a
+// kernel that writes (or completes by accumulation) the gradient g w.r.t. a tensor y = BN(z) [* rowscale]: sums [2C] (+)= [sum g, sum g*xhat],
+// xhat = (z - mean)*invstd, g read at the same [row, channel] position as z.  z == nullptr: no sums wanted.
+struct BnSumDst { const float* z; const float* mean; const float* invstd; double* sums; };
+__device__ __forceinline__ void bnsum_acc4(const BnSumDst& d, size_t off, const float4& g, const float4& mu, const float4& is, float4& s, float4& q) {
+  const float4 zz = *reinterpret_cast<const float4*>(d.z + off);
+  s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+  q.x += g.x * (zz.x - mu.x) * is.x; q.y += g.y * (zz.y - mu.y) * is.y; q.z += g.z * (zz.z - mu.z) * is.z; q.w += g.w * (zz.w - mu.w) * is.w;
+}
+
 // Feature pyramid stored as ONE row buffer: level l occupies rows [row0[l], row0[l] + B*H[l]*W[l]) and every level starts
 // at a multiple of 128 rows, so no GEMM / reduction tile straddles two levels.  Lets the shared-weight head layers run
 // all 5 levels in one launch (per-level BatchNorm parameters are lev_stride channels apart).

@@ -677,6 +677,77 @@ extern "C" int mmd_bn_bwd_apply_pyr(const float* g, const float* z, const float*
   return mmd_check_launch();
 }
 
+// ---------------------------------------------------------------- head gradients -> BiFPN output gradients, with their BatchNorm sums
+// out = a + b (+ c) over a pyramid row buffer [row0[n], C] (the two heads' input gradients and the MTA loss' feature gradient), and, for
+// every level whose feature map is the output of a BatchNorm (z_l: that level's own [B*H*W, C] raw conv output), the sums of that
+// BatchNorm's backward: sums_l [2C] (+)= [sum out, sum out*xhat].  Replaces two scale_acc launches per step + one per level and the five
+// mmd_bn_bwd_reduce launches of the last BiFPN cell.  Rows are walked in 128-row blocks (levels start at multiples of 128).
+struct PyrBnDst { const float* z[MMD_MAX_LEV]; const float* mean[MMD_MAX_LEV]; const float* invstd[MMD_MAX_LEV]; double* sums[MMD_MAX_LEV]; };
+template <typename T> __device__ __forceinline__ T pyr_sel(const T* arr, int lev) {
+  T v = arr[0];
+#pragma unroll
+  for (int i = 1; i < MMD_MAX_LEV; ++i) if (lev == i) v = arr[i];
+  return v;
+}
+__global__ __launch_bounds__(256) void pyr_add_bnsums_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ c3, float* __restrict__ out, int C, Pyr pyr,
+                                                            PyrBnDst d) {
+  __shared__ float sRed[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x * 64 + (tid & 15) * 4;
+  const bool cok = c < C;
+  const int r0 = blockIdx.y * 128;
+  const int lev = pyr_level_of_row(pyr, r0);
+  const int lrow0 = pyr_sel(pyr.row0, lev);
+  const int r1 = min(r0 + 128, lrow0 + pyr.B * pyr_sel(pyr.H, lev) * pyr_sel(pyr.W, lev));
+  const float* z = pyr_sel(d.z, lev);
+  float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0), s1 = mu, s2 = mu;
+  if (z && cok) { mu = mmd_ld4(pyr_sel(d.mean, lev) + c); is = mmd_ld4(pyr_sel(d.invstd, lev) + c); }
+  if (cok) {
+#pragma unroll 4
+    for (int row = r0 + (tid >> 4); row < r1; row += 16) {
+      const size_t off = (size_t)row * C + c;
+      float4 v = mmd_ld4(a + off);
+      const float4 u = mmd_ld4(b + off);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      if (c3) { const float4 t = mmd_ld4(c3 + off); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      mmd_st4(out + off, v);
+      if (z) {
+        const float4 zz = mmd_ld4(z + (size_t)(row - lrow0) * C + c);
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * (zz.x - mu.x) * is.x; s2.y += v.y * (zz.y - mu.y) * is.y;
+        s2.z += v.z * (zz.z - mu.z) * is.z; s2.w += v.w * (zz.w - mu.w) * is.w;
+      }
+    }
+  }
+  if (!z) return;                     // block-uniform
+  const float sa = block_chan_sum(s1, sRed, tid);
+  const float sb = block_chan_sum(s2, sRed, tid);
+  if (tid < 64 && blockIdx.x * 64 + tid < C) {
+    double* sums = pyr_sel(d.sums, lev);
+    atomicAdd(&sums[blockIdx.x * 64 + tid], (double)sa);
+    atomicAdd(&sums[C + blockIdx.x * 64 + tid], (double)sb);
+  }
+}
+// z / mean / invstd / sums: arrays of n level pointers (host arrays of device pointers; z[l] == NULL: no sums for that level)
+extern "C" int mmd_pyr_add_bnsums(const float* a, const float* b, const float* c, float* out, const int* pyr_desc, int C,
+                                  const float* const* z, const float* const* mean, const float* const* invstd, double* const* sums,
+                                  hipStream_t stream) {
+  if (!a || !b || !out || !pyr_desc || C <= 0 || (C & 3)) return MMD_EINVAL;
+  Pyr p;
+  if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
+  PyrBnDst d{};
+  for (int l = 0; l < p.n; ++l) {
+    if (z && z[l]) {
+      if (!mean || !invstd || !sums || !mean[l] || !invstd[l] || !sums[l]) return MMD_EINVAL;
+      d.z[l] = z[l]; d.mean[l] = mean[l]; d.invstd[l] = invstd[l]; d.sums[l] = sums[l];
+    }
+  }
+  const int M = p.row0[p.n];
+  hipLaunchKernelGGL(pyr_add_bnsums_kernel, dim3(cdiv(C, 64), cdiv(M, 128)), dim3(256), 0, stream, a, b, c, out, C, p, d);
+  return mmd_check_launch();
+}
+
 // ---------------------------------------------------------------- "augmented" step variant (ModelWithNMSLossAugmented)
 // merge_batch_0_1 (src/optimization/train_methods.py:291-308): image 1 of the audio batch becomes
 // log10(max(a0^10 + a1^10, 1e-7)) - literally the 10th POWER of the dB-scale spectrogram, as the reference computes it;

@@ -46,6 +46,12 @@ __device__ __forceinline__ float4 bn_bwd_eval4(float4 g, float4 z, float rs, int
 // (one thread per pixel x all output channels: 188 us for the 8-channel student stem).
 struct StemOp { int Cin, H, W, OH, OW, pad_t, pad_l; };
 
+// BatchNorm-backward sums of the launch's OUTPUT, taken in the epilogue: the output y (after the residual add) is the complete gradient
+// w.r.t. a tensor BN(z)*rowscale (+ skip), so the reduce pass of THAT BatchNorm - sum g', sum g'*xhat with g' = y * mul_b[image],
+// xhat = (z - mean)*invstd - rides here instead of a launch that re-reads y and z (the writer of the last contribution to a gradient
+// computes the sums of the total).  `stats` (or its slotted workspace) receives [sum g', sum g'*xhat].
+struct BnSumOp { const float* z; const float* mean; const float* invstd; const float* mul_b; int rows_per_image; };
+
 struct PwArgs {
   const float* x; const float* w; float* y;
   int M, K, N;
@@ -60,6 +66,7 @@ struct PwArgs {
   int bf16;                                  // host-side: operands rounded to bf16 at the MFMA input (mixed-precision mode)
   BnBwdOp bb;                                // PRO == 1: the A operand is a BatchNorm backward evaluated on the fly
   StemOp st;                                 // PRO == 2: the A operand is the im2col of an NCHW image, gathered on the fly
+  BnSumOp xs;                                // epilogue: `stats` = BatchNorm-backward sums of the output instead of (sum y, sum y^2)
 };
 
 

@@ -34,6 +34,16 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
+// epilogue helper of the BnSumOp mode: v = the final output value at `off` (row `row`) -> the two BatchNorm-backward sums
+__device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t off, int row, const float4& mu, const float4& is,
+                                          float4& s4, float4& q4) {
+  const float4 zz = mmd_ld4(xs.z + off);
+  if (xs.mul_b) { const float rs = xs.mul_b[row / xs.rows_per_image]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+  s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+  q4.x += v.x * (zz.x - mu.x) * is.x; q4.y += v.y * (zz.y - mu.y) * is.y;
+  q4.z += v.z * (zz.z - mu.z) * is.z; q4.w += v.w * (zz.w - mu.w) * is.w;
+}
+
 #define PW_BM 128
 #define PW_BK 32
 #define PW_LD 36
@@ -273,14 +283,18 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
   }
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
+  float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
+  if (a.xs.z && cok) { xmu = mmd_ld4(a.xs.mean + col); xis = mmd_ld4(a.xs.invstd + col); }
 #pragma unroll
   for (int i = 0; i < BM_T / RSTEP; ++i) {
     const int rl = rgrp + RSTEP * i, row = m0 + rl;
     if (cok && row < Mv) {
       float4 v = *reinterpret_cast<const float4*>(&smem[rl * LDC + cg * 4]);
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-      q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+      if (!a.xs.z) {
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+      }
       if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
       if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
       size_t off;
@@ -292,6 +306,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       }
       if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
       mmd_st4(a.y + off, v);
+      if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
     }
   }
   if (a.stats) {
@@ -528,6 +543,8 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
   }
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
+  float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
+  if (a.xs.z && cok) { xmu = mmd_ld4(a.xs.mean + col); xis = mmd_ld4(a.xs.invstd + col); }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rl = rgrp + 16 * i, row = m0 + rl;
@@ -539,8 +556,10 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     }
     if (cok && row < Mv) {
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-      q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+      if (!a.xs.z) {
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+      }
       if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
       if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
       size_t off;
@@ -552,6 +571,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       }
       if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
       mmd_st4(a.y + off, v);
+      if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
     }
   }
   if (a.stats) {
@@ -1179,6 +1199,48 @@ static int pw_bwd_data_bn_impl(const float* g, const float* z, const float* wt, 
                  dz_out, dgamma, dbeta};
   return pw_dispatch(a, stream);
 }
+// Same launch with two more jobs for its epilogue (both optional):
+//   residual: dx = BnBwd(g, z) * W + residual   (residual may be dx itself: in-place accumulation into a gradient that already holds
+//             the skip branch's / other consumers' contributions);
+//   xs_*:     dx is then the COMPLETE gradient w.r.t. a tensor BN'(xs_z) * xs_mul_b[image] (+ skip), and xs_sums [2K] (+)=
+//             [sum g', sum g' * xhat'], g' = dx * xs_mul_b[image], xhat' = (xs_z - xs_mean) * xs_invstd: the reduce pass of that upstream
+//             BatchNorm's backward (mmd_bn_bwd_reduce with act = NONE) without a launch of its own.  stats_ws / ws_slots as in mmd_pwconv_fwd.
+static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
+                                float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z,
+                                const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image,
+                                double* xs_sums, double* stats_ws, int ws_slots, hipStream_t stream, int bf16) {
+  if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
+  if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
+  if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  if (xs_z && (!xs_mean || !xs_invstd || !xs_sums || (xs_mul_b && xs_rows_per_image <= 0))) return MMD_EINVAL;
+  PwArgs a{};
+  a.x = g; a.w = wt; a.y = dx; a.M = M; a.K = N; a.N = K; a.rows_per_image = 1;
+  a.in_bn = mmd_make_bn(nullptr, nullptr, nullptr, 0, N);
+  a.bf16 = bf16;
+  a.residual = residual;
+  a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1,
+                 dz_out, dgamma, dbeta};
+  if (xs_z) {
+    a.xs = BnSumOp{xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image > 0 ? xs_rows_per_image : 1};
+    a.stats = xs_sums;
+    // (the BatchNorm-backward operand launches run 64-row tiles, or 128-row ones for N <= 32: count the blocks per address with 64)
+    if (stats_ws && ws_slots > 1 && cdiv(M, 64) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
+  }
+  return pw_dispatch(a, stream);
+}
+#define PW_BD2_PARAMS const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, \
+                      const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, \
+                      int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, \
+                      const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, \
+                      double* stats_ws, int ws_slots, hipStream_t stream
+#define PW_BD2_ARGS g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, dz_out, dgamma, dbeta, residual, \
+                    xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image, xs_sums, stats_ws, ws_slots, stream
+extern "C" int mmd_pwconv_bwd_data_bn2(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0); }
+extern "C" int mmd_pwconv_bwd_data_bn2_bf16(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 1); }
+
 extern "C" int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                       const float* scale, const float* shift, const float* mean, const float* invstd,
                                       const double* sums, long long count, int act, const float* mul_b, int rows_per_image,

@@ -217,7 +217,7 @@ extern "C" int mmd_pwconv_longk_mode(int mode) { if (mode < 0 || mode > 2) retur
 // -> 1 when the launch was taken.  Supported: fp32, plain or gate-only A operand, no pyramid / strided output, K >= 256, K % 4 == 0.
 int pw_longk_try(PwArgs& a, hipStream_t stream) {
   static const int off = getenv("MMD_NO_LONGK") ? 1 : 0;
-  if (off || g_longk_mode == 2 || a.bf16 || a.bb.z || a.st.Cin || a.pyr.n || a.y_batch_stride) return 0;
+  if (off || g_longk_mode == 2 || a.bf16 || a.bb.z || a.xs.z || a.st.Cin || a.pyr.n || a.y_batch_stride) return 0;
   if (a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE) return 0;
   if (a.stats_ws) return 0;
   const int M = a.M, K = a.K, N = a.N;

@@ -296,7 +296,7 @@ extern "C" int mmd_pwconv_rows_mode(int mode) { if (mode < 0 || mode > 2) return
 int pw_rows_try(PwArgs& a, hipStream_t stream) {
   static const int off = getenv("MMD_NO_ROWS") ? 1 : 0;
   static const int lds_blk = getenv("MMD_ROWS_LDS") ? atoi(getenv("MMD_ROWS_LDS")) : 120 * 1024;     // panel budget (one 8-wave block per CU)
-  if (off || a.bf16 || a.bb.z || a.st.Cin) return 0;
+  if (off || a.bf16 || a.bb.z || a.xs.z || a.st.Cin) return 0;
   const int M = a.M, K = a.K, N = a.N;
   if (K < 16 || K > 128 || (K & 7)) return 0;
   // Measured against the LDS-tiled kernels per shape of the step (tools/dev/gemm_bench.py, profiles/r02_notes.md): the row-slab kernel

@@ -68,8 +68,14 @@ class Feat:
 
 
 class GradSlot:
-    def __init__(self):
+    """Gradient w.r.t. one activation tensor, accumulated over its consumers.  `remaining` counts the contributions still to come (the
+    train forward counted the consumers); the kernel that writes the LAST one also produces the backward sums of the BatchNorm whose
+    output the tensor is (`sums`, valid when `have_sums`), so that BatchNorm needs no reduce launch of its own."""
+    def __init__(self, remaining: int = 0):
         self.t: Optional[torch.Tensor] = None
+        self.remaining = remaining
+        self.sums: Optional[torch.Tensor] = None
+        self.have_sums = False
 
 
 @dataclass
@@ -88,6 +94,9 @@ class LazyDz:
 
 
 LAZY_BN = not os.environ.get("MMD_NO_LAZY_BN")
+# BatchNorm-backward reduce passes folded into the launches that complete their upstream gradient (MMD_NO_BNSUM_FOLD=1: the round-2
+# schedule - a bn_bwd_reduce launch per BatchNorm and scale_acc launches for the skip / multi-consumer accumulations - for A/B timing)
+FOLD_SUMS = not os.environ.get("MMD_NO_BNSUM_FOLD")
 
 
 class Net:
@@ -142,6 +151,15 @@ class Net:
         self._leaf_pending: list = []        # other deferred leaves (closures), issued by _wg_flush
         self._wg_plans: Dict[tuple, dict] = {}  # (segment index, operand signature) -> planned table (built once: arena addresses repeat every step)
         self._wg_segment = 0
+        self._uses: Dict[int, int] = {}        # train forward: tensor -> number of gradient contributions its slot will receive
+        self._bnout: Dict[int, tuple] = {}     # train forward: tensor y = BN(z) [* mul_b[image]] (+ skip) -> (z, mean, invstd, C, mul_b, rows_per_image)
+        self._counting = False
+        self._theta_desc: Dict[tuple, torch.Tensor] = {}
+
+    def _use(self, f: "Feat"):
+        if self._counting:
+            k = f.z.data_ptr()
+            self._uses[k] = self._uses.get(k, 0) + 1
 
     # ------------------------------------------------------------------ parameters
     def load_state(self, state):
@@ -272,6 +290,9 @@ class Net:
         spec, ps = self.spec, self.ps
         B, Cin, S, _ = x.shape
         tape = self.tape if train else {}
+        self._counting = train
+        if train:
+            self._uses, self._bnout = {}, {}
         P = "backbone_net.model"
         # ---- stem: im2col + GEMM
         OH = (S + 1) // 2
@@ -297,6 +318,9 @@ class Net:
             q = f"{P}._blocks.{blk.idx}"
             inp = cur
             rec = {"inp": inp}
+            self._use(inp)                  # the block's own path ...
+            if blk.skip:
+                self._use(inp)              # ... and the identity skip
             fused_front = (not train and blk.expand != 1 and self.FUSE_FRONT and ps.flat.is_cuda
                            and _lib.LIB.load().mmd_mbconv_expand_dw_supported(inp.C, blk.cmid, blk.kernel, blk.stride) == 1)
             if fused_front:
@@ -339,6 +363,7 @@ class Net:
                 call("mmd_affine_act", z2, None, None, a2[4][0], a2[4][1], a2[4][2], a2[4][3], NONE, rs, H1 * W1, res, y, M1,
                      blk.cout)
                 rec.update(f1=f1, bn1=a1, pooled=pooled, hpre=hpre, gate=gate, z2=z2, bn2=a2, rs=rs)
+                self._bnout[y.data_ptr()] = (z2, a2[2], a2[3], blk.cout, rs, H1 * W1)
             else:
                 # frozen net: BN1+swish and the SE average pool ride in the depthwise epilogue (no separate pool pass)
                 b1 = ps.bn(f"{q}._bn1")
@@ -369,6 +394,8 @@ class Net:
         # ---- BiFPN
         feats = self._bifpn(taps, train, tape)
         # ---- heads
+        for f in feats:
+            self._use(f)                    # one contribution: heads' input gradients (+ the MTA loss' feature gradient) in one launch
         A = sum(f.H * f.W for f in feats) * spec.num_anchors
         reg = self._alloc(B, A, 4)
         cls = self._alloc(B, A, spec.num_classes)
@@ -378,6 +405,7 @@ class Net:
             tape["feats"] = feats
             tape["A"] = A
             tape["cls"] = cls
+            self._counting = False
             # every BN layer finalized in one launch: running stats + (scale, shift, mean, invstd) for the backward
             key = (B, S)
             if self._bn_count_key != key:
@@ -409,6 +437,7 @@ class Net:
                 y = self._alloc(x.M, W)
             call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, x.M, W)
             rec.update(zd=zdf, z=z, bn=a)
+            self._bnout[y.data_ptr()] = (z, a[2], a[3], W, None, 0)
         else:
             b = ps.bn(bn_name)
             y = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]), y=y)
@@ -427,6 +456,8 @@ class Net:
             call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, x.M, W)
             rec.update(z=z, bn=a)
             tape[name] = rec
+            self._use(x)
+            self._bnout[y.data_ptr()] = (z, a[2], a[3], W, None, 0)
         else:
             b = ps.bn(f"{name}.1")
             y = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]))
@@ -438,6 +469,7 @@ class Net:
         OH, OW = (x.H + 1) // 2, (x.W + 1) // 2
         y = self._alloc(x.B * OH * OW, x.C)
         call("mmd_maxpool_same_fwd", x.z, y, x.B, x.H, x.W, x.C)
+        self._use(x)
         return Feat(y, x.B, OH, OW, x.C)
 
     def _node(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
@@ -461,6 +493,9 @@ class Net:
         call("mmd_bifpn_node_dw_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
              self.ps.w(f"{cell}.{conv}.depthwise_conv.conv.weight"), f, zd, in0.B, in0.H, in0.W, in0.C)
         ff = Feat(f if f is not None else zd, in0.B, in0.H, in0.W, in0.C)
+        for operand in (in0, in1, up, pl):
+            if operand is not None:
+                self._use(operand)
         rec = {"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": ff, "conv": conv}
         out = self._sep_bn(f"{cell}.{conv}", ff, train, rec, y=y, zd=zd)
         rec["out"] = out
@@ -573,8 +608,30 @@ class Net:
                            "lev_stride": lev_stride}
 
     # ------------------------------------------------------------------ backward (student)
-    def _acc(self, slot: GradSlot, src: torch.Tensor):
-        """slot (+)= src ; first writer just adopts the tensor."""
+    def _slot(self, f: Feat) -> GradSlot:
+        k = f.z.data_ptr()
+        s = self._bw["slots"].get(k)
+        if s is None:
+            s = self._bw["slots"][k] = GradSlot(self._uses.get(k, 0))
+        return s
+
+    def _contrib(self, f: Feat, can_sum: bool):
+        """One gradient contribution to `f` is about to be written.  -> (slot, xs); xs = (z, mean, invstd, sums, mul_b, rows_per_image)
+        when this is the LAST contribution, f is the output of a BatchNorm and the writing kernel can take that BatchNorm's backward sums
+        over the completed gradient (`can_sum`); the caller passes xs to the kernel, which marks the slot's sums valid."""
+        s = self._slot(f)
+        s.remaining -= 1
+        info = self._bnout.get(f.z.data_ptr())
+        if not (FOLD_SUMS and can_sum and s.remaining == 0 and info is not None and self.ps.flat.is_cuda):
+            return s, None
+        z, mu, istd, C, mul_b, rpi = info
+        s.sums = self._zalloc((2 * C,), torch.float64)
+        s.have_sums = True
+        return s, (z, mu, istd, s.sums, mul_b, rpi)
+
+    def _acc(self, f: Feat, src: torch.Tensor):
+        """gradient of f (+)= src ; the first writer just adopts the tensor (a contribution without BatchNorm sums)."""
+        slot, _ = self._contrib(f, False)
         if slot.t is None:
             slot.t = src
         else:
@@ -683,7 +740,10 @@ class Net:
         return dz
 
     def _pw_bwd(self, dz: torch.Tensor, x: Feat, wkey: str, N: int, bias_key: Optional[str], want_dx: bool,
-                gate=None, plain_in=False) -> Optional[torch.Tensor]:
+                gate=None, plain_in=False, into: Optional[Feat] = None) -> Optional[torch.Tensor]:
+        """Gradients of a 1x1 conv.  into = the Feat whose gradient slot receives dx (normally x itself): dx is then written into / on top
+        of that slot by the GEMM's epilogue (no scale_acc launch), together with the backward sums of the BatchNorm that produced the
+        Feat when this is the slot's last contribution; returns None in that case."""
         ps = self.ps
         M, K = x.M, x.C
         if isinstance(dz, LazyDz):
@@ -700,10 +760,25 @@ class Net:
                          b["dbeta"])
                     self._wg_read_done = torch.cuda.current_stream().record_event() if ps.flat.is_cuda else None
                 return None
-            dx = self._alloc(M, K)
             dzm = self._alloc(M, N)
+            if into is not None and FOLD_SUMS:
+                slot, xs = self._contrib(into, True)
+                residual = slot.t
+                if slot.t is None:
+                    slot.t = self._alloc(M, K)
+                xsargs = (None, None, None, None, 0, None, None, 0)
+                if xs is not None:
+                    xsargs = (xs[0], xs[1], xs[2], xs[4], xs[5], xs[3], *self._stats_ws(xs[3], M, K))
+                call("mmd_pwconv_bwd_data_bn2" + self._sfx, L.g, L.z, ps.w_t(wkey), slot.t, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
+                     residual, *xsargs)
+                self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
+                return None
+            dx = self._alloc(M, K)
             call("mmd_pwconv_bwd_data_bn" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"])
             self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
+            if into is not None:
+                self._acc(into, dx)
+                return None
             return dx
         if bias_key:
             self._leaf(lambda dz=dz, gb=ps.g(bias_key): call("mmd_colsum", dz, gb, M, N))
@@ -713,6 +788,9 @@ class Net:
             return None
         dx = self._alloc(M, K)
         call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dx, M, K, N, 0)
+        if into is not None:
+            self._acc(into, dx)
+            return None
         return dx
 
     def _dw_bwd(self, dzd: torch.Tensor, x: Feat, wkey: str, k: int, s: int, want_dx: bool = True, bn_aff=None):
@@ -800,24 +878,25 @@ class Net:
         return g
 
     def backward(self, dcls_logit: torch.Tensor, dreg: torch.Tensor, dfeats: List[Optional[torch.Tensor]],
-                 stop_before: Optional[int] = None):
+                 stop_before: Optional[int] = None, dfeat_pyr: Optional[torch.Tensor] = None):
         """Accumulates parameter gradients into ps.grad.  dcls_logit [B,A,NC] is the gradient w.r.t. the
         classifier header's PRE-sigmoid output, dreg [B,A,4], dfeats[l] (nullable) w.r.t. the BiFPN outputs.
         stop_before=k: stop after backbone block k (heads, BiFPN and blocks >= k done, weight-gradient stream joined), so
-        that the caller can start the all-reduce of those gradients; backward_finish() runs blocks < k and the stem."""
+        that the caller can start the all-reduce of those gradients; backward_finish() runs blocks < k and the stem.
+        dfeat_pyr: the same gradients as dfeats as ONE pyramid row buffer (dfeats[l] are its level slices): the heads' input gradients
+        and it are then added in one launch that also takes the BatchNorm-backward sums of the last BiFPN cell's five output nodes."""
         spec, ps, tape = self.spec, self.ps, self.tape
         feats: List[Feat] = tape["feats"]
         A = tape["A"]
         slots: Dict[int, GradSlot] = {}
         self._bw = {"slots": slots, "stem_sums": None}
         self._wg_pending, self._leaf_pending, self._wg_segment = [], [], 0
-
-        def slot(f: Feat) -> GradSlot:
-            return slots.setdefault(f.z.data_ptr(), GradSlot())
-
-        for f, d in zip(feats, dfeats):
-            if d is not None:
-                slot(f).t = d
+        slot = self._slot
+        fold_heads = FOLD_SUMS and ps.flat.is_cuda and (dfeat_pyr is not None or all(d is None for d in dfeats))
+        if not fold_heads:
+            for f, d in zip(feats, dfeats):
+                if d is not None:
+                    slot(f).t = d
         # ---- heads: every layer handles the whole pyramid in one launch
         pyr = self._pyr
         desc, Mt = pyr["desc"], pyr["total"]
@@ -838,10 +917,27 @@ class Net:
         if main_stream is not None:
             main_stream.wait_stream(self._side)
         gsum = gparts[0]
-        call("mmd_scale_acc", gparts[1], gsum, None, 0, 0, 1, gsum.numel())
-        for lvl, f in enumerate(feats):
-            self._acc(slot(f), gsum[pyr["row0"][lvl]:pyr["row0"][lvl] + pyr["rows"][lvl]])
+        if fold_heads:
+            # classifier + regressor (+ MTA) gradients in one launch, which also takes the BatchNorm-backward sums of the five output nodes
+            vp = ctypes.c_void_p
+            ptrs = [[None] * 5 for _ in range(4)]
+            for lvl, f in enumerate(feats):
+                sl, xs = self._contrib(f, True)
+                sl.t = gsum[pyr["row0"][lvl]:pyr["row0"][lvl] + pyr["rows"][lvl]]
+                if xs is not None:
+                    for k in range(4):
+                        ptrs[k][lvl] = xs[k].data_ptr()
+            arrs = [(vp * 5)(*p_) for p_ in ptrs]
+            call("mmd_pyr_add_bnsums", gparts[0], gparts[1], dfeat_pyr, gsum, desc, C, *arrs)
+        else:
+            call("mmd_scale_acc", gparts[1], gsum, None, 0, 0, 1, gsum.numel())
+            for lvl, f in enumerate(feats):
+                self._acc(f, gsum[pyr["row0"][lvl]:pyr["row0"][lvl] + pyr["rows"][lvl]])
         # ---- BiFPN (cells and nodes in reverse)
+        n_nodes = sum(len(tape[f"bifpn.{c}.nodes"]) for c in range(spec.fpn_cells))
+        wdot_all = self._zalloc((4 * n_nodes,))
+        theta_desc, node_i = [], 0
+        xsn = lambda xs: (None, None, None, None) if xs is None else xs[:4]
         for c in reversed(range(spec.fpn_cells)):
             cell = f"bifpn.{c}"
             for rec in reversed(tape[cell + ".nodes"]):
@@ -851,7 +947,8 @@ class Net:
                     continue          # node output unused downstream (cannot happen in this topology)
                 name = f"{cell}.{rec['conv']}"
                 W = out.C
-                dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W, lazy=True)
+                dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W, lazy=True,
+                                  sums=s.sums if s.have_sums else None)
                 dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
                 # the depthwise weight gradient and the depthwise input gradient both come out of the fusion-backward launch below
                 if not self.NODE_WG:
@@ -861,57 +958,58 @@ class Net:
                 nth = th.numel()
                 # gradients of the same-resolution operands (in0, in1) come straight out of the fuse backward launch; dx is
                 # only materialised for an upsampled / pooled operand
-                same = []
+                same, xsargs = [], []
                 for operand in (in0, in1):
                     if operand is None:
                         same += [None, 0]
+                        xsargs += [None] * 4
                         continue
-                    sl = slot(operand)
+                    sl, xs = self._contrib(operand, True)
                     accumulate = 0 if sl.t is None else 1
                     if sl.t is None:
                         sl.t = self._alloc(operand.M, W)
                     same += [sl.t, accumulate]
+                    xsargs += xsn(xs)
                 assert in1 is None or same[0].data_ptr() != same[2].data_ptr()
                 # the gradient of an upsampled operand leaves the same launch (2x2 block sums); dx is only materialised for a
                 # pooled operand (its scatter follows the arg-max of overlapping windows)
                 dx = self._alloc(out.M, W) if pl is not None else None
                 upargs = (None, 0)
                 if up is not None:
-                    su = slot(up)
+                    su, xs = self._contrib(up, True)
                     upargs = (su.t, 1) if su.t is not None else (self._alloc(up.M, W), 0)
                     su.t = upargs[0]
-                wdot = self._zalloc((4,))
-                call("mmd_bifpn_node_dw_bwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                    xsargs += xsn(xs)
+                else:
+                    xsargs += [None] * 4
+                # the fusion-weight gradients of all nodes are finished by ONE launch after the BiFPN (their dot products land in wdot_all)
+                wdot = wdot_all[4 * node_i:4 * node_i + 4]
+                theta_desc.append((ps.entries[f"{cell}.{rec['theta']}"].off, nth))
+                node_i += 1
+                call("mmd_bifpn_node_dw_bwd2", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
                      ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
-                     ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None)
-                self._leaf(lambda th=th, wdot=wdot, gt=ps.g(f"{cell}.{rec['theta']}"), nth=nth: call("mmd_bifpn_theta_bwd", th, wdot, gt, nth))
-                wi = 1 + (1 if in1 is not None else 0)
-                for operand, kind in ((up, "up"), (pl, "pool")):
-                    if operand is None:
-                        continue
-                    sl = slot(operand)
+                     ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None, *xsargs)
+                if pl is not None:      # the pooled operand's gradient: gather over the windows whose arg-max it is
+                    wi = 1 + (1 if in1 is not None else 0) + (1 if up is not None else 0)
+                    sl, xs = self._contrib(pl, True)
                     accumulate = 0 if sl.t is None else 1
                     if sl.t is None:
-                        sl.t = self._alloc(operand.M, W)
-                    if kind == "up":
-                        pass          # written by the node launch above
-                    else:
-                        call("mmd_maxpool_same_bwd_acc", operand.z, dx, sl.t, th, nth, wi, accumulate, operand.B, operand.H,
-                             operand.W, W)
-                    wi += 1
+                        sl.t = self._alloc(pl.M, W)
+                    call("mmd_maxpool_same_bwd_acc2", pl.z, dx, sl.t, th, nth, wi, accumulate, pl.B, pl.H, pl.W, W, *xsn(xs))
             if c == 0:
                 first = tape[cell + ".first"]
                 c6, p6_in, p7_in = first["c6"], first["p6_in"], first["p7_in"]
                 s7, s6 = slot(p7_in), slot(p6_in)
                 if s7.t is not None:
+                    self._contrib(p6_in, False)
                     acc = 0 if s6.t is None else 1
                     if s6.t is None:
                         s6.t = self._alloc(p6_in.M, p6_in.C)
                     call("mmd_maxpool_same_bwd_acc", p6_in.z, s7.t, s6.t, None, 0, 0, acc, p6_in.B, p6_in.H, p6_in.W, p6_in.C)
                 if s6.t is not None:
-                    sc6 = slot(c6)
+                    sc6, xs = self._contrib(c6, True)
                     sc6.t = self._alloc(c6.M, c6.C)
-                    call("mmd_maxpool_same_bwd_acc", c6.z, s6.t, sc6.t, None, 0, 0, 0, c6.B, c6.H, c6.W, c6.C)
+                    call("mmd_maxpool_same_bwd_acc2", c6.z, s6.t, sc6.t, None, 0, 0, 0, c6.B, c6.H, c6.W, c6.C, *xsn(xs))
                 for nm in ("p5_down_channel_2", "p4_down_channel_2", "p5_down_channel", "p4_down_channel",
                            "p3_down_channel", "p5_to_p6"):
                     name = f"{cell}.{nm}"
@@ -921,9 +1019,14 @@ class Net:
                     if s.t is None:
                         continue
                     x: Feat = rec["x"]
-                    dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C, lazy=True)
-                    dx = self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, None, True)
-                    self._acc(slot(x), dx)
+                    dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.1", NONE, out.M, out.C, lazy=True,
+                                      sums=s.sums if s.have_sums else None)
+                    self._pw_bwd(dz, x, f"{name}.0.conv.weight", out.C, None, True, into=x)
+        if theta_desc:
+            key = tuple(theta_desc)
+            if key not in self._theta_desc:
+                self._theta_desc[key] = torch.tensor(theta_desc, dtype=torch.int64, device=self.device)
+            self._leaf(lambda d=self._theta_desc[key], n=len(theta_desc): call("mmd_bifpn_theta_bwd_batched", ps.flat, ps.grad, wdot_all, d, n))
         self._backward_blocks([b for b in spec.blocks if stop_before is None or b.idx >= stop_before])
         if stop_before is None:
             self.backward_finish(0)
@@ -940,11 +1043,7 @@ class Net:
     def _backward_blocks(self, blocks):
         """Backbone blocks in reverse."""
         spec, ps, tape = self.spec, self.ps, self.tape
-        slots = self._bw["slots"]
-
-        def slot(f: Feat) -> GradSlot:
-            return slots.setdefault(f.z.data_ptr(), GradSlot())
-
+        slot = self._slot
         P = "backbone_net.model"
         stem_sums = self._bw["stem_sums"]
         for blk in reversed(blocks):
@@ -958,14 +1057,15 @@ class Net:
             dy = s.t
             f1: Feat = rec["f1"]
             M1, HW1 = f1.M, f1.H * f1.W
-            dz2 = self._bn_bwd(dy, rec["z2"], rec["bn2"], f"{q}._bn2", NONE, M1, blk.cout, rpi=HW1, mul_b=rec["rs"], lazy=True)
+            dz2 = self._bn_bwd(dy, rec["z2"], rec["bn2"], f"{q}._bn2", NONE, M1, blk.cout, rpi=HW1, mul_b=rec["rs"], lazy=True,
+                               sums=s.sums if s.have_sums else None)
             g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
             # the skip branch may ADOPT dy as the gradient slot of the block input, and the block's own input gradient is later
             # accumulated into that buffer in place; with a lazy BatchNorm backward the project conv's weight-gradient GEMM (side
             # stream) still reads dy, so that later accumulation waits for it (the event is long past by then)
             dy_read = self._wg_read_done if (blk.skip and isinstance(dz2, LazyDz)) else None
             if blk.skip:
-                self._acc(slot(inp), dy)
+                self._acc(inp, dy)
             # squeeze-excite backward.  One pass over (z1, g1) pools d(gate) AND the partials of the BN-1 backward sums; the
             # SE kernels finish those sums once dpooled is known, so the expanded tensor is not read by a BN reduce pass
             a1 = rec["bn1"]
@@ -988,21 +1088,22 @@ class Net:
             if blk.expand != 1:
                 g0, sums0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, bn_aff=rec["bn0"])
                 dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0, lazy=True)
-                dx = self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True)
                 if dy_read is not None:
                     torch.cuda.current_stream().wait_event(dy_read)
-                self._acc(slot(inp), dx)
+                # the input gradient lands in (on top of) the block input's slot - which may be dy itself, adopted by the skip branch
+                # above - and, as that slot's last contribution, carries the previous block's BatchNorm-2 backward sums with it
+                self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True, into=inp)
             elif blk.idx == 0 and not blk.skip and blk.stride == 1 and slot(inp).t is None:
                 # block 0 consumes the stem activation directly and is its only consumer: the stem BN's backward sums ride
                 # in this input-gradient launch
                 g0, stem_sums = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
                                              bn_aff=(inp.scale, inp.shift, tape["stem"][2], tape["stem"][3]))
-                self._acc(slot(inp), g0)
+                self._acc(inp, g0)
             else:
                 g0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride)
                 if dy_read is not None:
                     torch.cuda.current_stream().wait_event(dy_read)
-                self._acc(slot(inp), g0)
+                self._acc(inp, g0)
         self._bw["stem_sums"] = stem_sums
 
     def _backward_stem(self):
@@ -1010,7 +1111,7 @@ class Net:
         P = "backbone_net.model"
         stem_sums = self._bw["stem_sums"]
         ximg, stem, mu, istd = tape["stem"]
-        s = self._bw["slots"].setdefault(stem.z.data_ptr(), GradSlot())
+        s = self._slot(stem)
         dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
         with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
             col = self._alloc(stem.M, ps.stem_kp)

@@ -348,7 +348,7 @@ class DistillEngine:
         # backward + optimizer
         if train:
             call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
-            st.backward(dcls, dreg, dfe, stop_before=self.ar_split)
+            st.backward(dcls, dreg, dfe, stop_before=self.ar_split, dfeat_pyr=d_all)
         self.out = {"reg": main[0:1], "cls": main[1:2], "kd": kd, "boxes": boxes, "nbox": nbox,
                     "cls_s": cls_s, "reg_s": reg_s, "feats_s": feats_s, "rows_t": rows_t, "cnt_t": cnt_t}
         return self.out

@@ -1256,3 +1256,162 @@ def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
     for a, b, what in zip(outs["ref"], outs["fused"], ("dx", "wdot", "d0", "d1", "dup (write)", "dup (accumulate)")):
         if a is not None:
             close(b, a, 1e-5, 1e-5 if what != "wdot" else 1e-3, what)
+
+
+# ---------------------------------------------------------------- round 3: "the last writer of a gradient takes the BatchNorm-backward sums"
+def _bn_sums_ref(gtot, z, mean, invstd, rs=None, rpi=1):
+    """[sum g', sum g'*xhat] in float64 (what mmd_bn_bwd_reduce(act=NONE, mul_b=rs) produces)."""
+    gt, zz = gtot.double().cpu(), z.double().cpu()
+    if rs is not None:
+        gt = gt * rs.double().cpu().repeat_interleave(rpi).view(-1, 1)
+    xh = (zz - mean.double().cpu()) * invstd.double().cpu()
+    return torch.cat([gt.sum(0), (gt * xh).sum(0)])
+
+
+def _sums_close(got, ref, what):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * scale + 1e-4, f"{what}: max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("M,K,N,act,rowscale,resid", [(512, 40, 24, 0, True, True), (4096, 96, 16, 1, False, False), (1000, 528, 88, 1, False, True),
+                                                       (8192, 112, 112, 0, False, True), (20480, 24, 144, 1, True, True), (130, 208, 1248, 0, True, False),
+                                                       (40960, 16, 96, 1, True, True)])
+def test_pwconv_bwd_data_bn2_residual_and_upstream_sums(M, K, N, act, rowscale, resid):
+    """mmd_pwconv_bwd_data_bn2 = mmd_pwconv_bwd_data_bn + residual (in place) + the backward sums of the UPSTREAM BatchNorm taken over the
+    completed gradient, against the launches it replaces (bwd_data_bn, scale_acc, bn_bwd_reduce)."""
+    torch.manual_seed(M + N + K)
+    B = 2
+    rpi = M // B
+    g_ = torch.randn(M, N); z_ = torch.randn(M, N) * 1.3 + 0.2
+    wt = (torch.randn(K, N) / math.sqrt(N))
+    sc, sh, mu, istd = torch.rand(N) + 0.5, torch.randn(N) * 0.1, torch.randn(N) * 0.2, torch.rand(N) + 0.5
+    rs = torch.tensor([1.25, 0.5]) if rowscale else None
+    sums = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    gd, zd, wtd = g(g_), g(z_), g(wt)
+    dsc, dsh, dmu, dis = g(sc), g(sh), g(mu), g(istd)
+    rsd = g(rs) if rowscale else None
+    call("mmd_bn_bwd_reduce", gd, zd, dsc, dsh, dmu, dis, act, None, rsd, None, rpi, None, sums, M, N, None, 0)
+    dx_ref = torch.empty(M, K, device=DEV); dzm_ref = torch.empty(M, N, device=DEV)
+    dga = torch.zeros(N, device=DEV); dbe = torch.zeros(N, device=DEV)
+    call("mmd_pwconv_bwd_data_bn", gd, zd, wtd, dx_ref, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dzm_ref, dga, dbe)
+    base = torch.randn(M, K)
+    total_ref = dx_ref.cpu() + (base if resid else 0)
+    # the upstream BatchNorm: y' = BN'(z') * rs'[image] with its own statistics
+    z_up = torch.randn(M, K) * 0.8 + 0.1
+    mu_up, is_up = torch.randn(K) * 0.2, torch.rand(K) + 0.5
+    rs_up = torch.tensor([0.75, 1.5])
+    ref = _bn_sums_ref(total_ref, z_up, mu_up, is_up, rs_up, rpi)
+    dx = g(base.clone()) if resid else torch.full((M, K), float("nan"), device=DEV)
+    dzm = torch.empty(M, N, device=DEV)
+    xs_sums = torch.zeros(2 * K, dtype=torch.float64, device=DEV)
+    slots = 64 if M >= 16384 else 0
+    ws = torch.zeros(slots * 2 * K, dtype=torch.float64, device=DEV) if slots else None
+    dga2 = torch.zeros(N, device=DEV); dbe2 = torch.zeros(N, device=DEV)
+    call("mmd_pwconv_bwd_data_bn2", gd, zd, wtd, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dzm, dga2, dbe2,
+         dx if resid else None, g(z_up), g(mu_up), g(is_up), g(rs_up), rpi, xs_sums, ws, slots)
+    close(dx, total_ref, 1e-5, 1e-5, "dx (+ residual)")
+    assert torch.equal(dzm, dzm_ref) and torch.equal(dga, dga2) and torch.equal(dbe, dbe2)
+    _sums_close(xs_sums, ref, "upstream BatchNorm sums")
+    if ws is not None:
+        assert not ws.any(), "slotted workspace must be left zero"
+
+
+@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 48), ("p7", 4, 4, 112), ("td", 6, 10, 224), ("td", 64, 64, 112)])
+def test_bifpn_node_dw_bwd2_operand_bn_sums(mode, H, W, C):
+    """mmd_bifpn_node_dw_bwd2: same gradients as mmd_bifpn_node_dw_bwd, plus the BatchNorm-backward sums of every operand gradient it
+    completes (written or accumulated), against float64 sums over the gradients the plain launch leaves."""
+    torch.manual_seed(17)
+    B = 2
+    in0 = torch.randn(B * H * W, C)
+    in1 = torch.randn(B * H * W, C) if mode == "bu" else None
+    up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
+    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7") else None
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    wd = torch.randn(9, C) / 3
+    dzd = torch.randn(B * H * W, C)
+    gp = lambda t: g(t) if t is not None else None
+    base0 = torch.randn(B * H * W, C)
+    baseu = torch.randn(B * (H // 2) * (W // 2), C) if up is not None else None
+
+    def run(entry, extra):
+        dx = torch.zeros(B * H * W, C, device=DEV); wdot = torch.zeros(4, device=DEV)
+        d0 = g(base0.clone()); d1 = torch.zeros(B * H * W, C, device=DEV) if in1 is not None else None
+        du = g(baseu.clone()) if up is not None else None
+        dwg = torch.zeros(9, C, device=DEV)
+        call(entry, gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(dzd), dx if pl is not None else None, wdot, B, H, W, C, d0, 1, d1, 0,
+             du, 1, dwg, *extra)
+        return dx, wdot, d0, d1, du, dwg
+
+    ref = run("mmd_bifpn_node_dw_bwd", ())
+    ops = []        # (z, mean, invstd, sums) per operand gradient: d0, d1, dup
+    for t in (in0, in1, up):
+        if t is None:
+            ops.append((None, None, None, None))
+        else:
+            ops.append((g(torch.randn_like(t) * 0.7 + 0.3), g(torch.randn(C) * 0.2), g(torch.rand(C) + 0.5),
+                        torch.zeros(2 * C, dtype=torch.float64, device=DEV)))
+    got = run("mmd_bifpn_node_dw_bwd2", [v for op in ops for v in op])
+    for a, b_, what in zip(ref, got, ("dx", "wdot", "d0", "d1", "dup", "dw")):
+        if a is not None:
+            close(b_, a, 1e-5, 1e-5 if what != "wdot" else 1e-3, what)
+    for gi, op, what in zip((2, 3, 4), ops, ("in0", "in1", "up")):
+        if op[0] is not None:
+            _sums_close(op[3], _bn_sums_ref(ref[gi], op[0], op[1], op[2]), f"BatchNorm sums of d {what}")
+
+
+@pytest.mark.parametrize("PH,PW,C,acc", [(16, 16, 112, 1), (7, 5, 48, 0), (64, 64, 112, 1)])
+def test_maxpool_bwd_acc2_bn_sums(PH, PW, C, acc):
+    torch.manual_seed(PH + C)
+    B = 2
+    OH, OW = (PH + 1) // 2, (PW + 1) // 2
+    src = torch.randn(B * PH * PW, C); dout = torch.randn(B * OH * OW, C)
+    theta = torch.tensor([0.6, 1.1, 0.9])
+    base = torch.randn(B * PH * PW, C)
+    d_ref = g(base.clone())
+    call("mmd_maxpool_same_bwd_acc", g(src), g(dout), d_ref, g(theta), 3, 2, acc, B, PH, PW, C)
+    z, mu, istd = torch.randn(B * PH * PW, C), torch.randn(C) * 0.3, torch.rand(C) + 0.5
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    d = g(base.clone())
+    call("mmd_maxpool_same_bwd_acc2", g(src), g(dout), d, g(theta), 3, 2, acc, B, PH, PW, C, g(z), g(mu), g(istd), sums)
+    assert torch.equal(d, d_ref)
+    _sums_close(sums, _bn_sums_ref(d_ref, z, mu, istd), "BatchNorm sums of the pooled operand's gradient")
+
+
+def test_pyr_add_bnsums_and_batched_theta():
+    import ctypes
+    torch.manual_seed(5)
+    B, C, sizes = 2, 112, [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    desc, row0, rows = _pyr(B, sizes)
+    tot = row0[-1]
+    a, b_, c_ = (torch.randn(tot, C) for _ in range(3))
+    zs = [torch.randn(r, C) for r in rows]
+    mus = [torch.randn(C) * 0.2 for _ in rows]; iss = [torch.rand(C) + 0.5 for _ in rows]
+    zd, md, isd = [g(t) for t in zs], [g(t) for t in mus], [g(t) for t in iss]
+    sm = [torch.zeros(2 * C, dtype=torch.float64, device=DEV) for _ in rows]
+    sm[3] = None; zd[3] = None                 # a level without a BatchNorm in front: summed, no sums
+    vp = ctypes.c_void_p
+    arr = lambda ts: (vp * 5)(*[None if t is None else t.data_ptr() for t in ts])
+    for third in (c_, None):
+        for s_ in sm:
+            if s_ is not None:
+                s_.zero_()
+        out = torch.full((tot, C), float("nan"), device=DEV)
+        call("mmd_pyr_add_bnsums", g(a), g(b_), g(third) if third is not None else None, out, desc, C, arr(zd), arr(md), arr(isd), arr(sm))
+        ref = a + b_ + (third if third is not None else 0)
+        for l, r in enumerate(rows):
+            sl = slice(row0[l], row0[l] + r)
+            assert torch.equal(out[sl].cpu(), ref[sl]) or (out[sl].cpu() - ref[sl]).abs().max() < 1e-6
+            if sm[l] is not None:
+                _sums_close(sm[l], _bn_sums_ref(ref[sl], zs[l], mus[l], iss[l]), f"level {l}")
+    # every node's d theta in one launch == the per-node launches
+    nodes = [(0, 2), (4, 3), (8, 2), (12, 3)]
+    theta = torch.tensor([0.7, 1.3, 0, 0, 0.4, -0.2, 0.9, 0, 1.0, 0.1, 0, 0, 0.3, 0.3, 0.3, 0])
+    wdot = torch.randn(4 * len(nodes))
+    ref_g = torch.zeros(16, device=DEV)
+    td, wd_ = g(theta), g(wdot)
+    for i, (off, n) in enumerate(nodes):
+        call("mmd_bifpn_theta_bwd", td[off:off + n], wd_[4 * i:4 * i + 4], ref_g[off:off + n], n)
+    got = torch.zeros(16, device=DEV)
+    call("mmd_bifpn_theta_bwd_batched", td, got, wd_, torch.tensor(nodes, dtype=torch.int64, device=DEV), len(nodes))
+    assert torch.equal(got, ref_g)
