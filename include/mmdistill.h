@@ -71,6 +71,8 @@ int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, co
 
 // + (z, mean, invstd, sums): the BatchNorm-backward sums of the completed gradient dst when this launch is its last contribution and
 // src = BN(z) (see mmd_bifpn_node_dw_bwd2).  C <= 512.
+int mmd_maxpool_bwd_sums_ok(int B, int PH, int PW, int C);
+
 int mmd_maxpool_same_bwd_acc2(const float* src, const float* dout, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int PH, int PW, int C, const float* z, const float* mean, const float* invstd, double* sums, hipStream_t stream);
 
 // Depthwise kxk TF-SAME conv, NHWC, fused producer BN+swish prologue, stats / eval-BN+swish / SE-pool epilogue.
@@ -94,6 +96,12 @@ int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float*
 // dw_grad (nullable; needs bn_sums): the conv's weight gradient [k*k, C] += out of the same launch, with the forward input taken as
 // swish(bn_z*bn_scale+bn_shift) - what mmd_dwconv_bwd_weight computes from x = bn_z with that producer transform.
 int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k, int stride, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad, hipStream_t stream);
+
+// Round 3: the same launch for an MBConv block's stride-1 depthwise conv (C >= 64) with the BatchNorm-1 (+swish) backward - including the
+// squeeze-excite terms: g' = (g1 * q_gate[img,c] + q_add[img,c]) * swish'(z1*scale+shift) - evaluated on the dY operand while its tile is
+// staged, instead of by mmd_bn_bwd_apply(mul_bc = gate, add_bc = dpooled) writing dz1 to HBM first; q_dgamma / q_dbeta (+)= from q_sums.
+// bn_* / dw_grad: as mmd_dwconv_bwd_data (all required).  Autograd of src/YetAnotherEfficientNet.py:462-474.
+int mmd_dwconv_bwd_data_bn1(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k, const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd, const double* q_sums, long long q_count, const float* q_gate, const float* q_add, float* q_dgamma, float* q_dbeta, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad, hipStream_t stream);
 
 // Weight gradient of the depthwise conv, tap-major dw[k*k, C] (+=).
 int mmd_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, hipStream_t stream);
@@ -130,6 +138,14 @@ int mmd_se_fc_bwd(const float* dgate, const float* gate, const float* hpre, cons
 
 // Weight/bias gradients of the SE FCs alone (mmd_se_fc_bwd with dwr == NULL skips them): dpe/dpr are mmd_se_fc_bwd's workspaces.
 int mmd_se_fc_wgrad(const float* dpe, const float* dpr, const float* hpre, const float* pooled, float* dwr, float* dbr, float* dwe, float* dbe, int B, int C, int S, hipStream_t stream);
+
+// mmd_se_fc_bwd's two data-gradient kernels as ONE launch (dh is not materialised; C <= 3072): dpe_ws [B,C], dpr_ws [B,S], dpooled [B,C],
+// and with pool5 / bn_sums the BatchNorm-1 backward sums, exactly as mmd_se_fc_bwd(dwr = NULL) (src/YetAnotherEfficientNet.py:469-474).
+int mmd_se_fc_bwd_fused(const float* dgate, const float* gate, const float* hpre, const float* wr, const float* we, float* dpe_ws, float* dpr_ws, float* dpooled, float dpool_scale, int B, int C, int S, const float* pool5, double* bn_sums, hipStream_t stream);
+
+// mmd_se_fc_wgrad for every squeeze-excite block of a backward segment in one launch.  desc: device array of n records of ten 8-byte fields
+// {dpe, dpr, hpre, pooled, dwr, dbr, dwe, dbe (pointers), C, S (64-bit ints)}; max_cs = the largest C*S among them.
+int mmd_se_fc_wgrad_batched(const void* desc, int n, int max_cs, int B, hipStream_t stream);
 
 // BN(+swish) backward pass 1: g = (g_in*mul+add)*act'(y); per-channel sum(g), sum(g*xhat). g_out may be NULL (g not stored).
 int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float* scale, const float* shift, const float* mean, const float* invstd, int act, const float* mul_bc, const float* mul_b, const float* add_bc, int rows_per_image, float* g_out, double* sums, int M, int C, double* stats_ws, int ws_slots, hipStream_t stream);

@@ -859,11 +859,17 @@ static int maxpool_bwd_impl(const float* src, const float* dout, float* dst, con
   int OH, OW, pt, pl;
   pool_geom(PH, &OH, &pt); pool_geom(PW, &OW, &pl);
   size_t total = (size_t)B * PH * PW * (C >> 2);
-  int iters = 1;
-  if (xs.z) { iters = cdiv(total, 256 * 512); if (iters > 16) iters = 16; if (iters < 1) iters = 1; }
+  // one item per thread: serial iterations cost more latency than they save in same-address atomics (measured: 15 -> 26 us average with up
+  // to 16 iterations); a launch with sums therefore wants <= ~1024 blocks (mmd_maxpool_bwd_sums_ok) - the 64 x 64 source level keeps its
+  // own reduce pass
+  const int iters = 1;
   hipLaunchKernelGGL(maxpool_bwd_acc_kernel, dim3(cdiv(total, 256 * (size_t)iters)), dim3(256), 0, stream, src, dout, dst, theta, ntheta, widx,
                      accumulate, B, PH, PW, C, OH, OW, pt, pl, xs, iters);
   return mmd_check_launch();
+}
+// 1 when mmd_maxpool_same_bwd_acc2's sums are worth taking for a [B, PH, PW, C] source (block count = depth of the same-address f64 atomics)
+extern "C" int mmd_maxpool_bwd_sums_ok(int B, int PH, int PW, int C) {
+  return (C <= MP_MAXC && (long long)B * PH * PW * (C >> 2) <= 1024ll * 256) ? 1 : 0;
 }
 extern "C" int mmd_maxpool_same_bwd_acc(const float* src, const float* dout, float* dst, const float* theta, int ntheta,
                                         int widx, int accumulate, int B, int PH, int PW, int C, hipStream_t stream) {

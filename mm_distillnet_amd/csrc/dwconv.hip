@@ -31,6 +31,13 @@ struct DwArgs {
   int noswz;
   int tiles_h, tiles_w, cchunks;
   Pyr pyr; long long lev_stride;
+  // PRO == 2 (input-gradient launch of an MBConv depthwise conv): the input is not a tensor but the BatchNorm-1(+swish, squeeze-excite)
+  // backward evaluated while the tile is staged,
+  //   dz1 = scale*( g' - m1 - xhat*m2 ),  g' = (x * q_gate[img,c] + q_add[img,c]) * swish'(q_z*scale + shift),  xhat = (q_z - mean)*invstd,
+  // x = g1 (gradient w.r.t. the gated activation), q_z = z1, [m1, m2] = q_sums / count: what mmd_bn_bwd_apply(mul_bc, add_bc) would write
+  // to HBM first ([M, C] write + read per block); q_dgamma / q_dbeta (+)= [sum g'*xhat, sum g'] by the first tile's blocks.
+  const float* q_z; const float* q_gate; const float* q_add; const float* q_scale; const float* q_shift; const float* q_mean;
+  const float* q_invstd; const double* q_sums; double q_inv_count; float* q_dgamma; float* q_dbeta;
 };
 
 // LANES = float4 lanes per pixel (16 -> 64-channel chunks; 8 / 4 -> 32- / 16-channel chunks for the thin early layers,
@@ -95,13 +102,58 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
   }
 }
 
+// PRO == 2 staging: see DwArgs::q_*.  Same tile walk as dw_stage_input, two tensors per pixel.
+template <int K, int S, int LANES = 16>
+__device__ __forceinline__ void dw_stage_input_bnbwd(const DwArgs& a, float* sIn, int b, int ih0, int iw0, int c0, int tid) {
+  using Cf = DwCfg<K, S, LANES>;
+  constexpr int NPIX = Cf::IH * Cf::IW;
+  constexpr int NIT = (NPIX + Cf::G - 1) / Cf::G;
+  const int c4 = (tid & (LANES - 1)) * 4;
+  const int c = c0 + c4;
+  const bool cok = c < a.C;
+  const int cc = cok ? c : 0;
+  float4 v[NIT], zv[NIT];
+  bool ok[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = tid / LANES + it * Cf::G;
+    const int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
+    ok[it] = cok && p < NPIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);
+    const size_t off = (((size_t)b * a.H + ihc) * a.W + iwc) * a.C + cc;
+    v[it] = mmd_ld4(a.x + off);
+    zv[it] = mmd_ld4(a.q_z + off);
+  }
+  const float4 gt = mmd_ld4(a.q_gate + (size_t)b * a.C + cc), ad = mmd_ld4(a.q_add + (size_t)b * a.C + cc);
+  const float4 a1 = mmd_ld4(a.q_scale + cc), sh = mmd_ld4(a.q_shift + cc), mu = mmd_ld4(a.q_mean + cc), is = mmd_ld4(a.q_invstd + cc);
+  float m1[4], m2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m1[i] = (float)(a.q_sums[cc + i] * a.q_inv_count); m2[i] = (float)(a.q_sums[a.C + cc + i] * a.q_inv_count); }
+  const float4 a2 = make_float4(-a1.x * is.x * m2[0], -a1.y * is.y * m2[1], -a1.z * is.z * m2[2], -a1.w * is.w * m2[3]);
+  const float4 a3 = make_float4(-a1.x * m1[0], -a1.y * m1[1], -a1.z * m1[2], -a1.w * m1[3]);
+  auto ev = [](float g, float z, float gate, float add, float s1, float s2, float s3, float mu_, float sh_) {
+    const float gp = (g * gate + add) * mmd_swish_grad(z * s1 + sh_);
+    return s1 * gp + s2 * (z - mu_) + s3;
+  };
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = tid / LANES + it * Cf::G;
+    float4 u = make_float4(0, 0, 0, 0);
+    if (ok[it]) {
+      u.x = ev(v[it].x, zv[it].x, gt.x, ad.x, a1.x, a2.x, a3.x, mu.x, sh.x); u.y = ev(v[it].y, zv[it].y, gt.y, ad.y, a1.y, a2.y, a3.y, mu.y, sh.y);
+      u.z = ev(v[it].z, zv[it].z, gt.z, ad.z, a1.z, a2.z, a3.z, mu.z, sh.z); u.w = ev(v[it].w, zv[it].w, gt.w, ad.w, a1.w, a2.w, a3.w, mu.w, sh.w);
+    }
+    if (p < NPIX) *reinterpret_cast<float4*>(&sIn[p * Cf::CC + c4]) = u;
+  }
+}
+
 // PRO / EPI: the launch's prologue and epilogue mode as compile-time parameters (PRO: producer transform; EPI 0 raw, 1 raw + BatchNorm
 // sums, 2 raw + `bz` sums, 3 folded BN / activation / pool, 4 any combination at run time) - as for dw3_rows_kernel, the union of all
 // modes costs registers and branches on every launch.
 // WG (with EPI 2): the weight gradient of the forward conv out of the same launch - the dY tile is in LDS, the forward input a0 = swish(u)
 // is recomputed for the BatchNorm sums anyway; k*k float4 sums per thread, one block reduction, k*k*CC atomics per block.  A depthwise
 // weight-gradient launch is a leaf whose kernel time the saturated chip pays in full (profiles/r02_notes.md).
-template <int K, int S, int LANES = 16, bool PRO = true, int EPI = 4, bool WG = false>
+template <int K, int S, int LANES = 16, int PRO = 1, int EPI = 4, bool WG = false>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   using Cf = DwCfg<K, S, LANES>;
   constexpr int CC = Cf::CC;
@@ -147,7 +199,15 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     float4 wv = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
     *reinterpret_cast<float4*>(&sW[tap * CC + q]) = wv;
   }
-  dw_stage_input<K, S, LANES, PRO>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+  if constexpr (PRO == 2) {
+    dw_stage_input_bnbwd<K, S, LANES>(a, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+    if (a.q_dgamma && b == 0 && th == 0 && tw == 0 && tid < CC && c0 + tid < a.C) {
+      a.q_dgamma[c0 + tid] += (float)a.q_sums[a.C + c0 + tid];
+      a.q_dbeta[c0 + tid] += (float)a.q_sums[c0 + tid];
+    }
+  } else {
+    dw_stage_input<K, S, LANES, PRO != 0>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
+  }
   __syncthreads();
 
   const int p = tid / LANES;
@@ -305,6 +365,13 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   const int epi = (a.stats && out) ? 4 : (a.bz ? 2 : (a.stats ? 1 : (out ? 3 : 0)));
   const dim3 grid((unsigned)nb), blk(256);
 #define MMD_DW_TILE(P, E) hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, P, E>), grid, blk, 0, st, a)
+  if constexpr (S == 1 && LANES == 16) {
+    if (a.q_z) {        // BatchNorm-1 backward evaluated in the prologue (MBConv input gradient; always with the BatchNorm-0 sums + weight gradient)
+      if (!(a.dwg && epi == 2 && !pro)) return MMD_EINVAL;
+      hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, 2, 2, true>), grid, blk, 0, st, a); goto launched;
+    }
+  }
+  if (a.q_z) return MMD_EINVAL;
   if constexpr (S == 1) {
     if (a.dwg && epi == 2 && !pro) { hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, false, 2, true>), grid, blk, 0, st, a); goto launched; }
   }
@@ -771,6 +838,37 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
     rc = mmd_check_launch();
   }
   mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * B * OH * OW * (double)C * k * k, 4.0 * ((double)B * H * W * C + (double)B * OH * OW * C));
+  return rc;
+}
+
+// Input gradient of an MBConv block's stride-1 depthwise conv with the BatchNorm-1 (+swish, squeeze-excite gate / pooled term) backward
+// evaluated in the prologue instead of by mmd_bn_bwd_apply: dY = BnBwd1(g1, z1; gate, dpooled, sums1) is never written to HBM.  Always
+// together with the BatchNorm-0 sums (bn_*) and the conv's weight gradient, as the engine runs these layers.  C >= 64 channels (64-wide chunks).
+extern "C" int mmd_dwconv_bwd_data_bn1(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
+                                       const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd,
+                                       const double* q_sums, long long q_count, const float* q_gate, const float* q_add,
+                                       float* q_dgamma, float* q_dbeta,
+                                       const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                       const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad,
+                                       hipStream_t stream) {
+  if (!g1 || !z1 || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C < 64 || (C & 3) || (k != 3 && k != 5)) return MMD_EINVAL;
+  if (!q_scale || !q_shift || !q_mean || !q_invstd || !q_sums || q_count <= 0 || !q_gate || !q_add) return MMD_EINVAL;
+  if ((q_dgamma == nullptr) != (q_dbeta == nullptr)) return MMD_EINVAL;
+  if (!bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd || !bn_sums || !dw_grad) return MMD_EINVAL;
+  int OH, OW;
+  const int pt = same_pad_lo(H, k, 1, &OH), pl = same_pad_lo(W, k, 1, &OW);
+  DwArgs a{};
+  a.x = g1; a.w = w; a.y = dx; a.B = B; a.H = H; a.W = W; a.C = C; a.OH = H; a.OW = W;
+  a.pad_t = k - 1 - pt; a.pad_l = k - 1 - pl; a.flip = 1;
+  a.stats = bn_sums; a.stats_ws = stats_ws; a.ws_slots = ws_slots;
+  a.bz = bn_z; a.bscale = bn_scale; a.bshift = bn_shift; a.bmean = bn_mean; a.binvstd = bn_invstd;
+  a.dwg = dw_grad;
+  a.q_z = z1; a.q_gate = q_gate; a.q_add = q_add; a.q_scale = q_scale; a.q_shift = q_shift; a.q_mean = q_mean; a.q_invstd = q_invstd;
+  a.q_sums = q_sums; a.q_inv_count = 1.0 / (double)q_count; a.q_dgamma = q_dgamma; a.q_dbeta = q_dbeta;
+  mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd1 H%lld C%lld k%lld s%lld", H, C, k, 1);
+  mmd_prof_begin(MMD_FAM_DW_BWD, stream);
+  const int rc = (k == 3) ? dw_fwd_launch<3, 1, 16>(a, stream) : dw_fwd_launch<5, 1, 16>(a, stream);
+  mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * B * OH * OW * (double)C * k * k, 4.0 * 4 * (double)B * H * W * C);
   return rc;
 }
 

@@ -395,6 +395,88 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
                        pooled, dwr, dbr, dwe, dbe, B, C, S);
   return mmd_check_launch();
 }
+// Both FC layers' backward in ONE launch (round 3: se_bwd_a + se_bwd_b were two dependent ~10 us launches on the backward's serial chain per
+// MBConv block).  Grid (B, ceil(C / 256)); every block first recomputes its image's hidden gradient - dpe[c] = dgate*gate*(1-gate) for all C
+// into LDS, then dh[j] = sum_c wet[j,c]*dpe[c] one wave per j (coalesced over c, S*C MACs per block: at most 186 K) - and then runs step 1b
+// for its 256 channels.  Same outputs as the two-kernel form (dpe, dpr, dpooled, BatchNorm-1 sums); dh is not materialised.
+#define SE_MAXC 3072
+__global__ __launch_bounds__(256) void se_bwd_ab_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                        const float* __restrict__ hpre, const float* __restrict__ wr,
+                                                        const float* __restrict__ wet, float* __restrict__ dpe, float* __restrict__ dpr,
+                                                        float* __restrict__ dpooled, float dpool_scale, int C, int S,
+                                                        const float* __restrict__ pool5, double* bn_sums, int B) {
+  __shared__ float sdpe[SE_MAXC];
+  __shared__ float sd[256];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int c = tid; c < C; c += 256) {
+    const float g = gate[(size_t)b * C + c];
+    const float d = dgate[(size_t)b * C + c] * g * (1.f - g);
+    sdpe[c] = d;
+    if (blockIdx.y == 0) dpe[(size_t)b * C + c] = d;
+  }
+  __syncthreads();
+  for (int j = wave; j < S; j += 4) {
+    const float* w = wet + (size_t)j * C;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w[c] * sdpe[c];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float d = acc * mmd_swish_grad(hpre[(size_t)b * S + j]);
+      sd[j] = d;
+      if (blockIdx.y == 0) dpr[(size_t)b * S + j] = d;
+    }
+  }
+  __syncthreads();
+  const int c = blockIdx.y * 256 + tid;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sd[j];
+  const float dp = acc * dpool_scale;
+  dpooled[(size_t)b * C + c] = dp;
+  if (bn_sums) {
+    const size_t i = (size_t)b * C + c, n = (size_t)B * C;
+    const float gt = gate[i];
+    atomicAdd(&bn_sums[c], (double)(gt * pool5[n + i] + dp * pool5[3 * n + i]));
+    atomicAdd(&bn_sums[C + c], (double)(gt * pool5[2 * n + i] + dp * pool5[4 * n + i]));
+  }
+}
+extern "C" int mmd_se_fc_bwd_fused(const float* dgate, const float* gate, const float* hpre, const float* wr, const float* we,
+                                   float* dpe_ws, float* dpr_ws, float* dpooled, float dpool_scale, int B, int C, int S,
+                                   const float* pool5, double* bn_sums, hipStream_t stream) {
+  if (!dgate || !gate || !hpre || !wr || !we || !dpe_ws || !dpr_ws || !dpooled) return MMD_EINVAL;
+  if (B <= 0 || C <= 0 || C > SE_MAXC || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_bwd_ab_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dgate, gate, hpre, wr, we, dpe_ws, dpr_ws, dpooled,
+                     dpool_scale, C, S, pool5, bn_sums, B);
+  return mmd_check_launch();
+}
+
+// The FC weight gradients of EVERY squeeze-excite block of a backward segment in one launch (they are leaves: 23 launches of ~9 us, each
+// behind its own cross-stream edge).  desc: n entries {dpe, dpr, hpre, pooled, dwr, dbr, dwe, dbe, C, S} (8 pointers + 2 ints as 10 x 8 bytes).
+struct SeWgDesc { const float* dpe; const float* dpr; const float* hpre; const float* pooled; float* dwr; float* dbr; float* dwe; float* dbe;
+                  long long C; long long S; };
+__global__ void se_fc_wgrad_batched_kernel(const SeWgDesc* __restrict__ desc, int B) {
+  const SeWgDesc d = desc[blockIdx.y];
+  const int C = (int)d.C, S = (int)d.S;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * S) return;
+  const int j = i / C, c = i % C;
+  float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float pe = d.dpe[(size_t)b * C + c], pr = d.dpr[(size_t)b * S + j];
+    a1 += pe * mmd_swish(d.hpre[(size_t)b * S + j]); b1 += pe;
+    a2 += pr * d.pooled[(size_t)b * C + c]; b2 += pr;
+  }
+  d.dwe[i] += a1;
+  if (j == 0) d.dbe[c] += b1;
+  d.dwr[i] += a2;
+  if (c == 0) d.dbr[j] += b2;
+}
+extern "C" int mmd_se_fc_wgrad_batched(const void* desc, int n, int max_cs, int B, hipStream_t stream) {
+  if (!desc || n <= 0 || max_cs <= 0 || B <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_fc_wgrad_batched_kernel, dim3(cdiv(max_cs, 256), n), dim3(256), 0, stream, (const SeWgDesc*)desc, B);
+  return mmd_check_launch();
+}
+
 // the weight-gradient half of mmd_se_fc_bwd on its own (a leaf of the backward graph: the engine issues it on the wgrad stream)
 extern "C" int mmd_se_fc_wgrad(const float* dpe, const float* dpr, const float* hpre, const float* pooled, float* dwr, float* dbr,
                                float* dwe, float* dbe, int B, int C, int S, hipStream_t stream) {

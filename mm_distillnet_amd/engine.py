@@ -97,6 +97,8 @@ LAZY_BN = not os.environ.get("MMD_NO_LAZY_BN")
 # BatchNorm-backward reduce passes folded into the launches that complete their upstream gradient (MMD_NO_BNSUM_FOLD=1: the round-2
 # schedule - a bn_bwd_reduce launch per BatchNorm and scale_acc launches for the skip / multi-consumer accumulations - for A/B timing)
 FOLD_SUMS = not os.environ.get("MMD_NO_BNSUM_FOLD")
+BN1_IN_DW = not os.environ.get("MMD_NO_BN1_IN_DW")    # MBConv: BatchNorm-1 backward in the depthwise input-gradient launch's prologue (no bn_bwd_apply, no dz1 tensor)
+SE_FUSED = not os.environ.get("MMD_NO_SE_FUSED")      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
 
 class Net:
@@ -155,6 +157,8 @@ class Net:
         self._bnout: Dict[int, tuple] = {}     # train forward: tensor y = BN(z) [* mul_b[image]] (+ skip) -> (z, mean, invstd, C, mul_b, rows_per_image)
         self._counting = False
         self._theta_desc: Dict[tuple, torch.Tensor] = {}
+        self._se_wg: list = []                 # squeeze-excite FC weight gradients of the current backward segment (one batched launch)
+        self._se_wg_tabs: Dict[tuple, torch.Tensor] = {}
 
     def _use(self, f: "Feat"):
         if self._counting:
@@ -890,7 +894,7 @@ class Net:
         A = tape["A"]
         slots: Dict[int, GradSlot] = {}
         self._bw = {"slots": slots, "stem_sums": None}
-        self._wg_pending, self._leaf_pending, self._wg_segment = [], [], 0
+        self._wg_pending, self._leaf_pending, self._wg_segment, self._se_wg = [], [], 0, []
         slot = self._slot
         fold_heads = FOLD_SUMS and ps.flat.is_cuda and (dfeat_pyr is not None or all(d is None for d in dfeats))
         if not fold_heads:
@@ -991,7 +995,7 @@ class Net:
                      ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None, *xsargs)
                 if pl is not None:      # the pooled operand's gradient: gather over the windows whose arg-max it is
                     wi = 1 + (1 if in1 is not None else 0) + (1 if up is not None else 0)
-                    sl, xs = self._contrib(pl, True)
+                    sl, xs = self._contrib(pl, _lib.LIB.load().mmd_maxpool_bwd_sums_ok(pl.B, pl.H, pl.W, W) == 1)
                     accumulate = 0 if sl.t is None else 1
                     if sl.t is None:
                         sl.t = self._alloc(pl.M, W)
@@ -1074,18 +1078,41 @@ class Net:
             dpe = self._alloc(f1.B, blk.cmid)
             dpr = self._alloc(f1.B, blk.se)
             dpooled = self._alloc(f1.B, blk.cmid)
-            dh = self._zalloc((f1.B, blk.se))
             sums1 = self._zalloc((2 * blk.cmid,), torch.float64)
-            call("mmd_se_fc_bwd", pool5[0], rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
-                 ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, None, None, None, None,
-                 f1.B, blk.cmid, blk.se, pool5, sums1)
-            self._leaf(lambda dpe=dpe, dpr=dpr, hp=rec["hpre"], po=rec["pooled"], g1_=ps.g(f"{q}._se_reduce.conv.weight"),
-                       g2_=ps.g(f"{q}._se_reduce.conv.bias"), g3_=ps.g(f"{q}._se_expand.conv.weight"), g4_=ps.g(f"{q}._se_expand.conv.bias"),
-                       nb=f1.B, cm=blk.cmid, se=blk.se: call("mmd_se_fc_wgrad", dpe, dpr, hp, po, g1_, g2_, g3_, g4_, nb, cm, se))
-            dz1 = self._bn_bwd(g1, f1.z, a1, f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
-                               add_bc=dpooled, sums=sums1)
+            segrads = (ps.g(f"{q}._se_reduce.conv.weight"), ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"),
+                       ps.g(f"{q}._se_expand.conv.bias"))
+            if SE_FUSED and ps.flat.is_cuda:
+                # both FC layers' data gradients in one launch; the FC weight gradients of all blocks of the segment in one launch at its end
+                call("mmd_se_fc_bwd_fused", pool5[0], rec["gate"], rec["hpre"], ps.w(f"{q}._se_reduce.conv.weight"),
+                     ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dpooled, 1.0 / HW1, f1.B, blk.cmid, blk.se, pool5, sums1)
+                self._se_wg.append((dpe, dpr, rec["hpre"], rec["pooled"], *segrads, blk.cmid, blk.se))
+            else:
+                dh = self._zalloc((f1.B, blk.se))
+                call("mmd_se_fc_bwd", pool5[0], rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
+                     ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, None, None, None, None,
+                     f1.B, blk.cmid, blk.se, pool5, sums1)
+                self._leaf(lambda dpe=dpe, dpr=dpr, hp=rec["hpre"], po=rec["pooled"], gs=segrads, nb=f1.B, cm=blk.cmid, se=blk.se:
+                           call("mmd_se_fc_wgrad", dpe, dpr, hp, po, *gs, nb, cm, se))
             f0: Feat = rec.get("f0", inp)
-            if blk.expand != 1:
+            # BatchNorm-1 backward evaluated in the prologue of the depthwise input-gradient launch (stride-1 blocks with an expand conv and
+            # >= 64 channels: 17 of D2's 23): dz1 is never written; the other blocks keep the apply pass
+            bn1_in_dw = (BN1_IN_DW and ps.flat.is_cuda and blk.expand != 1 and blk.stride == 1 and blk.cmid >= 64 and self.DW_WG)
+            if not bn1_in_dw:
+                dz1 = self._bn_bwd(g1, f1.z, a1, f"{q}._bn1", SWISH, M1, blk.cmid, rpi=HW1, mul_bc=rec["gate"],
+                                   add_bc=dpooled, sums=sums1)
+            if bn1_in_dw:
+                b1, a0 = ps.bn(f"{q}._bn1"), rec["bn0"]
+                wkey = f"{q}._depthwise_conv.conv.weight"
+                g0 = self._alloc(f0.M, f0.C)
+                sums0 = self._zalloc((2 * f0.C,), torch.float64)
+                call("mmd_dwconv_bwd_data_bn1", g1, f1.z, ps.w(wkey), g0, f0.B, f0.H, f0.W, f0.C, blk.kernel, a1[0], a1[1], a1[2], a1[3],
+                     sums1, M1, rec["gate"], dpooled, b1["dgamma"], b1["dbeta"], f0.z, a0[0], a0[1], a0[2], a0[3], sums0,
+                     *self._stats_ws(sums0, f0.M, f0.C), ps.g(wkey))
+                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0, lazy=True)
+                if dy_read is not None:
+                    torch.cuda.current_stream().wait_event(dy_read)
+                self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True, into=inp)
+            elif blk.expand != 1:
                 g0, sums0 = self._dw_bwd(dz1, f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, bn_aff=rec["bn0"])
                 dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0, lazy=True)
                 if dy_read is not None:
@@ -1105,6 +1132,14 @@ class Net:
                     torch.cuda.current_stream().wait_event(dy_read)
                 self._acc(inp, g0)
         self._bw["stem_sums"] = stem_sums
+        if self._se_wg:
+            recs, self._se_wg = self._se_wg, []
+            key = tuple((r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), r[3].data_ptr(), r[4].data_ptr()) for r in recs)
+            if key not in self._se_wg_tabs:
+                rows = [[t.data_ptr() for t in r[:8]] + [r[8], r[9]] for r in recs]
+                self._se_wg_tabs[key] = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            tab, nb = self._se_wg_tabs[key], recs[0][0].shape[0]
+            self._leaf(lambda tab=tab, n=len(recs), mx=max(r[8] * r[9] for r in recs), nb=nb: call("mmd_se_fc_wgrad_batched", tab, n, mx, nb))
 
     def _backward_stem(self):
         ps, tape = self.ps, self.tape

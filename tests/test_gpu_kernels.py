@@ -492,6 +492,18 @@ def test_se_path():
     close(dpooled2, dpooled, 1e-5, 1e-6); close(g2[0], gwr, 1e-5, 1e-6)
     close(sums2[:C], ref[:C], 2e-5, 2e-5, "BN-1 sum g from pooled partials")
     close(sums2[C:], ref[C:], 2e-5, 2e-5, "BN-1 sum g*xhat from pooled partials")
+    # round 3: the two data-gradient kernels as one launch, the FC weight gradients of several blocks as one batched launch
+    dpe3, dpr3, dpooled3 = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
+    sums3 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_se_fc_bwd_fused", pool5[0], dg, dh, g(wr), wet, dpe3, dpr3, dpooled3, 1.0 / HW, B, C, S, pool5, sums3)
+    assert torch.equal(dpe3, dpe) and torch.equal(dpr3, dpr) and torch.equal(dpooled3, dpooled2)
+    close(sums3, sums2, 1e-6, 1e-7, "BN-1 sums of the fused launch")
+    g3 = [torch.zeros_like(t) for t in (gwr, gbr, gwe, gbe)]
+    g4 = [torch.ones_like(t) for t in (gwr, gbr, gwe, gbe)]          # a second "block" (same operands) accumulating onto ones
+    tab = torch.tensor([[t.data_ptr() for t in (dpe3, dpr3, dh, dpool, *gs)] + [C, S] for gs in (g3, g4)], dtype=torch.int64, device=DEV)
+    call("mmd_se_fc_wgrad_batched", tab, 2, C * S, B)
+    for a_, b_, c_ in zip(g3, g4, g2):
+        assert torch.equal(a_, c_) and torch.allclose(b_, c_ + 1, rtol=0, atol=1e-6)
 
 
 def test_colsum_slice_sigmoid():
@@ -1415,3 +1427,38 @@ def test_pyr_add_bnsums_and_batched_theta():
     got = torch.zeros(16, device=DEV)
     call("mmd_bifpn_theta_bwd_batched", td, got, wd_, torch.tensor(nodes, dtype=torch.int64, device=DEV), len(nodes))
     assert torch.equal(got, ref_g)
+
+
+@pytest.mark.parametrize("k,H,W,C", [(3, 16, 16, 144), (5, 16, 12, 528), (5, 9, 7, 64), (3, 32, 32, 96)])
+def test_dwconv_bwd_data_bn1_prologue(k, H, W, C):
+    """mmd_dwconv_bwd_data_bn1 (BatchNorm-1 + swish + squeeze-excite backward evaluated while the dY tile is staged) against the two launches
+    it replaces: mmd_bn_bwd_apply(mul_bc = gate, add_bc = dpooled) -> mmd_dwconv_bwd_data(bn sums, weight gradient)."""
+    torch.manual_seed(k * 100 + C)
+    B = 2
+    M = B * H * W
+    g1, z1, z0 = torch.randn(M, C), torch.randn(M, C) * 1.2 + 0.1, torch.randn(M, C)
+    gate, dpool = torch.rand(B, C), torch.randn(B, C) * 0.05
+    sc1, sh1, mu1, is1, ga1 = torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.2, torch.rand(C) + 0.5, torch.rand(C) + 0.5
+    sc1 = ga1 * is1            # scale = gamma * invstd, as the engine's finalize produces it
+    sc0, sh0, mu0, is0 = torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.2, torch.rand(C) + 0.5
+    wd = torch.randn(k * k, C) / k
+    d = lambda t: g(t)
+    sums1 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", d(g1), d(z1), d(sc1), d(sh1), d(mu1), d(is1), 1, d(gate), None, d(dpool), H * W, None, sums1, M, C, None, 0)
+    outs = {}
+    for name in ("ref", "fused"):
+        dga, dbe = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx = torch.full((M, C), float("nan"), device=DEV)
+        sums0 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        dwg = torch.zeros(k * k, C, device=DEV)
+        if name == "ref":
+            dz1 = torch.empty(M, C, device=DEV)
+            call("mmd_bn_bwd_apply", d(g1), d(z1), d(mu1), d(is1), d(ga1), sums1, M, dz1, dga, dbe, M, C, d(sc1), d(sh1), 1, d(gate), None,
+                 d(dpool), H * W)
+            call("mmd_dwconv_bwd_data", dz1, d(wd), dx, B, H, W, C, k, 1, d(z0), d(sc0), d(sh0), d(mu0), d(is0), sums0, None, 0, dwg)
+        else:
+            call("mmd_dwconv_bwd_data_bn1", d(g1), d(z1), d(wd), dx, B, H, W, C, k, d(sc1), d(sh1), d(mu1), d(is1), sums1, M, d(gate), d(dpool),
+                 dga, dbe, d(z0), d(sc0), d(sh0), d(mu0), d(is0), sums0, None, 0, dwg)
+        outs[name] = (dx, sums0, dwg, dga, dbe)
+    for a_, b_, what in zip(outs["ref"], outs["fused"], ("dx", "BatchNorm-0 sums", "dw", "dgamma1", "dbeta1")):
+        close(b_, a_, 2e-5, 2e-5, what)
