@@ -315,10 +315,13 @@ int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, floa
 // tensor y' = BN'(xs_z) * xs_mul_b[image] (+ skip) (an MBConv block output / a tap), and xs_sums [2K] (+)= [sum g', sum g'*xhat'],
 // g' = dx * xs_mul_b[image], xhat' = (xs_z - xs_mean)*xs_invstd: the reduce pass of that upstream BatchNorm's backward, without a launch of
 // its own and without the scale_acc launch that added the skip gradient (src/YetAnotherEfficientNet.py:477-485).  stats_ws / ws_slots
-// (nullable / 0) as in mmd_pwconv_fwd: slotted sums for launches with more than 128 row tiles.
-int mmd_pwconv_bwd_data_bn2(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, hipStream_t stream);
+// (nullable / 0) as in mmd_pwconv_fwd: slotted sums for launches with more than 128 row tiles.  p5_* (an MBConv project conv; not with
+// residual / xs): dx = g1 is the gradient w.r.t. the gated activation, and p5_out [5][p5_B][K] (+)= what mmd_chan_pool_bwd(p5_z = z1,
+// p5_scale .. p5_invstd of BatchNorm-1, g1) computes - the pooled pass of the squeeze-excite / BatchNorm-1 backward - taken from the
+// output tiles instead of by a launch re-reading g1 and z1.
+int mmd_pwconv_bwd_data_bn2(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
 
-int mmd_pwconv_bwd_data_bn2_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, hipStream_t stream);
+int mmd_pwconv_bwd_data_bn2_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
 
 int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
 

@@ -52,6 +52,12 @@ struct StemOp { int Cin, H, W, OH, OW, pad_t, pad_l; };
 // computes the sums of the total).  `stats` (or its slotted workspace) receives [sum g', sum g'*xhat].
 struct BnSumOp { const float* z; const float* mean; const float* invstd; const float* mul_b; int rows_per_image; };
 
+// Epilogue of an MBConv project conv's input-gradient GEMM: its output g1 [M, N] is the gradient w.r.t. the squeeze-excite-gated activation;
+// the five per-(image, channel) sums the squeeze-excite backward and the BatchNorm-1 backward need (mmd_chan_pool_bwd's out5 [5][B][N]:
+// sum g1*a, g1*s', g1*s'*xhat, s', s'*xhat with u = z*scale+shift, a = swish(u), s' = swish'(u), xhat = (z-mean)*invstd) are taken from
+// the tile while it is written, instead of by a pass that re-reads g1 and z1.  A row tile must lie inside one image.
+struct Pool5Op { const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; float* out; int B; int rows_per_image; };
+
 struct PwArgs {
   const float* x; const float* w; float* y;
   int M, K, N;
@@ -67,6 +73,7 @@ struct PwArgs {
   BnBwdOp bb;                                // PRO == 1: the A operand is a BatchNorm backward evaluated on the fly
   StemOp st;                                 // PRO == 2: the A operand is the im2col of an NCHW image, gathered on the fly
   BnSumOp xs;                                // epilogue: `stats` = BatchNorm-backward sums of the output instead of (sum y, sum y^2)
+  Pool5Op p5;                                // epilogue: squeeze-excite / BatchNorm-1 backward partial sums of the output
 };
 
 

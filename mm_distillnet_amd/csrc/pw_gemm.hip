@@ -44,6 +44,26 @@ __device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t of
   q4.z += v.z * (zz.z - mu.z) * is.z; q4.w += v.w * (zz.w - mu.w) * is.w;
 }
 
+// Pool5Op epilogue: one output quad v (= g1) at `off` -> the five running sums (chan_pool_bwd_kernel's arithmetic)
+struct P5Coef { float4 sc, sh, mu, is; };
+__device__ __forceinline__ void pw_p5_acc(const Pool5Op& p, const P5Coef& q, const float4& v, size_t off, float4 (&acc)[5]) {
+  const float4 zz = mmd_ld4(p.z + off);
+  const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {v.x, v.y, v.z, v.w};
+  const float scv[4] = {q.sc.x, q.sc.y, q.sc.z, q.sc.w}, shv[4] = {q.sh.x, q.sh.y, q.sh.z, q.sh.w};
+  const float muv[4] = {q.mu.x, q.mu.y, q.mu.z, q.mu.w}, isv[4] = {q.is.x, q.is.y, q.is.z, q.is.w};
+  float r[5][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u = zv[i] * scv[i] + shv[i];
+    const float sg = mmd_sigmoid(u);
+    const float sp = sg * (1.0f + u * (1.0f - sg));
+    const float xh = (zv[i] - muv[i]) * isv[i];
+    r[0][i] = gv[i] * (u * sg); r[1][i] = gv[i] * sp; r[2][i] = gv[i] * sp * xh; r[3][i] = sp; r[4][i] = sp * xh;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { acc[k].x += r[k][0]; acc[k].y += r[k][1]; acc[k].z += r[k][2]; acc[k].w += r[k][3]; }
+}
+
 #define PW_BM 128
 #define PW_BK 32
 #define PW_LD 36
@@ -70,6 +90,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   constexpr int SM = (BM_T * LDC > (BM_T + BN_T) * PW_LD) ? BM_T * LDC : (BM_T + BN_T) * PW_LD;
   __shared__ float smem[SM];              // A|B tiles in the K loop, then the C tile for the vectorised epilogue
   __shared__ float sRed[2 * 4 * BN_T];
+  __shared__ float sRed5[(PRO == 1) ? 5 * 4 * BN_T : 1];      // Pool5Op sums (BatchNorm-backward operand launches only)
   float* const sA = smem;
   float* const sB = smem + BM_T * PW_LD;
 
@@ -285,6 +306,13 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
   float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
   if (a.xs.z && cok) { xmu = mmd_ld4(a.xs.mean + col); xis = mmd_ld4(a.xs.invstd + col); }
+  float4 p5a[(PRO == 1) ? 5 : 1];
+  P5Coef p5q;
+  if constexpr (PRO == 1) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) p5a[k] = make_float4(0, 0, 0, 0);
+    if (a.p5.z && cok) { p5q.sc = mmd_ld4(a.p5.scale + col); p5q.sh = mmd_ld4(a.p5.shift + col); p5q.mu = mmd_ld4(a.p5.mean + col); p5q.is = mmd_ld4(a.p5.invstd + col); }
+  }
 #pragma unroll
   for (int i = 0; i < BM_T / RSTEP; ++i) {
     const int rl = rgrp + RSTEP * i, row = m0 + rl;
@@ -307,6 +335,29 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
       mmd_st4(a.y + off, v);
       if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
+      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a); }
+    }
+  }
+  if constexpr (PRO == 1) {
+    if (a.p5.z) {        // block-uniform; the tile's rows lie inside one image (host-checked)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        float4 t = p5a[k];
+#pragma unroll
+        for (int o = CGN; o < 64; o <<= 1) {
+          t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64); t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+        }
+        if (lane < CGN) *reinterpret_cast<float4*>(&sRed5[(k * 4 + wave) * BN_T + lane * 4]) = t;
+      }
+      __syncthreads();
+      const int img = m0 / a.p5.rows_per_image;
+      for (int i = tid; i < 5 * BN_T; i += 256) {
+        const int k = i / BN_T, cl = i - k * BN_T;
+        if (n0 + cl < a.N) {
+          const float* r5 = &sRed5[k * 4 * BN_T + cl];
+          atomicAdd(&a.p5.out[((size_t)k * a.p5.B + img) * a.N + n0 + cl], r5[0] + r5[BN_T] + r5[2 * BN_T] + r5[3 * BN_T]);
+        }
+      }
     }
   }
   if (a.stats) {
@@ -368,6 +419,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
   __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
   __shared__ float sRed[2 * 4 * SK_BN];
+  __shared__ float sRed5[(PRO == 1) ? 5 * 4 * SK_BN : 1];
   const int tid = threadIdx.x;
   const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
   const int tn = t % a.ntn, tm = t / a.ntn;
@@ -545,6 +597,13 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
   float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
   if (a.xs.z && cok) { xmu = mmd_ld4(a.xs.mean + col); xis = mmd_ld4(a.xs.invstd + col); }
+  float4 p5a[(PRO == 1) ? 5 : 1];
+  P5Coef p5q;
+  if constexpr (PRO == 1) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) p5a[k] = make_float4(0, 0, 0, 0);
+    if (a.p5.z && cok) { p5q.sc = mmd_ld4(a.p5.scale + col); p5q.sh = mmd_ld4(a.p5.shift + col); p5q.mu = mmd_ld4(a.p5.mean + col); p5q.is = mmd_ld4(a.p5.invstd + col); }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rl = rgrp + 16 * i, row = m0 + rl;
@@ -572,6 +631,29 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
       mmd_st4(a.y + off, v);
       if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
+      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a); }
+    }
+  }
+  if constexpr (PRO == 1) {
+    if (a.p5.z) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        float4 tq = p5a[k];
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          tq.x += __shfl_xor(tq.x, o, 64); tq.y += __shfl_xor(tq.y, o, 64); tq.z += __shfl_xor(tq.z, o, 64); tq.w += __shfl_xor(tq.w, o, 64);
+        }
+        if (lane < 16) *reinterpret_cast<float4*>(&sRed5[(k * 4 + wave) * SK_BN + lane * 4]) = tq;
+      }
+      __syncthreads();
+      const int img = m0 / a.p5.rows_per_image;
+      for (int i = tid; i < 5 * SK_BN; i += 256) {
+        const int k = i / SK_BN, cl = i - k * SK_BN;
+        if (n0 + cl < a.N) {
+          const float* r5 = &sRed5[k * 4 * SK_BN + cl];
+          atomicAdd(&a.p5.out[((size_t)k * a.p5.B + img) * a.N + n0 + cl], r5[0] + r5[SK_BN] + r5[2 * SK_BN] + r5[3 * SK_BN]);
+        }
+      }
     }
   }
   if (a.stats) {
@@ -1205,12 +1287,19 @@ static int pw_bwd_data_bn_impl(const float* g, const float* z, const float* wt, 
 //   xs_*:     dx is then the COMPLETE gradient w.r.t. a tensor BN'(xs_z) * xs_mul_b[image] (+ skip), and xs_sums [2K] (+)=
 //             [sum g', sum g' * xhat'], g' = dx * xs_mul_b[image], xhat' = (xs_z - xs_mean) * xs_invstd: the reduce pass of that upstream
 //             BatchNorm's backward (mmd_bn_bwd_reduce with act = NONE) without a launch of its own.  stats_ws / ws_slots as in mmd_pwconv_fwd.
+//   p5_*:     (MBConv project conv; not together with residual / xs) dx = g1 is the gradient w.r.t. the squeeze-excite-gated activation
+//             a1 * gate: p5_out [5][p5_B][K] (+)= mmd_chan_pool_bwd(p5_z = z1, ..., g1) - the pooled pass of the squeeze-excite /
+//             BatchNorm-1 backward - from the output tiles (by its own launch when an image's rows are not a multiple of 128).
+extern "C" int mmd_chan_pool_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                 const float* g1, float* out5, int B, int rows_per_image, int C, hipStream_t stream);      // elt.hip
 static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                 const float* scale, const float* shift, const float* mean, const float* invstd,
                                 const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
                                 float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z,
                                 const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image,
-                                double* xs_sums, double* stats_ws, int ws_slots, hipStream_t stream, int bf16) {
+                                double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale,
+                                const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B,
+                                hipStream_t stream, int bf16) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
   if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
   if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
@@ -1229,15 +1318,27 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
     // (the BatchNorm-backward operand launches run 64-row tiles, or 128-row ones for N <= 32: count the blocks per address with 64)
     if (stats_ws && ws_slots > 1 && cdiv(M, 64) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
   }
+  if (p5_z) {
+    if (!p5_scale || !p5_shift || !p5_mean || !p5_invstd || !p5_out || p5_B <= 0 || M % p5_B || residual || xs_z) return MMD_EINVAL;
+    const int rpi = M / p5_B;
+    if (rpi % PW_BM == 0) {       // every row tile (32 / 64 / 128 rows) inside one image: the sums ride in the epilogue
+      a.p5 = Pool5Op{p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, p5_out, p5_B, rpi};
+      return pw_dispatch(a, stream);
+    }
+    const int rc = pw_dispatch(a, stream);      // ragged image size: the pooled pass as its own launch
+    return rc ? rc : mmd_chan_pool_bwd(p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, dx, p5_out, p5_B, rpi, K, stream);
+  }
   return pw_dispatch(a, stream);
 }
 #define PW_BD2_PARAMS const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, \
                       const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, \
                       int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, \
                       const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, \
-                      double* stats_ws, int ws_slots, hipStream_t stream
+                      double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, \
+                      const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream
 #define PW_BD2_ARGS g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, dz_out, dgamma, dbeta, residual, \
-                    xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image, xs_sums, stats_ws, ws_slots, stream
+                    xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image, xs_sums, stats_ws, ws_slots, p5_z, p5_scale, p5_shift, p5_mean, \
+                    p5_invstd, p5_out, p5_B, stream
 extern "C" int mmd_pwconv_bwd_data_bn2(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0); }
 extern "C" int mmd_pwconv_bwd_data_bn2_bf16(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 1); }
 

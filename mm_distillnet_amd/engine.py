@@ -98,7 +98,11 @@ LAZY_BN = not os.environ.get("MMD_NO_LAZY_BN")
 # schedule - a bn_bwd_reduce launch per BatchNorm and scale_acc launches for the skip / multi-consumer accumulations - for A/B timing)
 FOLD_SUMS = not os.environ.get("MMD_NO_BNSUM_FOLD")
 BN1_IN_DW = not os.environ.get("MMD_NO_BN1_IN_DW")    # MBConv: BatchNorm-1 backward in the depthwise input-gradient launch's prologue (no bn_bwd_apply, no dz1 tensor)
-SE_FUSED = not os.environ.get("MMD_NO_SE_FUSED")      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
+P5_IN_GEMM = not os.environ.get("MMD_NO_P5_IN_GEMM")  # MBConv: the pooled squeeze-excite / BN-1 backward pass in the project GEMM's epilogue (no chan_pool_bwd launch)
+SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
+# both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
+# (S*C MACs, serial per wave) - measured 17.0 -> 17.7 ms/step against the two wide launches; off unless MMD_SE_FUSED=1
+SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
 
 class Net:
@@ -744,7 +748,7 @@ class Net:
         return dz
 
     def _pw_bwd(self, dz: torch.Tensor, x: Feat, wkey: str, N: int, bias_key: Optional[str], want_dx: bool,
-                gate=None, plain_in=False, into: Optional[Feat] = None) -> Optional[torch.Tensor]:
+                gate=None, plain_in=False, into: Optional[Feat] = None, pool5: Optional[tuple] = None) -> Optional[torch.Tensor]:
         """Gradients of a 1x1 conv.  into = the Feat whose gradient slot receives dx (normally x itself): dx is then written into / on top
         of that slot by the GEMM's epilogue (no scale_acc launch), together with the backward sums of the BatchNorm that produced the
         Feat when this is the slot's last contribution; returns None in that case."""
@@ -774,10 +778,16 @@ class Net:
                 if xs is not None:
                     xsargs = (xs[0], xs[1], xs[2], xs[4], xs[5], xs[3], *self._stats_ws(xs[3], M, K))
                 call("mmd_pwconv_bwd_data_bn2" + self._sfx, L.g, L.z, ps.w_t(wkey), slot.t, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
-                     residual, *xsargs)
+                     residual, *xsargs, None, None, None, None, None, None, 0)
                 self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
                 return None
             dx = self._alloc(M, K)
+            if pool5 is not None:
+                # MBConv project conv: the pooled pass of the squeeze-excite / BatchNorm-1 backward over (z1, dx) rides in this launch's epilogue
+                call("mmd_pwconv_bwd_data_bn2" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
+                     None, None, None, None, None, 0, None, None, 0, *pool5)
+                self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
+                return dx
             call("mmd_pwconv_bwd_data_bn" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"])
             self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
             if into is not None:
@@ -1063,18 +1073,21 @@ class Net:
             M1, HW1 = f1.M, f1.H * f1.W
             dz2 = self._bn_bwd(dy, rec["z2"], rec["bn2"], f"{q}._bn2", NONE, M1, blk.cout, rpi=HW1, mul_b=rec["rs"], lazy=True,
                                sums=s.sums if s.have_sums else None)
-            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"])
+            # squeeze-excite backward.  One pass over (z1, g1) pools d(gate) AND the partials of the BN-1 backward sums (the SE kernels finish
+            # those sums once dpooled is known, so the expanded tensor is not read by a BN reduce pass); that pass rides in the epilogue of
+            # the project conv's input-gradient GEMM, which produces g1
+            a1 = rec["bn1"]
+            pool5 = self._zalloc((5, f1.B, blk.cmid))
+            p5 = (f1.z, a1[0], a1[1], a1[2], a1[3], pool5, f1.B) if (P5_IN_GEMM and isinstance(dz2, LazyDz) and ps.flat.is_cuda) else None
+            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"], pool5=p5)
             # the skip branch may ADOPT dy as the gradient slot of the block input, and the block's own input gradient is later
             # accumulated into that buffer in place; with a lazy BatchNorm backward the project conv's weight-gradient GEMM (side
             # stream) still reads dy, so that later accumulation waits for it (the event is long past by then)
             dy_read = self._wg_read_done if (blk.skip and isinstance(dz2, LazyDz)) else None
             if blk.skip:
                 self._acc(inp, dy)
-            # squeeze-excite backward.  One pass over (z1, g1) pools d(gate) AND the partials of the BN-1 backward sums; the
-            # SE kernels finish those sums once dpooled is known, so the expanded tensor is not read by a BN reduce pass
-            a1 = rec["bn1"]
-            pool5 = self._zalloc((5, f1.B, blk.cmid))
-            call("mmd_chan_pool_bwd", f1.z, a1[0], a1[1], a1[2], a1[3], g1, pool5, f1.B, HW1, blk.cmid)
+            if p5 is None:
+                call("mmd_chan_pool_bwd", f1.z, a1[0], a1[1], a1[2], a1[3], g1, pool5, f1.B, HW1, blk.cmid)
             dpe = self._alloc(f1.B, blk.cmid)
             dpr = self._alloc(f1.B, blk.se)
             dpooled = self._alloc(f1.B, blk.cmid)
@@ -1082,15 +1095,17 @@ class Net:
             segrads = (ps.g(f"{q}._se_reduce.conv.weight"), ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"),
                        ps.g(f"{q}._se_expand.conv.bias"))
             if SE_FUSED and ps.flat.is_cuda:
-                # both FC layers' data gradients in one launch; the FC weight gradients of all blocks of the segment in one launch at its end
+                # both FC layers' data gradients in one launch
                 call("mmd_se_fc_bwd_fused", pool5[0], rec["gate"], rec["hpre"], ps.w(f"{q}._se_reduce.conv.weight"),
                      ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dpooled, 1.0 / HW1, f1.B, blk.cmid, blk.se, pool5, sums1)
-                self._se_wg.append((dpe, dpr, rec["hpre"], rec["pooled"], *segrads, blk.cmid, blk.se))
             else:
                 dh = self._zalloc((f1.B, blk.se))
                 call("mmd_se_fc_bwd", pool5[0], rec["gate"], rec["hpre"], rec["pooled"], ps.w(f"{q}._se_reduce.conv.weight"),
                      ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dh, dpooled, 1.0 / HW1, None, None, None, None,
                      f1.B, blk.cmid, blk.se, pool5, sums1)
+            if SE_WG_BATCH and ps.flat.is_cuda:      # the FC weight gradients of all blocks of the segment in one launch at its end
+                self._se_wg.append((dpe, dpr, rec["hpre"], rec["pooled"], *segrads, blk.cmid, blk.se))
+            else:
                 self._leaf(lambda dpe=dpe, dpr=dpr, hp=rec["hpre"], po=rec["pooled"], gs=segrads, nb=f1.B, cm=blk.cmid, se=blk.se:
                            call("mmd_se_fc_wgrad", dpe, dpr, hp, po, *gs, nb, cm, se))
             f0: Feat = rec.get("f0", inp)

@@ -1321,7 +1321,7 @@ def test_pwconv_bwd_data_bn2_residual_and_upstream_sums(M, K, N, act, rowscale, 
     ws = torch.zeros(slots * 2 * K, dtype=torch.float64, device=DEV) if slots else None
     dga2 = torch.zeros(N, device=DEV); dbe2 = torch.zeros(N, device=DEV)
     call("mmd_pwconv_bwd_data_bn2", gd, zd, wtd, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dzm, dga2, dbe2,
-         dx if resid else None, g(z_up), g(mu_up), g(is_up), g(rs_up), rpi, xs_sums, ws, slots)
+         dx if resid else None, g(z_up), g(mu_up), g(is_up), g(rs_up), rpi, xs_sums, ws, slots, None, None, None, None, None, None, 0)
     close(dx, total_ref, 1e-5, 1e-5, "dx (+ residual)")
     assert torch.equal(dzm, dzm_ref) and torch.equal(dga, dga2) and torch.equal(dbe, dbe2)
     _sums_close(xs_sums, ref, "upstream BatchNorm sums")
@@ -1462,3 +1462,29 @@ def test_dwconv_bwd_data_bn1_prologue(k, H, W, C):
         outs[name] = (dx, sums0, dwg, dga, dbe)
     for a_, b_, what in zip(outs["ref"], outs["fused"], ("dx", "BatchNorm-0 sums", "dw", "dgamma1", "dbeta1")):
         close(b_, a_, 2e-5, 2e-5, what)
+
+
+@pytest.mark.parametrize("M,K,N,B", [(2048, 1248, 208, 8), (8192, 528, 88, 8), (16384, 144, 24, 4), (512, 96, 16, 2), (600, 144, 24, 2)])
+def test_pwconv_bwd_data_bn2_pool5_epilogue(M, K, N, B):
+    """The pooled pass of the squeeze-excite / BatchNorm-1 backward (mmd_chan_pool_bwd) taken from the output tiles of the project conv's
+    input-gradient GEMM, against the separate launch over the GEMM's output (incl. a ragged image size, which falls back to that launch)."""
+    torch.manual_seed(M + K)
+    rpi = M // B
+    g_ = torch.randn(M, N); z_ = torch.randn(M, N)
+    wt = torch.randn(K, N) / math.sqrt(N)
+    sc, sh, mu, istd = torch.rand(N) + 0.5, torch.randn(N) * 0.1, torch.randn(N) * 0.2, torch.rand(N) + 0.5
+    sums = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    gd, zd, wtd, dsc, dsh, dmu, dis = (g(t) for t in (g_, z_, wt, sc, sh, mu, istd))
+    call("mmd_bn_bwd_reduce", gd, zd, dsc, dsh, dmu, dis, 0, None, None, None, rpi, None, sums, M, N, None, 0)
+    z1 = torch.randn(M, K) * 1.1
+    s1, h1, m1, i1 = torch.rand(K) + 0.5, torch.randn(K) * 0.1, torch.randn(K) * 0.2, torch.rand(K) + 0.5
+    dx_ref = torch.empty(M, K, device=DEV); dzm = torch.empty(M, N, device=DEV)
+    call("mmd_pwconv_bwd_data_bn", gd, zd, wtd, dx_ref, M, K, N, dsc, dsh, dmu, dis, sums, M, 0, None, rpi, dzm, None, None)
+    p_ref = torch.zeros(5, B, K, device=DEV)
+    call("mmd_chan_pool_bwd", g(z1), g(s1), g(h1), g(m1), g(i1), dx_ref, p_ref, B, rpi, K)
+    dx = torch.empty(M, K, device=DEV); p5 = torch.zeros(5, B, K, device=DEV)
+    call("mmd_pwconv_bwd_data_bn2", gd, zd, wtd, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, 0, None, rpi, dzm, None, None,
+         None, None, None, None, None, 0, None, None, 0, g(z1), g(s1), g(h1), g(m1), g(i1), p5, B)
+    assert torch.equal(dx, dx_ref)
+    for k in range(5):
+        close(p5[k], p_ref[k], 1e-4, 1e-5, f"pool5[{k}]")
