@@ -567,10 +567,11 @@ class DistillEngine:
         return preds, labels
 
     @torch.no_grad()
-    def eval_losses(self, batch: Dict[str, torch.Tensor]):
-        """-> (reg, cls, kd_sum) python floats of one validation batch (eval-mode student; validate() upstream)."""
+    def eval_losses(self, batch: Dict[str, torch.Tensor], teacher_labels: Optional[List[tuple]] = None):
+        """-> (reg, cls, kd_sum) python floats of one validation batch (eval-mode student; validate() upstream,
+        src/optimization/train_methods.py:1135-1150: the sums over the step module's loss lists).  teacher_labels: as step_body."""
         self.student.refresh()
-        out = self.step_body(batch, None, train=False)
+        out = self.step_body(batch, None, teacher_labels=teacher_labels, train=False)
         return out["reg"].item(), out["cls"].item(), out["kd"].sum().item()
 
     def check_overflow(self):

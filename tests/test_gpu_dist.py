@@ -112,6 +112,54 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
     eng.optimizer_body()
     torch.cuda.synchronize()
     assert (eng.student.ps.flat.cpu() - torch.from_numpy(res[0][7])).abs().max().item() <= 2.5e-4      # one Adam step moves a weight by <= lr
+    # ---- the same two shards through the ORACLE (the reference's DDP semantics: every rank runs forward / backward on its own shard with
+    # its own BatchNorm statistics, DDP averages the gradients, every rank applies the same Adam step: src/optimization/train_methods.py:944-961)
+    import numpy as np
+    from oracle import step_ref as ST
+    from helpers import grad_state, make_state
+    from test_gpu_step import teacher_states, MODS
+    from mm_distillnet_amd.synth import synth_inputs
+    teachers = {k: v[1] for k, v in teacher_states(2, MODS).items()}
+    spec, st = make_state(2, 8, 24, "audio")
+    skip = [b for b in spec.blocks if b.skip]
+    ds = eng.make_drop_scale(B, torch.Generator(device="cuda").manual_seed(3)).cpu()
+    masks = {b.idx: torch.round(ds[i] * (1.0 - b.drop_rate)) for i, b in enumerate(skip)}
+    og, labels_equal = [], True
+    for rank in range(2):
+        so = grad_state(st)
+        hb = synth_inputs(B, S, seed=40 + rank)
+        ref = ST.distill_forward(so, teachers, hb, S, 2, masks)
+        ST.total_loss(ref).backward()
+        og.append({k: v.grad.detach().clone() for k, v in so.items() if v.requires_grad and v.grad is not None})
+        e1, _ = _build(1)
+        out = e1.step_body(_shard(rank), ds.to("cuda"))
+        torch.cuda.synchronize()
+        nb = out["nbox"].cpu().tolist()
+        labels_equal &= all(np.array_equal(out["boxes"][i, :nb[i]].cpu().numpy(), np.asarray(ref["labels"][i], dtype=np.float32).reshape(-1, 5))
+                            for i in range(B))
+    avg = {k: (og[0].get(k, 0) + og[1].get(k, 0)) / 2 for k in set(og[0]) | set(og[1])}      # DDP reduces zeros for a rank without that gradient
+    params = {k: v.detach().clone() for k, v in st.items() if k in avg}
+    ST.adam_step(params, avg, {})
+    # the two ranks' averaged gradient and their (identical) Adam-updated parameters, back in the reference's key names
+    eng.student.ps.grad.copy_((torch.from_numpy(res[0][6]) + torch.from_numpy(res[1][6])).to("cuda") / 2)
+    g2 = eng.student.ps.export_grads()
+    eng.student.ps.flat.copy_(torch.from_numpy(res[0][7]).to("cuda"))
+    w2 = eng.student.ps.export_state()
+    gtol = 2e-3 if labels_equal else 3e-2
+    print("two ranks vs oracle DDP: pseudo-labels %s the oracle's -> gradient tolerance %g of each tensor's largest value" % (
+        "equal" if labels_equal else "differ (integer truncation) from", gtol))
+    dot = n1 = n2 = 0.0
+    for k, a in avg.items():
+        b_ = g2[k].double(); a = a.double()
+        assert (a - b_).abs().max().item() <= gtol * max(a.abs().max().item(), 1e-12) + 1e-9, k
+        dot += float((a * b_).sum()); n1 += float((a * a).sum()); n2 += float((b_ * b_).sum())
+    assert dot / (n1 ** 0.5 * n2 ** 0.5) >= (0.9999 if labels_equal else 0.999)
+    lr, worst, close_n, n_el = 1e-4, 0.0, 0.0, 0
+    for k, a in params.items():
+        dlt = (w2[k].double() - a.double()).abs()
+        worst = max(worst, float(dlt.max())); close_n += float((dlt <= 0.05 * lr).sum()); n_el += dlt.numel()
+    print("two ranks vs oracle DDP: Adam-updated weights max |diff| %.2e, %.4f of the elements within 5 %% of lr" % (worst, close_n / n_el))
+    assert worst <= 2.0 * lr and close_n / n_el >= (0.99 if labels_equal else 0.95)
 
 
 def test_c_abi_rccl_communicator_one_rank():

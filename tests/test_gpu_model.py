@@ -145,3 +145,72 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     ov2 = ov[:-1] + ', "input_pipeline": "raw", "audio_augmentation_merge": "True", "exp_name": "exp_raw"}'
     loss2 = train.main(["--config_file", cfgf, "--overwrite", ov2, "--max_steps", "3"])
     assert np.isfinite(loss2)
+
+
+def test_validate_and_predict_vs_reference_golden(golden_dir):
+    """f1, the HIP half: DistillEngine.eval_losses / predict and trainer.validate against the reference's own validate() and
+    get_predictions_multiteacher (tests/golden/validate_d2_256.npz, made by tools/oracle/make_golden.py validate):
+      * with the reference's per-teacher rows fed back (no integer noise): per-batch reg / cls sums at 2e-4, KD terms 1e-4, and the merged
+        multi-teacher labels bit for bit;
+      * with the GPU teachers' / student's own decode + NMS: >= 95 % of the reference rows within 1 px, counts within 5 %, losses and the
+        val_loss / Test scalars of validate() at 2e-2.
+    Reference: src/optimization/train_methods.py:1083-1185, src/utils/utils.py:1720-1893."""
+    import configparser
+    from mm_distillnet_amd import trainer as TR
+    from mm_distillnet_amd.step import DistillEngine, StepConfig
+    from test_oracle_golden import val_states
+    g = np.load(os.path.join(golden_dir, "validate_d2_256.npz"))
+    S, N, B = int(g["image_size"]), int(g["n"]), int(g["batch"])
+    tstates, spec, st_s = val_states()
+    from mm_distillnet_amd.arch import make_spec
+    eng = DistillEngine(spec, {"rgb": make_spec(2, 3), "depth": make_spec(2, 3), "thermal": make_spec(2, 1)}, DEV, StepConfig(image_size=S))
+    eng.load(st_s, tstates)
+    data = synth_inputs(N, S, seed=61)
+    A = eng.student.anchors(S).shape[0]
+
+    def rows_match(got, ref):
+        assert abs(got.shape[0] - ref.shape[0]) <= max(2, 0.05 * ref.shape[0]), (got.shape, ref.shape)
+        return sum(int(got.shape[0] > 0 and (np.abs(got[:, :4] - r[:4]).max(1) <= 1.0).any()) for r in ref), ref.shape[0]
+
+    hit = tot = 0
+    for b in range(N // B):
+        batch = {k: v[b * B:(b + 1) * B].to(DEV) for k, v in data.items()}
+        # (a) reference labels in: everything downstream of the pseudo-labels at kernel tolerances
+        labels = eng.labels_from_rows([[g[f"teacher{ti}_img{b * B + i}"] for i in range(B)] for ti in range(3)], A)
+        reg, cls, kd = eng.eval_losses(batch, teacher_labels=labels)
+        np.testing.assert_allclose(reg, g["batch_reg"][b], rtol=2e-4)
+        np.testing.assert_allclose(cls, g["batch_cls"][b], rtol=2e-4)
+        np.testing.assert_allclose(eng.out["kd"].cpu().numpy(), g["batch_kd"][b].reshape(eng.out["kd"].shape), rtol=1e-4, atol=1e-5)
+        nb = eng.out["nbox"].cpu().tolist()
+        for i in range(B):
+            np.testing.assert_array_equal(eng.out["boxes"][i, :nb[i]].cpu().numpy(), g[f"label_img{b * B + i}"])
+        # (b) the GPU nets' own decode + NMS
+        preds, labs = eng.predict(batch)
+        for i in range(B):
+            h, t = rows_match(preds[i], g[f"pred_img{b * B + i}"]); hit += h; tot += t
+            h, t = rows_match(labs[i], g[f"label_img{b * B + i}"]); hit += h; tot += t
+    print("validate golden: %d / %d reference rows (student detections + merged labels) within 1 px" % (hit, tot))
+    assert hit >= 0.95 * tot
+
+    class Set(torch.utils.data.Dataset):
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return data["rgb"][i], data["thermal"][i], data["depth"][i], data["audio"][i], None, i
+
+    c = configparser.ConfigParser()
+    c["DEFAULT"] = {"batch_size": str(B), "num_workers": "0", "w_main": "1.0", "w_kd": "0.005", "num_epoches": "1"}
+
+    def collate(items):
+        cols = list(zip(*items))
+        return [torch.stack(cols[0]), torch.stack(cols[1]), torch.stack(cols[2]), torch.stack(cols[3]), list(cols[4]), list(cols[5])]
+
+    def to_batch(item):
+        return {"rgb": item[0].to(DEV), "thermal": item[1].to(DEV), "depth": item[2].to(DEV), "audio": item[3].to(DEV)}
+
+    w = TR.ScalarLog("val")
+    val_loss = TR.validate(eng, Set(), c["DEFAULT"], 0, w, to_batch, collate, 1)
+    np.testing.assert_allclose(val_loss, float(g["val_loss"]), rtol=2e-2)
+    for tag in ("Test/Regression_loss", "Test/Class_loss", "Test/KD", "Test/Total_loss"):      # the scalars validate() writes, same tags
+        np.testing.assert_allclose(w.data["val/" + tag][-1][2], float(g["scalar." + tag]), rtol=2e-2, atol=1e-6)

@@ -170,3 +170,46 @@ def test_step(golden_dir, variant):
         if k.startswith("adam.") and k.endswith(".head"):
             name = k[5:-5]
             check_summary(g, "adam." + name, params[name], 1e-5, 1e-6)
+
+
+VAL_MODS = {"rgb": (3, 21), "depth": (3, 22), "thermal": (1, 23)}
+VAL_BIAS = {"rgb": -2.0, "depth": -3.2, "thermal": -2.0}
+
+
+def val_states():
+    """tools/oracle/make_golden.py val_states(), repeated with the shared recipe."""
+    tstates = {k: make_state(2, cin, seed, k, cls_bias=VAL_BIAS[k])[1] for k, (cin, seed) in VAL_MODS.items()}
+    spec, st_s = make_state(2, 8, 24, "audio", cls_bias=-2.0)
+    return tstates, spec, st_s
+
+
+def test_validate_and_predictions_golden(golden_dir):
+    """The oracle's validation path (eval-mode student, no augmentation, no backward) against the reference's own validate() and
+    get_predictions_multiteacher run on a 4-sample synthetic set (tests/golden/validate_d2_256.npz): per-batch loss sums, the val_loss
+    / Test scalars assembled the way validate() does, student detections and merged multi-teacher labels row for row."""
+    g = np.load(os.path.join(golden_dir, "validate_d2_256.npz"))
+    S, N, B = int(g["image_size"]), int(g["n"]), int(g["batch"])
+    tstates, spec, st_s = val_states()
+    data = synth_inputs(N, S, seed=61)
+    tot = reg_t = cls_t = kd_t = 0.0
+    for b in range(N // B):
+        batch = {k: v[b * B:(b + 1) * B] for k, v in data.items()}
+        with torch.no_grad():
+            out = ST.distill_forward(st_s, tstates, batch, S, 2, None, training=False)
+        reg, cls, kd = out["reg"].item(), out["cls"].item(), torch.stack(out["kd"]).numpy()
+        np.testing.assert_allclose(reg, g["batch_reg"][b], rtol=1e-5)
+        np.testing.assert_allclose(cls, g["batch_cls"][b], rtol=1e-5)
+        np.testing.assert_allclose(kd, g["batch_kd"][b].reshape(kd.shape), rtol=1e-5, atol=1e-6)
+        tot += (1.0 * (reg + cls) + 0.005 * kd.sum()) * B; reg_t += reg * B; cls_t += cls * B; kd_t += kd.sum() * 0.005 * B
+        for i in range(B):
+            k = b * B + i
+            np.testing.assert_array_equal(np.asarray(out["labels"][i], dtype=np.float32).reshape(-1, 5), g[f"label_img{k}"])
+            for ti in range(3):
+                np.testing.assert_array_equal(np.asarray(out["per_teacher"][ti][i], dtype=np.float32).reshape(-1, 6), g[f"teacher{ti}_img{k}"])
+        preds = P.logits_to_ground_truth(out["logits_s"], S, 0.3, 0.5)
+        for i in range(B):
+            np.testing.assert_array_equal(np.asarray(preds[i], dtype=np.float32).reshape(-1, 6), g[f"pred_img{b * B + i}"])
+    np.testing.assert_allclose(tot / N, g["val_loss"], rtol=1e-5)
+    np.testing.assert_allclose(reg_t / N, g["scalar.Test/Regression_loss"], rtol=1e-5)
+    np.testing.assert_allclose(cls_t / N, g["scalar.Test/Class_loss"], rtol=1e-5)
+    np.testing.assert_allclose(kd_t / N, g["scalar.Test/KD"], rtol=1e-5)

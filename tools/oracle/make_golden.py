@@ -433,10 +433,123 @@ def golden_metrics():
           "n_pred", int(d["pred_counts"].sum()), "n_gt", int(d["lab_counts"].sum()))
 
 
+VAL_S, VAL_N, VAL_B = 256, 4, 2          # validation golden: 4 samples of 256^2 in batches of 2
+
+
+def val_states():
+    """Teacher / student states of the validation golden (tests repeat it through helpers.make_state): the step goldens' teachers and a
+    student whose classifier bias lets the eval-mode student emit detections."""
+    mods = {"rgb": (3, 21), "depth": (3, 22), "thermal": (1, 23)}
+    bias = {"rgb": -2.0, "depth": -3.2, "thermal": -2.0}
+    tstates = {k: make_state(2, cin, seed, k, cls_bias=bias[k])[1] for k, (cin, seed) in mods.items()}
+    spec, st_s = make_state(2, 8, 24, "audio", cls_bias=-2.0)
+    return mods, tstates, spec, st_s
+
+
+def golden_validate():
+    """The reference's validate() (src/optimization/train_methods.py:1083-1185) and get_predictions_multiteacher
+    (src/utils/utils.py:1720-1893) run as they are on a 4-sample synthetic set: eval-mode student, validate=True, per-batch loss sums
+    times the sample count over len(val_set), the Test/* scalars; student detections + merged multi-teacher pseudo ground truth."""
+    import inspect
+    import tempfile
+    tm = refshim.load_train_methods()
+    S, N, B = VAL_S, VAL_N, VAL_B
+    mods, tstates, spec, st_s = val_states()
+    data = synth_inputs(N, S, seed=61)
+    tmp = tempfile.mkdtemp()
+    for i in range(N):                       # get_predictions_multiteacher drops a <timestamp>.all.txt next to each sample
+        os.makedirs(os.path.join(tmp, f"drive{i}"))
+
+    class Set(torch.utils.data.Dataset):
+        valid_classes_dict = VALID
+        data_path = tmp
+
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return data["rgb"][i], data["thermal"][i], data["depth"][i], data["audio"][i], [], f"drive{i}/{1000 + i}"
+
+    teachers = torch.nn.ModuleDict()
+    for k in ("rgb", "depth", "thermal"):
+        teachers[k] = ref_model(2, mods[k][0], tstates[k])
+    teachers.eval()
+    student = ref_model(2, 8, st_s).train()          # validate() itself switches the student to eval()
+    model = tm.ModelWithNMSLoss(student, teachers, YetAnotherFocalLoss(), None, MTALoss(T="9", p="2"), cfg(S), VALID)
+
+    class Wrap(torch.nn.Module):                      # validate() reaches the student through model.module (DataParallel / DDP)
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+
+    c = configparser.ConfigParser()
+    c["DEFAULT"] = {"student": "YetAnotherEfficientDet_D2", "image_size": str(S), "conf_threshold": "0.3", "nms_threshold": "0.5",
+                    "valid_labels": "car", "batch_size": str(B), "num_workers": "0", "use_thermal": "True", "use_depth": "True",
+                    "use_rgb": "True", "w_main": "1.0", "w_div": "0.0", "w_kd": "0.005", "num_epoches": "1", "student_modality": "audio",
+                    "use_labels": "False"}
+    conf = c["DEFAULT"]
+
+    class Writer:
+        def __init__(self):
+            self.rows = {}
+
+        def add_scalar(self, tag, v, step):
+            self.rows[tag] = float(v)
+
+    # per-batch terms, recorded by wrapping the step module's forward
+    per_batch = []
+    inner = model.forward
+
+    def spy(*a, **k):
+        out = inner(*a, **k)
+        per_batch.append((float(torch.sum(torch.stack(out[0]))), float(torch.sum(torch.stack(out[1]))),
+                          torch.stack(out[2]).detach().numpy().copy(), bool(k.get("validate", False)), bool(k.get("augment", False))))
+        return out
+
+    model.forward = spy
+    w = Writer()
+    val_loss = tm.validate(Set(), Wrap(model), 0, conf, w)
+    assert not student.training and all(pb[3] and not pb[4] for pb in per_batch)
+    d = {"val_loss": np.float64(float(val_loss)), "n": np.int64(N), "batch": np.int64(B), "image_size": np.int64(S)}
+    for tag, v in w.rows.items():
+        d["scalar." + tag] = np.float64(v)
+    d["batch_reg"] = np.array([pb[0] for pb in per_batch]); d["batch_cls"] = np.array([pb[1] for pb in per_batch])
+    d["batch_kd"] = np.stack([pb[2] for pb in per_batch])
+    # get_predictions_multiteacher, with the numpy >= 1.25 fix applied to its text in memory (`ndarray == []`), as for train_methods
+    src = inspect.getsource(RU.get_predictions_multiteacher).replace("batch_labels[i] == []", "isListEmpty(batch_labels[i])")
+    ns = dict(RU.__dict__)
+    exec(compile(src, "get_predictions_multiteacher(patched)", "exec"), ns)
+    preds, labs, flat = ns["get_predictions_multiteacher"](teachers, student, Set(), conf)
+    k = 0
+    for bp, bl in zip(preds, labs):
+        for i in range(len(bl)):
+            d[f"pred_img{k}"] = np.asarray(bp[i] if len(bp) else [], dtype=np.float32).reshape(-1, 6)
+            d[f"label_img{k}"] = np.asarray(bl[i], dtype=np.float32).reshape(-1, 5)
+            k += 1
+    assert k == N
+    d["labels_flat"] = np.asarray(flat, dtype=np.float64)
+    # the teachers' own rows per image (what the tight GPU test feeds back in place of the GPU teachers' decode + NMS)
+    with torch.no_grad():
+        for ti, m in enumerate(("rgb", "depth", "thermal")):
+            for b0 in range(0, N, B):          # in the loader's batches of B (conv results can differ in the last bit with the batch size)
+                pred, _ = teachers[m](data[m][b0:b0 + B])
+                rows = RU.logits_to_ground_truth(pred, None, VALID, cfg(S), include_scores=True)
+                for i in range(B):
+                    d[f"teacher{ti}_img{b0 + i}"] = np.asarray(rows[i], dtype=np.float32).reshape(-1, 6)
+    np.savez_compressed(os.path.join(OUT, "validate_d2_256.npz"), **d)
+    print("validate", d["val_loss"], w.rows, "batch reg/cls", d["batch_reg"], d["batch_cls"],
+          "preds", [d[f"pred_img{i}"].shape[0] for i in range(N)], "labels", [d[f"label_img{i}"].shape[0] for i in range(N)])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step", "metrics"]
+    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step", "metrics", "validate"]
     if "metrics" in which:
         golden_metrics()
+    if "validate" in which:
+        golden_validate()
     if "keys" in which:
         golden_state_keys()
     if "net" in which:
