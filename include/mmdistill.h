@@ -33,6 +33,11 @@ int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const float* up, c
 int mmd_bifpn_node_fused_supported(int C);
 int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* w_pw, const float* bias, const float* scale, const float* shift, float* y, int B, int H, int W, int C, hipStream_t stream);
 
+// The same node for the TRAINABLE net in train mode: z = the raw 1x1-conv output (+ bias), stats [2C] (+)= [sum z, sum z^2] (the batch
+// statistics of the node's BatchNorm, src/YetAnotherEfficientDet.py:171-176), zd = the depthwise output (read by the 1x1 conv's weight
+// gradient in the backward).  C == 112.
+int mmd_bifpn_node_fwd_fused_train(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats, int B, int H, int W, int C, hipStream_t stream);
+
 // Backward of the fusion node, part 1: dx = df*swish'(x), wdot[i] += <dx, operand_i>.
 int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* df, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, hipStream_t stream);
 

@@ -199,15 +199,18 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
 constexpr int FN_C = 112, FN_Q = FN_C / 4, FN_FS = FN_C, FN_ZS = FN_C + 4, FN_WS = FN_C + 4, FN_NT = 512;
 constexpr int FN_U = (100 * FN_FS > FN_C * FN_WS) ? 100 * FN_FS : FN_C * FN_WS;      // input tile, later the 1x1 weights
 
-template <int MODE>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
+// TRAIN (the student's nodes): y = the RAW 1x1-conv output z (+ bias), its per-channel sums (sum z, sum z^2: the node's train-mode BatchNorm
+// statistics) go to `stats`, and the depthwise output tile is also stored (zd_out: the 1x1 conv's weight gradient reads it in the backward).
+template <int MODE, bool TRAIN = false>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
 __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ y,
-                                                                int tiles_h, int tiles_w) {
+                                                                int tiles_h, int tiles_w, float* __restrict__ zd_out, double* stats) {
   extern __shared__ float smem[];
   float* const sU = smem;                       // [100][FS] fused input tile | [C][WS] pointwise weights
   float* const sZ = smem + FN_U;                // [64][ZS] depthwise output tile
   float* const sWd = sZ + 64 * FN_ZS;           // [9][C] depthwise taps
+  float* const sSt = sWd + 9 * FN_C;            // TRAIN: [2][C] block sums
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
@@ -224,6 +227,7 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     wreg[i] = idx < NW4 ? mmd_ld4(wpw + (size_t)idx * 4) : make_float4(0, 0, 0, 0);
   }
   for (int i = tid; i < 9 * FN_Q; i += FN_NT) *reinterpret_cast<float4*>(&sWd[i * 4]) = mmd_ld4(wdw + (size_t)i * 4);
+  if (TRAIN) for (int i = tid; i < 2 * FN_C; i += FN_NT) sSt[i] = 0.f;
   // ---- phase 0: every global load of the thread's (pixel, quad) items is issued before the first use (one block per CU: nothing else
   // would hide six dependent load latencies); the pooled operand's 3x3 window is gathered in the second pass
   {
@@ -292,6 +296,10 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
         acc.x += x.x * k.x; acc.y += x.y * k.y; acc.z += x.z * k.z; acc.w += x.w * k.w;
       }
     *reinterpret_cast<float4*>(&sZ[p * FN_ZS + q * 4]) = acc;
+    if (TRAIN) {
+      const int oh = oh0 + orow, ow = ow0 + ocol;
+      if (oh < a.H && ow < a.W) mmd_st4(zd_out + (((size_t)b * a.H + oh) * a.W + ow) * FN_C + q * 4, acc);
+    }
   }
   __syncthreads();                                   // every read of the input tile is done: park the 1x1 weights in its place
 #pragma unroll
@@ -308,7 +316,8 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = min(((wave >> 2) + 2 * j) * 16 + r, FN_C - 1);
-    ebi[j] = bias ? bias[n] : 0.f; esc[j] = scale[n]; esh[j] = shift[n];
+    ebi[j] = bias ? bias[n] : 0.f;
+    if (!TRAIN) { esc[j] = scale[n]; esh[j] = shift[n]; } else { esc[j] = 1.f; esh[j] = 0.f; }
   }
   float af[28];
   {
@@ -339,12 +348,26 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     acc += acc1;
     const int n = ct * 16 + r;
     const float bi = ebi[j4], sc = esc[j4], sh = esh[j4];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int p = rt * 16 + 4 * g + i;
       const int oh = oh0 + (p >> 3), ow = ow0 + (p & 7);
-      if (oh < a.H && ow < a.W) y[(((size_t)b * a.H + oh) * a.W + ow) * FN_C + n] = (acc[i] + bi) * sc + sh;
+      if (oh < a.H && ow < a.W) {
+        const float v = TRAIN ? acc[i] + bi : (acc[i] + bi) * sc + sh;
+        y[(((size_t)b * a.H + oh) * a.W + ow) * FN_C + n] = v;
+        if (TRAIN) { s1 += v; s2 += v * v; }
+      }
     }
+    if (TRAIN) {      // lanes r, r+16, r+32, r+48 hold the same channel (pixel groups g): fold them, then the four row-tile waves through LDS
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (g == 0) { atomicAdd(&sSt[n], s1); atomicAdd(&sSt[FN_C + n], s2); }
+    }
+  }
+  if (TRAIN) {
+    __syncthreads();
+    for (int i = tid; i < 2 * FN_C; i += FN_NT) atomicAdd(&stats[i], (double)sSt[i]);
   }
 }
 
@@ -372,7 +395,7 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
   mmd_prof_begin(MMD_FAM_MBX, stream);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw)), blk(FN_NT);
-#define MMD_NODE_FWD(M) hipLaunchKernelGGL(bifpn_node_fused_kernel<M>, grid, blk, lds, stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw)
+#define MMD_NODE_FWD(M) hipLaunchKernelGGL(bifpn_node_fused_kernel<M>, grid, blk, lds, stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw, nullptr, nullptr)
   if (mode == 2) MMD_NODE_FWD(2);             // (in, up): top-down nodes
   else if (mode == 5) MMD_NODE_FWD(5);        // (in, td, pool): bottom-up nodes
   else if (mode == 4) MMD_NODE_FWD(4);        // (in, pool): p7_out
@@ -381,6 +404,37 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
 #undef MMD_NODE_FWD
   const double rows = (double)B * H * W;
   mmd_prof_end(MMD_FAM_MBX, stream, rows * C * (2.0 * 9 + 2.0 * C), 4.0 * rows * C * (a.ntheta + 1 + (pool ? 3 : 0)));
+  return mmd_check_launch();
+}
+
+// Whole TRAINABLE-net BiFPN node forward (train mode): z[B*H*W, C] = dw3x3(swish(fuse(operands))) · w_pw[C,C]ᵀ + bias (raw, pre-BatchNorm),
+// stats[2C] (+)= [sum z, sum z^2] (the BatchNorm's batch statistics), zd[B*H*W, C] = the depthwise output (kept for the backward).  One
+// launch instead of mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd(stats) on the student's forward chain.
+extern "C" int mmd_bifpn_node_fwd_fused_train(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
+                                              const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats,
+                                              int B, int H, int W, int C, hipStream_t stream) {
+  FuseArgs a{};
+  int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (rc || !w_dw || !w_pw || !z || !zd || !stats || C != FN_C || (in1 && up)) return MMD_EINVAL;
+  const int th = cdiv(H, 8), tw = cdiv(W, 8);
+  constexpr size_t lds = (size_t)(FN_U + 64 * FN_ZS + 9 * FN_C + 2 * FN_C) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
+  const dim3 grid((unsigned)(B * th * tw)), blk(FN_NT);
+#define MMD_NODE_FWD_T(M) hipLaunchKernelGGL((bifpn_node_fused_kernel<M, true>), grid, blk, lds, stream, a, w_dw, w_pw, bias, nullptr, nullptr, z, th, tw, zd, stats)
+  if (mode == 2) MMD_NODE_FWD_T(2);
+  else if (mode == 5) MMD_NODE_FWD_T(5);
+  else if (mode == 4) MMD_NODE_FWD_T(4);
+  else if (mode == 1) MMD_NODE_FWD_T(1);
+  else return MMD_EINVAL;
+#undef MMD_NODE_FWD_T
   return mmd_check_launch();
 }
 

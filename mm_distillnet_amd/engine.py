@@ -235,6 +235,7 @@ class Net:
     STATS_SLOTS = 0 if os.environ.get("MMD_NO_SLOTS") else 64
     DW_WG = not os.environ.get("MMD_NO_DW_WG")          # stride-1 backbone layers: depthwise weight gradient inside the input-gradient launch
     NODE_WG = not os.environ.get("MMD_NO_NODE_WG")      # BiFPN nodes: depthwise weight gradient inside the node's backward launch
+    FUSE_NODE_TRAIN = not os.environ.get("MMD_NO_NODE_FUSE_TRAIN")   # trainable net: a BiFPN node's forward (fusion, depthwise, 1x1 conv, BN sums) in one kernel
     FUSE_NODE = not os.environ.get("MMD_NO_NODE_FUSE")  # frozen nets: a BiFPN node (fusion, depthwise, 1x1 conv, BN) in one kernel
     FUSE_FRONT = not os.environ.get("MMD_NO_MBX")       # frozen nets: expand + depthwise of the thin-input blocks in one kernel
 
@@ -494,6 +495,29 @@ class Net:
                  self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
                  self.ps.w(f"{name}.pointwise_conv.conv.bias"), b["fscale"], b["fshift"], y, in0.B, in0.H, in0.W, in0.C)
             return Feat(y, in0.B, in0.H, in0.W, in0.C)
+        if (train and self.FUSE_NODE_TRAIN and self.NODE_WG and self.precision == "fp32" and self.ps.flat.is_cuda
+                and _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) == 1):
+            # trainable net: fusion + depthwise + 1x1 conv + BatchNorm sums in one launch (raw z out, depthwise output kept for the backward)
+            name, W = f"{cell}.{conv}", in0.C
+            bn_name = f"{name}.bn"
+            st = self._bn_stats(bn_name, True)
+            z, zd = self._alloc(in0.M, W), self._alloc(in0.M, W)
+            call("mmd_bifpn_node_fwd_fused_train", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                 self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
+                 self.ps.w(f"{name}.pointwise_conv.conv.bias"), z, zd, st, in0.B, in0.H, in0.W, W)
+            a = self._bn_aff(bn_name, True, st, in0.M)
+            if y is None:
+                y = self._alloc(in0.M, W)
+            call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, in0.M, W)
+            for operand in (in0, in1, up, pl):
+                if operand is not None:
+                    self._use(operand)
+            zdf = Feat(zd, in0.B, in0.H, in0.W, W)
+            out = Feat(y, in0.B, in0.H, in0.W, W)
+            self._bnout[y.data_ptr()] = (z, a[2], a[3], W, None, 0)
+            tape.setdefault(cell + ".nodes", []).append({"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": zdf, "conv": conv,
+                                                         "zd": zdf, "z": z, "bn": a, "out": out})
+            return out
         # the fused activation is not materialised: the node's backward launch recomputes it, also for the depthwise weight gradient
         # (MMD_NO_NODE_WG=1: the earlier form - f written here, weight gradient by its own launch on the side stream - for A/B timing)
         f = self._alloc(in0.M, in0.C) if (train and not self.NODE_WG) else None

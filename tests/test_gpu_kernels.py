@@ -1488,3 +1488,32 @@ def test_pwconv_bwd_data_bn2_pool5_epilogue(M, K, N, B):
     assert torch.equal(dx, dx_ref)
     for k in range(5):
         close(p5[k], p_ref[k], 1e-4, 1e-5, f"pool5[{k}]")
+
+
+@pytest.mark.parametrize("mode,H,W", [("td", 8, 8), ("bu", 16, 12), ("p7", 4, 4), ("td", 64, 64), ("bu", 6, 10), ("p7", 2, 2)])
+def test_bifpn_node_whole_fused_train(mode, H, W):
+    """Train-mode whole-node forward of the trainable net (raw 1x1 output + BatchNorm batch sums + the depthwise output kept for the
+    backward) against the two launches it replaces: mmd_bifpn_node_dw_fwd -> mmd_pwconv_fwd(bias, stats)."""
+    torch.manual_seed(19)
+    B, C = 2, 112
+    in0 = torch.randn(B * H * W, C)
+    in1 = torch.randn(B * H * W, C) if mode == "bu" else None
+    up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
+    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7") else None
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    wd = torch.randn(9, C) / 3
+    wp = torch.randn(C, C) / math.sqrt(C); bias = torch.randn(C) * 0.1
+    gp = lambda t: g(t) if t is not None else None
+    M = B * H * W
+    zd_ref = torch.zeros(M, C, device=DEV)
+    call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), None, zd_ref, B, H, W, C)
+    z_ref = torch.empty(M, C, device=DEV)
+    st_ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_pwconv_fwd", zd_ref, g(wp), z_ref, M, C, C, None, None, 0, None, None, None, 0, None, H * W, g(bias), None, None, 0,
+         None, st_ref, 0, 0, None, 0)
+    z = torch.full((M, C), float("nan"), device=DEV); zd = torch.full((M, C), float("nan"), device=DEV)
+    st = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bifpn_node_fwd_fused_train", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(wp), g(bias), z, zd, st, B, H, W, C)
+    close(zd, zd_ref, 1e-6, 1e-7, "depthwise output")
+    close(z, z_ref, 1e-4, 1e-5, "raw 1x1 output")
+    close(st[:C], st_ref[:C], 1e-4, 1e-4, "sum z"); close(st[C:], st_ref[C:], 1e-4, 1e-5, "sum z^2")

