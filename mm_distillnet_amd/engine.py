@@ -44,7 +44,10 @@ WG_GROUP = not os.environ.get("MMD_NO_WG_GROUP")
 # the OTHER leaves (depthwise / squeeze-excite / fusion-weight / bias gradients) stay forked off the main chain where they arise: small and
 # latency-bound, they fill the main chain's gaps - deferring them to the segment end as well measured 20.8-22.1 ms/step against 20.5
 WG_DEFER = WG_GROUP and bool(os.environ.get("MMD_WG_DEFER"))
-WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "60"))     # flush the grouped launch every WG_CHUNK recorded layers (two launches per D2 backward: 19.66 vs 19.8-20.2 ms/step for one, 20.5+ for four)
+# flush the grouped launch every WG_CHUNK recorded layers.  D2 records 99 layers per backward: 60 (round 2) = two launches, the second - every backbone layer below block 19 - alone at
+# the very end of the backward (0.93 ms exposed); 45 = three, the last one only blocks 4..0 + stem while the second overlaps the high-resolution blocks' main chain
+# (round 3, alternating runs: 16.52 / 16.81 -> 16.55 / 16.66 ms/step, medians 16.65 -> 16.47; 50: 16.70 / 16.82, 80: 16.99 / 17.01; round 2: 30 / 15 layers 20.5 / 20.8 vs 19.7 for 60)
+WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "45"))
 WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "4096"))      # rows per item: 4096 x (64x64 tile) measured best (1.33 ms per step vs 2.58 at 256)
 WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "4096"))
 

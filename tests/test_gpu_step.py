@@ -402,12 +402,12 @@ def test_full_size_step_graph_vs_oracle():
     masks = [{b.idx: torch.floor((1.0 - b.drop_rate) + torch.rand(B, generator=gen)) for b in skip} for _ in range(2)]
     ds = [torch.stack([m[b.idx] / (1.0 - b.drop_rate) for b in skip]).to(DEV) for m in masks]
     batch = {k: v.to(DEV) for k, v in hb.items()}
-    # ---- oracle: two consecutive steps (forward, losses, backward, Adam; running statistics carried in the state dict)
+    # ---- oracle: one step (forward, losses, backward, Adam) from its current state; called once per GPU step below
     so = grad_state(st_s)
     params = {k: v for k, v in so.items() if v.requires_grad}
     opt_state = {}
-    refs = []
-    for step in range(2):
+
+    def oracle_step(step):
         for v in params.values():
             v.grad = None
         ref = ST.distill_forward(so, tstates, hb, S, coef, masks[step])
@@ -415,10 +415,10 @@ def test_full_size_step_graph_vs_oracle():
         grads = {k: v.grad.detach().clone() for k, v in params.items() if v.grad is not None}
         with torch.no_grad():
             ST.adam_step(params, grads, opt_state)
-        refs.append({"reg": ref["reg"].item(), "cls": ref["cls"].item(), "kd": torch.stack(ref["kd"]).detach().numpy(), "grads": grads,
-                     "per_teacher": ref["per_teacher"], "labels": ref["labels"],
-                     "weights": {k: v.detach().clone() for k, v in params.items()}})
-        del ref
+        return {"reg": ref["reg"].item(), "cls": ref["cls"].item(), "kd": torch.stack(ref["kd"]).detach().numpy(), "grads": grads,
+                "per_teacher": ref["per_teacher"], "labels": ref["labels"], "weights": {k: v.detach().clone() for k, v in params.items()}}
+
+    refs = [oracle_step(0)]
     nlab = [int(np.size(l) // 6) for t in refs[0]["per_teacher"] for l in t]
     print("oracle pseudo-labels per (teacher, image):", nlab, "merged per image:", [int(np.size(l) // 5) for l in refs[0]["labels"]])
     assert sum(nlab) >= 3 * B * 10
@@ -450,6 +450,16 @@ def test_full_size_step_graph_vs_oracle():
     eng.capture(batch)
     lr = eng.lr
     for step in range(2):
+        if step == 1:
+            # the second step is compared from IDENTICAL states: the oracle continues from the HIP engine's parameters and running
+            # statistics after its first step (Adam's first step is sign-like, so the two trajectories differ by up to 2 lr on the few
+            # weights whose gradient is ~eps, and these random-weight nets amplify that to ~1 % of the next gradient)
+            w_gpu = eng.student.ps.export_state()
+            with torch.no_grad():
+                for k, v in so.items():
+                    if v.dtype.is_floating_point:
+                        v.copy_(w_gpu[k])
+            refs.append(oracle_step(1))
         out = eng.replay(batch, ds[step])
         torch.cuda.synchronize()
         eng.check_overflow()
