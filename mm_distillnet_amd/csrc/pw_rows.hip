@@ -4,8 +4,8 @@
 // expand convs 16->96 ... 120->720) and a tall M (B*H*W rows).  An LDS-tiled K loop has 1-4 iterations there, so its blocks run
 // load -> LDS -> barrier -> MFMA -> barrier -> store in lock step and the MFMA pipe idles ~60 % of the time (profiles/r01_notes.md).
 // This kernel removes the K loop and every barrier from the steady state:
-//   * the weight panel W[pcols, K] is staged ONCE per block into LDS (row stride K+4 floats: the 64 lanes' ds_read_b64
-//     fragments hit every bank exactly twice = the minimum) and stays resident;
+//   * the weight panel W[pcols, K] is staged ONCE per block into LDS (row stride K+4 floats: a 32-lane group's ds_read_b64
+//     fragments cover the 64 banks exactly once - as long as the reads stay single ds_read_b64, see the fragment loop) and stays resident;
 //   * each WAVE owns 16-row slabs of X: the whole-K A fragment of a slab lives in registers (K/4 VGPRs), loaded straight
 //     from global memory in the MFMA operand layout (lane (r, g) -> row r, k = 8kk + 2g + {0,1}: 32 B per row per
 //     instruction, all bytes of the 16 rows over the K/8 instructions issued back to back), the NEXT slab's fragment is
@@ -180,13 +180,20 @@ __global__ __launch_bounds__(512, 2) void pw_rows_kernel(PwArgs a, RowsArgs ra) 
         f32x4 acc[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* bp = sB + (cbase + r) * LDB + 2 * g;
+        // B fragments as single ds_read_b64 (32-lane groups, bank = dword address mod 64: rows r * (K+4) + 2g + {0,1} cover the 64 banks
+        // exactly once per group).  Left to itself the compiler pairs the reads of k groups kk and kk+1 (32 B apart) into ds_read2_b64,
+        // whose 16-lane groups bank modulo 32 - rows r and r+8 then collide (SQ_LDS_BANK_CONFLICT 139 % of the LDS cycles in
+        // profiles/r02_sq_counters_by_kernel.txt); an opaque LDS byte address per k group keeps them apart.
+        typedef const __attribute__((address_space(3))) f32x2* lds_f2p;
+        const unsigned bp0 = (unsigned)(uintptr_t)(lds_vptr)(uintptr_t)(sB + (cbase + r) * LDB + 2 * g);
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
           if ((ra.mode & RW_ABL_NOMFMA) && kk > 0) break;
           f32x2 b[C];
+          unsigned bpk = bp0 + kk * 32;
+          asm volatile("" : "+v"(bpk));
 #pragma unroll
-          for (int j = 0; j < C; ++j) b[j] = *reinterpret_cast<const f32x2*>(bp + j * 16 * LDB + kk * 8);
+          for (int j = 0; j < C; ++j) b[j] = *(lds_f2p)(uintptr_t)(bpk + j * 16 * LDB * 4);
 #pragma unroll
           for (int j = 0; j < C; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[kk].x, b[j].x, acc[j], 0, 0, 0);
 #pragma unroll
