@@ -1018,7 +1018,12 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
   }
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * N, stream);
-  mmd_prof_end(MMD_FAM_PW, stream, 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
+  // algorithmic bytes of the launch's contract: A, B, Y once each, plus what the fused prologue / epilogue jobs move by definition - the
+  // second A tensor (z) and the stored dz of a BatchNorm-backward operand, a residual, the z of the output's BatchNorm sums, the z1 of
+  // the pooled squeeze-excite pass
+  const double a_elems = (double)M * K * (a.bb.z ? (a.bb.dz_out ? 3.0 : 2.0) : 1.0);
+  const double y_elems = (double)M * N * (1.0 + (a.residual ? 1.0 : 0.0) + (a.xs.z ? 1.0 : 0.0) + (a.p5.z ? 1.0 : 0.0));
+  mmd_prof_end(MMD_FAM_PW, stream, 2.0 * M * (double)K * N, 4.0 * (a_elems + y_elems + (double)N * K));
   return mmd_check_launch();
 }
 

@@ -16,10 +16,13 @@ python tools/dev/trace_summary.py $kt 6 70 > $out/step_summary.txt; head -3 $out
 cp $ks $out/kernel_stats.csv
 grep -h '"metric"' $out/trace.log | tail -1 | cut -c1-200 > $out/bench_under_rocprof.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1 || { tail -5 $out/pmc_$c.log; exit 1; }
+  MMD_PROF_DUMP=$out/prof_dump_$c.csv rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1 || { tail -5 $out/pmc_$c.log; exit 1; }
 done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/dev/pmc_summary.py $f $w > $out/pmc_hbm_traffic.csv; cat $out/pmc_hbm_traffic.csv
+# the GEMM family's traffic per shape (excess over the algorithmic bytes: where the re-reads are)
+python tools/dev/pmc_by_shape.py $f $w $out/prof_dump_FETCH_SIZE.csv > $out/pmc_gemm_by_shape.txt 2>&1; head -30 $out/pmc_gemm_by_shape.txt
+python tools/dev/prof_by_shape.py $out/prof_dump_FETCH_SIZE.csv 1 80 > $out/by_shape.txt 2>&1
 # keep only the small summaries (the raw traces are tens of MB)
 rm -rf $out/trace $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 ls -la $out
