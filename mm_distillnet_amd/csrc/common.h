@@ -31,6 +31,39 @@ __device__ __forceinline__ float mmd_act(float x, int act) {
 __device__ __forceinline__ float4 mmd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void mmd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- bf16 storage of the wide (6x expanded) MBConv tensors in HBM ("w16", BASELINE config 5) ------------------------------------------
+// A tensor argument flagged w16 is a bf16 array behind the same `float*`-typed parameter; arithmetic stays fp32: loads widen exactly
+// (bf16 -> f32 is a 16-bit shift), stores round to nearest even (v_cvt_pk_bf16_f32).  Offsets are in ELEMENTS from `p`.
+typedef __bf16 mmd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mmd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned mmd_pk_bf16(float a, float b) {
+  mmd_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mmd_bf16x2));
+}
+__device__ __forceinline__ float4 mmd_ldw4(const float* p, size_t off, int w16) {
+  if (w16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(p + off);
+}
+__device__ __forceinline__ void mmd_stw4(float* p, size_t off, const float4& v, int w16) {
+  if (w16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + off) = make_uint2(mmd_pk_bf16(v.x, v.y), mmd_pk_bf16(v.z, v.w));
+  else *reinterpret_cast<float4*>(p + off) = v;
+}
+__device__ __forceinline__ float mmd_ldw1(const float* p, size_t off, int w16) {
+  if (w16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[off] << 16);
+  return p[off];
+}
+__device__ __forceinline__ void mmd_stw1(float* p, size_t off, float v, int w16) {
+  if (w16) reinterpret_cast<unsigned short*>(p)[off] = (unsigned short)(mmd_pk_bf16(v, 0.f) & 0xffffu);
+  else p[off] = v;
+}
+// row pointer of a [rows, C] tensor that may be w16: `float*` arithmetic in bytes of the actual element size
+__device__ __forceinline__ const float* mmd_roww(const float* base, size_t row, int C, int w16) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + row * (size_t)C * (w16 ? 2 : 4));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -38,6 +38,7 @@ struct DwArgs {
   // to HBM first ([M, C] write + read per block); q_dgamma / q_dbeta (+)= [sum g'*xhat, sum g'] by the first tile's blocks.
   const float* q_z; const float* q_gate; const float* q_add; const float* q_scale; const float* q_shift; const float* q_mean;
   const float* q_invstd; const double* q_sums; double q_inv_count; float* q_dgamma; float* q_dbeta;
+  int x16, y16, bz16, qz16;      // bf16 storage (common.h w16) of x, y, bz, q_z - tile kernel only
 };
 
 // LANES = float4 lanes per pixel (16 -> 64-channel chunks; 8 / 4 -> 32- / 16-channel chunks for the thin early layers,
@@ -57,7 +58,7 @@ template <int K, int S, int LANES = 16> struct DwCfg {
 // registers: copying the whole argument struct and patching it put it in scratch memory (296 B/lane)
 struct DwView {
   const float* x; int H, W, C;
-  float4 sc, sh; bool xf; int act;
+  float4 sc, sh; bool xf; int act; int x16;
 };
 
 __device__ __forceinline__ void dw_in_coef(const float* in_scale, const float* in_shift, const BnLive& bn, int c, bool cok,
@@ -88,7 +89,7 @@ __device__ __forceinline__ void dw_stage_input(const DwView& a, float* sIn, int 
     const int ih = ih0 + p / Cf::IW, iw = iw0 + p % Cf::IW;
     ok[it] = cok && p < NPIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
     const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);     // unconditional load, masked below
-    v[it] = mmd_ld4(a.x + (((size_t)b * a.H + ihc) * a.W + iwc) * a.C + (cok ? c : 0));
+    v[it] = mmd_ldw4(a.x, (((size_t)b * a.H + ihc) * a.W + iwc) * a.C + (cok ? c : 0), a.x16);
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -121,8 +122,8 @@ __device__ __forceinline__ void dw_stage_input_bnbwd(const DwArgs& a, float* sIn
     ok[it] = cok && p < NPIX && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
     const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);
     const size_t off = (((size_t)b * a.H + ihc) * a.W + iwc) * a.C + cc;
-    v[it] = mmd_ld4(a.x + off);
-    zv[it] = mmd_ld4(a.q_z + off);
+    v[it] = mmd_ldw4(a.x, off, a.x16);
+    zv[it] = mmd_ldw4(a.q_z, off, a.qz16);
   }
   const float4 gt = mmd_ld4(a.q_gate + (size_t)b * a.C + cc), ad = mmd_ld4(a.q_add + (size_t)b * a.C + cc);
   const float4 a1 = mmd_ld4(a.q_scale + cc), sh = mmd_ld4(a.q_shift + cc), mu = mmd_ld4(a.q_mean + cc), is = mmd_ld4(a.q_invstd + cc);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   const bool cok = c < a.C;
   const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
   DwView v;
-  v.x = a.x + ro; v.H = H; v.W = W; v.C = a.C; v.act = a.in_act;
+  v.x = a.x + ro; v.H = H; v.W = W; v.C = a.C; v.act = a.in_act; v.x16 = a.x16;      // (pyramid launches are never w16: ro is in fp32 elements)
   {
     BnLive bn = a.in_bn;
     const long long lo = (long long)lev * a.lev_stride;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     if (cok && oh < OH && ow < OW) {
       float4 v = acc[o];
       if (E_BZ && a.bz) {
-        const float4 zz = mmd_ld4(a.bz + (((size_t)b * OH + oh) * OW + ow) * a.C + c);
+        const float4 zz = mmd_ldw4(a.bz, (((size_t)b * OH + oh) * OW + ow) * a.C + c, a.bz16);
         if (WG) fq[o] = make_float4(mmd_swish(zz.x * bsc.x + bsh.x), mmd_swish(zz.y * bsc.y + bsh.y), mmd_swish(zz.z * bsc.z + bsh.z),
                                     mmd_swish(zz.w * bsc.w + bsh.w));
         float4 gg;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
         if (a.out_act == MMD_ACT_SWISH) { t.x = mmd_swish(t.x); t.y = mmd_swish(t.y); t.z = mmd_swish(t.z); t.w = mmd_swish(t.w); }
         pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
       }
-      mmd_st4(yout + (((size_t)b * OH + oh) * OW + ow) * a.C + c, t);
+      mmd_stw4(yout, (((size_t)b * OH + oh) * OW + ow) * a.C + c, t, a.y16);
     }
   }
   if (((E_ST || E_BZ) && a.stats) || (E_OUT && a.pool)) {
@@ -647,7 +648,7 @@ static int dw3_rows_go(DwArgs& a, hipStream_t st) {
 // producer transform the R + 2 loaded columns per R outputs make narrow strips (R < 4) more expensive than the tile's 1.56x halo.
 static int dw3_rows_launch(DwArgs& a, hipStream_t st) {
   static const int mode = getenv("MMD_DW_ROWS") ? atoi(getenv("MMD_DW_ROWS")) : 1;
-  if (!mode) return 1;
+  if (!mode || a.x16 || a.y16 || a.bz16 || a.qz16) return 1;      // (bf16 storage: tile kernel)
   if (a.stats && (a.out_scale || a.out_act != MMD_ACT_NONE || a.pool)) return 1;      // sums + folded epilogue together: tile kernel only
   const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
   const int lw = a.C <= 16 ? 4 : (a.C <= 32 ? 8 : 16);
@@ -699,6 +700,37 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   else rc = dw_fwd_launch<5, 2>(a, stream);
   mmd_prof_end(MMD_FAM_DW, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
                4.0 * ((double)B * H * W * C + (double)B * a.OH * a.OW * C));
+  return rc;
+}
+
+// same contract with bf16 storage of the wide tensors: w16 bit 0 = x, bit 1 = y are bf16 arrays (common.h)
+extern "C" int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
+                                  const float* in_scale, const float* in_shift, int in_act,
+                                  const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
+                                  const float* out_scale, const float* out_shift, int out_act,
+                                  double* stats, float* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
+  if (in_stats && (in_scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
+  DwArgs a{};
+  a.x = x; a.w = w; a.y = y; a.B = B; a.H = H; a.W = W; a.C = C;
+  a.pad_t = same_pad_lo(H, k, stride, &a.OH); a.pad_l = same_pad_lo(W, k, stride, &a.OW);
+  a.flip = 0; a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  a.in_bn = mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C);
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
+  a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
+  a.stats_ws = stats_ws; a.ws_slots = ws_slots;
+  a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1;
+  mmd_prof_tag(MMD_FAM_DW, "dw16 H%lld C%lld k%lld s%lld", H, C, k, stride);
+  mmd_prof_begin(MMD_FAM_DW, stream);
+  int rc;
+  if (k == 3 && stride == 1) rc = dw_fwd_launch<3, 1, 16>(a, stream);
+  else if (k == 3) rc = dw_fwd_launch<3, 2>(a, stream);
+  else if (stride == 1) rc = dw_fwd_launch<5, 1>(a, stream);
+  else rc = dw_fwd_launch<5, 2>(a, stream);
+  mmd_prof_end(MMD_FAM_DW, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
+               (a.x16 ? 2.0 : 4.0) * (double)B * H * W * C + (a.y16 ? 2.0 : 4.0) * (double)B * a.OH * a.OW * C);
   return rc;
 }
 
@@ -841,6 +873,13 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
   return rc;
 }
 
+extern "C" int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
+                                           const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd,
+                                           const double* q_sums, long long q_count, const float* q_gate, const float* q_add,
+                                           float* q_dgamma, float* q_dbeta,
+                                           const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                           const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad,
+                                           int w16, hipStream_t stream);
 // Input gradient of an MBConv block's stride-1 depthwise conv with the BatchNorm-1 (+swish, squeeze-excite gate / pooled term) backward
 // evaluated in the prologue instead of by mmd_bn_bwd_apply: dY = BnBwd1(g1, z1; gate, dpooled, sums1) is never written to HBM.  Always
 // together with the BatchNorm-0 sums (bn_*) and the conv's weight gradient, as the engine runs these layers.  C >= 64 channels (64-wide chunks).
@@ -851,6 +890,17 @@ extern "C" int mmd_dwconv_bwd_data_bn1(const float* g1, const float* z1, const f
                                        const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                        const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad,
                                        hipStream_t stream) {
+  return mmd_dwconv_bwd_data_bn1_w16(g1, z1, w, dx, B, H, W, C, k, q_scale, q_shift, q_mean, q_invstd, q_sums, q_count, q_gate, q_add, q_dgamma,
+                                     q_dbeta, bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_sums, stats_ws, ws_slots, dw_grad, 0, stream);
+}
+// bf16 storage: w16 bit 0 = g1, bit 1 = dx, bit 2 = z1, bit 3 = bn_z are bf16 arrays
+extern "C" int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
+                                           const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd,
+                                           const double* q_sums, long long q_count, const float* q_gate, const float* q_add,
+                                           float* q_dgamma, float* q_dbeta,
+                                           const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                           const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad,
+                                           int w16, hipStream_t stream) {
   if (!g1 || !z1 || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C < 64 || (C & 3) || (k != 3 && k != 5)) return MMD_EINVAL;
   if (!q_scale || !q_shift || !q_mean || !q_invstd || !q_sums || q_count <= 0 || !q_gate || !q_add) return MMD_EINVAL;
   if ((q_dgamma == nullptr) != (q_dbeta == nullptr)) return MMD_EINVAL;
@@ -865,6 +915,7 @@ extern "C" int mmd_dwconv_bwd_data_bn1(const float* g1, const float* z1, const f
   a.dwg = dw_grad;
   a.q_z = z1; a.q_gate = q_gate; a.q_add = q_add; a.q_scale = q_scale; a.q_shift = q_shift; a.q_mean = q_mean; a.q_invstd = q_invstd;
   a.q_sums = q_sums; a.q_inv_count = 1.0 / (double)q_count; a.q_dgamma = q_dgamma; a.q_dbeta = q_dbeta;
+  a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1; a.qz16 = (w16 >> 2) & 1; a.bz16 = (w16 >> 3) & 1;
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd1 H%lld C%lld k%lld s%lld", H, C, k, 1);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
   const int rc = (k == 3) ? dw_fwd_launch<3, 1, 16>(a, stream) : dw_fwd_launch<5, 1, 16>(a, stream);

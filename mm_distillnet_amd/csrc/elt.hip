@@ -155,7 +155,7 @@ extern "C" int mmd_affine_act(const float* z, const float* scale, const float* s
 __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, BnLive bn, int act,
                                                         const float* __restrict__ g, float* __restrict__ out,
-                                                        float out_scale, int rows_per_image, int C, int nsplit) {
+                                                        float out_scale, int rows_per_image, int C, int nsplit, int z16) {
   __shared__ float sRed[256];
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
 #pragma unroll 4
     for (int r = blockIdx.z * 16 + (tid >> 4); r < rows_per_image; r += 16 * nsplit) {
       size_t off = ((size_t)b * rows_per_image + r) * C + c;
-      float4 v = mmd_ld4(z + off);
+      float4 v = mmd_ldw4(z, off, z16);
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
       if (act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
       if (g) { float4 q = mmd_ld4(g + off); v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
   float s = block_chan_sum(acc, sRed, tid);
   if (tid < 64 && blockIdx.x * 64 + tid < C) atomicAdd(&out[(size_t)b * C + blockIdx.x * 64 + tid], s * out_scale);
 }
-extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* shift, const double* in_stats,
-                             const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
-                             float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
+static int chan_pool_impl(const float* z, const float* scale, const float* shift, const double* in_stats,
+                          const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
+                          float* out, float out_scale, int B, int rows_per_image, int C, int z16, hipStream_t stream) {
   if (!z || !out || B <= 0 || rows_per_image <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
   if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
@@ -192,9 +192,20 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
   mmd_prof_tag(MMD_FAM_ELT, "cpool B%lld R%lld C%lld", B, rows_per_image, C, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   hipLaunchKernelGGL(chan_pool_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift,
-                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, g, out, out_scale, rows_per_image, C, ns);
+                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, g, out, out_scale, rows_per_image, C, ns, z16);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * B * (double)rows_per_image * C * (g ? 2 : 1));
   return mmd_check_launch();
+}
+extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* shift, const double* in_stats,
+                             const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
+                             float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
+  return chan_pool_impl(z, scale, shift, in_stats, in_gamma, in_beta, in_count, act, g, out, out_scale, B, rows_per_image, C, 0, stream);
+}
+// z is a bf16 array (common.h w16)
+extern "C" int mmd_chan_pool_w16(const float* z, const float* scale, const float* shift, const double* in_stats,
+                                 const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
+                                 float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
+  return chan_pool_impl(z, scale, shift, in_stats, in_gamma, in_beta, in_count, act, g, out, out_scale, B, rows_per_image, C, 1, stream);
 }
 
 // Backward companion of the squeeze-excite pool: ONE pass over (z1, g1) yields, per (image, channel), everything the

@@ -27,6 +27,7 @@ struct MbxArgs {
   const float* wd; const float* sc1; const float* sh1;
   float* y; float* pool; float pool_scale;
   int B, H, W, Cin, C, OH, OW, pad_t, pad_l, tiles_h, tiles_w, cchunks;
+  int y16;      // y is a bf16 array (common.h w16)
 };
 
 template <int K, int S> struct MbxCfg;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
             t.x = mmd_swish(acc[o].x * osc.x + osh.x); t.y = mmd_swish(acc[o].y * osc.y + osh.y);
             t.z = mmd_swish(acc[o].z * osc.z + osh.z); t.w = mmd_swish(acc[o].w * osc.w + osh.w);
             pl.x += t.x; pl.y += t.y; pl.z += t.z; pl.w += t.w;
-            mmd_st4(a.y + (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + cb, t);
+            mmd_stw4(a.y, (((size_t)b * a.OH + oh) * a.OW + ow) * a.C + cb, t, a.y16);
           }
         }
       }
@@ -230,9 +231,9 @@ extern "C" int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stri
 
 // y[B,OH,OW,Cmid] = swish(dwconv_same(swish(x[B,H,W,Cin] · w_expand[Cmid,Cin]ᵀ * scale0 + shift0), w_dw[k*k,Cmid]) * scale1 + shift1);
 // pool[B,Cmid] += mean over OH x OW of y (pool may be null).  OH = ceil(H / stride).
-extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
-                                        const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
-                                        int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
+static int mbx_impl(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+                    const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                    int B, int H, int W, int Cin, int Cmid, int k, int stride, int y16, hipStream_t stream) {
   if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y || B <= 0 || H <= 0 || W <= 0) return MMD_EINVAL;
   if (!mmd_mbconv_expand_dw_supported(Cin, Cmid, k, stride)) return MMD_EINVAL;
   MbxArgs a{};
@@ -240,6 +241,7 @@ extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, c
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.C = Cmid;
   a.pad_t = mbx_same_pad_lo(H, k, stride, &a.OH); a.pad_l = mbx_same_pad_lo(W, k, stride, &a.OW);
   a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
+  a.y16 = y16;
   mmd_prof_tag(MMD_FAM_MBX, "mbx H%lld K%lld N%lld k%lld", H, Cin, Cmid, k * 10 + stride);
   mmd_prof_begin(MMD_FAM_MBX, stream);
   int rc;
@@ -252,6 +254,17 @@ extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, c
     default: rc = mbx_launch_ks<14>(a, k, stride, stream); break;
   }
   mmd_prof_end(MMD_FAM_MBX, stream, 2.0 * B * H * W * (double)Cin * Cmid + 2.0 * B * a.OH * a.OW * (double)Cmid * k * k,
-               4.0 * ((double)B * H * W * Cin + (double)B * a.OH * a.OW * Cmid));
+               4.0 * (double)B * H * W * Cin + (y16 ? 2.0 : 4.0) * (double)B * a.OH * a.OW * Cmid);
   return rc;
+}
+extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+                                        const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                        int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
+  return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 0, stream);
+}
+// y is stored as a bf16 array (common.h w16): the frozen nets' activated depthwise output, read back by the project conv
+extern "C" int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+                                            const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                            int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
+  return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 1, stream);
 }

@@ -74,6 +74,9 @@ struct PwArgs {
   StemOp st;                                 // PRO == 2: the A operand is the im2col of an NCHW image, gathered on the fly
   BnSumOp xs;                                // epilogue: `stats` = BatchNorm-backward sums of the output instead of (sum y, sum y^2)
   Pool5Op p5;                                // epilogue: squeeze-excite / BatchNorm-1 backward partial sums of the output
+  // bf16 storage ("w16", common.h): which tensors of the launch are bf16 arrays - the A operand x, the output y, and for the
+  // BatchNorm-backward operand launches the second A tensor bb.z, the stored dz (bb.dz_out) and the pooled pass' z (p5.z)
+  int x16, y16, z16, dz16, p5z16;
 };
 
 

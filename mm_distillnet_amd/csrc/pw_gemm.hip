@@ -46,8 +46,8 @@ __device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t of
 
 // Pool5Op epilogue: one output quad v (= g1) at `off` -> the five running sums (chan_pool_bwd_kernel's arithmetic)
 struct P5Coef { float4 sc, sh, mu, is; };
-__device__ __forceinline__ void pw_p5_acc(const Pool5Op& p, const P5Coef& q, const float4& v, size_t off, float4 (&acc)[5]) {
-  const float4 zz = mmd_ld4(p.z + off);
+__device__ __forceinline__ void pw_p5_acc(const Pool5Op& p, const P5Coef& q, const float4& v, size_t off, float4 (&acc)[5], int z16) {
+  const float4 zz = mmd_ldw4(p.z, off, z16);
   const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {v.x, v.y, v.z, v.w};
   const float scv[4] = {q.sc.x, q.sc.y, q.sc.z, q.sc.w}, shv[4] = {q.sh.x, q.sh.y, q.sh.z, q.sh.w};
   const float muv[4] = {q.mu.x, q.mu.y, q.mu.z, q.mu.w}, isv[4] = {q.is.x, q.is.y, q.is.z, q.is.w};
@@ -119,14 +119,14 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     int row = m0 + lrow + i * 32;
     rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
-    xrow[i] = a.x + (size_t)rr * a.K;
+    xrow[i] = mmd_roww(a.x, rr, a.K, a.x16);
     if constexpr (PRO == 2) {
       const int ow = rr % a.st.OW, t1 = rr / a.st.OW, oh = t1 % a.st.OH, b = t1 / a.st.OH;
       sih[i] = oh * 2 - a.st.pad_t; siw[i] = ow * 2 - a.st.pad_l;
       xrow[i] = a.x + (size_t)b * a.st.Cin * a.st.H * a.st.W;
       grow[i] = nullptr;
     } else if constexpr (PRO == 1) {
-      grow[i] = a.bb.z + (size_t)rr * a.K;                 // the second A tensor rides in the gate's registers
+      grow[i] = mmd_roww(a.bb.z, rr, a.K, a.z16);          // the second A tensor rides in the gate's registers
       rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
     } else if constexpr (PRO == 3) {
       grow[i] = nullptr;
@@ -187,19 +187,19 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       kcur = kc;
       bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
-      for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
+      for (int i = 0; i < NA; ++i) { ra[i] = mmd_ldw4(xrow[i], kc, a.x16); rg[i] = mmd_ldw4(grow[i], kc, a.z16); }
     } else if constexpr (PRO == 3) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) ra[i] = mmd_ld4(xrow[i] + kc);
+      for (int i = 0; i < NA; ++i) ra[i] = mmd_ldw4(xrow[i], kc, a.x16);
     } else if constexpr (PRO == 4) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) { ra[i] = mmd_ld4(xrow[i] + kc); rg[i] = mmd_ld4(grow[i] + kc); }
+      for (int i = 0; i < NA; ++i) { ra[i] = mmd_ldw4(xrow[i], kc, a.x16); rg[i] = mmd_ld4(grow[i] + kc); }
     } else {
       if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, rsc, rsh);
       else if (a.in_scale) { rsc = mmd_ld4(a.in_scale + kc); rsh = mmd_ld4(a.in_shift + kc); }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        ra[i] = mmd_ld4(xrow[i] + kc);
+        ra[i] = mmd_ldw4(xrow[i], kc, a.x16);
         if (a.gate) rg[i] = mmd_ld4(grow[i] + kc);
       }
     }
@@ -215,7 +215,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
         v.x = (mk & 1) ? v.x : 0.f; v.y = (mk & 2) ? v.y : 0.f; v.z = (mk & 4) ? v.z : 0.f; v.w = (mk & 8) ? v.w : 0.f;
       } else if constexpr (PRO == 1) {
         v = bn_bwd_eval4(v, rg[i], rowsc[i], a.bb.act, bq);
-        if (a.bb.dz_out && tn == 0 && kok && rok[i]) mmd_st4(a.bb.dz_out + (size_t)(m0 + lrow + i * 32) * a.K + kcur, v);
+        if (a.bb.dz_out && tn == 0 && kok && rok[i]) mmd_stw4(a.bb.dz_out, (size_t)(m0 + lrow + i * 32) * a.K + kcur, v, a.dz16);
       } else if constexpr (PRO == 3) {
       } else if constexpr (PRO == 4) {
         v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w;
@@ -333,9 +333,9 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
         off = (size_t)row * a.N + col;
       }
       if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-      mmd_st4(a.y + off, v);
+      mmd_stw4(a.y, off, v, a.y16);
       if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
-      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a); }
+      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a, a.p5z16); }
     }
   }
   if constexpr (PRO == 1) {
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     int row = m0 + lrow + i * 8;
     rok[i] = row < Mv;
     int rr = rok[i] ? row : 0;
-    xrow[i] = a.x + (size_t)rr * a.K;
+    xrow[i] = mmd_roww(a.x, rr, a.K, a.x16);
     if constexpr (PRO == 1) {
-      grow[i] = a.bb.z + (size_t)rr * a.K;
+      grow[i] = mmd_roww(a.bb.z, rr, a.K, a.z16);
       rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
     } else if constexpr (PRO == 3) {
       grow[i] = nullptr;
@@ -481,19 +481,19 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     if constexpr (PRO == 1) {
       bn_bwd_coef4(a.bb, kc, s.bq);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ld4(xrow[i] + kc); s.rg[i] = mmd_ld4(grow[i] + kc); }
+      for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ldw4(xrow[i], kc, a.x16); s.rg[i] = mmd_ldw4(grow[i], kc, a.z16); }
     } else if constexpr (PRO == 3) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s.ra[i] = mmd_ld4(xrow[i] + kc);
+      for (int i = 0; i < 4; ++i) s.ra[i] = mmd_ldw4(xrow[i], kc, a.x16);
     } else if constexpr (PRO == 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ld4(xrow[i] + kc); s.rg[i] = mmd_ld4(grow[i] + kc); }
+      for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ldw4(xrow[i], kc, a.x16); s.rg[i] = mmd_ld4(grow[i] + kc); }
     } else {
       if (a.in_bn.stats) bn_live_coef4(a.in_bn, kc, s.rsc, s.rsh);
       else if (a.in_scale) { s.rsc = mmd_ld4(a.in_scale + kc); s.rsh = mmd_ld4(a.in_shift + kc); }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        s.ra[i] = mmd_ld4(xrow[i] + kc);
+        s.ra[i] = mmd_ldw4(xrow[i], kc, a.x16);
         if (a.gate) s.rg[i] = mmd_ld4(grow[i] + kc);
       }
     }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       float4 v = s.ra[i];
       if constexpr (PRO == 1) {
         v = bn_bwd_eval4(v, s.rg[i], rowsc[i], a.bb.act, s.bq);
-        if (a.bb.dz_out && tn == 0 && s.kok && rok[i]) mmd_st4(a.bb.dz_out + (size_t)(m0 + lrow + i * 8) * a.K + s.kc, v);
+        if (a.bb.dz_out && tn == 0 && s.kok && rok[i]) mmd_stw4(a.bb.dz_out, (size_t)(m0 + lrow + i * 8) * a.K + s.kc, v, a.dz16);
       } else if constexpr (PRO == 3) {
       } else if constexpr (PRO == 4) {
         v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w;
@@ -629,9 +629,9 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
         off = (size_t)row * a.N + col;
       }
       if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-      mmd_st4(a.y + off, v);
+      mmd_stw4(a.y, off, v, a.y16);
       if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
-      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a); }
+      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a, a.p5z16); }
     }
   }
   if constexpr (PRO == 1) {
@@ -907,8 +907,9 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
                               const float* bias, const float* out_scale, const float* out_shift, int out_act,
                               const float* residual, double* stats,
                               long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots,
-                              hipStream_t stream, int bf16) {
+                              hipStream_t stream, int bf16, int w16 = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !x || !w || !y) return MMD_EINVAL;
+  if ((w16 & 2) && (residual || y_batch_stride)) return MMD_EINVAL;      // a bf16 output has no residual / strided form
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
   if ((out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -918,6 +919,7 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
            bias, out_scale, out_shift, out_act, residual, stats, nullptr, 0, y_batch_stride, y_offset, 0, 0, Pyr{},
            {0, 0, 0, 0, 0}, 0, bf16};
   if (stats && stats_ws && ws_slots > 1 && cdiv(M, PW_BM) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
+  a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1;
   return pw_dispatch(a, stream);
 }
 
@@ -933,6 +935,18 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
 extern "C" int mmd_pwconv_fwd(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 0); }
 // same contract, operands rounded to bf16 at the MFMA input (fp32 accumulate, fp32 in/out tensors)
 extern "C" int mmd_pwconv_fwd_bf16(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 1); }
+// same contract with bf16 STORAGE of the wide operand ("w16", common.h): w16 bit 0 = x is a bf16 array, bit 1 = y is (no residual / strided
+// output then); bf16_mma = 1 selects the bf16 MFMA as mmd_pwconv_fwd_bf16.  BatchNorm sums are taken from the fp32 values before rounding.
+extern "C" int mmd_pwconv_fwd_w16(const float* x, const float* w, float* y, int M, int K, int N,
+                                  const float* in_scale, const float* in_shift, int in_act,
+                                  const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
+                                  const float* gate, int rows_per_image,
+                                  const float* bias, const float* out_scale, const float* out_shift, int out_act,
+                                  const float* residual, double* stats,
+                                  long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, int bf16_mma, int w16,
+                                  hipStream_t stream) {
+  return pw_fwd_impl(PW_FWD_ARGS, bf16_mma, w16);
+}
 
 int mmd_pw_stem_gemm(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l,
                      int Kp, int Cout, const float* out_scale, const float* out_shift, int out_act, double* stats,
@@ -966,11 +980,12 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   // 64x64 tiles (2x2 waves) for layers with sq_min <= big_tiles < sq_tiles
   static const int sq_tiles = getenv("MMD_SQ_TILES") ? atoi(getenv("MMD_SQ_TILES")) : 800;
   static const int sq_min = getenv("MMD_SQ_MIN") ? atoi(getenv("MMD_SQ_MIN")) : 160;
-  if (pw_rows_try(a, stream) == 1) {
+  const bool w16 = a.x16 || a.y16 || a.z16 || a.dz16 || a.p5z16;      // bf16 storage: the LDS-tiled kernels only
+  if (!w16 && pw_rows_try(a, stream) == 1) {
     // thin-K row-slab kernel (pw_rows.hip) took the launch
-  } else if (pw_longk_try(a, stream) == 1) {
+  } else if (!w16 && pw_longk_try(a, stream) == 1) {
     // long-K small-M kernel with the LDS-DMA pipelined K loop (pw_longk.hip)
-  } else if (use_stream && K <= 128 && big_tiles >= 160) {
+  } else if (use_stream && !w16 && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
     else pw_stream_launch<2, 2>(a, stream);
@@ -1066,6 +1081,7 @@ struct WgArgs {
   const float* gate; int rows_per_image;
   int mchunk; int ntn; int ntk; int nblk;
   BnBwdOp bb; float* dgamma; float* dbeta;      // BNP: dy is BnBwd(dy = g, bb.z) evaluated on the fly; dgamma/dbeta (+)= from bb.sums
+  int dy16, x16;                                // bf16 storage of dy / x (common.h w16)
 };
 #define WG_LD 68
 #ifndef WG_BR
@@ -1121,12 +1137,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
       int row = mb + lrow + i * 16;
       s.rok[i] = row < mend;
       const int rc = s.rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
-      s.rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+      s.rd[i] = mmd_ldw4(a.dy, (size_t)rc * a.N + (nok ? n0 + c4 : 0), a.dy16);
       if constexpr (BNP) {
         s.rz[i] = mmd_ld4(a.bb.z + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
         s.rrs[i] = a.bb.mul_b ? a.bb.mul_b[rc / a.bb.rows_per_image] : 1.f;
       }
-      s.rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
+      s.rx[i] = mmd_ldw4(a.x, (size_t)rc * a.K + (kok ? k0 + c4 : 0), a.x16);
       if (a.gate) s.rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
     }
   };
@@ -1199,12 +1215,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgArgs a) {
 static int pw_wgrad_impl(const float* dy, const float* x, float* dw, int M, int K, int N,
                                      const float* in_scale, const float* in_shift, int in_act,
                                      const float* gate, int rows_per_image, hipStream_t stream, int bf16,
-                                     const BnBwdOp* bb = nullptr, float* dgamma = nullptr, float* dbeta = nullptr) {
+                                     const BnBwdOp* bb = nullptr, float* dgamma = nullptr, float* dbeta = nullptr, int w16 = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !dy || !x || !dw) return MMD_EINVAL;
   if (gate && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
   WgArgs a{dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image > 0 ? rows_per_image : 1, 0, 0, 0, 0, BnBwdOp{}, nullptr, nullptr};
   if (bb) { a.bb = *bb; a.dgamma = dgamma; a.dbeta = dbeta; }
+  a.dy16 = w16 & 1; a.x16 = (w16 >> 1) & 1;
   a.ntn = cdiv(N, 64); a.ntk = cdiv(K, 64);
   int tiles = a.ntn * a.ntk;
   // enough blocks to fill 256 CUs a few times over, but every split ends in N*K fp32 atomics (1.3 TB/s chip-wide):
@@ -1254,6 +1271,12 @@ static int pw_wgrad_bn_impl(const float* g, const float* z, const float* x, floa
                      mul_b, bn_rows_per_image, dgamma, dbeta, stream
 extern "C" int mmd_pwconv_bwd_weight_bn(PW_WGBN_PARAMS) { return pw_wgrad_bn_impl(PW_WGBN_ARGS, 0); }
 extern "C" int mmd_pwconv_bwd_weight_bn_bf16(PW_WGBN_PARAMS) { return pw_wgrad_bn_impl(PW_WGBN_ARGS, 1); }
+// bf16 storage: w16 bit 0 = dy, bit 1 = x are bf16 arrays
+extern "C" int mmd_pwconv_bwd_weight_w16(const float* dy, const float* x, float* dw, int M, int K, int N,
+                                         const float* in_scale, const float* in_shift, int in_act,
+                                         const float* gate, int rows_per_image, int bf16_mma, int w16, hipStream_t stream) {
+  return pw_wgrad_impl(dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, bf16_mma, nullptr, nullptr, nullptr, w16);
+}
 extern "C" int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N,
                                           const float* in_scale, const float* in_shift, int in_act,
                                           const float* gate, int rows_per_image, hipStream_t stream) {
@@ -1304,7 +1327,7 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
                                 const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image,
                                 double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale,
                                 const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B,
-                                hipStream_t stream, int bf16) {
+                                hipStream_t stream, int bf16, int w16 = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
   if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
   if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
@@ -1317,6 +1340,8 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
   a.residual = residual;
   a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1,
                  dz_out, dgamma, dbeta};
+  a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1; a.z16 = (w16 >> 2) & 1; a.dz16 = (w16 >> 3) & 1; a.p5z16 = (w16 >> 4) & 1;
+  if (a.y16 && (residual || xs_z)) return MMD_EINVAL;
   if (xs_z) {
     a.xs = BnSumOp{xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image > 0 ? xs_rows_per_image : 1};
     a.stats = xs_sums;
@@ -1330,6 +1355,7 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
       a.p5 = Pool5Op{p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, p5_out, p5_B, rpi};
       return pw_dispatch(a, stream);
     }
+    if (a.y16 || a.p5z16) return MMD_EINVAL;      // (the stand-alone pooled pass reads fp32 tensors)
     const int rc = pw_dispatch(a, stream);      // ragged image size: the pooled pass as its own launch
     return rc ? rc : mmd_chan_pool_bwd(p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, dx, p5_out, p5_B, rpi, K, stream);
   }
@@ -1346,6 +1372,15 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
                     p5_invstd, p5_out, p5_B, stream
 extern "C" int mmd_pwconv_bwd_data_bn2(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0); }
 extern "C" int mmd_pwconv_bwd_data_bn2_bf16(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 1); }
+// bf16 storage of the wide tensors: w16 bit 0 = g, bit 1 = dx, bit 2 = z, bit 3 = dz_out, bit 4 = p5_z are bf16 arrays
+extern "C" int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b,
+                      int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z,
+                      const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums,
+                      double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift,
+                      const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, int bf16_mma, int w16, hipStream_t stream) {
+  return pw_bwd_data_bn2_impl(PW_BD2_ARGS, bf16_mma, w16);
+}
 
 extern "C" int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                       const float* scale, const float* shift, const float* mean, const float* invstd,
