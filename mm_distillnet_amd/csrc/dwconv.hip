@@ -58,7 +58,7 @@ template <int K, int S, int LANES = 16> struct DwCfg {
 // registers: copying the whole argument struct and patching it put it in scratch memory (296 B/lane)
 struct DwView {
   const float* x; int H, W, C;
-  float4 sc, sh; bool xf; int act; int x16;
+  float4 sc, sh; bool xf; int act; int x16 = 0;      // x16: x is a bf16 array (set by dw_fwd_kernel only; every other user reads fp32)
 };
 
 __device__ __forceinline__ void dw_in_coef(const float* in_scale, const float* in_shift, const BnLive& bn, int c, bool cok,

@@ -54,7 +54,7 @@ class StepConfig:
     cand_cap: int = 0                  # rows per image of the candidate / pseudo-label arrays; 0 = every anchor (the reference
                                        # has no cap, src/utils/utils.py:179-205), so nothing can overflow
     augment: bool = False              # cfg audio_augmentation_merge (ModelWithNMSLossAugmented.forward augment=True)
-    precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors)
+    precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors); "bf16_hbm": + the wide MBConv tensors stored as bf16
 
 
 class DistillEngine:

@@ -327,7 +327,7 @@ def test_dwconv(k, s, H, W, C):
         got = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
         dx2 = torch.empty_like(dxo)
         call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx2, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got, None, 0, None)
-        assert torch.equal(dx2, dxo)
+        close(dx2, dxo, 1e-6, 1e-7, "dx of the BatchNorm-sum variant")      # (another instantiation of the tile kernel: same taps, the fp32 contraction may differ in the last bit)
         close(got, ref, 1e-5, 1e-5, "BN sums fused into dw bwd-data")
         if True:         # ... and the conv's weight gradient out of the same launch (x = swish(BN(z)) recomputed from z)
             got2 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
@@ -1646,7 +1646,7 @@ def test_w16_mbconv_backward_launches():
     sums0 = outs["ref"][1]
     base = torch.randn(M, cin)
     dx_ref = g(base.clone()); dz_ref = torch.empty(M, cmid, device=DEV)
-    none15 = (None,) * 5 + (0,) + (None, None, 0) + (None,) * 6 + (0,)
+    none15 = (None,) * 4 + (0,) + (None, None, 0) + (None,) * 6 + (0,)      # no upstream sums, no pooled pass
     call("mmd_pwconv_bwd_data_bn2_bf16", g(g0f), g(z0), g(wt_e), dx_ref, M, cin, cmid, g(sc0), g(sh0), g(mu0), g(is0), sums0, M, 1, None, H * W,
          dz_ref, None, None, dx_ref, *none15)
     dx = g(base.clone()); dz16 = torch.empty(M, cmid, dtype=torch.bfloat16, device=DEV)
