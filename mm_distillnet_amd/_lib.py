@@ -15,6 +15,9 @@ import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMD_LIB") or os.path.join(PKG, "libmmdistill_hip.so")      # MMD_LIB: another build of the same library (A/B timing)
+# the same sources built WITH the bf16-storage branches (csrc/common.h "w16"): the *_w16 entry points are bound to this one, so the
+# default library - the fp32 headline path - carries no run-time storage tests
+LIB16_PATH = os.environ.get("MMD_LIB16") or os.path.join(PKG, "libmmdistill_hip_w16.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "mmdistill.h")
 
 _CT = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
@@ -44,17 +47,18 @@ def parse_header(path: str = HEADER) -> Dict[str, list]:
 
 
 class _Lib:
-    def __init__(self):
+    def __init__(self, path: str = LIB_PATH):
         self._dll = None
         self._sigs = None
+        self._path = path
 
     def load(self):
         if self._dll is None:
-            if not os.path.exists(LIB_PATH):
+            if not os.path.exists(self._path):
                 raise RuntimeError(
-                    f"{LIB_PATH} is missing: build it with `python -m mm_distillnet_amd.build` "
+                    f"{self._path} is missing: build it with `python -m mm_distillnet_amd.build` "
                     "(there is no CPU or PyTorch fallback for the HIP path)")
-            self._dll = ctypes.CDLL(LIB_PATH)
+            self._dll = ctypes.CDLL(self._path)
             self._sigs = parse_header()
             for name, types in self._sigs.items():
                 fn = getattr(self._dll, name)
@@ -68,6 +72,7 @@ class _Lib:
 
 
 LIB = _Lib()
+LIB16 = _Lib(LIB16_PATH)
 
 
 def _ptr(x):
@@ -88,7 +93,7 @@ def stream_ptr() -> int:
 
 def call(name: str, *args):
     """Invoke `name` with tensors -> device pointers, appending the current torch HIP stream."""
-    dll = LIB.load()
+    dll = (LIB16 if name.endswith("_w16") else LIB).load()
     fn = getattr(dll, name)
     conv = [_ptr(a) for a in args]
     if len(fn.argtypes) == len(conv) + 1:

@@ -13,12 +13,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-std=c
          "-Wno-unused-result"] + os.environ.get("MMD_EXTRA_HIPCC_FLAGS", "").split()
 
 
+LIB16 = os.path.join(PKG, "libmmdistill_hip_w16.so")
+# Two builds of the same sources: LIB with the bf16-storage ("w16", csrc/common.h) branches compiled out - the fp32 / bf16-operand
+# paths, i.e. the headline workload, pay nothing for them - and LIB16 with them; _lib.py sends the *_w16 entry points to LIB16.
+VARIANTS = ((LIB, "build", ["-DMMD_NO_W16"]), (LIB16, os.path.join("build", "w16"), []))
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
     srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
-    return any(os.path.getmtime(s) > t for s in srcs)
+    for lib, _, _ in VARIANTS:
+        if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+            return True
+    return False
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -26,25 +32,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    objs = []
-    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
-    procs = []
     hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))
-    for s in srcs:
-        o = os.path.join(PKG, "build", os.path.basename(s)[:-4] + ".o")
-        objs.append(o)
-        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
-            continue            # object newer than its source and every header
-        procs.append((s, subprocess.Popen([hipcc, *FLAGS, "-c", s, "-o", o], stdout=subprocess.PIPE,
-                                          stderr=subprocess.STDOUT)))
+    procs, objs = [], {lib: [] for lib, _, _ in VARIANTS}
+    for lib, odir, extra in VARIANTS:
+        os.makedirs(os.path.join(PKG, odir), exist_ok=True)
+        for s in srcs:
+            o = os.path.join(PKG, odir, os.path.basename(s)[:-4] + ".o")
+            objs[lib].append(o)
+            if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
+                continue            # object newer than its source and every header
+            procs.append((s, subprocess.Popen([hipcc, *FLAGS, *extra, "-c", s, "-o", o], stdout=subprocess.PIPE,
+                                              stderr=subprocess.STDOUT)))
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {s}")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    if verbose:
-        print(f"built {LIB}")
+    for lib, _, _ in VARIANTS:
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs[lib]])
+        if verbose:
+            print(f"built {lib}")
     return LIB
 
 

@@ -40,28 +40,39 @@ __device__ __forceinline__ unsigned mmd_pk_bf16(float a, float b) {
   mmd_f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mmd_bf16x2));
 }
+// The library is built twice (mm_distillnet_amd/build.py): libmmdistill_hip.so with -DMMD_NO_W16 - the storage branches compiled out, every
+// tensor fp32: the run-time test per load / store costs the fp32 headline step 0.1 ms (16.50 -> 16.62 ms, alternating runs) - and
+// libmmdistill_hip_w16.so with them; the host binds the *_w16 entry points to the second one.  In the first a *_w16 call with a non-zero
+// mask is refused (MMD_EINVAL).
+#ifdef MMD_NO_W16
+#define MMD_W16(x) false
+#define MMD_W16_BUILD 0
+#else
+#define MMD_W16(x) (x)
+#define MMD_W16_BUILD 1
+#endif
 __device__ __forceinline__ float4 mmd_ldw4(const float* p, size_t off, int w16) {
-  if (w16) {
+  if (MMD_W16(w16)) {
     const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off);
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
   }
   return *reinterpret_cast<const float4*>(p + off);
 }
 __device__ __forceinline__ void mmd_stw4(float* p, size_t off, const float4& v, int w16) {
-  if (w16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + off) = make_uint2(mmd_pk_bf16(v.x, v.y), mmd_pk_bf16(v.z, v.w));
+  if (MMD_W16(w16)) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + off) = make_uint2(mmd_pk_bf16(v.x, v.y), mmd_pk_bf16(v.z, v.w));
   else *reinterpret_cast<float4*>(p + off) = v;
 }
 __device__ __forceinline__ float mmd_ldw1(const float* p, size_t off, int w16) {
-  if (w16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[off] << 16);
+  if (MMD_W16(w16)) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[off] << 16);
   return p[off];
 }
 __device__ __forceinline__ void mmd_stw1(float* p, size_t off, float v, int w16) {
-  if (w16) reinterpret_cast<unsigned short*>(p)[off] = (unsigned short)(mmd_pk_bf16(v, 0.f) & 0xffffu);
+  if (MMD_W16(w16)) reinterpret_cast<unsigned short*>(p)[off] = (unsigned short)(mmd_pk_bf16(v, 0.f) & 0xffffu);
   else p[off] = v;
 }
 // row pointer of a [rows, C] tensor that may be w16: `float*` arithmetic in bytes of the actual element size
 __device__ __forceinline__ const float* mmd_roww(const float* base, size_t row, int C, int w16) {
-  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + row * (size_t)C * (w16 ? 2 : 4));
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + row * (size_t)C * (MMD_W16(w16) ? 2 : 4));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -709,6 +709,7 @@ extern "C" int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int 
                                   const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                                   const float* out_scale, const float* out_shift, int out_act,
                                   double* stats, float* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream) {
+  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -901,6 +902,7 @@ extern "C" int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, con
                                            const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                            const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad,
                                            int w16, hipStream_t stream) {
+  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   if (!g1 || !z1 || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C < 64 || (C & 3) || (k != 3 && k != 5)) return MMD_EINVAL;
   if (!q_scale || !q_shift || !q_mean || !q_invstd || !q_sums || q_count <= 0 || !q_gate || !q_add) return MMD_EINVAL;
   if ((q_dgamma == nullptr) != (q_dbeta == nullptr)) return MMD_EINVAL;

@@ -945,6 +945,7 @@ extern "C" int mmd_pwconv_fwd_w16(const float* x, const float* w, float* y, int 
                                   const float* residual, double* stats,
                                   long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, int bf16_mma, int w16,
                                   hipStream_t stream) {
+  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   return pw_fwd_impl(PW_FWD_ARGS, bf16_mma, w16);
 }
 
@@ -1275,6 +1276,7 @@ extern "C" int mmd_pwconv_bwd_weight_bn_bf16(PW_WGBN_PARAMS) { return pw_wgrad_b
 extern "C" int mmd_pwconv_bwd_weight_w16(const float* dy, const float* x, float* dw, int M, int K, int N,
                                          const float* in_scale, const float* in_shift, int in_act,
                                          const float* gate, int rows_per_image, int bf16_mma, int w16, hipStream_t stream) {
+  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   return pw_wgrad_impl(dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, bf16_mma, nullptr, nullptr, nullptr, w16);
 }
 extern "C" int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N,
@@ -1379,6 +1381,7 @@ extern "C" int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const
                       const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums,
                       double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift,
                       const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, int bf16_mma, int w16, hipStream_t stream) {
+  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   return pw_bwd_data_bn2_impl(PW_BD2_ARGS, bf16_mma, w16);
 }
 

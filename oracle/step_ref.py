@@ -27,7 +27,7 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
                     drop_masks: Optional[Dict[int, torch.Tensor]] = None, conf_threshold: float = 0.3,
                     nms_threshold: float = 0.5, T: float = 9.0, p: float = 2.0, training: bool = True,
                     kd_mode: str = "pairwise", inclusive_nms: bool = False, augment: bool = False,
-                    aug_rgb: Optional[torch.Tensor] = None):
+                    aug_rgb: Optional[torch.Tensor] = None, per_teacher_labels: Optional[list] = None):
     """-> dict(reg[1], cls[1], kd: list of Tensor[5] per teacher (pairwise) or [Tensor[5]] (list),
                labels: merged [m,5] per image, logits_s, features_s)"""
     audio = batch["audio"]
@@ -53,8 +53,11 @@ def distill_forward(student: Dict[str, torch.Tensor], teachers: Dict[str, Dict[s
                 feats_t = [f.clone() for f in feats_t]
                 for f in feats_t:
                     f[1] = (f[0] + f[1]) / 2
-            per_teacher.append(P.logits_to_ground_truth(logits_t, image_size, conf_threshold, nms_threshold,
-                                                        inclusive=inclusive_nms))
+            if per_teacher_labels is not None:      # test aid: pseudo-labels computed elsewhere (e.g. by an fp32 run, to compare numerics modes on equal labels)
+                per_teacher.append(per_teacher_labels[len(per_teacher)])
+            else:
+                per_teacher.append(P.logits_to_ground_truth(logits_t, image_size, conf_threshold, nms_threshold,
+                                                            inclusive=inclusive_nms))
         if kd_mode == "pairwise":
             kd.append(L.mta_loss(feats_s, feats_t, T, p))
         else:

@@ -160,7 +160,7 @@ def test_d4_768_step_vs_oracle():
     mode of the same step bounded against the fp32 one."""
     from oracle import step_ref as ST
     from helpers import grad_state
-    S, B, coef = 768, 1, 4
+    S, B, coef = 768, 2, 4
     eng, spec = build("pairwise", S, coef=coef)
     teachers = {k: v[1] for k, v in teacher_states(coef, MODS).items()}
     _, st = make_state(coef, 8, 24, "audio")
@@ -185,13 +185,14 @@ def test_d4_768_step_vs_oracle():
     eng.check_overflow()
     tot = hit = 0
     for ti in range(3):
-        r = np.asarray(ref["per_teacher"][ti][0], dtype=np.float32).reshape(-1, 6)
-        n = int(out["cnt_t"][ti][0].item())
-        got = out["rows_t"][ti][0, :n].cpu().numpy()
-        assert abs(n - r.shape[0]) <= max(2, 0.05 * r.shape[0]), (ti, n, r.shape[0])
-        for row in r:
-            tot += 1
-            hit += int(n > 0 and (np.abs(got[:, :4] - row[:4]).max(1) <= 1.0).any())
+        for i in range(B):
+            r = np.asarray(ref["per_teacher"][ti][i], dtype=np.float32).reshape(-1, 6)
+            n = int(out["cnt_t"][ti][i].item())
+            got = out["rows_t"][ti][i, :n].cpu().numpy()
+            assert abs(n - r.shape[0]) <= max(2, 0.05 * r.shape[0]), (ti, i, n, r.shape[0])
+            for row in r:
+                tot += 1
+                hit += int(n > 0 and (np.abs(got[:, :4] - row[:4]).max(1) <= 1.0).any())
     assert hit >= 0.95 * tot, (hit, tot)
     # (2) with the oracle's labels: losses 2e-4 (kd 1e-4), gradient direction / norm over all parameters
     labels = eng.labels_from_rows(ref["per_teacher"], A)
@@ -215,130 +216,52 @@ def test_d4_768_step_vs_oracle():
     cos, ratio = compare(grads)
     print("D4/768 fp32 step gradient: cos %.6f norm ratio %.5f" % (cos, ratio))
     assert cos > 0.9995 and abs(ratio - 1.0) < 5e-3, (cos, ratio)
-    # (3) bf16 mixed precision (cfg precision = bf16, configs[4]'s numerics): same labels; operand rounding 2^-9 through ~200 layers
+    # (3) bf16 mixed precision (configs[4]'s numerics): "bf16" = bf16 MFMA operands, "bf16_hbm" = + bf16 storage of the wide MBConv tensors.
+    # Same labels.  The yardstick is the ORACLE's own emulation of each mode (oracle/effdet_ref.py BF16_PW / W16) run through the same step:
+    # the rule itself moves the gradient by some angle from fp32; the HIP gradient must stay within twice that angle of both the fp32
+    # gradient and the emulation's (two implementations of one rounding rule decorrelate: a last-bit difference upstream flips roundings
+    # downstream), and the losses within twice the emulation's own loss shift.
+    from oracle import effdet_ref as O
     loss32 = (out["reg"].item(), out["cls"].item(), out["kd"].cpu().numpy().copy())
+    g32 = {k: v.grad.detach().clone() for k, v in so.items() if v.requires_grad and v.grad is not None}
     del eng
-    eng_b, _ = build("pairwise", S, precision="bf16", coef=coef)
-    ob = eng_b.step_body(batch, ds, teacher_labels=eng_b.labels_from_rows(ref["per_teacher"], A))
-    torch.cuda.synchronize()
-    assert abs(ob["reg"].item() - loss32[0]) < 0.1 * abs(loss32[0]) and abs(ob["cls"].item() - loss32[1]) < 0.1 * abs(loss32[1])
-    np.testing.assert_allclose(ob["kd"].cpu().numpy(), loss32[2], rtol=0.1, atol=1e-3)
-    cos_b, ratio_b = compare(eng_b.student.ps.export_grads())
-    print("D4/768 bf16 step gradient vs fp32 oracle: cos %.4f norm ratio %.4f" % (cos_b, ratio_b))
-    # statistical bound, as for the D2 train-mode bf16 net test (tests/test_gpu_net.py): 2^-9 operand rounding through ~300 layers with
-    # train-mode BatchNorm over ONE image decorrelates part of the gradient (measured cos 0.70, norm ratio 1.001); a layout / indexing
-    # bug gives cos ~ 0
-    assert cos_b > 0.5 and 0.8 < ratio_b < 1.25, (cos_b, ratio_b)
 
+    def cosine(ga, gb):
+        d = a2 = b2 = 0.0
+        for k, u in ga.items():
+            if gb.get(k) is None:
+                continue
+            u, w = u.double(), gb[k].double()
+            d += float((u * w).sum()); a2 += float((u * u).sum()); b2 += float((w * w).sum())
+        return d / (a2 ** 0.5 * b2 ** 0.5)
 
-def test_graph_variants_plain_and_list_augmented():
-    """traditional_nms_kdlist_augmented alternates, iteration by iteration, between the plain KD-list step and the one with the extra
-    RGB-teacher pass: one set of hipGraphs per variant, picked by the batch's keys; each replays its own eager step."""
-    S, B = 128, 2
-    eng, spec = build("list", S)
-    ref, _ = build("list", S)
-    plain = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
-    aug = dict(plain, aug_rgb=synth_inputs(B, S, seed=6)["rgb"].to(DEV))
-    ds = eng.make_drop_scale(B, torch.Generator(device=DEV).manual_seed(1))
-    def sync_state():      # both engines start every step from the same parameters / running statistics / optimizer state, so a step is
-        # compared like a first step (two free-running engines drift apart by up to 2 lr per weight and step - Adam's first steps are
-        # sign-like - and train-mode BatchNorm over 2 x 128^2 amplifies that to a few % of the classification loss)
-        for dst, src in ((eng.student.ps, ref.student.ps),):
-            for name in ("flat", "rmean", "rvar", "nbt"):
-                getattr(dst, name).copy_(getattr(src, name))
-        for name in ("exp_avg", "exp_avg_sq", "adam_main", "adam_head", "head_active"):
-            getattr(eng, name).copy_(getattr(ref, name))
-        eng.student.refresh()
-
-    for batch in (plain, aug, plain, aug):
-        sync_state()
-        o = eng.replay(batch, ds)
-        r = ref.step(batch, ds)
+    for precision in ("bf16", "bf16_hbm"):
+        se = grad_state(st)
+        O.BF16_PW, O.W16 = True, precision == "bf16_hbm"
+        try:
+            refe = ST.distill_forward(se, teachers, hb, S, coef, masks, per_teacher_labels=ref["per_teacher"])
+            ST.total_loss(refe).backward()
+        finally:
+            O.BF16_PW, O.W16 = False, False
+        gem = {k: v.grad for k, v in se.items() if v.requires_grad and v.grad is not None}
+        eng_b, _ = build("pairwise", S, precision=precision, coef=coef)
+        ob = eng_b.step_body(batch, ds, teacher_labels=eng_b.labels_from_rows(ref["per_teacher"], A))
         torch.cuda.synchronize()
-        assert o["nbox"].tolist() == r["nbox"].tolist()
-        np.testing.assert_allclose(o["kd"].cpu().numpy(), r["kd"].cpu().numpy(), rtol=2e-3, atol=1e-5)
-        np.testing.assert_allclose(o["cls"].cpu().numpy(), r["cls"].cpu().numpy(), rtol=2e-3)
-        assert (eng.student.ps.flat - ref.student.ps.flat).abs().max().item() <= 2.5e-4      # one Adam step of <= lr each, from equal states
-    assert set(eng._graphs) == {"plain", "aug"}
+        ghip = eng_b.student.ps.export_grads()
+        c_emu, c_hip, c_he = cosine(gem, g32), cosine(ghip, g32), cosine(ghip, gem)
+        shift = max(abs(refe["cls"].item() - ref["cls"].item()) / abs(ref["cls"].item()), abs(refe["reg"].item() - ref["reg"].item()) / abs(ref["reg"].item()))
+        print("D4/768 %s step: gradient cos emulation vs fp32 %.4f, HIP vs fp32 %.4f, HIP vs emulation %.4f; loss shift of the emulation %.2e, of HIP cls %.2e reg %.2e" % (
+            precision, c_emu, c_hip, c_he, shift, abs(ob["cls"].item() - loss32[1]) / abs(loss32[1]), abs(ob["reg"].item() - loss32[0]) / abs(loss32[0])))
+        assert (1 - c_hip) <= 2.0 * (1 - c_emu) + 2e-2 and (1 - c_he) <= 2.0 * (1 - c_emu) + 2e-2, (precision, c_emu, c_hip, c_he)
+        assert abs(ob["reg"].item() - loss32[0]) <= (2.0 * shift + 2e-2) * abs(loss32[0]) and abs(ob["cls"].item() - loss32[1]) <= (2.0 * shift + 2e-2) * abs(loss32[1])
+        np.testing.assert_allclose(ob["kd"].cpu().numpy(), loss32[2], rtol=0.1, atol=1e-3)
+        del eng_b
+        torch.cuda.empty_cache()
 
 
-def test_graph_replay_matches_eager():
-    """The captured hipGraphs must reproduce the eager step: same pseudo-labels and losses, gradients equal up to the
-    run-to-run noise of fp32 atomics (measured eager-vs-eager: ~2e-4 of the largest gradient at this tiny size), and
-    every replay must start from cleared accumulators (labels of a frozen teacher cannot change between replays)."""
-    S, B = 128, 2
-    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
-    eng_a, spec = build("pairwise", S)
-    eng_b, _ = build("pairwise", S)
-    g = torch.Generator(device=DEV).manual_seed(1)
-    ds = eng_a.make_drop_scale(B, g)
-    eng_b.capture(batch)
-    oa = eng_a.step_body(batch, ds)
-    eng_b.static["drop_scale"].copy_(ds)
-    eng_b.g_main.replay()
-    torch.cuda.synchronize()
-    ob = eng_b.out
-    assert oa["nbox"].tolist() == ob["nbox"].tolist()
-    for k in ("reg", "cls", "kd"):
-        np.testing.assert_allclose(oa[k].cpu().numpy(), ob[k].cpu().numpy(), rtol=1e-4, atol=1e-6)
-    ga, gb = eng_a.student.ps.grad, eng_b.student.ps.grad
-    assert torch.isfinite(gb).all()
-    assert (ga - gb).abs().max().item() <= 2e-3 * ga.abs().max().item()
-    eng_a.optimizer_body(); eng_b.g_opt.replay()
-    torch.cuda.synchronize()
-    assert eng_a.adam_main[0].item() == eng_b.adam_main[0].item() == 1.0
-    assert torch.equal(eng_a.student.ps.nbt, eng_b.student.ps.nbt)
-    # replays 2 and 3: frozen teachers + same inputs -> identical labels every time
-    for _ in range(2):
-        eng_b.replay(batch, ds)
-    torch.cuda.synchronize()
-    assert eng_b.out["nbox"].tolist() == oa["nbox"].tolist()
-    assert torch.isfinite(eng_b.student.ps.flat).all() and eng_b.adam_main[0].item() == 3.0
-
-
-def test_split_backward_matches_unsplit():
-    """The data-parallel step issues the backward in two segments (heads + BiFPN + backbone blocks >= k, then the early
-    blocks + stem) so that the all-reduce of the first segment's gradients overlaps the second.  Same kernels, same order:
-    gradients equal the unsplit backward's up to fp32-atomics noise, eagerly and through the three captured graphs."""
-    S, B = 128, 2
-    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
-    eng_a, spec = build("pairwise", S)
-    eng_b, _ = build("pairwise", S)
-    eng_c, _ = build("pairwise", S)
-    k = eng_b._default_split()
-    assert 0 < k < len(spec.blocks)
-    eng_b.ar_split = eng_c.ar_split = k
-    (p0,), tail = eng_b.grad_buckets()
-    n = eng_b.student.ps.n_params
-    assert sorted([p0] + tail) == [(0, p0[0]), p0, (p0[1], n)]            # the three ranges tile the buffer
-    assert (p0[1] - p0[0]) > 0.9 * n
-    g = torch.Generator(device=DEV).manual_seed(1)
-    ds = eng_a.make_drop_scale(B, g)
-    eng_a.step_body(batch, ds)
-    eng_b.step_body(batch, ds)
-    torch.cuda.synchronize()
-    ga, gb = eng_a.student.ps.grad, eng_b.student.ps.grad
-    tol = 2e-3 * ga.abs().max().item()
-    # after segment 1 the overlapped bucket is final, the early blocks' weights have no gradient yet
-    assert (ga[p0[0]:p0[1]] - gb[p0[0]:p0[1]]).abs().max().item() <= tol
-    assert gb[:p0[0]].abs().max().item() == 0.0
-    eng_b.backward_tail()
-    torch.cuda.synchronize()
-    assert (ga - gb).abs().max().item() <= tol
-    eng_c.capture(batch)
-    assert eng_c.g_tail is not None
-    eng_c.replay(batch, ds)
-    torch.cuda.synchronize()
-    eng_a.optimizer_body()
-    torch.cuda.synchronize()
-    assert (ga - eng_c.student.ps.grad).abs().max().item() <= tol
-    fa, fc = eng_a.student.ps.flat, eng_c.student.ps.flat
-    assert torch.isfinite(fc).all()
-    assert (fa - fc).abs().max().item() <= 2.5e-4            # one Adam step moves a weight by at most lr = 1e-4
-
-
-def test_bf16_step_runs_and_replays():
-    """cfg `precision = bf16`: the whole distillation step (three teachers, student, losses, backward, Adam) with the 1x1
+@pytest.mark.parametrize("precision", ["bf16", "bf16_hbm"])
+def test_bf16_step_runs_and_replays(precision):
+    """cfg `precision = bf16` / `bf16_hbm` (+ bf16 storage of the wide MBConv tensors): the whole distillation step (three teachers, student, losses, backward, Adam) with the 1x1
     convs on the bf16 MFMA.  At this test size (2 x 128^2, train-mode BatchNorm over a handful of samples) rounding noise
     is amplified far beyond what a real batch sees (tests/test_gpu_net.py), so only coarse agreement with the fp32 step
     is asserted; the exact statements are that the step is finite, trains (Adam moves every touched weight by ~lr) and
@@ -346,9 +269,10 @@ def test_bf16_step_runs_and_replays():
     S, B = 128, 2
     batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
     eng_a, spec = build("pairwise", S)
-    eng_b, _ = build("pairwise", S, precision="bf16")
-    eng_c, _ = build("pairwise", S, precision="bf16")
+    eng_b, _ = build("pairwise", S, precision=precision)
+    eng_c, _ = build("pairwise", S, precision=precision)
     assert eng_b.student._sfx == "_bf16" and all(t._sfx == "_bf16" for t in eng_b.teachers.values())
+    assert eng_b.student.w16 == (precision == "bf16_hbm")
     g = torch.Generator(device=DEV).manual_seed(1)
     ds = eng_a.make_drop_scale(B, g)
     p0 = eng_b.student.ps.flat.clone()
