@@ -56,6 +56,14 @@ int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, c
 // launch of its own on the backward's serial chain (autograd of the BatchNorm in SeparableConvBlock, src/YetAnotherEfficientDet.py:171-176).
 int mmd_bifpn_node_dw_bwd2(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, hipStream_t stream);
 
+// + the POOLED operand's gradient out of the same launch (round 3): dpool [B, 2H, 2W, C] += w_pool * g at the arg-max element of every output
+// pixel's 3x3 / stride-2 SAME window (first maximum in scan order; a winning zero-padding element swallows the gradient - torch's max-pool
+// backward, src/YetAnotherEfficientNet.py:68-104), fp32 atomics on a buffer holding zeros or the earlier contributions - instead of dx + a
+// mmd_maxpool_same_bwd_acc launch.  A scattered gradient has no last writer, so the BatchNorm-backward sums of a pooled tensor are kept
+// linearly: (zp, meanp, invstdp, sumsp) receive the sums of this launch's share; own bit 0 / 1 / 2: the sums of d0 / d1 / dup likewise
+// cover this launch's share instead of the accumulated total.
+int mmd_bifpn_node_dw_bwd3(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, hipStream_t stream);
+
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
 
 // d theta of every fusion node of a net in ONE launch: desc [nodes][2] = (offset of the node's theta in theta_base / dtheta_base, its

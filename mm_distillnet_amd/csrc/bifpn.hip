@@ -39,6 +39,30 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
   return m;
 }
 
+// The same window with the arg-max per channel: arg[q] = tap index (3*i + j) of the FIRST maximum in row-major scan order (torch's max-pool
+// backward picks that one), -1 when a zero-padding element wins (it swallows the gradient).
+__device__ __forceinline__ void pool_window_arg(const float* __restrict__ src, int b, int oh, int ow, int c, int PH, int PW,
+                                                int C, int pad_t, int pad_l, int (&arg)[4]) {
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) arg[q] = -1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int y = oh * 2 - pad_t + i;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int x = ow * 2 - pad_l + j;
+      const bool in = y >= 0 && y < PH && x >= 0 && x < PW;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (in) v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (vv[q] > best[q]) { best[q] = vv[q]; arg[q] = in ? i * 3 + j : -1; }
+    }
+  }
+}
+
 // MODE: -1 = operand set read from the arguments at run time; otherwise bit 0 = in1, bit 1 = up, bit 2 = pool present (compile time: the node
 // backward kernel is instantiated per operand set - the run-time form keeps every operand's registers and branches alive)
 template <int MODE = -1>
@@ -503,12 +527,18 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
                                                          float* __restrict__ dup, int acc_up, float* __restrict__ dwg,
-                                                         int tiles_h, int tiles_w, int cchunks, BnSumDst x0, BnSumDst x1, BnSumDst xu) {
+                                                         int tiles_h, int tiles_w, int cchunks, BnSumDst x0, BnSumDst x1, BnSumDst xu,
+                                                         float* dpl, BnSumDst xp, int own) {
+  // dpl (MODE & 4): the POOLED operand's gradient [B, 2H, 2W, C], scattered from here - every output pixel adds w_pool * g to the arg-max
+  // element of its 3x3 window with fp32 atomics (dpl holds zeros or the earlier contributions) - instead of materialising dx for a gather
+  // launch over the 4x larger source map (mmd_maxpool_same_bwd_acc: 22 launches of ~22 us per D2 step).  A scattered gradient has no last
+  // writer, so the BatchNorm-backward sums of such a tensor are kept LINEARLY: every contribution adds the sums of its own share -
+  // own bit 0 / 1 / 2: the sums of d0 / d1 / dup are taken over this launch's share, not over the accumulated total; xp: this scatter's share.
   constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
   __shared__ float sIn[IH * IW * 64];
   __shared__ float sW[9 * 64];
   __shared__ float sred[4 * 3];
-  __shared__ float sBn[3 * 2 * 4 * 64];            // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel]
+  __shared__ float sBn[4 * 2 * 4 * 64];            // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel]
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
@@ -562,7 +592,9 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   // gradient, the operand is a BatchNorm output; replaces the mmd_bn_bwd_reduce launch of the operand's node)
   const float4 z4 = make_float4(0, 0, 0, 0);
   float4 bs0 = z4, bq0 = z4, bs1 = z4, bq1 = z4, bsu = z4, bqu = z4, mu0 = z4, is0 = z4, mu1 = z4, is1 = z4, muu = z4, isu = z4;
+  float4 bsp = z4, bqp = z4, mup = z4, isp = z4;
   if (cok) {
+    if ((MODE & 4) && xp.z) { mup = mmd_ld4(xp.mean + c); isp = mmd_ld4(xp.invstd + c); }
     if (x0.z) { mu0 = mmd_ld4(x0.mean + c); is0 = mmd_ld4(x0.invstd + c); }
     if ((MODE & 1) && x1.z) { mu1 = mmd_ld4(x1.mean + c); is1 = mmd_ld4(x1.invstd + c); }
     if ((MODE & 2) && xu.z) { muu = mmd_ld4(xu.mean + c); isu = mmd_ld4(xu.invstd + c); }
@@ -582,15 +614,36 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       if (dx) mmd_st4(dx + off, g);
       if (d0) {
         float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
+        const float4 mine = v;
         if (acc0) { float4 q = mmd_ld4(d0 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         mmd_st4(d0 + off, v);
-        if (x0.z) bnsum_acc4(x0, off, v, mu0, is0, bs0, bq0);
+        if (x0.z) bnsum_acc4(x0, off, (own & 1) ? mine : v, mu0, is0, bs0, bq0);
       }
       if (d1) {
         float4 v = make_float4(g.x * w[1], g.y * w[1], g.z * w[1], g.w * w[1]);
+        const float4 mine = v;
         if (acc1) { float4 q = mmd_ld4(d1 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
         mmd_st4(d1 + off, v);
-        if ((MODE & 1) && x1.z) bnsum_acc4(x1, off, v, mu1, is1, bs1, bq1);
+        if ((MODE & 1) && x1.z) bnsum_acc4(x1, off, (own & 2) ? mine : v, mu1, is1, bs1, bq1);
+      }
+      if ((MODE & 4) && dpl) {
+        int arg[4];
+        pool_window_arg(a.pl, b, oh, ow, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, arg);
+        const float wp = w[1 + ((MODE & 1) ? 1 : 0) + ((MODE & 2) ? 1 : 0)];
+        const float gv[4] = {g.x * wp, g.y * wp, g.z * wp, g.w * wp};
+        const float muv[4] = {mup.x, mup.y, mup.z, mup.w}, isv[4] = {isp.x, isp.y, isp.z, isp.w};
+        float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (arg[q] >= 0) {
+            const int yy = oh * 2 - a.pad_t + arg[q] / 3, xx = ow * 2 - a.pad_l + arg[q] % 3;
+            const size_t so = (((size_t)b * a.PH + yy) * a.PW + xx) * a.C + c + q;
+            atomicAdd(&dpl[so], gv[q]);
+            if (xp.z) { sv[q] = gv[q]; qv[q] = gv[q] * (xp.z[so] - muv[q]) * isv[q]; }
+          }
+        }
+        bsp.x += sv[0]; bsp.y += sv[1]; bsp.z += sv[2]; bsp.w += sv[3];
+        bqp.x += qv[0]; bqp.y += qv[1]; bqp.z += qv[2]; bqp.w += qv[3];
       }
       int wi = 0;
       d[wi++] += g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
@@ -614,9 +667,10 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       if (lane < 32 && cok && uy < (a.H >> 1) && ux < (a.W >> 1)) {
         float* o = dup + (((size_t)b * (a.H >> 1) + uy) * (a.W >> 1) + ux) * a.C + c;
         sv.x *= wu; sv.y *= wu; sv.z *= wu; sv.w *= wu;
+        const float4 mine = sv;
         if (acc_up) { float4 pv = mmd_ld4(o); sv.x += pv.x; sv.y += pv.y; sv.z += pv.z; sv.w += pv.w; }
         mmd_st4(o, sv);
-        if (xu.z) bnsum_acc4(xu, (size_t)(o - dup), sv, muu, isu, bsu, bqu);
+        if (xu.z) bnsum_acc4(xu, (size_t)(o - dup), (own & 4) ? mine : sv, muu, isu, bsu, bqu);
       }
     }
   }
@@ -630,6 +684,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     if (x0.z) { put(bs0, 0); put(bq0, 1); }
     if ((MODE & 1) && x1.z) { put(bs1, 2); put(bq1, 3); }
     if ((MODE & 2) && xu.z) { put(bsu, 4); put(bqu, 5); }
+    if ((MODE & 4) && xp.z) { put(bsp, 6); put(bqp, 7); }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { float v = wave_sum(d[i]); if (lane == 0) sred[wave * 3 + i] = v; }
@@ -666,6 +721,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     if (x0.z) flush(x0, 0);
     if ((MODE & 1) && x1.z) flush(x1, 1);
     if ((MODE & 2) && xu.z) flush(xu, 2);
+    if ((MODE & 4) && xp.z) flush(xp, 3);
   }
   if (dwg) {
     float* sRedW = sIn;                             // [4 waves][9][64]
@@ -687,17 +743,19 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
 static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up, const float* pool,
                             const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
                             int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
-                            float* dw_grad, BnSumDst x0, BnSumDst x1, BnSumDst xu, hipStream_t stream) {
+                            float* dw_grad, BnSumDst x0, BnSumDst x1, BnSumDst xu, hipStream_t stream,
+                            float* dpl = nullptr, BnSumDst xp = BnSumDst{}, int own = 0) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
+  if ((dpl && !pool) || (xp.z && (!dpl || !xp.mean || !xp.invstd || !xp.sums))) return MMD_EINVAL;
   if ((x0.z && (!d0 || !x0.mean || !x0.invstd || !x0.sums)) || (x1.z && (!d1 || !x1.mean || !x1.invstd || !x1.sums)) ||
       (xu.z && (!dup || !xu.mean || !xu.invstd || !xu.sums)))
     return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
-#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu)
+#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own)
   switch (mode) {          // the operand sets of BiFPN._forward_fast_attention: (in, up), (in, td, pool), (in, pool); others through the generic forms
     case 2: MMD_NODE_BWD(2); break;
     case 5: MMD_NODE_BWD(5); break;
@@ -728,6 +786,24 @@ extern "C" int mmd_bifpn_node_dw_bwd2(const float* in0, const float* in1, const 
                                       const float* zu, const float* meanu, const float* invstdu, double* sumsu, hipStream_t stream) {
   return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
                           BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream);
+}
+
+// mmd_bifpn_node_dw_bwd2 + the POOLED operand's gradient out of the same launch: dpool [B, 2H, 2W, C] (holding zeros or the earlier
+// contributions) += w_pool * g at the arg-max element of every output pixel's 3x3 / stride-2 window (fp32 atomics; replaces dx +
+// mmd_maxpool_same_bwd_acc).  A scattered gradient has no last writer: the BatchNorm-backward sums of a pooled tensor are therefore kept
+// linearly - (zp, meanp, invstdp, sumsp) receive the sums of THIS launch's share, and `own` (bit 0 / 1 / 2 for d0 / d1 / dup) makes the
+// other operands' sums cover this launch's share as well, instead of the accumulated total (for operands that are pooled elsewhere).
+extern "C" int mmd_bifpn_node_dw_bwd3(const float* in0, const float* in1, const float* up, const float* pool,
+                                      const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
+                                      int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                      float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0,
+                                      const float* z1, const float* mean1, const float* invstd1, double* sums1,
+                                      const float* zu, const float* meanu, const float* invstdu, double* sumsu,
+                                      float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own,
+                                      hipStream_t stream) {
+  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
+                          BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
+                          dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own);
 }
 
 // d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   

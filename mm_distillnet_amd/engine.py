@@ -80,6 +80,7 @@ class GradSlot:
         self.remaining = remaining
         self.sums: Optional[torch.Tensor] = None
         self.have_sums = False
+        self.linear_ok = True          # linear-sum mode (a tensor that is max-pooled somewhere): every contribution so far added its share
 
 
 @dataclass
@@ -103,6 +104,9 @@ LAZY_BN = not os.environ.get("MMD_NO_LAZY_BN")
 # schedule - a bn_bwd_reduce launch per BatchNorm and scale_acc launches for the skip / multi-consumer accumulations - for A/B timing)
 FOLD_SUMS = not os.environ.get("MMD_NO_BNSUM_FOLD")
 BN1_IN_DW = not os.environ.get("MMD_NO_BN1_IN_DW")    # MBConv: BatchNorm-1 backward in the depthwise input-gradient launch's prologue (no bn_bwd_apply, no dz1 tensor)
+# BiFPN: the pooled operand's gradient scattered (fp32 atomics at the window arg-max) by the node backward launch itself, no dx tensor and no
+# max-pool gather launch over the 4x larger source map; the BatchNorm sums of pooled tensors are then kept linearly (every contribution adds its share)
+POOL_SCATTER = not os.environ.get("MMD_NO_POOL_SCATTER")
 P5_IN_GEMM = not os.environ.get("MMD_NO_P5_IN_GEMM")  # MBConv: the pooled squeeze-excite / BN-1 backward pass in the project GEMM's epilogue (no chan_pool_bwd launch)
 SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
 # both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
@@ -165,6 +169,7 @@ class Net:
         self._leaf_pending: list = []        # other deferred leaves (closures), issued by _wg_flush
         self._wg_plans: Dict[tuple, dict] = {}  # (segment index, operand signature) -> planned table (built once: arena addresses repeat every step)
         self._wg_segment = 0
+        self._linear: set = set()              # train forward: tensors that are a BiFPN node's POOLED operand (their gradient is scattered: linear sums)
         self._uses: Dict[int, int] = {}        # train forward: tensor -> number of gradient contributions its slot will receive
         self._bnout: Dict[int, tuple] = {}     # train forward: tensor y = BN(z) [* mul_b[image]] (+ skip) -> (z, mean, invstd, C, mul_b, rows_per_image)
         self._counting = False
@@ -320,7 +325,7 @@ class Net:
         tape = self.tape if train else {}
         self._counting = train
         if train:
-            self._uses, self._bnout = {}, {}
+            self._uses, self._bnout, self._linear = {}, {}, set()
         P = "backbone_net.model"
         # ---- stem: im2col + GEMM
         OH = (S + 1) // 2
@@ -534,6 +539,8 @@ class Net:
             for operand in (in0, in1, up, pl):
                 if operand is not None:
                     self._use(operand)
+            if pl is not None:
+                self._linear.add(pl.z.data_ptr())
             zdf = Feat(zd, in0.B, in0.H, in0.W, W)
             out = Feat(y, in0.B, in0.H, in0.W, W)
             self._bnout[y.data_ptr()] = (z, a[2], a[3], W, None, 0)
@@ -550,6 +557,8 @@ class Net:
         for operand in (in0, in1, up, pl):
             if operand is not None:
                 self._use(operand)
+        if pl is not None and train:
+            self._linear.add(pl.z.data_ptr())
         rec = {"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": ff, "conv": conv}
         out = self._sep_bn(f"{cell}.{conv}", ff, train, rec, y=y, zd=zd)
         rec["out"] = out
@@ -676,12 +685,23 @@ class Net:
         s = self._slot(f)
         s.remaining -= 1
         info = self._bnout.get(f.z.data_ptr())
+        if FOLD_SUMS and POOL_SCATTER and info is not None and self.ps.flat.is_cuda and f.z.data_ptr() in self._linear:
+            # linear mode (the tensor is max-pooled by some node, whose backward scatters into its gradient): every contribution adds the
+            # sums of its OWN share (7th element = 1); they are complete when the last one has, provided none was unable to
+            if not can_sum:
+                s.linear_ok = False
+                return s, None
+            z, mu, istd, C, mul_b, rpi = info
+            if s.sums is None:
+                s.sums = self._zalloc((2 * C,), torch.float64)
+            s.have_sums = s.remaining == 0 and s.linear_ok
+            return s, (z, mu, istd, s.sums, mul_b, rpi, 1)
         if not (FOLD_SUMS and can_sum and s.remaining == 0 and info is not None and self.ps.flat.is_cuda):
             return s, None
         z, mu, istd, C, mul_b, rpi = info
         s.sums = self._zalloc((2 * C,), torch.float64)
         s.have_sums = True
-        return s, (z, mu, istd, s.sums, mul_b, rpi)
+        return s, (z, mu, istd, s.sums, mul_b, rpi, 0)
 
     def _acc(self, f: Feat, src: torch.Tensor):
         """gradient of f (+)= src ; the first writer just adopts the tensor (a contribution without BatchNorm sums)."""
@@ -1051,8 +1071,8 @@ class Net:
                 nth = th.numel()
                 # gradients of the same-resolution operands (in0, in1) come straight out of the fuse backward launch; dx is
                 # only materialised for an upsampled / pooled operand
-                same, xsargs = [], []
-                for operand in (in0, in1):
+                same, xsargs, own = [], [], 0
+                for oi, operand in enumerate((in0, in1)):
                     if operand is None:
                         same += [None, 0]
                         xsargs += [None] * 4
@@ -1063,25 +1083,44 @@ class Net:
                         sl.t = self._alloc(operand.M, W)
                     same += [sl.t, accumulate]
                     xsargs += xsn(xs)
+                    own |= (1 << oi) if (xs is not None and xs[6]) else 0
                 assert in1 is None or same[0].data_ptr() != same[2].data_ptr()
                 # the gradient of an upsampled operand leaves the same launch (2x2 block sums); dx is only materialised for a
                 # pooled operand (its scatter follows the arg-max of overlapping windows)
-                dx = self._alloc(out.M, W) if pl is not None else None
+                scatter = POOL_SCATTER and FOLD_SUMS and pl is not None and ps.flat.is_cuda
+                dx = self._alloc(out.M, W) if (pl is not None and not scatter) else None
                 upargs = (None, 0)
                 if up is not None:
                     su, xs = self._contrib(up, True)
                     upargs = (su.t, 1) if su.t is not None else (self._alloc(up.M, W), 0)
                     su.t = upargs[0]
                     xsargs += xsn(xs)
+                    own |= 4 if (xs is not None and xs[6]) else 0
                 else:
                     xsargs += [None] * 4
                 # the fusion-weight gradients of all nodes are finished by ONE launch after the BiFPN (their dot products land in wdot_all)
                 wdot = wdot_all[4 * node_i:4 * node_i + 4]
                 theta_desc.append((ps.entries[f"{cell}.{rec['theta']}"].off, nth))
                 node_i += 1
-                call("mmd_bifpn_node_dw_bwd2", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-                     ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
-                     ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None, *xsargs)
+                if scatter or own:
+                    # scatter: the pooled operand's gradient leaves this launch too - added to each window's arg-max with atomics, on top of the
+                    # earlier contributions (or of zeros: a zero-initialised arena buffer when this is the first one); own: an operand that is
+                    # max-pooled by ANOTHER node keeps its BatchNorm sums linearly, this launch adds the sums of its share
+                    dplargs = (None, None, None, None, None)
+                    if scatter:
+                        sl, xs = self._contrib(pl, True)
+                        if sl.t is None:
+                            sl.t = self._zalloc((pl.M, W))
+                        dplargs = (sl.t, *xsn(xs))
+                    call("mmd_bifpn_node_dw_bwd3", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                         ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
+                         ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None, *xsargs, *dplargs, own)
+                    if scatter or pl is None:
+                        continue
+                else:
+                    call("mmd_bifpn_node_dw_bwd2", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                         ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, dx, wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
+                         ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None, *xsargs)
                 if pl is not None:      # the pooled operand's gradient: gather over the windows whose arg-max it is
                     wi = 1 + (1 if in1 is not None else 0) + (1 if up is not None else 0)
                     sl, xs = self._contrib(pl, _lib.LIB.load().mmd_maxpool_bwd_sums_ok(pl.B, pl.H, pl.W, W) == 1)

@@ -1659,3 +1659,44 @@ def test_w16_mbconv_backward_launches():
     call("mmd_pwconv_bwd_weight_bf16", g(dz16.float().cpu()), g(xin), dwe_ref, M, cin, cmid, None, None, 0, None, 1)
     call("mmd_pwconv_bwd_weight_w16", dz16, g(xin), dwe, M, cin, cmid, None, None, 0, None, 1, 1, 1)
     close(dwe, dwe_ref, 2e-5, 1e-6, "expand weight gradient from the bf16-stored dz")
+
+
+@pytest.mark.parametrize("mode,H,W,C", [("bu", 16, 12, 48), ("p7", 4, 4, 112), ("bu", 32, 32, 112), ("bu", 3, 5, 112)])
+def test_bifpn_node_dw_bwd3_pooled_scatter_and_linear_sums(mode, H, W, C):
+    """mmd_bifpn_node_dw_bwd3: the pooled operand's gradient scattered by the node backward launch (atomics at each window's arg-max, on
+    top of earlier contributions) against dx + mmd_maxpool_same_bwd_acc, and the LINEAR BatchNorm sums - of the scatter's share and, with
+    the own bits, of this launch's share of d0 / d1 - against float64 sums over the differences the launches leave."""
+    torch.manual_seed(29)
+    B = 2
+    in0 = torch.randn(B * H * W, C)
+    in1 = torch.randn(B * H * W, C) if mode == "bu" else None
+    pl = torch.randn(B * 4 * H * W, C) - 1.0            # mostly negative: zero padding wins some border windows
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    nth = theta.numel()
+    wd = torch.randn(9, C) / 3
+    dzd = torch.randn(B * H * W, C)
+    gp = lambda t: g(t) if t is not None else None
+    base0, base1, basep = torch.randn(B * H * W, C), torch.randn(B * H * W, C), torch.randn(B * 4 * H * W, C)
+    # reference: plain node backward with dx, then the gather launch
+    dx = torch.zeros(B * H * W, C, device=DEV); wdot = torch.zeros(4, device=DEV)
+    d0, d1 = g(base0.clone()), (g(base1.clone()) if in1 is not None else None)
+    dwg = torch.zeros(9, C, device=DEV)
+    call("mmd_bifpn_node_dw_bwd", gp(in0), gp(in1), None, gp(pl), g(theta), g(wd), g(dzd), dx, wdot, B, H, W, C, d0, 1, d1, 1, None, 0, dwg)
+    dp_ref = g(basep.clone())
+    call("mmd_maxpool_same_bwd_acc", g(pl), dx, dp_ref, g(theta), nth, nth - 1, 1, B, 2 * H, 2 * W, C)
+    # scatter form with linear sums for d0 (own), d1 (own) and the pooled operand
+    mk = lambda t: (g(torch.randn_like(t) * 0.7 + 0.3), g(torch.randn(C) * 0.2), g(torch.rand(C) + 0.5), torch.zeros(2 * C, dtype=torch.float64, device=DEV))
+    x0, xp = mk(in0), mk(pl)
+    x1 = mk(in1) if in1 is not None else (None, None, None, None)
+    wdot2 = torch.zeros(4, device=DEV); dwg2 = torch.zeros(9, C, device=DEV)
+    e0, e1, dp = g(base0.clone()), (g(base1.clone()) if in1 is not None else None), g(basep.clone())
+    call("mmd_bifpn_node_dw_bwd3", gp(in0), gp(in1), None, gp(pl), g(theta), g(wd), g(dzd), None, wdot2, B, H, W, C, e0, 1, e1, 1, None, 0, dwg2,
+         *x0, *x1, None, None, None, None, dp, *xp, 1 | (2 if in1 is not None else 0))
+    close(e0, d0, 1e-6, 1e-7, "d0"); close(wdot2, wdot, 1e-4, 1e-3, "wdot"); close(dwg2, dwg, 1e-5, 1e-6, "dw")
+    if in1 is not None:
+        close(e1, d1, 1e-6, 1e-7, "d1")
+    close(dp, dp_ref, 1e-5, 1e-6, "pooled operand gradient: scatter vs gather")
+    _sums_close(xp[3], _bn_sums_ref(dp_ref.cpu() - basep, xp[0], xp[1], xp[2]), "linear sums of the scatter's share")
+    _sums_close(x0[3], _bn_sums_ref(d0.cpu() - base0, x0[0], x0[1], x0[2]), "linear sums of d0's share (own)")
+    if in1 is not None:
+        _sums_close(x1[3], _bn_sums_ref(d1.cpu() - base1, x1[0], x1[1], x1[2]), "linear sums of d1's share (own)")
