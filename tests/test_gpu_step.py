@@ -235,7 +235,9 @@ def test_d4_768_step_vs_oracle():
             d += float((u * w).sum()); a2 += float((u * u).sum()); b2 += float((w * w).sum())
         return d / (a2 ** 0.5 * b2 ** 0.5)
 
-    for precision in ("bf16", "bf16_hbm"):
+    # (at this size only configs[4]'s own mode, bf16_hbm - a superset of "bf16"'s rounding; the operand-only mode is held to the same kind of
+    # bound by tests/test_gpu_net.py at D2 train / D4 eval: a second emulated oracle step here would cost another minute of CPU time)
+    for precision in ("bf16_hbm",):
         se = grad_state(st)
         O.BF16_PW, O.W16 = True, precision == "bf16_hbm"
         try:
