@@ -619,7 +619,10 @@ class Net:
     def _alloc_pyr(self, pyr, C: int) -> torch.Tensor:
         t = self._alloc(pyr["total"], C)
         if pyr["padded"]:          # padding rows are multiplied in the weight-gradient GEMMs: they must be zeros, not stale bits
-            call("mmd_memset_async", t, 0, t.numel() * 4)
+            for l in range(len(pyr["rows"])):       # (only the pad rows: a whole-buffer memset per pyramid tensor cost 1.8 ms/step at 768)
+                lo, hi = pyr["row0"][l] + pyr["rows"][l], pyr["row0"][l + 1]
+                if hi > lo:
+                    call("mmd_memset_async", t[lo:hi], 0, (hi - lo) * C * 4)
         return t
 
     def _head(self, hname: str, feats: List[Feat], per_anchor: int, out: torch.Tensor, A: int, out_act: int,
