@@ -100,7 +100,7 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     sys.path.insert(0, root)
     import train, evaluate
-    ov = '{"image_size": 128, "batch_size": 2, "synthetic_length": 8, "num_epoches": 1, "exp_name": "exp", "resume": "False"}'
+    ov = '{"image_size": 128, "batch_size": 2, "synthetic_length": 8, "num_epoches": 1, "exp_name": "exp", "resume": "False", "num_workers": 0}'
     cfgf = os.path.join(root, "configs", "mm-distillnet.cfg")
     loss = train.main(["--config_file", cfgf, "--overwrite", ov, "--max_steps", "3"])
     assert np.isfinite(loss)

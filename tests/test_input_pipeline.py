@@ -101,3 +101,34 @@ def test_device_pipeline_batch_matches_oracle():
         th = s["thermal"].numpy().view(np.uint16)
         np.testing.assert_allclose(batch["thermal"][b].cpu().numpy(), I.prepare_thermal(th, 96), rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(batch["audio"][b].cpu().numpy(), I.prepare_audio(s["audio"].numpy(), 96), rtol=1e-5, atol=2e-4)
+
+
+def test_collate_raw_stacks_equal_frames_only():
+    from mm_distillnet_amd.data import RawSyntheticMultimodalDetection, collate_raw
+    ds = RawSyntheticMultimodalDetection({"seed": 3}, length=3, frame_hw=(20, 24), mel_hw=(8, 8))
+    samples = [ds[i] for i in range(3)]
+    st = collate_raw(samples)
+    assert isinstance(st, dict) and st["rgb"].shape == (3, 20, 24, 3) and st["thermal"].dtype == torch.int16 and st["id"] == [0, 1, 2]
+    assert torch.equal(st["audio"][2], samples[2]["audio"])
+    odd = dict(samples[1], rgb=samples[1]["rgb"][:10])
+    out = collate_raw([samples[0], odd])          # mixed frame sizes: the per-sample list, untouched
+    assert isinstance(out, list) and out[0] is samples[0] and out[1] is odd
+
+
+@pytest.mark.gpu
+def test_device_pipeline_stacked_and_pinned_paths_match_list_path():
+    """The stacked batch `collate_raw` makes (one H2D copy per modality), pageable or already pinned as DataLoader(pin_memory=True)
+    hands it over, gives the same device batch, bit for bit, as the list of per-sample dicts."""
+    from mm_distillnet_amd.data import RawSyntheticMultimodalDetection, DeviceInputPipeline, collate_raw
+    ds = RawSyntheticMultimodalDetection({"seed": 24, "image_size": 96}, length=3, frame_hw=(54, 72), mel_hw=(32, 32))
+    samples = [ds[i] for i in range(3)]
+    pipe = DeviceInputPipeline(96, "cuda:0")
+    ref = {k: v.clone() for k, v in pipe.submit(samples).wait().items()}
+    st = collate_raw(samples)
+    got = {k: v.clone() for k, v in pipe.submit(st).wait().items()}
+    pinned = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in st.items()}
+    got_p = {k: v.clone() for k, v in pipe.submit(pinned).wait().items()}
+    pipe.submit(st).wait()          # (the pinned batch's copies are consumed before its tensors may go)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got_p[k]), k

@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from mm_distillnet_amd.arch import make_spec  # noqa: E402
-from mm_distillnet_amd.data import (SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, collate,  # noqa: E402
+from mm_distillnet_amd.data import (SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, collate, collate_raw,  # noqa: E402
                                     valid_classes_dict)
 from mm_distillnet_amd import trainer as TR  # noqa: E402
 from mm_distillnet_amd.model import filter_state_dict  # noqa: E402
@@ -153,11 +153,11 @@ def main(argv=None):
     train_set, val_set = Set(cfg, "train"), Set(cfg, "val")
     pipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
     vpipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
-    collate_fn = (lambda b: b) if raw else collate
+    collate_fn = collate_raw if raw else collate
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank) if world > 1 else None
     loader = torch.utils.data.DataLoader(train_set, batch_size=cfg.getint("batch_size"), shuffle=sampler is None,
                                          drop_last=True, collate_fn=collate_fn,
-                                         num_workers=cfg.getint("num_workers", 0), sampler=sampler, pin_memory=not raw)
+                                         num_workers=cfg.getint("num_workers", 0), sampler=sampler, pin_memory=True)
 
     def to_batch(item):
         if raw:
@@ -181,6 +181,9 @@ def main(argv=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         t0, n_img, out = time.time(), 0, None
+        # MMD_TRAIN_TIMING=1: host seconds per segment of the loop (loader / input wait / capture+replay / submit / logging), printed per epoch
+        seg = {"loader": 0.0, "input": 0.0, "step": 0.0, "submit": 0.0, "log": 0.0} if os.environ.get("MMD_TRAIN_TIMING") else None
+        tick = time.perf_counter
         it = iter(loader)
         # one batch of look-ahead: the raw pipeline transforms batch n+1 on its copy stream while the step of batch n runs
         nxt = next(it, None)
@@ -189,7 +192,10 @@ def main(argv=None):
         i_iter = 0
         while nxt is not None:
             item = nxt
+            ts = tick()
             batch = staged.wait() if raw else to_batch(item)
+            if seg is not None:
+                seg["input"] += tick() - ts
             if kdlist_aug and TR.kdlist_augment_now(epoch):
                 # traditional_nms_kdlist_augmented (traditional.py:121-124, train_methods.py:50-162): the batch's audio is replaced by
                 # its mix with other recordings' audio (`label, audio = train_set.yield_batch(...)`).  Whether those recordings' RGB frames
@@ -200,12 +206,16 @@ def main(argv=None):
                 batch = dict(batch, audio=mixed.to(dev, non_blocking=True))
                 if kdlist_pass:
                     batch["aug_rgb"] = aug_rgb.to(dev, non_blocking=True)
+            ts = tick()
             nxt = next(it, None)
+            t1 = tick()
             if not captured:
                 eng.capture(batch); captured = True
             out = eng.replay(batch)
+            t2 = tick()
             if raw and nxt is not None:
                 staged = pipe.submit(nxt)        # after replay(): the static inputs were copied out of `batch` on the compute stream
+            t3 = tick()
             n_img += batch["audio"].shape[0]; steps += 1
             if steps % 10 == 0 or steps == 1:
                 reg, cls, kd = out["reg"].item(), out["cls"].item(), out["kd"].sum().item()
@@ -217,6 +227,8 @@ def main(argv=None):
                 writer.add_scalar("Train/Total_loss", loss, gstep); writer.add_scalar("Train_/Regression_loss", reg, gstep)
                 writer.add_scalar("Train/Class_loss", cls, gstep); writer.add_scalar("Train/KLDiv", 0.0, gstep)
                 writer.add_scalar("Train/KD", kd, gstep)
+            if seg is not None:
+                seg["loader"] += t1 - ts; seg["step"] += t2 - t1; seg["submit"] += t3 - t2; seg["log"] += tick() - t3
             i_iter += 1
             if 0 < args.max_steps <= steps:
                 stop = True
@@ -231,6 +243,8 @@ def main(argv=None):
         loss = w_main * (out["reg"].item() + out["cls"].item()) + w_kd * out["kd"].sum().item()
         loss = TR.allreduce_mean(loss, world, dev)
         logger.info("epoch %d: %.1f images/sec on this rank, last loss %.5f", epoch + 1, n_img / (time.time() - t0), loss)
+        if seg is not None:
+            logger.info("epoch %d host seconds: %s (wall %.2f, %d steps)", epoch + 1, {k: round(v, 3) for k, v in seg.items()}, time.time() - t0, i_iter)
         sched.step(loss)
         if no_validation:
             if stop:
