@@ -95,8 +95,8 @@ def tune_teacher_bias(spec, state, x, device, target_per_image=40):
 def cpu_baseline(sstate, tstates, S, sample_b, coef=2):
     from oracle import step_ref as ST
     from mm_distillnet_amd.arch import make_spec as ms
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(ncpu, 64)))
+    from mm_distillnet_amd.hostinfo import limit_torch_threads
+    limit_torch_threads(64)         # this process' CPU share (affinity and cgroup quota), at most 64
     log("cpu baseline on %d threads" % torch.get_num_threads())
     batch = synth_inputs(sample_b, S, seed=77)
     spec = ms(coef, 8)

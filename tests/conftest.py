@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle's CPU work on the host's CPU SHARE (cgroup quota), not on one thread per visible core
+    from mm_distillnet_amd.hostinfo import limit_torch_threads
+    limit_torch_threads()
 
 
 @pytest.fixture(scope="session")

@@ -35,12 +35,31 @@ def _shard(rank):
     return {k: v.to("cuda") for k, v in synth_inputs(B, S, seed=40 + rank).items()}
 
 
-def _worker(rank, world, port, q):
+def _gather_cpu(t):
+    """all_gather of a device tensor through host copies (the test's own bookkeeping: gloo moves device tensors very slowly)."""
     import torch.distributed as dist
+    mine = t.detach().cpu()
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return out
+
+
+def _worker(rank, world, port, q):
+    import time
+    import torch.distributed as dist
+    t0 = time.time()
+
+    def mark(what):
+        if rank == 0:
+            print("[rank 0 %6.1f s] %s" % (time.time() - t0, what), flush=True)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from mm_distillnet_amd.hostinfo import cpu_share
+    torch.set_num_threads(max(1, cpu_share() // world))       # (a spawned child starts from torch's default: one thread per visible core)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    mark("process group up")
     eng, spec = _build(world)
+    mark("engine built")
     batch = _shard(rank)
     ds = eng.make_drop_scale(B, torch.Generator(device="cuda").manual_seed(3))      # same masks as the single-rank runs
     # eager data-parallel step, phase by phase (what DistillEngine.step does), keeping the local gradient for the check
@@ -51,31 +70,31 @@ def _worker(rank, world, port, q):
     (p0,), tail = eng.grad_buckets()
     seg1 = g[p0[0]:p0[1]].clone()
     assert g[:p0[0]].abs().max().item() == 0.0            # the early blocks' gradients do not exist yet
+    mark("first backward segment done")
     eng.allreduce_grads(0)                                 # overlaps the second backward segment
     eng.backward_tail()
     torch.cuda.synchronize()
     local = g.clone(); local[p0[0]:p0[1]] = seg1           # this rank's own gradient, before any reduction
     eng.allreduce_grads(1)
     torch.cuda.synchronize()
-    both = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(both, local)
-    summed_ok = bool(torch.equal(g, both[0] + both[1]))
+    mark("both all-reduce phases done")
+    both = _gather_cpu(local)
+    summed_ok = bool(torch.equal(g.cpu(), both[0] + both[1]))
     ha = int(eng.head_active.item())
     eng.optimizer_body()
     torch.cuda.synchronize()
-    flats = [torch.empty_like(eng.student.ps.flat) for _ in range(world)]
-    dist.all_gather(flats, eng.student.ps.flat)
+    flats = _gather_cpu(eng.student.ps.flat)
     same_params = bool(torch.equal(flats[0], flats[1]))
-    rms = [torch.empty_like(eng.student.ps.rmean) for _ in range(world)]
-    dist.all_gather(rms, eng.student.ps.rmean)
+    rms = _gather_cpu(eng.student.ps.rmean)
     bn_per_rank = not bool(torch.equal(rms[0], rms[1]))    # plain BatchNorm2d: running statistics stay per rank
+    mark("eager step checked")
     # captured path: three graphs + the collectives issued between them
     eng2, _ = _build(world)
     eng2.capture(batch)
     eng2.replay(batch, ds)
     torch.cuda.synchronize()
-    f2 = [torch.empty_like(eng2.student.ps.flat) for _ in range(world)]
-    dist.all_gather(f2, eng2.student.ps.flat)
+    mark("captured step replayed")
+    f2 = _gather_cpu(eng2.student.ps.flat)
     graph_ok = bool(torch.equal(f2[0], f2[1])) and (eng2.student.ps.flat - eng.student.ps.flat).abs().max().item() <= 2.5e-4
     q.put((rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, local.cpu().numpy(), eng.student.ps.flat.cpu().numpy(), my_labels))      # numpy: pickled by value (torch tensors travel as shared-memory handles that die with the child)
     dist.barrier()
@@ -83,6 +102,8 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_one_gpu_match_single_rank_runs():
+    import time
+    t_start = time.time()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -97,6 +118,7 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
         assert summed_ok, "all-reduced buffer != sum of the ranks' gradients"
         assert same_params and bn_per_rank and graph_ok, (rank, same_params, bn_per_rank, graph_ok)
     assert res[0][2] == res[1][2]                          # head_active agreed (MAX-reduced)
+    print("[parent %6.1f s] both ranks done" % (time.time() - t_start), flush=True)
     # single-rank runs of the two shards: same gradients (up to the atomics' summation order), and Adam on (gA + gB) / 2
     grads, single_labels = [], []
     for rank in range(2):
@@ -131,6 +153,7 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
     eng.optimizer_body()
     torch.cuda.synchronize()
     assert (eng.student.ps.flat.cpu() - torch.from_numpy(res[0][7])).abs().max().item() <= 2.5e-4      # one Adam step moves a weight by <= lr
+    print("[parent %6.1f s] single-rank runs compared" % (time.time() - t_start), flush=True)
     # ---- the same two shards through the ORACLE (the reference's DDP semantics: every rank runs forward / backward on its own shard with
     # its own BatchNorm statistics, DDP averages the gradients, every rank applies the same Adam step: src/optimization/train_methods.py:944-961)
     import numpy as np
@@ -184,6 +207,7 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
     for k, a in params.items():
         dlt = (w2[k].double() - a.double()).abs()
         worst = max(worst, float(dlt.max())); close_n += float((dlt <= 0.05 * lr).sum()); n_el += dlt.numel()
+    print("[parent %6.1f s] oracle DDP compared" % (time.time() - t_start), flush=True)
     print("two ranks vs oracle DDP: Adam-updated weights max |diff| %.2e, %.4f of the elements within 5 %% of lr" % (worst, close_n / n_el))
     assert worst <= 2.05 * lr and close_n / n_el >= (0.99 if labels_equal else 0.95)
 

@@ -160,7 +160,7 @@ def test_d4_768_step_vs_oracle():
     mode of the same step bounded against the fp32 one."""
     from oracle import step_ref as ST
     from helpers import grad_state
-    S, B, coef = 768, 1, 4      # (B = 1: the oracle's CPU step at this size takes ~25 s per image and runs twice here; B >= 2 bounds of the same kind: tests/test_gpu_net.py)
+    S, B, coef = 768, 2, 4
     eng, spec = build("pairwise", S, coef=coef)
     teachers = {k: v[1] for k, v in teacher_states(coef, MODS).items()}
     _, st = make_state(coef, 8, 24, "audio")
@@ -235,9 +235,7 @@ def test_d4_768_step_vs_oracle():
             d += float((u * w).sum()); a2 += float((u * u).sum()); b2 += float((w * w).sum())
         return d / (a2 ** 0.5 * b2 ** 0.5)
 
-    # (at this size only configs[4]'s own mode, bf16_hbm - a superset of "bf16"'s rounding; the operand-only mode is held to the same kind of
-    # bound by tests/test_gpu_net.py at D2 train / D4 eval: a second emulated oracle step here would cost another minute of CPU time)
-    for precision in ("bf16_hbm",):
+    for precision in ("bf16", "bf16_hbm"):
         se = grad_state(st)
         O.BF16_PW, O.W16 = True, precision == "bf16_hbm"
         try:

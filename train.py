@@ -124,6 +124,9 @@ def main(argv=None):
     rank, local = args.rank, args.local_rank
     ngpu = cfg.getint("ngpu", 1)
     world = int(os.environ.get("WORLD_SIZE", ngpu * args.nodes if cfg.get("engine") == "DistributedDataParallel" else 1))
+    from mm_distillnet_amd.hostinfo import cpu_share
+    # host-side torch ops on this rank's part of the CPU share (cgroup quota), not one thread per visible core
+    torch.set_num_threads(max(1, cpu_share() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", ngpu if world > 1 else 1)))))
     os.makedirs(cfg["exp_name"], exist_ok=True)
     logging.basicConfig(level=logging.INFO, handlers=[logging.StreamHandler(),
                                                       logging.FileHandler(f"{cfg['exp_name']}/{os.path.basename(cfg['exp_name'].rstrip('/'))}.{rank}.log")])
