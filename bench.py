@@ -173,6 +173,9 @@ def main():
         local = int(os.environ["MMD_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    # host-side torch ops (weight generation, teacher calibration): this rank's part of the CPU share, not one thread per visible core
+    from mm_distillnet_amd.hostinfo import cpu_share
+    torch.set_num_threads(max(1, cpu_share() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     pg = None
     if world > 1:
         import torch.distributed as dist
@@ -252,7 +255,9 @@ def main():
     # "slow" mode (~5 % apart) depending on the process / time window (profiles/r02_notes.md); the 20-step mean above cannot tell which
     # one it landed in, the median and spread of 100 steps next to it can.
     per = []
-    for _ in range(max(int(os.environ.get("MMD_BENCH_PERSTEP", "100")), 1)):
+    # (bounded to ~20 s of steps; `ms` is the max over the ranks, so every rank runs the same count and the per-sample barriers pair up)
+    n_per = max(5, min(int(os.environ.get("MMD_BENCH_PERSTEP", "100")), int(20e3 / max(ms, 1e-3))))
+    for _ in range(n_per):
         barrier() if world > 1 else torch.cuda.synchronize()
         t1 = time.perf_counter()
         run()
