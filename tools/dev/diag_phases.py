@@ -35,7 +35,7 @@ def timeit(name, g, n=10):
     print(f"{name:<44} {(time.perf_counter() - t0) / n * 1e3:8.3f} ms", flush=True)
 
 
-def cap(fn):
+def cap(fn, stream=None):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -43,7 +43,7 @@ def cap(fn):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with (torch.cuda.graph(g) if stream is None else torch.cuda.graph(g, stream=stream)):
         fn()
     return g
 
@@ -160,3 +160,31 @@ torch.cuda.synchronize()
 print(f"{'teacher graph || teacher-less step graph':<44} {(time.perf_counter() - t0) / 10 * 1e3:8.3f} ms", flush=True)
 timeit("teacher-less step graph alone", g_noteach)
 timeit("teacher graph alone", g_teach)
+
+# ---- the same pair with the teacher-less step graph replayed on (and, second variant, captured on) a HIGH-priority stream: do the
+# student's kernels then get the CUs first?
+s_hi = torch.cuda.Stream(priority=-1)
+def both_prio(g_student):
+    cur = torch.cuda.current_stream()
+    s2.wait_stream(cur); s_hi.wait_stream(cur)
+    with torch.cuda.stream(s2):
+        g_teach.replay()
+    with torch.cuda.stream(s_hi):
+        g_student.replay()
+    cur.wait_stream(s2); cur.wait_stream(s_hi)
+def time_pair(label, g_student):
+    for _ in range(3):
+        both_prio(g_student)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        both_prio(g_student)
+    torch.cuda.synchronize()
+    print(f"{label:<44} {(time.perf_counter() - t0) / 10 * 1e3:8.3f} ms", flush=True)
+time_pair("teacher graph || step graph on a high-priority stream", g_noteach)
+for mod, net in tn:
+    net.begin_step = (lambda: None)
+    net.forward = (lambda x, train=False, _m=mod: cached[_m])
+g_hi = cap(lambda: eng.step_body(eng.static, ds), stream=s_hi)
+torch.cuda.synchronize()
+time_pair("  ... and captured on it", g_hi)
