@@ -235,6 +235,7 @@ def test_d4_768_step_vs_oracle():
             d += float((u * w).sum()); a2 += float((u * u).sum()); b2 += float((w * w).sum())
         return d / (a2 ** 0.5 * b2 ** 0.5)
 
+    emu = {}
     for precision in ("bf16", "bf16_hbm"):
         se = grad_state(st)
         O.BF16_PW, O.W16 = True, precision == "bf16_hbm"
@@ -243,16 +244,27 @@ def test_d4_768_step_vs_oracle():
             ST.total_loss(refe).backward()
         finally:
             O.BF16_PW, O.W16 = False, False
-        gem = {k: v.grad for k, v in se.items() if v.requires_grad and v.grad is not None}
+        emu[precision] = ({k: v.grad for k, v in se.items() if v.requires_grad and v.grad is not None},
+                          max(abs(refe["cls"].item() - ref["cls"].item()) / abs(ref["cls"].item()),
+                              abs(refe["reg"].item() - ref["reg"].item()) / abs(ref["reg"].item())))
+    # The loss shift of a rounding mode on this random-weight D4 net is a noisy quantity: the emulation (deterministic) shifts by 11 % in one
+    # mode and 4 % in the other, the HIP step (fp32 atomics upstream of the roundings) by 5 - 11 % from run to run of ONE mode.  The bound
+    # therefore takes the larger of the two emulated shifts as the scale of the effect.
+    shift = max(v[1] for v in emu.values())
+    for precision in ("bf16", "bf16_hbm"):
+        gem = emu[precision][0]
         eng_b, _ = build("pairwise", S, precision=precision, coef=coef)
         ob = eng_b.step_body(batch, ds, teacher_labels=eng_b.labels_from_rows(ref["per_teacher"], A))
         torch.cuda.synchronize()
         ghip = eng_b.student.ps.export_grads()
         c_emu, c_hip, c_he = cosine(gem, g32), cosine(ghip, g32), cosine(ghip, gem)
-        shift = max(abs(refe["cls"].item() - ref["cls"].item()) / abs(ref["cls"].item()), abs(refe["reg"].item() - ref["reg"].item()) / abs(ref["reg"].item()))
         print("D4/768 %s step: gradient cos emulation vs fp32 %.4f, HIP vs fp32 %.4f, HIP vs emulation %.4f; loss shift of the emulation %.2e, of HIP cls %.2e reg %.2e" % (
-            precision, c_emu, c_hip, c_he, shift, abs(ob["cls"].item() - loss32[1]) / abs(loss32[1]), abs(ob["reg"].item() - loss32[0]) / abs(loss32[0])))
+            precision, c_emu, c_hip, c_he, emu[precision][1], abs(ob["cls"].item() - loss32[1]) / abs(loss32[1]), abs(ob["reg"].item() - loss32[0]) / abs(loss32[0])))
         assert (1 - c_hip) <= 2.0 * (1 - c_emu) + 2e-2 and (1 - c_he) <= 2.0 * (1 - c_emu) + 2e-2, (precision, c_emu, c_hip, c_he)
+        # (with cos_emu ~ 0.4 the angle bound above is loose; what separates a working mode from an indexing bug - uncorrelated gradients,
+        # cos ~ 0 - is that the HIP gradient is as aligned with fp32 and with the emulation as the emulation is with fp32: measured ratios
+        # 1.02 - 1.17 and 1.4 - 1.5)
+        assert c_hip >= 0.75 * c_emu and c_he >= 0.75 * c_emu, (precision, c_emu, c_hip, c_he)
         assert abs(ob["reg"].item() - loss32[0]) <= (2.0 * shift + 2e-2) * abs(loss32[0]) and abs(ob["cls"].item() - loss32[1]) <= (2.0 * shift + 2e-2) * abs(loss32[1])
         np.testing.assert_allclose(ob["kd"].cpu().numpy(), loss32[2], rtol=0.1, atol=1e-3)
         del eng_b
