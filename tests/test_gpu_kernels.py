@@ -439,9 +439,10 @@ def test_affine_act_residual_and_fold():
     close(y, ref, 1e-4, 1e-5)
 
 
-def test_se_path():
+@pytest.mark.parametrize("C,S", [(144, 6), (1248, 52)])      # an early and a late MBConv stage of D2
+def test_se_path(C, S):
     torch.manual_seed(2)
-    B, HW, C, S = 3, 64, 144, 6
+    B, HW = 3, 64
     z = torch.randn(B * HW, C, requires_grad=True)
     sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
     wr = (torch.randn(S, C) / 12).requires_grad_(True); br = torch.randn(S, requires_grad=True)
