@@ -1160,6 +1160,8 @@ class Net:
         if theta_desc:
             key = tuple(theta_desc)
             if key not in self._theta_desc:
+                if self.arena.frozen:       # (under capture the upload would be recorded as a copy from a host temporary)
+                    raise RuntimeError("fusion-weight gradient operands moved after graph capture")
                 self._theta_desc[key] = torch.tensor(theta_desc, dtype=torch.int64, device=self.device)
             self._leaf(lambda d=self._theta_desc[key], n=len(theta_desc): call("mmd_bifpn_theta_bwd_batched", ps.flat, ps.grad, wdot_all, d, n))
         self._backward_blocks([b for b in spec.blocks if stop_before is None or b.idx >= stop_before])
@@ -1278,6 +1280,8 @@ class Net:
             recs, self._se_wg = self._se_wg, []
             key = tuple((r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), r[3].data_ptr(), r[4].data_ptr()) for r in recs)
             if key not in self._se_wg_tabs:
+                if self.arena.frozen:
+                    raise RuntimeError("squeeze-excite weight-gradient operands moved after graph capture")
                 rows = [[t.data_ptr() for t in r[:8]] + [r[8], r[9]] for r in recs]
                 self._se_wg_tabs[key] = torch.tensor(rows, dtype=torch.int64, device=self.device)
             tab, nb = self._se_wg_tabs[key], recs[0][0].shape[0]
