@@ -38,3 +38,22 @@ def limit_torch_threads(cap: int | None = None) -> int:
     n = cpu_share() if cap is None else max(1, min(cpu_share(), cap))
     torch.set_num_threads(n)
     return n
+
+
+def free_memory_gb() -> float:
+    """Host memory this process may still take: min(what the machine has available, cgroup limit - cgroup usage), in GiB."""
+    try:
+        import psutil
+        free = float(psutil.virtual_memory().available)
+    except Exception:
+        free = math.inf
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            l = open(lim).read().strip()
+            if l != "max":
+                free = min(free, float(l) - float(open(cur).read().strip()))
+            break
+        except (OSError, ValueError):
+            continue
+    return free / 2 ** 30

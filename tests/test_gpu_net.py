@@ -137,8 +137,8 @@ def test_net_eval_512_vs_oracle(B):
 def _full_size_batch():
     """B = 8, the benchmark's per-GPU batch.  The oracle's autograd tape needs ~3 GB of host memory per image at 512^2: a host
     without it SKIPS (loudly) - the test never shrinks to a smaller batch on its own."""
-    import psutil
-    free_gb = psutil.virtual_memory().available / 2 ** 30
+    from mm_distillnet_amd.hostinfo import free_memory_gb
+    free_gb = free_memory_gb()          # (machine-available and cgroup limit)
     if free_gb < 48:
         pytest.skip(f"full-size parity test needs >= 48 GB of free host memory for the oracle (have {free_gb:.0f} GB): NOT RUN at B = 8")
     print(f"full-size parity test: B = 8 ({free_gb:.0f} GB of host memory free)")

@@ -313,12 +313,12 @@ def test_full_size_step_graph_vs_oracle(teach):
     masks: teachers on staggered side streams, decode + NMS + cross-teacher merge at ~60 candidates per teacher and image, focal loss over
     A = 49 104 anchors, the MTA terms, the student's backward incl. the grouped weight gradients, Adam, and the same again from the updated
     weights.  Reference: src/optimization/train_methods.py:436-517, src/optimization/traditional.py:171-190."""
-    import psutil
     import bench as BN
     from oracle import step_ref as ST
     from helpers import grad_state
     S, B, coef = 512, 8, 2
-    free_gb = psutil.virtual_memory().available / 2 ** 30
+    from mm_distillnet_amd.hostinfo import free_memory_gb
+    free_gb = free_memory_gb()          # (machine-available and cgroup limit)
     if free_gb < 64:
         pytest.skip(f"full-size step test needs >= 64 GB of free host memory for the oracle's autograd tape (have {free_gb:.0f} GB): NOT RUN at B = 8")
     print(f"full-size whole-step parity test: B = {B}, {S} x {S} ({free_gb:.0f} GB of host memory free)")
