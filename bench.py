@@ -213,6 +213,16 @@ def main():
     eng.load(sstate, tstates)
     if os.environ.get("MMD_COMM") == "rccl" and (world > 1 or eng.force_ar):
         eng.init_comm(rank)      # gradient exchange through the C ABI's own RCCL communicator (csrc/comm.hip) instead of torch.distributed
+    # what the collective layer ITSELF reports (a scaling record can then show that RCCL saw N ranks, not just that N processes ran)
+    collective = {"backend": None, "ranks": 1, "c_abi": False}
+    if world > 1 or eng.force_ar:
+        import torch.distributed as dist
+        collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "c_abi": eng.comm is not None}
+        if eng.comm is not None:
+            import ctypes
+            n_c = ctypes.c_int(0)
+            rc = _lib.LIB.load().mmd_comm_count(eng.comm, ctypes.cast(ctypes.pointer(n_c), ctypes.c_void_p))
+            collective["c_abi_ranks"] = n_c.value if rc == 0 else None
     if world > 1:   # identical initial student on every rank (DDP broadcasts parameters and buffers at construction) and identical teachers
         import torch.distributed as dist
         for net in [eng.student] + list(eng.teachers.values()):
@@ -280,10 +290,14 @@ def main():
     cpu = None
     if rank == 0:
         dll = _lib.LIB.load()
+        # the *_w16 entry points live in the second build of the library, which has its own profiler state: enable and collect on both
+        dlls = [dll] + ([_lib.LIB16.load()] if args.precision == "bf16_hbm" else [])
         if os.environ.get("MMD_PROF_DUMP"):
-            dll.mmd_prof_dump_to(os.environ["MMD_PROF_DUMP"].encode())
+            for i, d in enumerate(dlls):
+                d.mmd_prof_dump_to((os.environ["MMD_PROF_DUMP"] + (".w16" if i else "")).encode())
         for fam in FAMILIES:
-            dll.mmd_prof_enable(fam, 1)
+            for d in dlls:
+                d.mmd_prof_enable(fam, 1)
         torch.cuda.synchronize()
         # one eager step on a single stream (teachers, weight-gradient and head side branches folded onto it), so that an
         # event pair brackets one kernel running alone - the same condition as the serialised rocprofv3 kernel trace
@@ -298,12 +312,16 @@ def main():
         import ctypes
         res = {}
         for fam in FAMILIES:
-            buf = (ctypes.c_double * 4)()
-            dll.mmd_prof_collect(fam, buf)
-            dll.mmd_prof_enable(fam, 0)
-            res[fam] = list(buf)
+            tot = [0.0] * 4
+            for d in dlls:
+                buf = (ctypes.c_double * 4)()
+                d.mmd_prof_collect(fam, buf)
+                d.mmd_prof_enable(fam, 0)
+                tot = [a + b for a, b in zip(tot, buf)]
+            res[fam] = tot
         log("family times ms: %s" % {f: round(res[f][1], 3) for f in res})
-        dll.mmd_prof_dump_to(None)
+        for d in dlls:
+            d.mmd_prof_dump_to(None)
         fam = max(res, key=lambda f: res[f][1])
         n, tms, fl, by = res[fam]
         name, bound = FAMILIES[fam]
@@ -354,7 +372,7 @@ def main():
                                        + ": full 3-teacher (RGB+thermal+depth) -> audio student distillation step, EfficientDet-D%d, "
                                          "%dx%d, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % (args.coef, S, S, B),
                            "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
-                           "graph": use_graph, "pseudo_label_boxes_per_image": nbox},
+                           "graph": use_graph, "pseudo_label_boxes_per_image": nbox, "collective": collective},
                 "per_step": per_step, "roofline": roof, "cpu_baseline": cpu}
         sys.stdout.flush()
         os.write(real_out, (json.dumps(line) + "\n").encode())

@@ -381,6 +381,8 @@ int mmd_comm_unique_id(void* out128);
 int mmd_comm_init(void** comm_out, int rank, int world, const void* unique_id128);
 // In place, asynchronous on `stream`; dtype 0 = float32, 1 = int32; op 0 = sum, 1 = max.
 int mmd_comm_allreduce_bucket(void* comm, void* buf, long long count, int dtype, int op, hipStream_t stream);
+// ranks RCCL reports for the communicator (ncclCommCount) -> *(int*)count_out
+int mmd_comm_count(void* comm, void* count_out);
 int mmd_comm_destroy(void* comm);
 
 // ---------------------------------------------------------------------------------------------------------------------------------

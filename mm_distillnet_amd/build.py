@@ -19,11 +19,18 @@ LIB16 = os.path.join(PKG, "libmmdistill_hip_w16.so")
 VARIANTS = ((LIB, "build", ["-DMMD_NO_W16"]), (LIB16, os.path.join("build", "w16"), []))
 
 
+def _want_flags(extra) -> str:
+    return " ".join([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *FLAGS, *extra])
+
+
 def needs_build() -> bool:
     srcs = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
-    for lib, _, _ in VARIANTS:
+    for lib, odir, extra in VARIANTS:
         if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
             return True
+        stamp = os.path.join(PKG, odir, "flags.stamp")
+        if os.path.exists(stamp) and open(stamp).read() != _want_flags(extra):
+            return True         # built with other flags (an A/B build): rebuild rather than silently reuse
     return False
 
 
@@ -32,14 +39,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    # (include/mmdistill.h is the binding contract; no kernel source includes it, so it does not date the objects)
     hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))
     procs, objs = [], {lib: [] for lib, _, _ in VARIANTS}
     for lib, odir, extra in VARIANTS:
         os.makedirs(os.path.join(PKG, odir), exist_ok=True)
+        # objects are only reused when they were compiled with this exact flag list (A/B builds with MMD_EXTRA_HIPCC_FLAGS, -DMMD_NO_W16)
+        stamp, want = os.path.join(PKG, odir, "flags.stamp"), _want_flags(extra)
+        # (no stamp yet = objects of a tree from before the stamps: they were built with the default flags)
+        same_flags = (open(stamp).read() == want) if os.path.exists(stamp) else not os.environ.get("MMD_EXTRA_HIPCC_FLAGS")
+        open(stamp, "w").write(want)
         for s in srcs:
             o = os.path.join(PKG, odir, os.path.basename(s)[:-4] + ".o")
             objs[lib].append(o)
-            if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
+            if not force and same_flags and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_t):
                 continue            # object newer than its source and every header
             procs.append((s, subprocess.Popen([hipcc, *FLAGS, *extra, "-c", s, "-o", o], stdout=subprocess.PIPE,
                                               stderr=subprocess.STDOUT)))

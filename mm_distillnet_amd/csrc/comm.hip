@@ -14,7 +14,8 @@ typedef int (*fn_get_id)(UniqueId*);
 typedef int (*fn_init)(Comm*, int, UniqueId, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*fn_destroy)(Comm);
-struct Api { void* lib; fn_get_id get_id; fn_init init; fn_allreduce allreduce; fn_destroy destroy; };
+typedef int (*fn_count)(Comm, int*);
+struct Api { void* lib; fn_get_id get_id; fn_init init; fn_allreduce allreduce; fn_destroy destroy; fn_count count; };
 Api* api() {
   static Api a{};
   static bool tried = false;
@@ -27,6 +28,7 @@ Api* api() {
       a.init = (fn_init)dlsym(a.lib, "ncclCommInitRank");
       a.allreduce = (fn_allreduce)dlsym(a.lib, "ncclAllReduce");
       a.destroy = (fn_destroy)dlsym(a.lib, "ncclCommDestroy");
+      a.count = (fn_count)dlsym(a.lib, "ncclCommCount");
       if (!a.get_id || !a.init || !a.allreduce || !a.destroy) a.lib = nullptr;
     }
   }
@@ -69,6 +71,17 @@ extern "C" int mmd_comm_allreduce_bucket(void* comm, void* buf, long long count,
   const int nccl_dtype = dtype == 0 ? 7 /* ncclFloat32 */ : 2 /* ncclInt32 */;
   const int nccl_op = op == 0 ? 0 /* ncclSum */ : 2 /* ncclMax */;
   return a->allreduce(buf, buf, (size_t)count, nccl_dtype, nccl_op, comm, stream) == 0 ? MMD_OK : MMD_ELAUNCH;
+}
+
+// Number of ranks RCCL itself reports for the communicator (ncclCommCount): what a scaling record cites as "RCCL saw N ranks".
+extern "C" int mmd_comm_count(void* comm, void* count_out) {
+  if (!comm || !count_out) return MMD_EINVAL;
+  Api* a = api();
+  if (!a || !a->count) return MMD_ENOLIB;
+  int n = 0;
+  if (a->count(comm, &n) != 0) return MMD_ELAUNCH;
+  *(int*)count_out = n;
+  return MMD_OK;
 }
 
 extern "C" int mmd_comm_destroy(void* comm) {

@@ -783,8 +783,8 @@ template <typename T> __device__ __forceinline__ T pyr_sel(const T* arr, int lev
   for (int i = 1; i < MMD_MAX_LEV; ++i) if (lev == i) v = arr[i];
   return v;
 }
-__global__ __launch_bounds__(256) void pyr_add_bnsums_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                            const float* __restrict__ c3, float* __restrict__ out, int C, Pyr pyr,
+__global__ __launch_bounds__(256) void pyr_add_bnsums_kernel(const float* a, const float* __restrict__ b,
+                                                            const float* __restrict__ c3, float* out, int C, Pyr pyr,   // out may alias a (in place)
                                                             PyrBnDst d) {
   __shared__ float sRed[256];
   const int tid = threadIdx.x;

@@ -853,6 +853,7 @@ class Net:
                 if into is not None:
                     assert not x.w16
                     slot, xs = self._contrib(into, True)
+                    assert xs is None or not xs[6], "the GEMM epilogue sums the accumulated total: not a linear-sum (pooled) tensor"
                     residual = slot.t
                     if slot.t is None:
                         slot.t = self._alloc(M, K)
@@ -873,6 +874,7 @@ class Net:
                 return None if into is not None else dx
             if into is not None and FOLD_SUMS:
                 slot, xs = self._contrib(into, True)
+                assert xs is None or not xs[6], "the GEMM epilogue sums the accumulated total: not a linear-sum (pooled) tensor"
                 residual = slot.t
                 if slot.t is None:
                     slot.t = self._alloc(M, K)

@@ -1,7 +1,7 @@
 """Two data-parallel ranks on ONE GPU (both processes on cuda:0, gloo carrying the collectives): the N > 1 step path end to end -
 split backward, phased all-reduce of the flat student gradient buffer, head_active MAX-reduce, 1/N folded into Adam, per-rank
-BatchNorm statistics - against single-rank runs of the same two shards.  (RCCL itself needs two devices; the driver's 8-GPU run
-covers it.  Reference: DDP wrap + DistributedSampler, src/optimization/train_methods.py:944-961, src/optimization/traditional.py:58-71.)"""
+BatchNorm statistics - against single-rank runs of the same two shards.  (RCCL itself needs two devices: `test_two_ranks_rccl` below runs
+the same workers over it wherever two devices are visible and skips on a one-GPU box.  Reference: DDP wrap + DistributedSampler, src/optimization/train_methods.py:944-961, src/optimization/traditional.py:58-71.)"""
 import os
 import socket
 
@@ -36,15 +36,21 @@ def _shard(rank):
 
 
 def _gather_cpu(t):
-    """all_gather of a device tensor through host copies (the test's own bookkeeping: gloo moves device tensors very slowly)."""
+    """all_gather of a device tensor through host copies (the test's own bookkeeping: gloo moves device tensors very slowly);
+    over RCCL ("nccl" backend: device tensors only) the gather runs on the devices and the result is copied down."""
     import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        mine = t.detach().contiguous()
+        out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, mine)
+        return [o.cpu() for o in out]
     mine = t.detach().cpu()
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", c_abi=False):
     import time
     import torch.distributed as dist
     t0 = time.time()
@@ -55,10 +61,22 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     from mm_distillnet_amd.hostinfo import cpu_share
     torch.set_num_threads(max(1, cpu_share() // world))       # (a spawned child starts from torch's default: one thread per visible core)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mark("process group up")
+    if backend == "nccl":          # one device per rank: RCCL over xGMI / PCIe between them
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:%d" % rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    mark("process group up (%s, %d ranks)" % (dist.get_backend(), dist.get_world_size()))
     eng, spec = _build(world)
+    comm_ranks = None
+    if c_abi:                      # MMD_COMM=rccl: the exchange through the C ABI's own communicator (csrc/comm.hip)
+        import ctypes
+        from mm_distillnet_amd import _lib
+        eng.init_comm(rank)
+        n_c = ctypes.c_int(0)
+        assert _lib.LIB.load().mmd_comm_count(eng.comm, ctypes.cast(ctypes.pointer(n_c), ctypes.c_void_p)) == 0
+        comm_ranks = n_c.value
     mark("engine built")
     batch = _shard(rank)
     ds = eng.make_drop_scale(B, torch.Generator(device="cuda").manual_seed(3))      # same masks as the single-rank runs
@@ -90,14 +108,19 @@ def _worker(rank, world, port, q):
     mark("eager step checked")
     # captured path: three graphs + the collectives issued between them
     eng2, _ = _build(world)
+    if c_abi:
+        eng2.init_comm(rank)
     eng2.capture(batch)
     eng2.replay(batch, ds)
     torch.cuda.synchronize()
     mark("captured step replayed")
     f2 = _gather_cpu(eng2.student.ps.flat)
     graph_ok = bool(torch.equal(f2[0], f2[1])) and (eng2.student.ps.flat - eng.student.ps.flat).abs().max().item() <= 2.5e-4
-    q.put((rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, local.cpu().numpy(), eng.student.ps.flat.cpu().numpy(), my_labels))      # numpy: pickled by value (torch tensors travel as shared-memory handles that die with the child)
+    q.put((rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, local.cpu().numpy(), eng.student.ps.flat.cpu().numpy(), my_labels,
+           (dist.get_backend(), dist.get_world_size(), comm_ranks)))      # numpy: pickled by value (torch tensors travel as shared-memory handles that die with the child)
     dist.barrier()
+    if c_abi:
+        eng.close_comm(); eng2.close_comm()
     dist.destroy_process_group()
 
 
@@ -114,7 +137,7 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, _, _, _ in res:
+    for rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, _, _, _, _ in res:
         assert summed_ok, "all-reduced buffer != sum of the ranks' gradients"
         assert same_params and bn_per_rank and graph_ok, (rank, same_params, bn_per_rank, graph_ok)
     assert res[0][2] == res[1][2]                          # head_active agreed (MAX-reduced)
@@ -212,6 +235,33 @@ def test_two_ranks_one_gpu_match_single_rank_runs():
     assert worst <= 2.05 * lr and close_n / n_el >= (0.99 if labels_equal else 0.95)
 
 
+@pytest.mark.parametrize("path", ["torch.distributed", "c_abi"])
+def test_two_ranks_rccl(path):
+    """The same two-rank step over RCCL proper: one process per device (0 and 1), `nccl` backend = RCCL, the gradient exchange either
+    through torch.distributed's ProcessGroupNCCL or through the C ABI's own communicator (MMD_COMM=rccl, csrc/comm.hip).  Self-activating:
+    skipped on a one-GPU box, runs wherever two devices are visible.  Checks what the gloo variant checks inside the workers - the reduced
+    buffer is the bit-exact sum of the two ranks' local gradients, both ranks hold identical parameters after Adam, BatchNorm statistics
+    stay per rank, the three-graph captured path equals the eager one - plus that RCCL itself reports two ranks."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl", path == "c_abi")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, summed_ok, ha, same_params, bn_per_rank, graph_ok, _, _, _, (backend, ranks, comm_ranks) in res:
+        assert backend == "nccl" and ranks == 2, (backend, ranks)
+        assert comm_ranks == (2 if path == "c_abi" else None), comm_ranks
+        assert summed_ok, "all-reduced buffer != sum of the ranks' gradients"
+        assert same_params and bn_per_rank and graph_ok, (rank, same_params, bn_per_rank, graph_ok)
+    assert res[0][2] == res[1][2]
+
+
 def test_c_abi_rccl_communicator_one_rank():
     """mmd_comm_* (csrc/comm.hip): a one-rank RCCL communicator through the C ABI - rendezvous token, init, in-place
     all-reduce of a gradient range (sum) and of the head_active flag (max) on a side stream, destroy.  With one rank the collective
@@ -233,4 +283,6 @@ def test_c_abi_rccl_communicator_one_rank():
     torch.cuda.synchronize()
     assert torch.equal(g, ref) and int(flag.item()) == 1
     assert dll.mmd_comm_allreduce_bucket(h, None, 4, 0, 0, None) == -22
+    n_c = ctypes.c_int(0)
+    assert dll.mmd_comm_count(h, ctypes.cast(ctypes.pointer(n_c), ctypes.c_void_p)) == 0 and n_c.value == 1
     assert dll.mmd_comm_destroy(h) == 0

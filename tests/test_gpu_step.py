@@ -277,6 +277,112 @@ def test_d4_768_step_vs_oracle(B):
         torch.cuda.empty_cache()
 
 
+def test_graph_variants_plain_and_list_augmented():
+    """traditional_nms_kdlist_augmented alternates, iteration by iteration, between the plain KD-list step and the one with the extra
+    RGB-teacher pass: one set of hipGraphs per variant, picked by the batch's keys; each replays its own eager step."""
+    S, B = 128, 2
+    eng, spec = build("list", S)
+    ref, _ = build("list", S)
+    plain = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
+    aug = dict(plain, aug_rgb=synth_inputs(B, S, seed=6)["rgb"].to(DEV))
+    ds = eng.make_drop_scale(B, torch.Generator(device=DEV).manual_seed(1))
+    def sync_state():      # both engines start every step from the same parameters / running statistics / optimizer state, so a step is
+        # compared like a first step (two free-running engines drift apart by up to 2 lr per weight and step - Adam's first steps are
+        # sign-like - and train-mode BatchNorm over 2 x 128^2 amplifies that to a few % of the classification loss)
+        for dst, src in ((eng.student.ps, ref.student.ps),):
+            for name in ("flat", "rmean", "rvar", "nbt"):
+                getattr(dst, name).copy_(getattr(src, name))
+        for name in ("exp_avg", "exp_avg_sq", "adam_main", "adam_head", "head_active"):
+            getattr(eng, name).copy_(getattr(ref, name))
+        eng.student.refresh()
+
+    for batch in (plain, aug, plain, aug):
+        sync_state()
+        o = eng.replay(batch, ds)
+        r = ref.step(batch, ds)
+        torch.cuda.synchronize()
+        assert o["nbox"].tolist() == r["nbox"].tolist()
+        np.testing.assert_allclose(o["kd"].cpu().numpy(), r["kd"].cpu().numpy(), rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(o["cls"].cpu().numpy(), r["cls"].cpu().numpy(), rtol=2e-3)
+        assert (eng.student.ps.flat - ref.student.ps.flat).abs().max().item() <= 2.5e-4      # one Adam step of <= lr each, from equal states
+    assert set(eng._graphs) == {"plain", "aug"}
+
+
+def test_graph_replay_matches_eager():
+    """The captured hipGraphs must reproduce the eager step: same pseudo-labels and losses, gradients equal up to the
+    run-to-run noise of fp32 atomics (measured eager-vs-eager: ~2e-4 of the largest gradient at this tiny size), and
+    every replay must start from cleared accumulators (labels of a frozen teacher cannot change between replays)."""
+    S, B = 128, 2
+    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
+    eng_a, spec = build("pairwise", S)
+    eng_b, _ = build("pairwise", S)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    ds = eng_a.make_drop_scale(B, g)
+    eng_b.capture(batch)
+    oa = eng_a.step_body(batch, ds)
+    eng_b.static["drop_scale"].copy_(ds)
+    eng_b.g_main.replay()
+    torch.cuda.synchronize()
+    ob = eng_b.out
+    assert oa["nbox"].tolist() == ob["nbox"].tolist()
+    for k in ("reg", "cls", "kd"):
+        np.testing.assert_allclose(oa[k].cpu().numpy(), ob[k].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    ga, gb = eng_a.student.ps.grad, eng_b.student.ps.grad
+    assert torch.isfinite(gb).all()
+    assert (ga - gb).abs().max().item() <= 2e-3 * ga.abs().max().item()
+    eng_a.optimizer_body(); eng_b.g_opt.replay()
+    torch.cuda.synchronize()
+    assert eng_a.adam_main[0].item() == eng_b.adam_main[0].item() == 1.0
+    assert torch.equal(eng_a.student.ps.nbt, eng_b.student.ps.nbt)
+    # replays 2 and 3: frozen teachers + same inputs -> identical labels every time
+    for _ in range(2):
+        eng_b.replay(batch, ds)
+    torch.cuda.synchronize()
+    assert eng_b.out["nbox"].tolist() == oa["nbox"].tolist()
+    assert torch.isfinite(eng_b.student.ps.flat).all() and eng_b.adam_main[0].item() == 3.0
+
+
+def test_split_backward_matches_unsplit():
+    """The data-parallel step issues the backward in two segments (heads + BiFPN + backbone blocks >= k, then the early
+    blocks + stem) so that the all-reduce of the first segment's gradients overlaps the second.  Same kernels, same order:
+    gradients equal the unsplit backward's up to fp32-atomics noise, eagerly and through the three captured graphs."""
+    S, B = 128, 2
+    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=5).items()}
+    eng_a, spec = build("pairwise", S)
+    eng_b, _ = build("pairwise", S)
+    eng_c, _ = build("pairwise", S)
+    k = eng_b._default_split()
+    assert 0 < k < len(spec.blocks)
+    eng_b.ar_split = eng_c.ar_split = k
+    (p0,), tail = eng_b.grad_buckets()
+    n = eng_b.student.ps.n_params
+    assert sorted([p0] + tail) == [(0, p0[0]), p0, (p0[1], n)]            # the three ranges tile the buffer
+    assert (p0[1] - p0[0]) > 0.9 * n
+    g = torch.Generator(device=DEV).manual_seed(1)
+    ds = eng_a.make_drop_scale(B, g)
+    eng_a.step_body(batch, ds)
+    eng_b.step_body(batch, ds)
+    torch.cuda.synchronize()
+    ga, gb = eng_a.student.ps.grad, eng_b.student.ps.grad
+    tol = 2e-3 * ga.abs().max().item()
+    # after segment 1 the overlapped bucket is final, the early blocks' weights have no gradient yet
+    assert (ga[p0[0]:p0[1]] - gb[p0[0]:p0[1]]).abs().max().item() <= tol
+    assert gb[:p0[0]].abs().max().item() == 0.0
+    eng_b.backward_tail()
+    torch.cuda.synchronize()
+    assert (ga - gb).abs().max().item() <= tol
+    eng_c.capture(batch)
+    assert eng_c.g_tail is not None
+    eng_c.replay(batch, ds)
+    torch.cuda.synchronize()
+    eng_a.optimizer_body()
+    torch.cuda.synchronize()
+    assert (ga - eng_c.student.ps.grad).abs().max().item() <= tol
+    fa, fc = eng_a.student.ps.flat, eng_c.student.ps.flat
+    assert torch.isfinite(fc).all()
+    assert (fa - fc).abs().max().item() <= 2.5e-4            # one Adam step moves a weight by at most lr = 1e-4
+
+
 @pytest.mark.parametrize("precision", ["bf16", "bf16_hbm"])
 def test_bf16_step_runs_and_replays(precision):
     """cfg `precision = bf16` / `bf16_hbm` (+ bf16 storage of the wide MBConv tensors): the whole distillation step (three teachers, student, losses, backward, Adam) with the 1x1
