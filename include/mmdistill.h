@@ -140,19 +140,6 @@ int mmd_chan_pool(const float* z, const float* scale, const float* shift, const 
 // Squeeze-excite FCs: gate = sigmoid(We*swish(Wr*pooled+br)+be) (src/YetAnotherEfficientNet.py:471-474).
 int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
 
-// Round 4: the squeeze-excite FC pair WITHOUT launches of its own (replaces the adaptive_avg_pool2d -> _se_reduce -> swish -> _se_expand ->
-// sigmoid sequence of src/YetAnotherEfficientNet.py:469-474 together with the op in front of it).  The launch that completes an image's
-// pooled sums keeps an arrival counter per image (se_cnt [B], zero on entry); the workgroup whose agent-scope add arrives last runs the
-// image's two FC layers once and writes se_gate [B, C] (and se_hpre [B, S], which the backward reads).  se_wr [S, C], se_br [S],
-// se_wet [S, C] = the expand FC weight transposed, se_be [C].  Results are bit-identical to mmd_se_fc_fwd on the same pooled sums;
-// when a kernel variant has no LDS room for the tail the entry point runs mmd_se_fc_fwd's launches itself (same outputs).
-//   mmd_dwconv_fwd_se:            frozen nets: depthwise conv + folded BN + swish + pool (mmd_dwconv_fwd with out_scale / pool) + FCs
-//   mmd_mbconv_expand_dw_fwd_se:  frozen nets: fused expand + depthwise + pool (mmd_mbconv_expand_dw_fwd) + FCs
-//   mmd_chan_pool_se:             trainable net: pool of swish(BN1(z1)) (mmd_chan_pool with g = NULL) + FCs
-int mmd_dwconv_fwd_se(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const float* out_scale, const float* out_shift, int out_act, float* pool, void* se_cnt, const float* se_wr, const float* se_br, const float* se_wet, const float* se_be, float* se_hpre, float* se_gate, int S, hipStream_t stream);
-int mmd_mbconv_expand_dw_fwd_se(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, void* se_cnt, const float* se_wr, const float* se_br, const float* se_wet, const float* se_be, float* se_hpre, float* se_gate, int S, hipStream_t stream);
-int mmd_chan_pool_se(const float* z, const float* scale, const float* shift, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, int act, float* out, float out_scale, int B, int rows_per_image, int C, void* se_cnt, const float* se_wr, const float* se_br, const float* se_wet, const float* se_be, float* se_hpre, float* se_gate, int S, hipStream_t stream);
-
 // One pass over (z1, g1): out5[5][B][C] += (sum g1*swish(u), sum g1*swish'(u), sum g1*swish'(u)*xhat, sum swish'(u), sum swish'(u)*xhat)
 // per (image, channel): d(gate) for the SE backward plus the partials of the BatchNorm-1 backward sums (autograd of
 // src/YetAnotherEfficientNet.py:466-476), so the expanded tensor is not read again by a BN reduce pass.
@@ -346,12 +333,6 @@ int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, floa
 // p5_scale .. p5_invstd of BatchNorm-1, g1) computes - the pooled pass of the squeeze-excite / BatchNorm-1 backward - taken from the
 // output tiles instead of by a launch re-reading g1 and z1.
 int mmd_pwconv_bwd_data_bn2(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
-// Round 4: mmd_pwconv_bwd_data_bn2's p5 form (MBConv project conv) + the squeeze-excite FC pair's backward without launches of its own:
-// the workgroup whose pooled sums arrive last for an image (se_cnt [p5_B], zero on entry) computes se_dpe [B, K] = dgate*gate*(1-gate),
-// se_dpr [B, S], se_dpooled [B, K] and adds the BatchNorm-1 backward sums to bn1_sums [2K] - mmd_se_fc_bwd(dwr = NULL)'s outputs
-// (autograd of src/YetAnotherEfficientNet.py:469-474).  se_wr [S, K], se_wet [S, K] (expand FC weight transposed); bf16_mma = 1 rounds the
-// GEMM operands to bf16 at the MFMA input (precision "bf16").
-int mmd_pwconv_bwd_data_bn2_se(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, void* se_cnt, const float* se_gate, const float* se_hpre, const float* se_wr, const float* se_wet, float* se_dpe, float* se_dpr, float* se_dpooled, double* bn1_sums, float dpool_scale, int S, int bf16_mma, hipStream_t stream);
 
 int mmd_pwconv_bwd_data_bn2_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
 

@@ -12,7 +12,6 @@
 // Epilogue: raw per-channel sum / sum-of-squares for train-mode BN (double atomics), or eval-mode
 // BN+swish and the squeeze-excite average pool.
 #include "common.h"
-#include "se_tail.h"
 #include <cstdlib>
 
 struct DwArgs {
@@ -40,7 +39,6 @@ struct DwArgs {
   const float* q_z; const float* q_gate; const float* q_add; const float* q_scale; const float* q_shift; const float* q_mean;
   const float* q_invstd; const double* q_sums; double q_inv_count; float* q_dgamma; float* q_dbeta;
   int x16, y16, bz16, qz16;      // bf16 storage (common.h w16) of x, y, bz, q_z - tile kernel only
-  SeTail se;                     // EPI 3 with `pool`: the image's squeeze-excite FC pair by the last-arriving workgroup (se_tail.h)
 };
 
 // LANES = float4 lanes per pixel (16 -> 64-channel chunks; 8 / 4 -> 32- / 16-channel chunks for the thin early layers,
@@ -313,9 +311,6 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       }
     }
   }
-  if constexpr (EPI == 3) {
-    if (a.se.cnt) mmd_se_tail_fwd<256>(a.se, b, sIn);      // (block-uniform; the tile is dead: the tail starts with a barrier)
-  }
   if constexpr (WG) {
     static_assert(S == 1 && Cf::IH * Cf::IW >= 4 * K * K, "weight-gradient reduction aliases the input tile");
     // dw[i][j] += sum_q a0[q] * dY[q - (i - p, j - p)]: the launch's (flipped-tap) window of dY around q, read once more from the LDS tile
@@ -369,9 +364,6 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
   const bool out = a.out_scale || a.out_act != MMD_ACT_NONE || a.pool;
   const int epi = (a.stats && out) ? 4 : (a.bz ? 2 : (a.stats ? 1 : (out ? 3 : 0)));
-  // squeeze-excite tail: needs the pooled epilogue and C + S floats of the (then dead) input tile; otherwise the caller runs the FC launches
-  if (a.se.cnt && (epi != 3 || !a.pool || Cf::IH * Cf::IW * Cf::CC < a.se.C + a.se.S)) a.se.cnt = nullptr;
-  a.se.nblk = a.tiles_h * a.tiles_w * a.cchunks;
   const dim3 grid((unsigned)nb), blk(256);
 #define MMD_DW_TILE(P, E) hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, P, E>), grid, blk, 0, st, a)
   if constexpr (S == 1 && LANES == 16) {
@@ -425,7 +417,6 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
   constexpr int CC = 4 * LW;
   __shared__ float sRed[2 * 4 * CC];
   __shared__ float sRedW[WG ? 4 * 9 * CC : 1];
-  __shared__ float sSe[EPI == 3 ? MMD_SE_MAXC + MMD_SE_MAXS : 1];      // squeeze-excite tail scratch (pooled vector + hidden vector)
   const int tid = threadIdx.x, c4 = (tid & (LW - 1)) * 4, strip = tid / LW;
   int bid = (a.noswz || a.pyr.n) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   // pyramid launch: this block's level (unrolled selects, as in dw_fwd_kernel); every level uses the same R and rows per block, a
@@ -606,9 +597,6 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
       }
     }
   }
-  if constexpr (EPI == 3) {
-    if (a.se.cnt) mmd_se_tail_fwd<256>(a.se, b, sSe);
-  }
   if constexpr (WG) {
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -647,8 +635,6 @@ static int dw3_rows_go(DwArgs& a, hipStream_t st) {
   if (!a.stats || a.ws_slots < 2 || nb / a.cchunks <= MMD_STATS_DEPTH) a.stats_ws = nullptr;
   const bool pro = a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE;
   const int epi = a.bz ? 2 : (a.stats ? 1 : ((a.out_scale || a.out_act != MMD_ACT_NONE || a.pool) ? 3 : 0));
-  if (a.se.cnt && (epi != 3 || !a.pool || a.pyr.n || a.se.C > MMD_SE_MAXC || a.se.S > MMD_SE_MAXS)) a.se.cnt = nullptr;
-  a.se.nblk = gm.colblocks * gm.rowblocks * a.cchunks;
   const dim3 grid((unsigned)nb), blk(256);
 #define MMD_DW3_ROWS(P, E) hipLaunchKernelGGL((dw3_rows_kernel<R, LW, P, E>), grid, blk, 0, st, a, gm)
   if (pro) { if (epi == 0) MMD_DW3_ROWS(true, 0); else if (epi == 1) MMD_DW3_ROWS(true, 1); else if (epi == 2) MMD_DW3_ROWS(true, 2); else MMD_DW3_ROWS(true, 3); }
@@ -686,13 +672,11 @@ static int same_pad_lo(int n, int k, int s, int* out) {
 }
 
 // y[B,OH,OW,C] = dwconv_same(pro(x)[B,H,W,C], w[k*k,C]); OH = ceil(H/stride).
-extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
-                             float* hpre, float* gate, int B, int C, int S, hipStream_t stream);      // elt.hip
-static int dw_fwd_impl(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
-                       const float* in_scale, const float* in_shift, int in_act,
-                       const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
-                       const float* out_scale, const float* out_shift, int out_act,
-                       double* stats, float* pool, double* stats_ws, int ws_slots, const SeTail* se, hipStream_t stream) {
+extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
+                              const float* in_scale, const float* in_shift, int in_act,
+                              const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
+                              const float* out_scale, const float* out_shift, int out_act,
+                              double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -705,7 +689,6 @@ static int dw_fwd_impl(const float* x, const float* w, float* y, int B, int H, i
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
   a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
   a.stats_ws = stats_ws; a.ws_slots = ws_slots;
-  if (se) { a.se = *se; a.se.pooled = pool; a.se.C = C; }
   mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW, stream);
   int rc = 1;
@@ -717,35 +700,7 @@ static int dw_fwd_impl(const float* x, const float* w, float* y, int B, int H, i
   else rc = dw_fwd_launch<5, 2>(a, stream);
   mmd_prof_end(MMD_FAM_DW, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
                4.0 * ((double)B * H * W * C + (double)B * a.OH * a.OW * C));
-  // the launch could not take the squeeze-excite tail (no room in its LDS tile, not a pooled epilogue): the FC pair as launches
-  if (rc == MMD_OK && se && !a.se.cnt) rc = mmd_se_fc_fwd(pool, se->wr, se->br, se->wet, se->be, se->hpre, se->gate, B, C, se->S, stream);
   return rc;
-}
-extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
-                              const float* in_scale, const float* in_shift, int in_act,
-                              const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
-                              const float* out_scale, const float* out_shift, int out_act,
-                              double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream) {
-  return dw_fwd_impl(x, w, y, B, H, W, C, k, stride, in_scale, in_shift, in_act, in_stats, in_gamma, in_beta, in_count, out_scale, out_shift,
-                     out_act, stats, pool, stats_ws, ws_slots, nullptr, stream);
-}
-// Frozen-net MBConv middle: depthwise conv + folded BN + swish + squeeze-excite average pool (`pool`, zero on entry) AND the image's
-// squeeze-excite FC pair (src/YetAnotherEfficientNet.py:469-474) -> gate [B, C] (+ hpre [B, S]), computed by the last-arriving workgroup
-// of each image (se_tail.h) - no FC launches.  se_cnt: [B] zeroed arrival counters.  Falls back to mmd_se_fc_fwd's two launches when the
-// kernel variant the geometry picks has no room for the tail.  se_wr [S, C], se_br [S], se_wet [S, C] (transposed expand weight), se_be [C].
-extern "C" int mmd_dwconv_fwd_se(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
-                                 const float* in_scale, const float* in_shift, int in_act,
-                                 const float* out_scale, const float* out_shift, int out_act, float* pool,
-                                 void* se_cnt, const float* se_wr, const float* se_br, const float* se_wet, const float* se_be,
-                                 float* se_hpre, float* se_gate, int S, hipStream_t stream) {
-  if (!pool || !se_cnt || !se_wr || !se_br || !se_wet || !se_be || !se_hpre || !se_gate || S <= 0 || S > MMD_SE_MAXS || C > MMD_SE_MAXC)
-    return MMD_EINVAL;
-  SeTail se{};
-  se.cnt = (unsigned*)se_cnt; se.wr = se_wr; se.br = se_br; se.wet = se_wet; se.be = se_be; se.hpre = se_hpre; se.gate = se_gate; se.S = S;
-  static const int off = getenv("MMD_NO_SE_TAIL") ? 1 : 0;
-  if (off) se.cnt = nullptr;
-  return dw_fwd_impl(x, w, y, B, H, W, C, k, stride, in_scale, in_shift, in_act, nullptr, nullptr, nullptr, 0, out_scale, out_shift,
-                     out_act, nullptr, pool, nullptr, 0, &se, stream);
 }
 
 // same contract with bf16 storage of the wide tensors: w16 bit 0 = x, bit 1 = y are bf16 arrays (common.h)

@@ -5,7 +5,6 @@
 // Per-channel reductions: shuffle over the 4 row-groups of a wave (lanes l^16, l^32), then LDS over
 // the 4 waves, then one double/float atomic per channel per block.
 #include "common.h"
-#include "se_tail.h"
 #include <cstdlib>
 
 #define ROWS_PER_BLOCK 256
@@ -156,9 +155,8 @@ extern "C" int mmd_affine_act(const float* z, const float* scale, const float* s
 __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, BnLive bn, int act,
                                                         const float* __restrict__ g, float* __restrict__ out,
-                                                        float out_scale, int rows_per_image, int C, int nsplit, int z16, SeTail se) {
+                                                        float out_scale, int rows_per_image, int C, int nsplit, int z16) {
   __shared__ float sRed[256];
-  __shared__ float sSe[MMD_SE_MAXC + MMD_SE_MAXS];      // squeeze-excite tail scratch
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   const int b = blockIdx.y;
@@ -182,11 +180,10 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
   }
   float s = block_chan_sum(acc, sRed, tid);
   if (tid < 64 && blockIdx.x * 64 + tid < C) atomicAdd(&out[(size_t)b * C + blockIdx.x * 64 + tid], s * out_scale);
-  if (se.cnt) mmd_se_tail_fwd<256>(se, b, sSe);
 }
 static int chan_pool_impl(const float* z, const float* scale, const float* shift, const double* in_stats,
                           const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
-                          float* out, float out_scale, int B, int rows_per_image, int C, int z16, hipStream_t stream, const SeTail* set = nullptr) {
+                          float* out, float out_scale, int B, int rows_per_image, int C, int z16, hipStream_t stream) {
   if (!z || !out || B <= 0 || rows_per_image <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return MMD_EINVAL;
   if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
@@ -194,10 +191,8 @@ static int chan_pool_impl(const float* z, const float* scale, const float* shift
   int ns = cdiv(1024, base); int mx = cdiv(rows_per_image, 64); if (ns > mx) ns = mx; if (ns < 1) ns = 1;
   mmd_prof_tag(MMD_FAM_ELT, "cpool B%lld R%lld C%lld", B, rows_per_image, C, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
-  SeTail se{};
-  if (set) { se = *set; se.pooled = out; se.C = C; se.nblk = cdiv(C, 64) * ns; }
   hipLaunchKernelGGL(chan_pool_kernel, dim3(cdiv(C, 64), B, ns), dim3(256), 0, stream, z, scale, shift,
-                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, g, out, out_scale, rows_per_image, C, ns, z16, se);
+                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, g, out, out_scale, rows_per_image, C, ns, z16);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * B * (double)rows_per_image * C * (g ? 2 : 1));
   return mmd_check_launch();
 }
@@ -205,24 +200,6 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
                              const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
                              float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
   return chan_pool_impl(z, scale, shift, in_stats, in_gamma, in_beta, in_count, act, g, out, out_scale, B, rows_per_image, C, 0, stream);
-}
-// Trainable-net squeeze-excite: the average pool over swish(BN1(z1)) (live BatchNorm coefficients) AND the image's FC pair -> gate [B, C],
-// hpre [B, S] by the last-arriving workgroup of each image (se_tail.h): no FC launches.  `out` (pooled) and se_cnt [B] zero on entry.
-extern "C" int mmd_chan_pool_se(const float* z, const float* scale, const float* shift, const double* in_stats,
-                                const float* in_gamma, const float* in_beta, long long in_count, int act,
-                                float* out, float out_scale, int B, int rows_per_image, int C,
-                                void* se_cnt, const float* se_wr, const float* se_br, const float* se_wet, const float* se_be,
-                                float* se_hpre, float* se_gate, int S, hipStream_t stream) {
-  if (!se_cnt || !se_wr || !se_br || !se_wet || !se_be || !se_hpre || !se_gate || S <= 0 || S > MMD_SE_MAXS || C > MMD_SE_MAXC) return MMD_EINVAL;
-  SeTail se{};
-  se.cnt = (unsigned*)se_cnt; se.wr = se_wr; se.br = se_br; se.wet = se_wet; se.be = se_be; se.hpre = se_hpre; se.gate = se_gate; se.S = S;
-  static const int off = getenv("MMD_NO_SE_TAIL") ? 1 : 0;
-  if (off) {
-    extern int mmd_se_fc_fwd_c(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int, int, hipStream_t);
-    const int rc = chan_pool_impl(z, scale, shift, in_stats, in_gamma, in_beta, in_count, act, nullptr, out, out_scale, B, rows_per_image, C, 0, stream);
-    return rc ? rc : mmd_se_fc_fwd_c(out, se_wr, se_br, se_wet, se_be, se_hpre, se_gate, B, C, S, stream);
-  }
-  return chan_pool_impl(z, scale, shift, in_stats, in_gamma, in_beta, in_count, act, nullptr, out, out_scale, B, rows_per_image, C, 0, stream, &se);
 }
 // z is a bf16 array (common.h w16)
 extern "C" int mmd_chan_pool_w16(const float* z, const float* scale, const float* shift, const double* in_stats,
@@ -332,14 +309,8 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   for (int j = 0; j < S; ++j) acc += wet[(size_t)j * C + c] * sh[j];      // wet [S][C]: coalesced over c
   gate[(size_t)b * C + c] = mmd_sigmoid(acc);
 }
-int mmd_se_fc_fwd_c(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
-                    float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
 extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
                              float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
-  return mmd_se_fc_fwd_c(pooled, wr, br, we, be, hpre, gate, B, C, S, stream);
-}
-int mmd_se_fc_fwd_c(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
-                    float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
   if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256) return MMD_EINVAL;
   hipLaunchKernelGGL(se_hidden_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S);
   hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, hpre, we, be, gate, C, S);

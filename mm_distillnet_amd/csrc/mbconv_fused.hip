@@ -20,7 +20,6 @@
 //  phase 2 (VALU): threads = (channel quad, pixel group); each group owns a strip of R outputs along W, as in dwconv.hip.
 // LDS pixel stride 20 floats: 16 consecutive pixels x one 16-B quad land on 64 distinct banks in phase 1's ds_write_b128.
 #include "common.h"
-#include "se_tail.h"
 #include <cstdlib>
 
 struct MbxArgs {
@@ -29,7 +28,6 @@ struct MbxArgs {
   float* y; float* pool; float pool_scale;
   int B, H, W, Cin, C, OH, OW, pad_t, pad_l, tiles_h, tiles_w, cchunks;
   int y16;      // y is a bf16 array (common.h w16)
-  SeTail se;    // the image's squeeze-excite FC pair by the last-arriving workgroup (se_tail.h)
 };
 
 template <int K, int S> struct MbxCfg;
@@ -193,7 +191,6 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
     __syncthreads();                                           // sE is rewritten by the next sub-chunk
   }
   if (a.pool && tid < CC) atomicAdd(&a.pool[(size_t)b * a.C + c0 + tid], sPool[tid] * a.pool_scale);
-  if (a.se.cnt) mmd_se_tail_fwd<NT>(a.se, b, sE);      // (the expanded tile is dead: the loop's last barrier is behind every wave)
 }
 
 static int mbx_same_pad_lo(int n, int k, int s, int* out) {
@@ -213,8 +210,6 @@ static int mbx_launch(MbxArgs& a, hipStream_t st) {
   constexpr int IH = (Cf::TH - 1) * S + K, IW = (Cf::TW - 1) * S + K;
   constexpr size_t lds = (size_t)((IH * IW + 15) / 16 * 16 * MBX_LD + K * K * MBX_CC + 5 * MBX_CC + MBX_CC * 4 * NK) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
-  if (a.se.cnt && (!a.pool || (IH * IW + 15) / 16 * 16 * MBX_LD < a.se.C + a.se.S)) a.se.cnt = nullptr;      // no room for the tail: FC launches
-  a.se.nblk = a.tiles_h * a.tiles_w * a.cchunks;
   hipLaunchKernelGGL((mbx_kernel<NK, K, S>), dim3((unsigned)nb), dim3(MBX_NW * 64), lds, st, a);
   return mmd_check_launch();
 }
@@ -236,11 +231,9 @@ extern "C" int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stri
 
 // y[B,OH,OW,Cmid] = swish(dwconv_same(swish(x[B,H,W,Cin] · w_expand[Cmid,Cin]ᵀ * scale0 + shift0), w_dw[k*k,Cmid]) * scale1 + shift1);
 // pool[B,Cmid] += mean over OH x OW of y (pool may be null).  OH = ceil(H / stride).
-extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
-                             float* hpre, float* gate, int B, int C, int S, hipStream_t stream);      // elt.hip
 static int mbx_impl(const float* x, const float* w_expand, const float* scale0, const float* shift0,
                     const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
-                    int B, int H, int W, int Cin, int Cmid, int k, int stride, int y16, hipStream_t stream, const SeTail* se = nullptr) {
+                    int B, int H, int W, int Cin, int Cmid, int k, int stride, int y16, hipStream_t stream) {
   if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y || B <= 0 || H <= 0 || W <= 0) return MMD_EINVAL;
   if (!mmd_mbconv_expand_dw_supported(Cin, Cmid, k, stride)) return MMD_EINVAL;
   MbxArgs a{};
@@ -249,7 +242,6 @@ static int mbx_impl(const float* x, const float* w_expand, const float* scale0, 
   a.pad_t = mbx_same_pad_lo(H, k, stride, &a.OH); a.pad_l = mbx_same_pad_lo(W, k, stride, &a.OW);
   a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
   a.y16 = y16;
-  if (se) { a.se = *se; a.se.pooled = pool; a.se.C = Cmid; }
   mmd_prof_tag(MMD_FAM_MBX, "mbx H%lld K%lld N%lld k%lld", H, Cin, Cmid, k * 10 + stride);
   mmd_prof_begin(MMD_FAM_MBX, stream);
   int rc;
@@ -263,28 +255,12 @@ static int mbx_impl(const float* x, const float* w_expand, const float* scale0, 
   }
   mmd_prof_end(MMD_FAM_MBX, stream, 2.0 * B * H * W * (double)Cin * Cmid + 2.0 * B * a.OH * a.OW * (double)Cmid * k * k,
                4.0 * (double)B * H * W * Cin + (y16 ? 2.0 : 4.0) * (double)B * a.OH * a.OW * Cmid);
-  if (rc == MMD_OK && se && !a.se.cnt) rc = mmd_se_fc_fwd(pool, se->wr, se->br, se->wet, se->be, se->hpre, se->gate, B, Cmid, se->S, stream);
   return rc;
 }
 extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
                                         const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
                                         int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
   return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 0, stream);
-}
-// + the image's squeeze-excite FC pair -> gate [B, Cmid], hpre [B, S] by the last-arriving workgroup of each image (se_tail.h; contract
-// as mmd_dwconv_fwd_se).  `pool` and se_cnt [B] zero on entry.
-extern "C" int mmd_mbconv_expand_dw_fwd_se(const float* x, const float* w_expand, const float* scale0, const float* shift0,
-                                           const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
-                                           int B, int H, int W, int Cin, int Cmid, int k, int stride,
-                                           void* se_cnt, const float* se_wr, const float* se_br, const float* se_wet, const float* se_be,
-                                           float* se_hpre, float* se_gate, int S, hipStream_t stream) {
-  if (!pool || !se_cnt || !se_wr || !se_br || !se_wet || !se_be || !se_hpre || !se_gate || S <= 0 || S > MMD_SE_MAXS || Cmid > MMD_SE_MAXC)
-    return MMD_EINVAL;
-  SeTail se{};
-  se.cnt = (unsigned*)se_cnt; se.wr = se_wr; se.br = se_br; se.wet = se_wet; se.be = se_be; se.hpre = se_hpre; se.gate = se_gate; se.S = S;
-  static const int off = getenv("MMD_NO_SE_TAIL") ? 1 : 0;
-  if (off) se.cnt = nullptr;
-  return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 0, stream, &se);
 }
 // y is stored as a bf16 array (common.h w16): the frozen nets' activated depthwise output, read back by the project conv
 extern "C" int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0,

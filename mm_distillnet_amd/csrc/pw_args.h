@@ -1,7 +1,6 @@
 // Argument block shared by the 1x1-conv GEMM kernels (pw_gemm.hip: LDS-tiled K loop; pw_rows.hip: thin-K row-slab kernel).
 #pragma once
 #include "common.h"
-#include "se_tail.h"
 
 // BatchNorm(+swish, +drop-connect row scale) backward as a GEMM operand prologue: instead of a separate pass that writes
 //   dz[m,c] = scale_c * ( g'[m,c] - m1_c - (z[m,c] - mean_c) * invstd_c * m2_c ),   g' = g * mul_b[image(m)] * swish'(z*scale_c + shift_c)
@@ -78,7 +77,6 @@ struct PwArgs {
   // bf16 storage ("w16", common.h): which tensors of the launch are bf16 arrays - the A operand x, the output y, and for the
   // BatchNorm-backward operand launches the second A tensor bb.z, the stored dz (bb.dz_out) and the pooled pass' z (p5.z)
   int x16, y16, z16, dz16, p5z16;
-  SeTailBwd sb;                              // with p5: the image's squeeze-excite FC backward by the last-arriving workgroup (se_tail.h)
 };
 
 

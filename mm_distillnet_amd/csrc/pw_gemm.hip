@@ -358,11 +358,6 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
           atomicAdd(&a.p5.out[((size_t)k * a.p5.B + img) * a.N + n0 + cl], r5[0] + r5[BN_T] + r5[2 * BN_T] + r5[3 * BN_T]);
         }
       }
-      if (a.sb.cnt) {       // squeeze-excite FC backward of image `img` once its five pooled sums are complete (the C tile is dead)
-        SeTailBwd sb = a.sb;
-        sb.nblk = (a.p5.rows_per_image / BM_T) * a.ntn;
-        mmd_se_tail_bwd<256>(sb, img, smem);
-      }
     }
   }
   if (a.stats) {
@@ -658,11 +653,6 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
           const float* r5 = &sRed5[k * 4 * SK_BN + cl];
           atomicAdd(&a.p5.out[((size_t)k * a.p5.B + img) * a.N + n0 + cl], r5[0] + r5[SK_BN] + r5[2 * SK_BN] + r5[3 * SK_BN]);
         }
-      }
-      if (a.sb.cnt) {
-        SeTailBwd sb = a.sb;
-        sb.nblk = (a.p5.rows_per_image / SK_BM) * a.ntn;
-        mmd_se_tail_bwd<256>(sb, img, sA);
       }
     }
   }
@@ -1332,9 +1322,6 @@ static int pw_bwd_data_bn_impl(const float* g, const float* z, const float* wt, 
 //             BatchNorm-1 backward - from the output tiles (by its own launch when an image's rows are not a multiple of 128).
 extern "C" int mmd_chan_pool_bwd(const float* z, const float* scale, const float* shift, const float* mean, const float* invstd,
                                  const float* g1, float* out5, int B, int rows_per_image, int C, hipStream_t stream);      // elt.hip
-extern "C" int mmd_se_fc_bwd_fused(const float* dgate, const float* gate, const float* hpre, const float* wr, const float* we, float* dpe_ws,
-                                   float* dpr_ws, float* dpooled, float dpool_scale, int B, int C, int S, const float* pool5,
-                                   double* bn_sums, hipStream_t stream);      // elt.hip
 static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,
                                 const float* scale, const float* shift, const float* mean, const float* invstd,
                                 const double* sums, long long count, int act, const float* mul_b, int rows_per_image,
@@ -1342,7 +1329,7 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
                                 const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image,
                                 double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale,
                                 const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B,
-                                hipStream_t stream, int bf16, int w16 = 0, const SeTailBwd* sb = nullptr) {
+                                hipStream_t stream, int bf16, int w16 = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
   if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
   if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
@@ -1366,23 +1353,13 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
   if (p5_z) {
     if (!p5_scale || !p5_shift || !p5_mean || !p5_invstd || !p5_out || p5_B <= 0 || M % p5_B || residual || xs_z) return MMD_EINVAL;
     const int rpi = M / p5_B;
-    static const int no_tail = getenv("MMD_NO_SE_TAIL") ? 1 : 0;
     if (rpi % PW_BM == 0) {       // every row tile (32 / 64 / 128 rows) inside one image: the sums ride in the epilogue
       a.p5 = Pool5Op{p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, p5_out, p5_B, rpi};
-      if (sb && !no_tail && K <= MMD_SE_MAXC && sb->S <= MMD_SE_MAXS) { a.sb = *sb; a.sb.pool5 = p5_out; a.sb.B = p5_B; a.sb.C = K; }
-      int rc = pw_dispatch(a, stream);
-      if (rc == MMD_OK && sb && !a.sb.cnt)      // (tail switched off): the FC backward as a launch
-        rc = mmd_se_fc_bwd_fused(p5_out, sb->gate, sb->hpre, sb->wr, sb->wet, sb->dpe, sb->dpr, sb->dpooled, sb->dpool_scale, p5_B, K, sb->S,
-                                 p5_out, sb->bn_sums, stream);
-      return rc;
+      return pw_dispatch(a, stream);
     }
     if (a.y16 || a.p5z16) return MMD_EINVAL;      // (the stand-alone pooled pass reads fp32 tensors)
-    int rc = pw_dispatch(a, stream);      // ragged image size: the pooled pass as its own launch
-    if (rc == MMD_OK) rc = mmd_chan_pool_bwd(p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, dx, p5_out, p5_B, rpi, K, stream);
-    if (rc == MMD_OK && sb)
-      rc = mmd_se_fc_bwd_fused(p5_out, sb->gate, sb->hpre, sb->wr, sb->wet, sb->dpe, sb->dpr, sb->dpooled, sb->dpool_scale, p5_B, K, sb->S,
-                               p5_out, sb->bn_sums, stream);
-    return rc;
+    const int rc = pw_dispatch(a, stream);      // ragged image size: the pooled pass as its own launch
+    return rc ? rc : mmd_chan_pool_bwd(p5_z, p5_scale, p5_shift, p5_mean, p5_invstd, dx, p5_out, p5_B, rpi, K, stream);
   }
   return pw_dispatch(a, stream);
 }
@@ -1396,26 +1373,6 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
                     xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image, xs_sums, stats_ws, ws_slots, p5_z, p5_scale, p5_shift, p5_mean, \
                     p5_invstd, p5_out, p5_B, stream
 extern "C" int mmd_pwconv_bwd_data_bn2(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0); }
-// MBConv project conv's input gradient (mmd_pwconv_bwd_data_bn2 with the p5_* pooled pass) AND the squeeze-excite FC pair's backward
-// (autograd of src/YetAnotherEfficientNet.py:469-474; what mmd_se_fc_bwd computes: se_dpe [B, K], se_dpr [B, S] for the FC weight gradients,
-// se_dpooled [B, K], bn1_sums [2K] += the BatchNorm-1 backward sums) by the last-arriving workgroup of each image (se_tail.h): no FC
-// launches on the backward's chain.  se_cnt [p5_B] zero on entry; se_wet = expand FC weight transposed [S, K].  Ragged image sizes / the
-// MMD_NO_SE_TAIL switch run the same math as a launch behind the GEMM (mmd_se_fc_bwd_fused).
-extern "C" int mmd_pwconv_bwd_data_bn2_se(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale,
-                      const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act,
-                      const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta,
-                      const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd,
-                      float* p5_out, int p5_B, void* se_cnt, const float* se_gate, const float* se_hpre, const float* se_wr,
-                      const float* se_wet, float* se_dpe, float* se_dpr, float* se_dpooled, double* bn1_sums, float dpool_scale, int S,
-                      int bf16_mma, hipStream_t stream) {
-  if (!p5_z || !se_cnt || !se_gate || !se_hpre || !se_wr || !se_wet || !se_dpe || !se_dpr || !se_dpooled || !bn1_sums || S <= 0) return MMD_EINVAL;
-  SeTailBwd sb{};
-  sb.cnt = (unsigned*)se_cnt; sb.gate = se_gate; sb.hpre = se_hpre; sb.wr = se_wr; sb.wet = se_wet; sb.dpe = se_dpe; sb.dpr = se_dpr;
-  sb.dpooled = se_dpooled; sb.bn_sums = bn1_sums; sb.dpool_scale = dpool_scale; sb.S = S;
-  return pw_bwd_data_bn2_impl(g, z, wt, dx, M, K, N, scale, shift, mean, invstd, sums, count, act, mul_b, rows_per_image, dz_out, dgamma, dbeta,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, p5_z, p5_scale, p5_shift, p5_mean, p5_invstd,
-                              p5_out, p5_B, stream, bf16_mma, 0, &sb);
-}
 extern "C" int mmd_pwconv_bwd_data_bn2_bf16(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 1); }
 // bf16 storage of the wide tensors: w16 bit 0 = g, bit 1 = dx, bit 2 = z, bit 3 = dz_out, bit 4 = p5_z are bf16 arrays
 extern "C" int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift,

@@ -111,10 +111,7 @@ P5_IN_GEMM = not os.environ.get("MMD_NO_P5_IN_GEMM")  # MBConv: the pooled squee
 SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
 # both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
 # (S*C MACs, serial per wave) - measured 17.0 -> 17.7 ms/step against the two wide launches; off unless MMD_SE_FUSED=1
-SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))
-# round 4: the squeeze-excite FC pairs run inside the launch that completes the pooled sums - by the last-arriving workgroup of each
-# image (csrc/se_tail.h) - instead of as two launches per block and direction (MMD_NO_SE_TAIL=1: the launches, for A/B timing)
-SE_TAIL = not os.environ.get("MMD_NO_SE_TAIL")      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
+SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
 
 class Net:
@@ -389,13 +386,9 @@ class Net:
                 z1, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, stats=st1, y16=wide)
                 a1 = self._bn_aff(f"{q}._bn1", True, st1, M1)
                 f1 = Feat(z1, B, H1, W1, blk.cmid, a1[0], a1[1], SWISH, a1[4], w16=wide)
-                if SE_TAIL and not wide and ps.flat.is_cuda:
-                    call("mmd_chan_pool_se", z1, *self._xf(f1)[:2], *self._xf(f1)[3:], SWISH, pooled, 1.0 / (H1 * W1), B, H1 * W1, blk.cmid,
-                         self._zalloc((B,), torch.int32), *se_w, hpre, gate, blk.se)
-                else:
-                    call("mmd_chan_pool_w16" if wide else "mmd_chan_pool", z1, *self._xf(f1)[:2], *self._xf(f1)[3:], SWISH, None, pooled, 1.0 / (H1 * W1), B,
-                         H1 * W1, blk.cmid)
-                    call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
+                call("mmd_chan_pool_w16" if wide else "mmd_chan_pool", z1, *self._xf(f1)[:2], *self._xf(f1)[3:], SWISH, None, pooled, 1.0 / (H1 * W1), B,
+                     H1 * W1, blk.cmid)
+                call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 st2 = self._bn_stats(f"{q}._bn2", True)
                 z2 = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, stats=st2, gate=gate)
                 a2 = self._bn_aff(f"{q}._bn2", True, st2, M1)
@@ -410,25 +403,17 @@ class Net:
             else:
                 # frozen net: BN1+swish and the SE average pool ride in the depthwise epilogue (no separate pool pass)
                 b1 = ps.bn(f"{q}._bn1")
-                se_tail = SE_TAIL and not wide and ps.flat.is_cuda      # the FC pair inside the pooling launch (last-arriving workgroup per image)
-                se_args = (self._zalloc((B,), torch.int32), *se_w, hpre, gate, blk.se) if se_tail else ()
                 if fused_front:
                     b0 = ps.bn(f"{q}._bn0")
                     a1v = self._alloc16(M1, blk.cmid) if wide else self._alloc(M1, blk.cmid)
-                    call("mmd_mbconv_expand_dw_fwd_w16" if wide else ("mmd_mbconv_expand_dw_fwd_se" if se_tail else "mmd_mbconv_expand_dw_fwd"),
-                         inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
+                    call("mmd_mbconv_expand_dw_fwd_w16" if wide else "mmd_mbconv_expand_dw_fwd", inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
                          ps.w(f"{q}._depthwise_conv.conv.weight"), b1["fscale"], b1["fshift"], a1v, pooled, B, inp.H, inp.W, inp.C,
-                         blk.cmid, blk.kernel, blk.stride, *se_args)
-                elif se_tail:
-                    a1v = self._alloc(M1, blk.cmid)
-                    call("mmd_dwconv_fwd_se", f0.z, ps.w(f"{q}._depthwise_conv.conv.weight"), a1v, B, f0.H, f0.W, f0.C, blk.kernel, blk.stride,
-                         f0.scale, f0.shift, f0.act, b1["fscale"], b1["fshift"], SWISH, pooled, *se_args)
+                         blk.cmid, blk.kernel, blk.stride)
                 else:
                     a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
                                          out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled, y16=wide)
                 f1 = Feat(a1v, B, H1, W1, blk.cmid, w16=wide)
-                if not se_tail:
-                    call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
+                call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 b2 = ps.bn(f"{q}._bn2")
                 y = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, gate=gate,
                              out_aff=(b2["fscale"], b2["fshift"]), residual=res)
@@ -837,8 +822,7 @@ class Net:
         return dz
 
     def _pw_bwd(self, dz: torch.Tensor, x: Feat, wkey: str, N: int, bias_key: Optional[str], want_dx: bool,
-                gate=None, plain_in=False, into: Optional[Feat] = None, pool5: Optional[tuple] = None,
-                se: Optional[tuple] = None) -> Optional[torch.Tensor]:
+                gate=None, plain_in=False, into: Optional[Feat] = None, pool5: Optional[tuple] = None) -> Optional[torch.Tensor]:
         """Gradients of a 1x1 conv.  into = the Feat whose gradient slot receives dx (normally x itself): dx is then written into / on top
         of that slot by the GEMM's epilogue (no scale_acc launch), together with the backward sums of the BatchNorm that produced the
         Feat when this is the slot's last contribution; returns None in that case."""
@@ -902,12 +886,6 @@ class Net:
                 self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
                 return None
             dx = self._alloc(M, K)
-            if pool5 is not None and se is not None:
-                # ... and the squeeze-excite FC pair's backward by the last-arriving workgroup of each image (round 4: no FC launches)
-                call("mmd_pwconv_bwd_data_bn2_se", L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"], *pool5, *se,
-                     1 if self.precision == "bf16" else 0)
-                self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
-                return dx
             if pool5 is not None:
                 # MBConv project conv: the pooled pass of the squeeze-excite / BatchNorm-1 backward over (z1, dx) rides in this launch's epilogue
                 call("mmd_pwconv_bwd_data_bn2" + self._sfx, L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
@@ -1226,14 +1204,7 @@ class Net:
             a1 = rec["bn1"]
             pool5 = self._zalloc((5, f1.B, blk.cmid))
             p5 = (f1.z, a1[0], a1[1], a1[2], a1[3], pool5, f1.B) if (P5_IN_GEMM and isinstance(dz2, LazyDz) and ps.flat.is_cuda) else None
-            dpe = self._alloc(f1.B, blk.cmid)
-            dpr = self._alloc(f1.B, blk.se)
-            dpooled = self._alloc(f1.B, blk.cmid)
-            sums1 = self._zalloc((2 * blk.cmid,), torch.float64)
-            se_tail = SE_TAIL and p5 is not None and not f1.w16
-            se = (self._zalloc((f1.B,), torch.int32), rec["gate"], rec["hpre"], ps.w(f"{q}._se_reduce.conv.weight"),
-                  ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dpooled, sums1, 1.0 / HW1, blk.se) if se_tail else None
-            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"], pool5=p5, se=se)
+            g1 = self._pw_bwd(dz2, f1, f"{q}._project_conv.conv.weight", blk.cout, None, True, gate=rec["gate"], pool5=p5)
             # the skip branch may ADOPT dy as the gradient slot of the block input, and the block's own input gradient is later
             # accumulated into that buffer in place; with a lazy BatchNorm backward the project conv's weight-gradient GEMM (side
             # stream) still reads dy, so that later accumulation waits for it (the event is long past by then)
@@ -1242,11 +1213,13 @@ class Net:
                 self._acc(inp, dy)
             if p5 is None:
                 call("mmd_chan_pool_bwd", f1.z, a1[0], a1[1], a1[2], a1[3], g1, pool5, f1.B, HW1, blk.cmid)
+            dpe = self._alloc(f1.B, blk.cmid)
+            dpr = self._alloc(f1.B, blk.se)
+            dpooled = self._alloc(f1.B, blk.cmid)
+            sums1 = self._zalloc((2 * blk.cmid,), torch.float64)
             segrads = (ps.g(f"{q}._se_reduce.conv.weight"), ps.g(f"{q}._se_reduce.conv.bias"), ps.g(f"{q}._se_expand.conv.weight"),
                        ps.g(f"{q}._se_expand.conv.bias"))
-            if se_tail:
-                pass            # done inside the project conv's input-gradient launch
-            elif SE_FUSED and ps.flat.is_cuda:
+            if SE_FUSED and ps.flat.is_cuda:
                 # both FC layers' data gradients in one launch
                 call("mmd_se_fc_bwd_fused", pool5[0], rec["gate"], rec["hpre"], ps.w(f"{q}._se_reduce.conv.weight"),
                      ps.w(f"{q}._se_expand.conv.weight"), dpe, dpr, dpooled, 1.0 / HW1, f1.B, blk.cmid, blk.se, pool5, sums1)

@@ -507,78 +507,6 @@ def test_se_path(C, S):
         assert torch.equal(a_, c_) and torch.allclose(b_, c_ + 1, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("kind,k,s,H,W,C,S,B", [
-    ("dw", 5, 1, 32, 32, 720, 30, 8),      # tile kernel, D2's 32^2 stage at its real size
-    ("dw", 3, 2, 16, 16, 96, 4, 3), ("dw", 5, 2, 17, 12, 48, 2, 2),
-    ("dw", 3, 1, 32, 32, 528, 22, 8),      # row-streaming kernel (R = 2)
-    ("dw", 3, 1, 16, 16, 2112, 88, 8),     # row-streaming kernel (R = 1), the widest D2 layer
-    ("dw", 3, 1, 6, 260, 16, 4, 2),        # 16-channel chunks: the LDS tile of the narrow variants still holds C + S floats
-    ("dw", 3, 1, 4, 4, 112, 28, 2),        # tile kernel, tiny map
-    ("mbx", 3, 1, 32, 32, 144, 6, 4), ("mbx", 5, 2, 40, 24, 144, 6, 3), ("mbx", 5, 1, 24, 16, 288, 12, 8),
-    ("pool", 0, 0, 16, 16, 1248, 52, 8), ("pool", 0, 0, 64, 64, 288, 12, 8), ("pool", 0, 0, 3, 5, 48, 2, 2)])
-def test_se_tail_forward(kind, k, s, H, W, C, S, B):
-    """Round 4: the squeeze-excite FC pair run by the last-arriving workgroup of the pooling launch (csrc/se_tail.h;
-    src/YetAnotherEfficientNet.py:469-474) - the three producers (depthwise epilogue, fused expand+depthwise kernel, trainable net's
-    pool) against torch fp32, and bit for bit against mmd_se_fc_fwd run on the very sums the launch left in `pool`; repeated launches
-    (fresh counters) give the same gate every time (a stale or early read of another workgroup's sums would not)."""
-    torch.manual_seed(k * 100 + s * 10 + C + H)
-    wr = torch.randn(S, C) / math.sqrt(C); br = torch.randn(S) * 0.3
-    we = torch.randn(C, S) / math.sqrt(S); be = torch.randn(C) * 0.3
-    wet = g(we.t())
-    osc, osh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
-    se_w = (g(wr), g(br), wet, g(be))
-    if kind == "dw":
-        x = torch.randn(B, C, H, W)
-        w = torch.randn(C, 1, k, k) / k
-        y = swish(F.conv2d(same_pad(x, k, s), w, stride=s, groups=C) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
-        xn, wn = g(nhwc(x)), g(w.reshape(C, k * k).t())
-    elif kind == "mbx":
-        cin = C // 6
-        x = torch.randn(B, cin, H, W)
-        w0 = torch.randn(C, cin) / math.sqrt(cin)
-        sc0, sh0 = torch.rand(C) + 0.5, torch.randn(C) * 0.2
-        w = torch.randn(C, 1, k, k) / k
-        e = swish(F.conv2d(x, w0.view(C, cin, 1, 1)) * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1))
-        y = swish(F.conv2d(same_pad(e, k, s), w, stride=s, groups=C) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
-        xn, w0n, wn = g(nhwc(x)), g(w0), g(w.reshape(C, k * k).t())
-    else:
-        x = torch.randn(B, C, H, W)
-        y = swish(x * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
-        xn = g(nhwc(x))
-    OH, OW = y.shape[-2:]
-    pooled = y.mean((2, 3))
-    hpre = pooled @ wr.t() + br
-    gate = torch.sigmoid(swish(hpre) @ we.t() + be)
-    gates = []
-    for rep in range(6):
-        yo = torch.full((B * OH * OW, C), float("nan"), device=DEV)
-        pool = torch.zeros(B, C, device=DEV)
-        cnt = torch.zeros(B, dtype=torch.int32, device=DEV)
-        dh = torch.full((B, S), float("nan"), device=DEV); dg = torch.full((B, C), float("nan"), device=DEV)
-        if kind == "dw":
-            call("mmd_dwconv_fwd_se", xn, wn, yo, B, H, W, C, k, s, None, None, 0, g(osc), g(osh), 1, pool, cnt, *se_w, dh, dg, S)
-        elif kind == "mbx":
-            call("mmd_mbconv_expand_dw_fwd_se", xn, w0n, g(sc0), g(sh0), wn, g(osc), g(osh), yo, pool, B, H, W, cin, C, k, s, cnt, *se_w, dh, dg, S)
-        else:
-            call("mmd_chan_pool_se", xn, g(osc), g(osh), None, None, None, 0, 1, pool, 1.0 / (H * W), B, H * W, C, cnt, *se_w, dh, dg, S)
-        if rep == 0:
-            if kind != "pool":
-                close(yo.view(B, OH, OW, C), nhwc(y), 2e-4, 1e-5, "output")
-            close(pool, pooled, 2e-4, 1e-5, "pool")
-            close(dh, hpre, 2e-4, 1e-5, "hidden"); close(dg, gate, 2e-4, 1e-5, "gate")
-            c = cnt.cpu()
-            assert int(c.min()) == int(c.max())            # every image saw the same number of arrivals (0: the launch form fell back)
-            print("arrivals per image:", int(c[0]))
-        # the FC launches on the sums this launch left behind: same arithmetic, same order -> same bits
-        dh2, dg2 = torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
-        call("mmd_se_fc_fwd", pool, *se_w, dh2, dg2, B, C, S)
-        # (bit-equal when hipcc contracts the two kernels' dot products alike; 1e-6 otherwise - a stale pooled value would be off by 1e-2)
-        if rep == 0:
-            print("tail vs FC launches bit-equal:", torch.equal(dh, dh2) and torch.equal(dg, dg2))
-        close(dh, dh2, 1e-6, 1e-7, "hidden, tail vs FC launches on the same sums (rep %d)" % rep)
-        close(dg, dg2, 1e-6, 1e-7, "gate, tail vs FC launches on the same sums (rep %d)" % rep)
-
-
 def test_colsum_slice_sigmoid():
     torch.manual_seed(3)
     a = torch.randn(700, 36)
@@ -1561,28 +1489,6 @@ def test_pwconv_bwd_data_bn2_pool5_epilogue(M, K, N, B):
     assert torch.equal(dx, dx_ref)
     for k in range(5):
         close(p5[k], p_ref[k], 1e-4, 1e-5, f"pool5[{k}]")
-    # round 4: the same launch + the squeeze-excite FC pair's backward by each image's last-arriving workgroup (csrc/se_tail.h), against
-    # mmd_se_fc_bwd run on the pooled sums that launch left behind; repeated with fresh counters
-    S = max(1, K // 24)
-    gate, hpre = torch.rand(B, K) * 0.8 + 0.1, torch.randn(B, S)
-    wr, wet = torch.randn(S, K) / math.sqrt(K), torch.randn(S, K) / math.sqrt(S)
-    gt, hp, wrd, wetd = g(gate), g(hpre), g(wr), g(wet)
-    for rep in range(4):
-        dx2 = torch.empty(M, K, device=DEV); p5b = torch.zeros(5, B, K, device=DEV)
-        cnt = torch.zeros(B, dtype=torch.int32, device=DEV)
-        dpe, dpr, dpo = (torch.full(sh_, float("nan"), device=DEV) for sh_ in ((B, K), (B, S), (B, K)))
-        s1b = torch.zeros(2 * K, dtype=torch.float64, device=DEV)
-        call("mmd_pwconv_bwd_data_bn2_se", gd, zd, wtd, dx2, M, K, N, dsc, dsh, dmu, dis, sums, M, 0, None, rpi, dzm, None, None,
-             g(z1), g(s1), g(h1), g(m1), g(i1), p5b, B, cnt, gt, hp, wrd, wetd, dpe, dpr, dpo, s1b, 1.0 / rpi, S, 0)
-        assert torch.equal(dx2, dx_ref)
-        dpe_r, dpr_r, dpo_r = torch.empty(B, K, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, K, device=DEV)
-        s1r = torch.zeros(2 * K, dtype=torch.float64, device=DEV)
-        call("mmd_se_fc_bwd", p5b[0], gt, hp, gt, wrd, wetd, dpe_r, dpr_r, torch.zeros(B, S, device=DEV), dpo_r, 1.0 / rpi, None, None, None, None,
-             B, K, S, p5b, s1r)
-        close(dpe, dpe_r, 1e-6, 1e-7, "dpe"); close(dpr, dpr_r, 2e-5, 1e-6, "dpr"); close(dpo, dpo_r, 2e-5, 1e-6, "dpooled")
-        close(s1b, s1r, 2e-5, 2e-5, "BatchNorm-1 sums")
-        if rep == 0:
-            print("arrivals per image:", cnt.cpu().tolist())
 
 
 @pytest.mark.parametrize("mode,H,W", [("td", 8, 8), ("bu", 16, 12), ("p7", 4, 4), ("td", 64, 64), ("bu", 6, 10), ("p7", 2, 2)])
