@@ -50,6 +50,10 @@ WG_DEFER = WG_GROUP and bool(os.environ.get("MMD_WG_DEFER"))
 WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "45"))
 WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "4096"))      # rows per item: 4096 x (64x64 tile) measured best (1.33 ms per step vs 2.58 at 256)
 WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "4096"))
+# grid of a flush that runs BESIDE the backward's main chain (every flush but the last of a segment).  A chip-filling grid of these long-running
+# blocks starves the chain's kernels of CU slots (round 4 trace: the two M131072 K24 N144 input-gradient GEMMs next to the second flush took
+# 380 us apiece against 77 us alone); a thin persistent grid leaves the chain its slots and has ~2 ms of backward left to finish in
+WG_BLOCKS_MID = int(os.environ.get("MMD_WG_GRID_MID", "4096"))
 
 
 @dataclass
@@ -176,6 +180,17 @@ class Net:
         self._theta_desc: Dict[tuple, torch.Tensor] = {}
         self._se_wg: list = []                 # squeeze-excite FC weight gradients of the current backward segment (one batched launch)
         self._se_wg_tabs: Dict[tuple, torch.Tensor] = {}
+        # test aid ("teacher forcing"): probe = dict that receives a copy of every materialised unit output of a forward (stem, MBConv
+        # blocks, BiFPN down-channel convs and nodes); force_out = dict name -> rows [M, C] written over that output AFTER the probe, so the
+        # next unit consumes the given tensor instead of this net's own (tests/test_gpu_net.py::test_teacher_forced_units_bf16)
+        self.probe: Optional[Dict[str, torch.Tensor]] = None
+        self.force_out: Optional[Dict[str, torch.Tensor]] = None
+
+    def _tf(self, name: str, t: torch.Tensor):
+        if self.probe is not None:
+            self.probe[name] = t.clone()
+        if self.force_out is not None and name in self.force_out:
+            t.copy_(self.force_out[name].view_as(t))
 
     def _use(self, f: "Feat"):
         if self._counting:
@@ -345,6 +360,7 @@ class Net:
             # prologue, which would redo them for every halo pixel (1.6x for 3x3, 2.25x for 5x5 tiles)
             call("mmd_stem_conv_fwd", x, wstem, z, B, Cin, S, S, ps.stem_kp, spec.stem_out, sc, sh, SWISH, None, None, 0)
             cur = Feat(z, B, OH, OH, spec.stem_out)
+            self._tf("stem", z)
         taps: List[Feat] = []
         skip_i = 0
         for blk in spec.blocks:
@@ -422,6 +438,7 @@ class Net:
             if blk.idx == self.mark_block and self.ps.flat.is_cuda:
                 self.mark_event = torch.cuda.current_stream().record_event()      # "this net is past block k" (step.py staggers the teachers on it)
             cur = Feat(y, B, H1, W1, blk.cout)
+            self._tf(f"blk{blk.idx}", y)
             rec["out"] = cur
             if train:
                 tape[f"blk{blk.idx}"] = rec
@@ -498,6 +515,7 @@ class Net:
             b = ps.bn(f"{name}.1")
             y = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]))
         out = Feat(y, x.B, x.H, x.W, W)
+        self._tf(name, y)
         rec["out"] = out
         return out
 
@@ -510,6 +528,12 @@ class Net:
 
     def _node(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
               pl: Optional[Feat], train: bool, tape: dict, y=None) -> Feat:
+        out = self._node_impl(cell, conv, theta, in0, in1, up, pl, train, tape, y)
+        self._tf(f"{cell}.{conv}", out.z)
+        return out
+
+    def _node_impl(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
+                   pl: Optional[Feat], train: bool, tape: dict, y=None) -> Feat:
         th = self.ps.w(f"{cell}.{theta}")
         if (not train and self.FUSE_NODE and self.ps.flat.is_cuda
                 and _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) == 1):
@@ -750,7 +774,7 @@ class Net:
             return
         self._wg_pending.append((dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi))
         if WG_CHUNK > 0 and len(self._wg_pending) >= WG_CHUNK:
-            self._wg_flush()
+            self._wg_flush(final=False)
 
     def _leaf(self, fn):
         """A leaf of the backward graph other than a 1x1-conv weight gradient (depthwise / squeeze-excite / fusion-weight / bias
@@ -762,9 +786,10 @@ class Net:
             with self._wgrad_stream():
                 fn()
 
-    def _wg_flush(self):
+    def _wg_flush(self, final: bool = True):
         """Launch the deferred weight gradients of this backward segment: one persistent grid over all (layer, tile, split) items
-        and one fold, on the weight-gradient stream behind everything issued so far."""
+        and one fold, on the weight-gradient stream behind everything issued so far.  final: nothing of the main chain runs beside
+        this flush (end of a backward segment): full-width grid; otherwise the thin one (WG_BLOCKS_MID)."""
         pend, self._wg_pending = self._wg_pending, []
         leaves, self._leaf_pending = self._leaf_pending, []
         seg = self._wg_segment
@@ -801,7 +826,8 @@ class Net:
             self._wg_plans[(seg, sig)] = plan
         ws = self._alloc(plan["ws"])
         with self._wgrad_stream():
-            call("mmd_wgrad_grouped", plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS, plan["flops"], plan["bytes"])
+            call("mmd_wgrad_grouped", plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS if final else WG_BLOCKS_MID,
+                 plan["flops"], plan["bytes"])
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
                 mul_bc=None, mul_b=None, add_bc=None, sums=None, lazy: bool = False, w16: bool = False):

@@ -120,6 +120,18 @@ class _Store16(torch.autograd.Function):
         return (_r16(g) if ctx.bwd else g), None, None
 
 
+# Oracle-only tap: when a dict, forward() records the output of every unit the HIP engine materialises - "stem" (eval: activated),
+# "blk<i>" (MBConv block outputs), "bifpn.<c>.<down-channel | conv*_up | conv*_down>" (NCHW tensors, detached) - so a test can hand each
+# unit of the HIP net exactly the inputs this restatement saw ("teacher forcing": rounding differences cannot compound across units).
+TAP = None
+
+
+def _tap(name, x):
+    if TAP is not None:
+        TAP[name] = x.detach().clone()
+    return x
+
+
 def _mbx_fused(cin, cmid):
     return cin in (16, 24, 32, 40, 48, 56) and cmid % 48 == 0
 
@@ -197,6 +209,8 @@ def backbone(state, x, coef, training, drop_masks):
     p = "backbone_net.model"
     x = conv_same(x, state[p + "._conv_stem.conv.weight"], stride=2)
     x = swish(batchnorm(state, p + "._bn0", x, training))
+    if not training:
+        _tap("stem", x)
     blocks = block_table(coef)
     n = len(blocks)
     fm, last = [], None
@@ -205,7 +219,7 @@ def backbone(state, x, coef, training, drop_masks):
         dm = None if drop_masks is None else drop_masks.get(i)
         if training and blk[6] and rate and dm is None:
             raise ValueError("training-mode oracle needs an explicit drop mask for block %d" % i)
-        x = mbconv(state, f"{p}._blocks.{i}", x, blk, training, rate, dm)
+        x = _tap(f"blk{i}", mbconv(state, f"{p}._blocks.{i}", x, blk, training, rate, dm))
         if blk[1] == 2:
             fm.append(last)
         elif i == n - 1:
@@ -236,7 +250,7 @@ def _up(x):
 def bifpn_cell(state, p, feats, first, training):
     def dc(name, x):
         x = pw_conv(x, state[f"{p}.{name}.0.conv.weight"], state[f"{p}.{name}.0.conv.bias"])
-        return batchnorm(state, f"{p}.{name}.1", x, training)
+        return _tap(f"{p}.{name}", batchnorm(state, f"{p}.{name}.1", x, training))
 
     if first:
         p3, p4, p5 = feats
@@ -245,7 +259,7 @@ def bifpn_cell(state, p, feats, first, training):
         p3_in, p4_in, p5_in = dc("p3_down_channel", p3), dc("p4_down_channel", p4), dc("p5_down_channel", p5)
     else:
         p3_in, p4_in, p5_in, p6_in, p7_in = feats
-    sc = lambda n, x: sepconv(state, f"{p}.{n}", x, training)
+    sc = lambda n, x: _tap(f"{p}.{n}", sepconv(state, f"{p}.{n}", x, training))
     w = _fw(state, p + ".p6_w1"); p6_up = sc("conv6_up", swish(w[0] * p6_in + w[1] * _up(p7_in)))
     w = _fw(state, p + ".p5_w1"); p5_up = sc("conv5_up", swish(w[0] * p5_in + w[1] * _up(p6_up)))
     w = _fw(state, p + ".p4_w1"); p4_up = sc("conv4_up", swish(w[0] * p4_in + w[1] * _up(p5_up)))
