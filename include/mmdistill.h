@@ -336,6 +336,16 @@ int mmd_pwconv_bwd_data_bn2(const float* g, const float* z, const float* wt, flo
 
 int mmd_pwconv_bwd_data_bn2_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
 
+// Round 4: backward of an MBConv EXPAND conv with its train-mode BatchNorm-0 + swish in ONE pass over the 6x expanded gradient, for the
+// thin-input high-resolution blocks (autograd of `_expand_conv` -> `_bn0` -> swish, src/YetAnotherEfficientNet.py:456-460):
+//   dz0 = BnBwd0(g0, z0) evaluated once per element into LDS (never written to HBM);  dx[M, Cin] = dz0 . w[Cmid, Cin] (+ residual, may be dx);
+//   dw[Cmid, Cin] += dz0^T . x[M, Cin];  dgamma / dbeta (+)= the reduce pass' sums;  optional xs_* as in mmd_pwconv_bwd_data_bn2 (dx completes
+//   the gradient of an upstream BatchNorm output: xs_sums[2 Cin] (+)= its backward sums).
+// Replaces mmd_pwconv_bwd_data_bn2 (which stores dz0 for the weight gradient) + the layer's entry in mmd_wgrad_grouped (which reads it back).
+// mmd_mbconv_expand_bwd_supported(Cin, Cmid) -> 1 for (16, 96), (24, 144), (32, 192).
+int mmd_mbconv_expand_bwd_supported(int Cin, int Cmid);
+int mmd_mbconv_expand_bwd_fused(const float* g0, const float* z0, const float* x, const float* w, float* dx, const float* residual, float* dw, int M, int Cin, int Cmid, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, float* dgamma, float* dbeta, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, hipStream_t stream);
+
 int mmd_pwconv_bwd_data_bn_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
 
 int mmd_pwconv_bwd_weight_bn(const float* g, const float* z, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int bn_rows_per_image, float* dgamma, float* dbeta, hipStream_t stream);

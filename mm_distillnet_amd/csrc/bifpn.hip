@@ -220,16 +220,27 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
 //            per launch); 28 (row, column) tiles over 8 waves
 //   epilogue (acc + bias) * scale + shift straight from the accumulators (16 lanes = 64 contiguous bytes of one pixel).
 // 86 KB of LDS (one block per CU).
-constexpr int FN_C = 112, FN_Q = FN_C / 4, FN_FS = FN_C, FN_ZS = FN_C + 4, FN_WS = FN_C + 4, FN_NT = 512;
-constexpr int FN_U = (100 * FN_FS > FN_C * FN_WS) ? 100 * FN_FS : FN_C * FN_WS;      // input tile, later the 1x1 weights
+// Round 4: the width is a template parameter.  FC in {64, 112, 160, 224} (EfficientDet-D0 / D2 / D3 / D4; a multiple of 16).  Up to 160 the 1x1
+// weights are parked in LDS as described; at FC = 224 (BASELINE configs[4]: 157 KB for the two tiles alone) they do not fit, and phase 2
+// takes its B fragments straight from L2 (the [C, C] matrix is 200 KB: L2-resident after the first tile of a launch).
+constexpr int FN_NT = 512;
+template <int FC> struct FnCfg {
+  static constexpr int Q = FC / 4, FS = FC, ZS = FC + 4, WS = FC + 4, KR = FC / 4, CT = FC / 16;
+  static constexpr bool PARK = FC <= 160;
+  static constexpr int U = (PARK && FC * WS > 100 * FS) ? FC * WS : 100 * FS;      // input tile, later (PARK) the 1x1 weights
+  static constexpr size_t lds(bool train) { return (size_t)(U + 64 * ZS + 9 * FC + (train ? 2 * FC : 0)) * sizeof(float); }
+};
 
 // TRAIN (the student's nodes): y = the RAW 1x1-conv output z (+ bias), its per-channel sums (sum z, sum z^2: the node's train-mode BatchNorm
 // statistics) go to `stats`, and the depthwise output tile is also stored (zd_out: the 1x1 conv's weight gradient reads it in the backward).
-template <int MODE, bool TRAIN = false>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
+template <int MODE, bool TRAIN = false, int FC = 112>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
 __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ y,
                                                                 int tiles_h, int tiles_w, float* __restrict__ zd_out, double* stats) {
+  using Cf = FnCfg<FC>;
+  constexpr int FN_C = FC, FN_Q = Cf::Q, FN_FS = Cf::FS, FN_ZS = Cf::ZS, FN_WS = Cf::WS, FN_U = Cf::U, KR = Cf::KR, CT = Cf::CT;
+  constexpr bool PARK = Cf::PARK;
   extern __shared__ float smem[];
   float* const sU = smem;                       // [100][FS] fused input tile | [C][WS] pointwise weights
   float* const sZ = smem + FN_U;                // [64][ZS] depthwise output tile
@@ -243,12 +254,14 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid, oh0 = th * 8, ow0 = tw * 8;
   // the 1x1 weights of the whole node, in flight while phases 0 and 1 run
-  constexpr int NW4 = FN_C * FN_Q, WPT = (NW4 + FN_NT - 1) / FN_NT;
+  constexpr int NW4 = FN_C * FN_Q, WPT = PARK ? (NW4 + FN_NT - 1) / FN_NT : 1;
   float4 wreg[WPT];
+  if constexpr (PARK) {
 #pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int idx = tid + i * FN_NT;
-    wreg[i] = idx < NW4 ? mmd_ld4(wpw + (size_t)idx * 4) : make_float4(0, 0, 0, 0);
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * FN_NT;
+      wreg[i] = idx < NW4 ? mmd_ld4(wpw + (size_t)idx * 4) : make_float4(0, 0, 0, 0);
+    }
   }
   for (int i = tid; i < 9 * FN_Q; i += FN_NT) *reinterpret_cast<float4*>(&sWd[i * 4]) = mmd_ld4(wdw + (size_t)i * 4);
   if (TRAIN) for (int i = tid; i < 2 * FN_C; i += FN_NT) sSt[i] = 0.f;
@@ -326,46 +339,49 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     }
   }
   __syncthreads();                                   // every read of the input tile is done: park the 1x1 weights in its place
+  if constexpr (PARK) {
 #pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int idx = tid + i * FN_NT;
-    if (idx < NW4) { const int n = idx / FN_Q, k4 = idx - n * FN_Q; *reinterpret_cast<float4*>(&sU[n * FN_WS + k4 * 4]) = wreg[i]; }
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * FN_NT;
+      if (idx < NW4) { const int n = idx / FN_Q, k4 = idx - n * FN_Q; *reinterpret_cast<float4*>(&sU[n * FN_WS + k4 * 4]) = wreg[i]; }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // ---- phase 2
   const int lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave & 3;
-  float ebi[4], esc[4], esh[4];                  // epilogue coefficients of the wave's column tiles (ct = (wave >> 2) + 2 j)
+  constexpr int NJ = (CT + 1) / 2;               // column tiles per wave
+  float ebi[NJ], esc[NJ], esh[NJ];               // epilogue coefficients of the wave's column tiles (ct = (wave >> 2) + 2 j)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = min(((wave >> 2) + 2 * j) * 16 + r, FN_C - 1);
     ebi[j] = bias ? bias[n] : 0.f;
     if (!TRAIN) { esc[j] = scale[n]; esh[j] = shift[n]; } else { esc[j] = 1.f; esh[j] = 0.f; }
   }
-  float af[28];
+  float af[KR];
   {
-    const float* ap = &sZ[(rt * 16 + r) * FN_ZS + g * 28];
+    const float* ap = &sZ[(rt * 16 + r) * FN_ZS + g * KR];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < KR / 4; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(ap + 4 * j);
       af[4 * j] = v.x; af[4 * j + 1] = v.y; af[4 * j + 2] = v.z; af[4 * j + 3] = v.w;
     }
   }
 #pragma unroll
-  for (int j4 = 0; j4 < 4; ++j4) {
+  for (int j4 = 0; j4 < NJ; ++j4) {
     const int ct = (wave >> 2) + 2 * j4;
-    if (ct >= 7) break;                                  // wave-uniform
-    float bf[28];
-    const float* bp = &sU[(ct * 16 + r) * FN_WS + g * 28];
+    if (ct >= CT) break;                                 // wave-uniform
+    float bf[KR];
+    const float* bp = PARK ? &sU[(ct * 16 + r) * FN_WS + g * KR] : wpw + (size_t)(ct * 16 + r) * FN_C + g * KR;      // LDS-parked / straight from L2
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < KR / 4; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(bp + 4 * j);
       bf[4 * j] = v.x; bf[4 * j + 1] = v.y; bf[4 * j + 2] = v.z; bf[4 * j + 3] = v.w;
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};      // two chains: a dependent MFMA waits ~8 passes for its accumulator
 #pragma unroll
-    for (int k = 0; k < 28; k += 2) {
+    for (int k = 0; k < KR; k += 2) {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k], bf[k], acc, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k + 1], bf[k + 1], acc1, 0, 0, 0);
     }
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
 }
 
 // 1 when mmd_bifpn_node_fwd_fused has a kernel for this width (the caller keeps mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd otherwise)
-extern "C" int mmd_bifpn_node_fused_supported(int C) { return C == FN_C ? 1 : 0; }
+extern "C" int mmd_bifpn_node_fused_supported(int C) { return (C == 64 || C == 112 || C == 160 || C == 224) ? 1 : 0; }
 
 // Whole frozen-net BiFPN node: y[B*H*W, C] = ((dw3x3(swish(fuse(operands))) · w_pw[C,C]ᵀ) + bias) * scale + shift.
 extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
@@ -404,28 +420,29 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
                                         float* y, int B, int H, int W, int C, hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
-  if (rc || !w_dw || !w_pw || !scale || !shift || !y || C != FN_C || (in1 && up)) return MMD_EINVAL;      // (no BiFPN node fuses in1 AND up)
+  if (rc || !w_dw || !w_pw || !scale || !shift || !y || !mmd_bifpn_node_fused_supported(C) || (in1 && up)) return MMD_EINVAL;      // (no BiFPN node fuses in1 AND up)
   const int th = cdiv(H, 8), tw = cdiv(W, 8);
-  constexpr size_t lds = (size_t)(FN_U + 64 * FN_ZS + 9 * FN_C) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   mmd_prof_tag(MMD_FAM_MBX, "node H%lld C%lld ops%lld", H, C, a.ntheta, 0);
   mmd_prof_begin(MMD_FAM_MBX, stream);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw)), blk(FN_NT);
-#define MMD_NODE_FWD(M) hipLaunchKernelGGL(bifpn_node_fused_kernel<M>, grid, blk, lds, stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw, nullptr, nullptr)
-  if (mode == 2) MMD_NODE_FWD(2);             // (in, up): top-down nodes
-  else if (mode == 5) MMD_NODE_FWD(5);        // (in, td, pool): bottom-up nodes
-  else if (mode == 4) MMD_NODE_FWD(4);        // (in, pool): p7_out
-  else if (mode == 1) MMD_NODE_FWD(1);
-  else return MMD_EINVAL;
+  rc = MMD_EINVAL;
+#define MMD_NODE_FWD(M, FC_) do { static bool attr = false; \
+    if (!attr) { hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<M, false, FC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((bifpn_node_fused_kernel<M, false, FC_>), grid, blk, FnCfg<FC_>::lds(false), stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw, nullptr, nullptr); \
+    rc = MMD_OK; } while (0)
+#define MMD_NODE_FWD_C(FC_) do { \
+    if (mode == 2) MMD_NODE_FWD(2, FC_);            /* (in, up): top-down nodes */ \
+    else if (mode == 5) MMD_NODE_FWD(5, FC_);       /* (in, td, pool): bottom-up nodes */ \
+    else if (mode == 4) MMD_NODE_FWD(4, FC_);       /* (in, pool): p7_out */ \
+    else if (mode == 1) MMD_NODE_FWD(1, FC_); } while (0)
+  if (C == 112) MMD_NODE_FWD_C(112);
+  else if (C == 224) MMD_NODE_FWD_C(224);
+  else if (C == 160) MMD_NODE_FWD_C(160);
+  else MMD_NODE_FWD_C(64);
+#undef MMD_NODE_FWD_C
 #undef MMD_NODE_FWD
+  if (rc) return rc;
   const double rows = (double)B * H * W;
   mmd_prof_end(MMD_FAM_MBX, stream, rows * C * (2.0 * 9 + 2.0 * C), 4.0 * rows * C * (a.ntheta + 1 + (pool ? 3 : 0)));
   return mmd_check_launch();
@@ -439,26 +456,25 @@ extern "C" int mmd_bifpn_node_fwd_fused_train(const float* in0, const float* in1
                                               int B, int H, int W, int C, hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
-  if (rc || !w_dw || !w_pw || !z || !zd || !stats || C != FN_C || (in1 && up)) return MMD_EINVAL;
+  if (rc || !w_dw || !w_pw || !z || !zd || !stats || !mmd_bifpn_node_fused_supported(C) || (in1 && up)) return MMD_EINVAL;
   const int th = cdiv(H, 8), tw = cdiv(W, 8);
-  constexpr size_t lds = (size_t)(FN_U + 64 * FN_ZS + 9 * FN_C + 2 * FN_C) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw)), blk(FN_NT);
-#define MMD_NODE_FWD_T(M) hipLaunchKernelGGL((bifpn_node_fused_kernel<M, true>), grid, blk, lds, stream, a, w_dw, w_pw, bias, nullptr, nullptr, z, th, tw, zd, stats)
-  if (mode == 2) MMD_NODE_FWD_T(2);
-  else if (mode == 5) MMD_NODE_FWD_T(5);
-  else if (mode == 4) MMD_NODE_FWD_T(4);
-  else if (mode == 1) MMD_NODE_FWD_T(1);
-  else return MMD_EINVAL;
+  rc = MMD_EINVAL;
+#define MMD_NODE_FWD_T(M, FC_) do { static bool attr = false; \
+    if (!attr) { hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<M, true, FC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((bifpn_node_fused_kernel<M, true, FC_>), grid, blk, FnCfg<FC_>::lds(true), stream, a, w_dw, w_pw, bias, nullptr, nullptr, z, th, tw, zd, stats); \
+    rc = MMD_OK; } while (0)
+#define MMD_NODE_FWD_TC(FC_) do { \
+    if (mode == 2) MMD_NODE_FWD_T(2, FC_); else if (mode == 5) MMD_NODE_FWD_T(5, FC_); else if (mode == 4) MMD_NODE_FWD_T(4, FC_); \
+    else if (mode == 1) MMD_NODE_FWD_T(1, FC_); } while (0)
+  if (C == 112) MMD_NODE_FWD_TC(112);
+  else if (C == 224) MMD_NODE_FWD_TC(224);
+  else if (C == 160) MMD_NODE_FWD_TC(160);
+  else MMD_NODE_FWD_TC(64);
+#undef MMD_NODE_FWD_TC
 #undef MMD_NODE_FWD_T
+  if (rc) return rc;
   return mmd_check_launch();
 }
 

@@ -115,7 +115,12 @@ P5_IN_GEMM = not os.environ.get("MMD_NO_P5_IN_GEMM")  # MBConv: the pooled squee
 SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
 # both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
 # (S*C MACs, serial per wave) - measured 17.0 -> 17.7 ms/step against the two wide launches; off unless MMD_SE_FUSED=1
-SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
+SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))
+# round 4: backward of the thin-input high-resolution expand convs (BatchNorm-0 backward, input gradient, weight gradient) in one pass over
+# the 6x expanded gradient (csrc/mbconv_bwd_fused.hip): dz0 is neither stored nor read back, and the layer leaves the grouped weight-gradient
+# launch at the exposed end of the backward.  Taken for layers with at least this many rows (MMD_NO_MBW=1: the two-GEMM form, for A/B timing)
+MBW_FUSED = not os.environ.get("MMD_NO_MBW")
+MBW_MIN_ROWS = int(os.environ.get("MMD_MBW_MIN_ROWS", "32768"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
 
 class Net:
@@ -266,6 +271,15 @@ class Net:
     FUSE_NODE_TRAIN = not os.environ.get("MMD_NO_NODE_FUSE_TRAIN")   # trainable net: a BiFPN node's forward (fusion, depthwise, 1x1 conv, BN sums) in one kernel
     FUSE_NODE = not os.environ.get("MMD_NO_NODE_FUSE")  # frozen nets: a BiFPN node (fusion, depthwise, 1x1 conv, BN) in one kernel
     FUSE_FRONT = not os.environ.get("MMD_NO_MBX")       # frozen nets: expand + depthwise of the thin-input blocks in one kernel
+    # widths above 160 (D4's 224): the whole-node kernel holds two 8x8-pixel tiles in 157 KB of LDS (one block per CU) and reads its 1x1
+    # weights from L2 - a win on the latency-bound small maps, a loss on the large ones, where the two-launch path runs a chip-filling GEMM
+    # (round 4, D4 / 768^2 at B = 8: every level fused 56.7 ms/step against 54.0 unfused)
+    NODE_FUSE_WIDE_MAXROWS = int(os.environ.get("MMD_NODE_FUSE_WIDE_MAXROWS", "4608"))
+
+    def _node_fusable(self, in0: "Feat") -> bool:
+        if not self.ps.flat.is_cuda or _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) != 1:
+            return False
+        return in0.C <= 160 or in0.M <= self.NODE_FUSE_WIDE_MAXROWS
 
     def _stats_ws(self, stats, M: int, C: int):
         """(workspace, slots) for a BatchNorm-sum producer over M rows: the thin full-resolution layers would send
@@ -535,8 +549,7 @@ class Net:
     def _node_impl(self, cell: str, conv: str, theta: str, in0: Feat, in1: Optional[Feat], up: Optional[Feat],
                    pl: Optional[Feat], train: bool, tape: dict, y=None) -> Feat:
         th = self.ps.w(f"{cell}.{theta}")
-        if (not train and self.FUSE_NODE and self.ps.flat.is_cuda
-                and _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) == 1):
+        if not train and self.FUSE_NODE and self._node_fusable(in0):
             # frozen net: fusion + depthwise + 1x1 conv + folded BN in one launch, the depthwise output never leaves the CU
             name = f"{cell}.{conv}"
             b = self.ps.bn(f"{name}.bn")
@@ -546,8 +559,9 @@ class Net:
                  self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
                  self.ps.w(f"{name}.pointwise_conv.conv.bias"), b["fscale"], b["fshift"], y, in0.B, in0.H, in0.W, in0.C)
             return Feat(y, in0.B, in0.H, in0.W, in0.C)
-        if (train and self.FUSE_NODE_TRAIN and self.NODE_WG and self.precision == "fp32" and self.ps.flat.is_cuda
-                and _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) == 1):
+        # (also in the bf16 modes: the node's 1x1 conv then runs exact fp32 products in the forward - closer to the fp32 reference than the
+        # mode's operand-rounding rule asks for; its two gradient GEMMs follow the mode)
+        if train and self.FUSE_NODE_TRAIN and self.NODE_WG and self._node_fusable(in0):
             # trainable net: fusion + depthwise + 1x1 conv + BatchNorm sums in one launch (raw z out, depthwise output kept for the backward)
             name, W = f"{cell}.{conv}", in0.C
             bn_name = f"{name}.bn"
@@ -898,6 +912,19 @@ class Net:
                      residual, *xsargs, *p5args, 1, bd16)
                 self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs, w16=wg16)
                 return None if into is not None else dx
+            if (into is not None and FOLD_SUMS and MBW_FUSED and M >= MBW_MIN_ROWS and L.act == SWISH and L.mul_b is None and gate is None
+                    and not x.w16 and x.scale is None and x.bn is None and x.act == NONE and ps.flat.is_cuda
+                    and _lib.LIB.load().mmd_mbconv_expand_bwd_supported(K, N) == 1):
+                # thin-input expand conv of a high-resolution block: one pass over (g0, z0) - input gradient, weight gradient, no dz0 in HBM
+                slot, xs = self._contrib(into, True)
+                assert xs is None or not xs[6], "the epilogue sums the accumulated total: not a linear-sum (pooled) tensor"
+                residual = slot.t
+                if slot.t is None:
+                    slot.t = self._alloc(M, K)
+                xsa = (None, None, None, None, 0, None) if xs is None else (xs[0], xs[1], xs[2], xs[4], xs[5], xs[3])
+                call("mmd_mbconv_expand_bwd_fused", L.g, L.z, x.z, ps.w(wkey), slot.t, residual, ps.g(wkey), M, K, N, L.aff[0], L.aff[1], L.aff[2],
+                     L.aff[3], L.sums, L.count, b["dgamma"], b["dbeta"], *xsa)
+                return None
             if into is not None and FOLD_SUMS:
                 slot, xs = self._contrib(into, True)
                 assert xs is None or not xs[6], "the GEMM epilogue sums the accumulated total: not a linear-sum (pooled) tensor"

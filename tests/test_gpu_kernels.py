@@ -1027,12 +1027,15 @@ def test_bifpn_node_dw_fused(mode, H, W, C):
     assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("C", [112, 224, 160, 64])      # D2 (headline), D4 (BASELINE configs[4]: 1x1 weights straight from L2), D3, D0
 @pytest.mark.parametrize("mode,H,W", [("td", 8, 8), ("bu", 16, 12), ("p7", 4, 4), ("td", 64, 64), ("bu", 32, 32), ("bu", 6, 10), ("p7", 2, 2)])
-def test_bifpn_node_whole_fused(mode, H, W):
+def test_bifpn_node_whole_fused(mode, H, W, C):
     """Whole frozen-net BiFPN node in one kernel (fusion + swish + depthwise 3x3 + 1x1 conv + bias + folded BN; BiFPN._forward_fast_attention
     + SeparableConvBlock(norm=True), src/YetAnotherEfficientDet.py:150-185,338-390) against the two launches it replaces and torch."""
     torch.manual_seed(11)
-    B, C = 2, 112
+    B = 2
+    if C != 112 and H == 64:
+        pytest.skip("the large map is covered at the headline width")
     in0 = torch.randn(B * H * W, C)
     in1 = torch.randn(B * H * W, C) if mode == "bu" else None
     up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
@@ -1043,7 +1046,7 @@ def test_bifpn_node_whole_fused(mode, H, W):
     sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
     gp = lambda t: g(t) if t is not None else None
     dll = _lib.LIB.load()
-    assert dll.mmd_bifpn_node_fused_supported(C) == 1 and dll.mmd_bifpn_node_fused_supported(224) == 0
+    assert dll.mmd_bifpn_node_fused_supported(C) == 1 and dll.mmd_bifpn_node_fused_supported(88) == 0
     z = torch.zeros(B * H * W, C, device=DEV)
     call("mmd_bifpn_node_dw_fwd", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), None, z, B, H, W, C)
     y_ref = torch.empty(B * H * W, C, device=DEV)
@@ -1055,7 +1058,7 @@ def test_bifpn_node_whole_fused(mode, H, W):
     ref = (z.cpu().double() @ wp.double().t() + bias.double()) * sc.double() + sh.double()
     close(y, ref, 2e-4, 1e-5, "whole node vs fp64 GEMM of the depthwise output")
     with pytest.raises(RuntimeError):
-        call("mmd_bifpn_node_fwd_fused", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(wp), g(bias), g(sc), g(sh), y, B, H, W, 64)
+        call("mmd_bifpn_node_fwd_fused", gp(in0), gp(in1), gp(up), gp(pl), g(theta), g(wd), g(wp), g(bias), g(sc), g(sh), y, B, H, W, 88)
 
 
 def test_slotted_bn_sums_match_direct():
@@ -1330,6 +1333,59 @@ def test_pwconv_bwd_data_bn2_residual_and_upstream_sums(M, K, N, act, rowscale, 
         assert not ws.any(), "slotted workspace must be left zero"
 
 
+@pytest.mark.parametrize("M,Cin,C,resid,xs", [(40960, 16, 96, True, True), (20480, 24, 144, True, True), (8192, 32, 192, False, False),
+                                              (1000, 24, 144, True, False), (131072, 24, 144, True, True), (70, 16, 96, False, True)])
+def test_mbconv_expand_bwd_fused(M, Cin, C, resid, xs):
+    """Round 4: the expand conv's backward (BatchNorm-0 + swish backward, input gradient (+ residual, + upstream BatchNorm sums), weight
+    gradient) in one pass over (g0, z0) - csrc/mbconv_bwd_fused.hip - against the launches it replaces: mmd_pwconv_bwd_data_bn2 (which
+    stores dz0) and mmd_pwconv_bwd_weight on that stored dz0; and against float64 torch."""
+    torch.manual_seed(M + C)
+    B = 2
+    rpi = M // B
+    g0 = torch.randn(M, C); z0 = torch.randn(M, C) * 1.3 + 0.2
+    x = torch.randn(M, Cin)
+    w = torch.randn(C, Cin) / math.sqrt(Cin)
+    sc, sh, mu, istd = torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.2, torch.rand(C) + 0.5
+    gd, zd, xd, wd = g(g0), g(z0), g(x), g(w)
+    dsc, dsh, dmu, dis = g(sc), g(sh), g(mu), g(istd)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", gd, zd, dsc, dsh, dmu, dis, 1, None, None, None, rpi, None, sums, M, C, None, 0)
+    base = torch.randn(M, Cin)
+    z_up = torch.randn(M, Cin) * 0.8 + 0.1
+    mu_up, is_up, rs_up = torch.randn(Cin) * 0.2, torch.rand(Cin) + 0.5, torch.tensor([0.75, 1.5])
+    # the launches it replaces
+    dx_ref = g(base.clone()) if resid else torch.full((M, Cin), float("nan"), device=DEV)
+    dzm = torch.empty(M, C, device=DEV)
+    dga_r = torch.zeros(C, device=DEV); dbe_r = torch.zeros(C, device=DEV)
+    xs_ref = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    call("mmd_pwconv_bwd_data_bn2", gd, zd, g(w.t()), dx_ref, M, Cin, C, dsc, dsh, dmu, dis, sums, M, 1, None, rpi, dzm, dga_r, dbe_r,
+         dx_ref if resid else None, g(z_up) if xs else None, g(mu_up) if xs else None, g(is_up) if xs else None, g(rs_up) if xs else None, rpi,
+         xs_ref if xs else None, None, 0, None, None, None, None, None, None, 0)
+    dw_ref = torch.full((C, Cin), 0.5, device=DEV)
+    call("mmd_pwconv_bwd_weight", dzm, xd, dw_ref, M, Cin, C, None, None, 0, None, 1)
+    # the single pass
+    dx = g(base.clone()) if resid else torch.full((M, Cin), float("nan"), device=DEV)
+    dw = torch.full((C, Cin), 0.5, device=DEV)
+    dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
+    xs_sums = torch.zeros(2 * Cin, dtype=torch.float64, device=DEV)
+    assert _lib.LIB.load().mmd_mbconv_expand_bwd_supported(Cin, C) == 1 and _lib.LIB.load().mmd_mbconv_expand_bwd_supported(48, 288) == 0
+    call("mmd_mbconv_expand_bwd_fused", gd, zd, xd, wd, dx, dx if resid else None, dw, M, Cin, C, dsc, dsh, dmu, dis, sums, M, dga, dbe,
+         g(z_up) if xs else None, g(mu_up) if xs else None, g(is_up) if xs else None, g(rs_up) if xs else None, rpi, xs_sums if xs else None)
+    close(dx, dx_ref, 2e-5, 1e-6, "dx (+ residual) vs the GEMM launch")
+    close(dw, dw_ref, 2e-4, 1e-5, "dW vs the weight-gradient launch on the stored dz0")
+    assert torch.equal(dga, dga_r) and torch.equal(dbe, dbe_r)
+    if xs:
+        _sums_close(xs_sums, xs_ref.cpu(), "upstream BatchNorm sums vs the GEMM launch's")
+    # float64 torch
+    m1, m2 = sums[:C].cpu() / M, sums[C:].cpu() / M
+    u = z0.double() * sc.double() + sh.double()
+    sg = torch.sigmoid(u)
+    gp = g0.double() * (sg * (1 + u * (1 - sg)))
+    dz = sc.double() * (gp - m1 - (z0.double() - mu.double()) * istd.double() * m2)
+    close(dx, dz @ w.double() + (base.double() if resid else 0), 2e-4, 1e-5, "dx vs float64")
+    close(dw - 0.5, dz.t() @ x.double(), 3e-4, 1e-5, "dW vs float64")
+
+
 @pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 48), ("p7", 4, 4, 112), ("td", 6, 10, 224), ("td", 64, 64, 112)])
 def test_bifpn_node_dw_bwd2_operand_bn_sums(mode, H, W, C):
     """mmd_bifpn_node_dw_bwd2: same gradients as mmd_bifpn_node_dw_bwd, plus the BatchNorm-backward sums of every operand gradient it
@@ -1491,12 +1547,15 @@ def test_pwconv_bwd_data_bn2_pool5_epilogue(M, K, N, B):
         close(p5[k], p_ref[k], 1e-4, 1e-5, f"pool5[{k}]")
 
 
+@pytest.mark.parametrize("C", [112, 224, 160, 64])
 @pytest.mark.parametrize("mode,H,W", [("td", 8, 8), ("bu", 16, 12), ("p7", 4, 4), ("td", 64, 64), ("bu", 6, 10), ("p7", 2, 2)])
-def test_bifpn_node_whole_fused_train(mode, H, W):
+def test_bifpn_node_whole_fused_train(mode, H, W, C):
     """Train-mode whole-node forward of the trainable net (raw 1x1 output + BatchNorm batch sums + the depthwise output kept for the
     backward) against the two launches it replaces: mmd_bifpn_node_dw_fwd -> mmd_pwconv_fwd(bias, stats)."""
     torch.manual_seed(19)
-    B, C = 2, 112
+    B = 2
+    if C != 112 and H == 64:
+        pytest.skip("the large map is covered at the headline width")
     in0 = torch.randn(B * H * W, C)
     in1 = torch.randn(B * H * W, C) if mode == "bu" else None
     up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None

@@ -487,7 +487,8 @@ def test_teacher_forced_units(case, precision):
         ds = torch.ones(sum(1 for b in spec.blocks if b.skip), B, device=DEV)
     cls, reg, feats = net.forward(x.to(DEV), train=train, drop_scale=ds)
     torch.cuda.synchronize()
-    tol = 1e-4 if precision == "fp32" else 1e-2
+    # (train mode: BatchNorm over the batch's few samples - 64 per channel on the 4 x 4 level here - amplifies a unit's rounding differences)
+    tol = 1e-4 if precision == "fp32" else (3e-2 if train else 1e-2)
     assert set(net.probe) == set(tap), (sorted(set(tap) ^ set(net.probe)))
     worst = []
     for name, ref in tap.items():
