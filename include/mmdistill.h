@@ -292,6 +292,9 @@ typedef struct MmdWgradLayer {
 } MmdWgradLayer;
 int mmd_wgrad_plan(MmdWgradLayer* layers_host, int n, int rows_per_item, int* n_items, int* n_tiles, long long* ws_floats);
 int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks, double flops, double bytes, hipStream_t stream);
+// precision "bf16" (BASELINE configs[4]): the same launch with both operands rounded to bf16 at the MFMA input, fp32 accumulate
+// (mmd_pwconv_bwd_weight_bf16's arithmetic for every layer of the table)
+int mmd_wgrad_grouped_bf16(const void* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks, double flops, double bytes, hipStream_t stream);
 
 // dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
 int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);

@@ -48,7 +48,24 @@ static int wg_tile() {
   return t == 128 ? 128 : 64;
 }
 
-template <int T>
+// BF (precision "bf16": BASELINE configs[4]): both operands are rounded to bf16 (RNE) at the MFMA input, fp32 accumulate - the arithmetic of
+// pw_wgrad_kernel<BF = true> (pw_gemm.hip) and of the oracle's BF16_PW rule; tensors and LDS tiles stay fp32.  Round 4: until then the
+// bf16 mode ran one launch per layer (D4 / 768^2: 130 launches, 5.9 ms of kernel time per step).
+typedef __bf16 gw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gw_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned gw_pk(float a, float b) {
+  gw_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gw_bf16x2));
+}
+// lane (r, h) of the 32x32x16 bf16 MFMA supplies k = 8h .. 8h + 7 of its row / column r: here 8 consecutive ROWS of the staged slab
+__device__ __forceinline__ gw_bf16x8 gw_gather8(const float* q, int ld) {
+  gw_u32x4 u = {gw_pk(q[0], q[ld]), gw_pk(q[2 * ld], q[3 * ld]), gw_pk(q[4 * ld], q[5 * ld]), gw_pk(q[6 * ld], q[7 * ld])};
+  return __builtin_bit_cast(gw_bf16x8, u);
+}
+
+template <int T, bool BF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void wgrad_grouped_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
   constexpr int LD = T + 4, NTH = T / 4, RPP = 256 / NTH, NL = GW_BR / RPP, S = T / 64;
   __shared__ float sD[GW_BR * LD];
@@ -119,6 +136,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const float* const px = &sX[h * LD + wk * S * 32 + r];
     auto mma = [&](auto nu_c, auto nv_c) {
       constexpr int NU = decltype(nu_c)::value, NV = decltype(nv_c)::value;
+      if constexpr (BF) {
+#pragma unroll
+        for (int gq = 0; gq < GW_BR / 16; ++gq) {
+          gw_bf16x8 dv[NU], xv[NV];
+#pragma unroll
+          for (int u = 0; u < NU; ++u) dv[u] = gw_gather8(&sD[(gq * 16 + h * 8) * LD + (wn * S + u) * 32 + r], LD);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) xv[v] = gw_gather8(&sX[(gq * 16 + h * 8) * LD + (wk * S + v) * 32 + r], LD);
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv[u], xv[v], acc[u][v], 0, 0, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int tt = 0; tt < GW_BR / 2; ++tt) {
         float dv[NU], xv[NV];
@@ -224,20 +256,31 @@ extern "C" int mmd_wgrad_plan(MmdWgradLayer* layers, int n, int rows_per_item, i
 }
 
 // layers_dev: the planned table in device memory; ws: workspace of ws_floats floats (needs no initialisation).
-extern "C" int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
-                                 double flops, double bytes, hipStream_t stream) {
+static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
+                              double flops, double bytes, int bf16, hipStream_t stream) {
   if (!layers_dev || n_layers <= 0 || n_layers > GW_MAXL || n_items <= 0 || n_tiles <= 0 || !ws) return MMD_EINVAL;
   if (blocks <= 0) blocks = 1024;
   if (blocks > n_items) blocks = n_items;
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wgrouped L%lld items%lld tiles%lld b%lld", n_layers, n_items, n_tiles, blocks);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
   if (wg_tile() == 128) {
-    hipLaunchKernelGGL(wgrad_grouped_kernel<128>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    if (bf16) hipLaunchKernelGGL((wgrad_grouped_kernel<128, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<128, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     hipLaunchKernelGGL(wgrad_fold_kernel<128>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
   } else {
-    hipLaunchKernelGGL(wgrad_grouped_kernel<64>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    if (bf16) hipLaunchKernelGGL((wgrad_grouped_kernel<64, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<64, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     hipLaunchKernelGGL(wgrad_fold_kernel<64>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
   }
   mmd_prof_end(MMD_FAM_PW_WGRAD, stream, flops, bytes);
   return mmd_check_launch();
+}
+extern "C" int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
+                                 double flops, double bytes, hipStream_t stream) {
+  return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, 0, stream);
+}
+// precision "bf16": operands rounded to bf16 at the MFMA input (mmd_pwconv_bwd_weight_bf16's arithmetic), same table / workspace / fold
+extern "C" int mmd_wgrad_grouped_bf16(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
+                                      double flops, double bytes, hipStream_t stream) {
+  return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, 1, stream);
 }

@@ -274,7 +274,7 @@ class Net:
     # widths above 160 (D4's 224): the whole-node kernel holds two 8x8-pixel tiles in 157 KB of LDS (one block per CU) and reads its 1x1
     # weights from L2 - a win on the latency-bound small maps, a loss on the large ones, where the two-launch path runs a chip-filling GEMM
     # (round 4, D4 / 768^2 at B = 8: every level fused 56.7 ms/step against 54.0 unfused)
-    NODE_FUSE_WIDE_MAXROWS = int(os.environ.get("MMD_NODE_FUSE_WIDE_MAXROWS", "4608"))
+    NODE_FUSE_WIDE_MAXROWS = int(os.environ.get("MMD_NODE_FUSE_WIDE_MAXROWS", "1152"))      # (neutral there: fewer launches, same time; 4608: +0.4 ms; every level: +2.7 ms)
 
     def _node_fusable(self, in0: "Feat") -> bool:
         if not self.ps.flat.is_cuda or _lib.LIB.load().mmd_bifpn_node_fused_supported(in0.C) != 1:
@@ -779,7 +779,10 @@ class Net:
                   in_act: int = NONE, gate=None, rpi: int = 1, w16: int = 0):
         """dW[N,K] (+)= dY^T pro(X).  Grouped mode: recorded, computed by _wg_flush() at the end of the backward segment.
         w16: bit 0 = dy, bit 1 = x are bf16 arrays (per-layer launch)."""
-        if not WG_GROUP or self.precision != "fp32" or not self.ps.flat.is_cuda:
+        # precision "bf16": grouped as well (round 4, mmd_wgrad_grouped_bf16) where the per-layer launches are skeleton-bound - D2 / 512^2 in
+        # bf16 15.50 -> 14.64 ms/step; at D4 / 768^2 the layers are tall enough that the per-layer launches on the side stream measure the
+        # same or better (53.0-53.3 vs 53.5-53.8 ms), so tall nets keep them (rows of the stem output decide; MMD_WG_GROUP_BF16=0/1 forces)
+        if not WG_GROUP or w16 or not self.ps.flat.is_cuda or (self.precision != "fp32" and not self._group_bf16()):
             with self._wgrad_stream():
                 if w16:
                     call("mmd_pwconv_bwd_weight_w16", dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi, 1, w16)
@@ -789,6 +792,13 @@ class Net:
         self._wg_pending.append((dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi))
         if WG_CHUNK > 0 and len(self._wg_pending) >= WG_CHUNK:
             self._wg_flush(final=False)
+
+    def _group_bf16(self) -> bool:
+        env = os.environ.get("MMD_WG_GROUP_BF16")
+        if env is not None:
+            return env not in ("", "0")
+        stem = self.tape.get("stem")
+        return stem is None or stem[1].M <= 600000
 
     def _leaf(self, fn):
         """A leaf of the backward graph other than a 1x1-conv weight gradient (depthwise / squeeze-excite / fusion-weight / bias
@@ -840,7 +850,7 @@ class Net:
             self._wg_plans[(seg, sig)] = plan
         ws = self._alloc(plan["ws"])
         with self._wgrad_stream():
-            call("mmd_wgrad_grouped", plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS if final else WG_BLOCKS_MID,
+            call("mmd_wgrad_grouped" + self._sfx, plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS if final else WG_BLOCKS_MID,
                  plan["flops"], plan["bytes"])
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,

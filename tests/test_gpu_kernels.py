@@ -256,6 +256,16 @@ def test_wgrad_grouped_matches_torch_and_is_deterministic():
     for (M, K, N, fl), ref, o0, o1 in zip(shapes, refs, outs[0], outs[1]):
         close(o0, ref, 3e-4, 1e-5, f"grouped dW M{M} K{K} N{N} {fl}")
         assert torch.equal(o0, o1), (M, K, N)          # different grid sizes, same bits: the fold order is fixed
+    # precision "bf16" (round 4): the same table on the bf16 MFMA - against the per-layer bf16 launch (same operand rounding, other summation
+    # order) and against a float64 GEMM of the rounded operands
+    call("mmd_wgrad_grouped_bf16", table, len(shapes), ni.value, nt.value, ws, 0, 0.0, 0.0)
+    torch.cuda.synchronize()
+    for (M, K, N, fl), (dx, dd, dw, dsc, dsh, dg) in zip(shapes, keep):
+        one = torch.zeros(N, K, device=DEV)
+        call("mmd_pwconv_bwd_weight_bf16", dd, dx, one, M, K, N, dsc, dsh, 1 if "aff" in fl else 0, dg, M // 2)
+        close(dw, one, 2e-4, 1e-4, f"grouped bf16 dW vs the per-layer bf16 launch M{M} K{K} N{N} {fl}")
+        if not fl:
+            close(dw, _bf(dd.cpu()).double().t() @ _bf(dx.cpu()).double(), 2e-4, 2e-3, f"grouped bf16 dW vs rounded operands M{M} K{K} N{N}")
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 24, 40), (4096, 16, 96), (1000, 528, 88), (130, 112, 180)])
