@@ -64,6 +64,17 @@ int mmd_bifpn_node_dw_bwd2(const float* in0, const float* in1, const float* up, 
 // cover this launch's share instead of the accumulated total.
 int mmd_bifpn_node_dw_bwd3(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, hipStream_t stream);
 
+// Round 4, "lazy" BiFPN operands of the trainable net: a node's / down-channel conv's train-mode BatchNorm (no activation) is applied by its
+// CONSUMERS while they load the operand, instead of by an mmd_affine_act launch behind every producer (40 launches on the student's forward
+// chain; BiFPN._forward_fast_attention, src/YetAnotherEfficientDet.py:320-392).  Operand i (order in0, in1, up, pool) then holds the RAW 1x1
+// output z_i; host arrays of 4 entries describe the transforms, a null entry = plain tensor.
+//   forward:  y_i = z_i * scale_i + shift_i with (scale, shift) derived in-kernel from the live batch sums op_stats4[i] [2C] (double),
+//             op_gamma4[i], op_beta4[i], op_count4[i] (long long rows) - bit-identical to mmd_bn_finalize's coefficients.  C <= 160.
+//   backward: op_scale4[i] / op_shift4[i] = the finalized coefficients; applied wherever the launch needs the operand's value (fused
+//             activation, fusion-weight dot products, pool arg-max); gradients / BatchNorm sums are w.r.t. the BatchNorm output as before.
+int mmd_bifpn_node_fwd_fused_train_lz(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats, int B, int H, int W, int C, const void* op_stats4, const void* op_gamma4, const void* op_beta4, const void* op_count4, hipStream_t stream);
+int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, const void* op_scale4, const void* op_shift4, hipStream_t stream);
+
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
 
 // d theta of every fusion node of a net in ONE launch: desc [nodes][2] = (offset of the node's theta in theta_base / dtheta_base, its

@@ -14,7 +14,37 @@ struct FuseArgs {
   const float* in0; const float* in1; const float* up; const float* pl;
   const float* theta; int ntheta;
   int B, H, W, C, PH, PW, pad_t, pad_l;
+  // Round 4, "lazy" operands of the trainable net: operand i (order in0, in1, up, pool) is the RAW output z_i of its producer's 1x1 conv and
+  // its train-mode BatchNorm is applied while the operand is loaded, y_i = z_i * scale_i + shift_i - the producer node then needs no
+  // mmd_affine_act launch (40 launches on the student's forward chain).  Forward: coefficients derived from the live batch sums (ost / oga /
+  // obe / oic, as BnLive); backward: the finalized (osc, osh).  lazy = bit mask of the operands that carry a transform.
+  const double* ost[4]; const float* oga[4]; const float* obe[4]; double oic[4];
+  const float* osc[4]; const float* osh[4];
+  int lazy;
 };
+// per-block coefficient table of the lazy operands in LDS: tab[(2 op + {0 scale, 1 shift}) * 64 + channel of the block's 64-channel chunk];
+// a thread reads its quad where it needs it (kept out of registers: the node backward kernel runs at 190-240 VGPRs as it is)
+struct FuseCoef {
+  const float* tab; int c4;
+  __device__ __forceinline__ float4 sc(int op) const { return *reinterpret_cast<const float4*>(tab + (2 * op) * 64 + c4); }
+  __device__ __forceinline__ float4 sh(int op) const { return *reinterpret_cast<const float4*>(tab + (2 * op + 1) * 64 + c4); }
+};
+// fills tab [8][64] for the chunk starting at channel c0 (all threads of a 256-thread block call it; followed by a barrier at the caller)
+__device__ __forceinline__ void fuse_coef_fill(const FuseArgs& a, int c0, float* tab) {
+  for (int i = threadIdx.x; i < 4 * 64; i += 256) {
+    const int op = i >> 6, cl = i & 63, c = c0 + cl;
+    float sc = 1.f, sh = 0.f;
+    if ((a.lazy >> op & 1) && c < a.C) {
+      if (a.ost[op]) { BnLive bn; bn.stats = a.ost[op]; bn.gamma = a.oga[op]; bn.beta = a.obe[op]; bn.inv_count = a.oic[op]; bn.C = a.C; bn.eps = 1e-3f;
+                       bn_live_coef(bn, c, sc, sh); }
+      else { sc = a.osc[op][c]; sh = a.osh[op][c]; }
+    }
+    tab[(2 * op) * 64 + cl] = sc; tab[(2 * op + 1) * 64 + cl] = sh;
+  }
+}
+__device__ __forceinline__ float4 fuse_aff4(const float4& v, const float4& sc, const float4& sh) {
+  return make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+}
 
 __device__ __forceinline__ void fuse_weights(const float* theta, int n, float* w) {
   float r[3] = {0.f, 0.f, 0.f}, s = 0.f;
@@ -22,8 +52,11 @@ __device__ __forceinline__ void fuse_weights(const float* theta, int n, float* w
   for (int i = 0; i < 3; ++i) w[i] = r[i] / (s + FUSE_EPS);
 }
 
+// aff: the source holds raw BatchNorm inputs - every in-image element is transformed (x * sc + sh) before the max; the zero padding is
+// the padding of the TRANSFORMED map (the reference pads the BatchNorm output) and stays zero
 __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int b, int oh, int ow, int c, int PH, int PW,
-                                              int C, int pad_t, int pad_l) {
+                                              int C, int pad_t, int pad_l, bool aff = false, float4 sc = make_float4(1, 1, 1, 1),
+                                              float4 sh = make_float4(0, 0, 0, 0)) {
   float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -32,7 +65,10 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
     for (int j = 0; j < 3; ++j) {
       int x = ow * 2 - pad_l + j;
       float4 v = make_float4(0, 0, 0, 0);   // zero padding takes part in the max
-      if (y >= 0 && y < PH && x >= 0 && x < PW) v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c);
+      if (y >= 0 && y < PH && x >= 0 && x < PW) {
+        v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c);
+        if (aff) v = fuse_aff4(v, sc, sh);
+      }
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   }
@@ -42,7 +78,8 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
 // The same window with the arg-max per channel: arg[q] = tap index (3*i + j) of the FIRST maximum in row-major scan order (torch's max-pool
 // backward picks that one), -1 when a zero-padding element wins (it swallows the gradient).
 __device__ __forceinline__ void pool_window_arg(const float* __restrict__ src, int b, int oh, int ow, int c, int PH, int PW,
-                                                int C, int pad_t, int pad_l, int (&arg)[4]) {
+                                                int C, int pad_t, int pad_l, int (&arg)[4], bool aff = false,
+                                                float4 sc = make_float4(1, 1, 1, 1), float4 sh = make_float4(0, 0, 0, 0)) {
   float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
   for (int q = 0; q < 4; ++q) arg[q] = -1;
@@ -54,7 +91,7 @@ __device__ __forceinline__ void pool_window_arg(const float* __restrict__ src, i
       const int x = ow * 2 - pad_l + j;
       const bool in = y >= 0 && y < PH && x >= 0 && x < PW;
       float4 v = make_float4(0, 0, 0, 0);
-      if (in) v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c);
+      if (in) { v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c); if (aff) v = fuse_aff4(v, sc, sh); }
       const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -67,22 +104,32 @@ __device__ __forceinline__ void pool_window_arg(const float* __restrict__ src, i
 // backward kernel is instantiated per operand set - the run-time form keeps every operand's registers and branches alive)
 template <int MODE = -1>
 __device__ __forceinline__ float4 fuse_presum(const FuseArgs& a, const float* w, int b, int h, int x, int c, float4* o0,
-                                              float4* o1, float4* o2, float4* o3) {
+                                              float4* o1, float4* o2, float4* o3, const FuseCoef* fc = nullptr) {
   const bool has1 = MODE < 0 ? a.in1 != nullptr : (MODE & 1) != 0;
   const bool hasu = MODE < 0 ? a.up != nullptr : (MODE & 2) != 0;
   const bool hasp = MODE < 0 ? a.pl != nullptr : (MODE & 4) != 0;
   size_t off = (((size_t)b * a.H + h) * a.W + x) * a.C + c;
   int wi = 0;
   float4 s = make_float4(0, 0, 0, 0);
-  float4 v = mmd_ld4(a.in0 + off); *o0 = v;
+  float4 v = mmd_ld4(a.in0 + off);
+  if (fc) v = fuse_aff4(v, fc->sc(0), fc->sh(0));
+  *o0 = v;
   s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
-  if (has1) { v = mmd_ld4(a.in1 + off); *o1 = v; s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi; }
+  if (has1) {
+    v = mmd_ld4(a.in1 + off);
+    if (fc) v = fuse_aff4(v, fc->sc(1), fc->sh(1));
+    *o1 = v; s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
+  }
   if (hasu) {
-    v = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (h >> 1)) * (a.W >> 1) + (x >> 1)) * a.C + c); *o2 = v;
+    v = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (h >> 1)) * (a.W >> 1) + (x >> 1)) * a.C + c);
+    if (fc) v = fuse_aff4(v, fc->sc(2), fc->sh(2));
+    *o2 = v;
     s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
   }
   if (hasp) {
-    v = pool_window(a.pl, b, h, x, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l); *o3 = v;
+    v = fc ? pool_window(a.pl, b, h, x, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, (a.lazy & 8) != 0, fc->sc(3), fc->sh(3))
+           : pool_window(a.pl, b, h, x, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l);
+    *o3 = v;
     s.x += w[wi] * v.x; s.y += w[wi] * v.y; s.z += w[wi] * v.z; s.w += w[wi] * v.w; ++wi;
   }
   return s;
@@ -228,7 +275,8 @@ template <int FC> struct FnCfg {
   static constexpr int Q = FC / 4, FS = FC, ZS = FC + 4, WS = FC + 4, KR = FC / 4, CT = FC / 16;
   static constexpr bool PARK = FC <= 160;
   static constexpr int U = (PARK && FC * WS > 100 * FS) ? FC * WS : 100 * FS;      // input tile, later (PARK) the 1x1 weights
-  static constexpr size_t lds(bool train) { return (size_t)(U + 64 * ZS + 9 * FC + (train ? 2 * FC : 0)) * sizeof(float); }
+  static constexpr bool LAZY_OK = FC <= 160;                                       // room for the lazy operands' coefficient table (train form)
+  static constexpr size_t lds(bool train) { return (size_t)(U + 64 * ZS + 9 * FC + (train ? 2 * FC + (LAZY_OK ? 8 * FC : 0) : 0)) * sizeof(float); }
 };
 
 // TRAIN (the student's nodes): y = the RAW 1x1-conv output z (+ bias), its per-channel sums (sum z, sum z^2: the node's train-mode BatchNorm
@@ -246,9 +294,24 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   float* const sZ = smem + FN_U;                // [64][ZS] depthwise output tile
   float* const sWd = sZ + 64 * FN_ZS;           // [9][C] depthwise taps
   float* const sSt = sWd + 9 * FN_C;            // TRAIN: [2][C] block sums
+  float* const sAf = sSt + 2 * FN_C;            // TRAIN, lazy operands: [4 operands][scale | shift][C]
+  constexpr bool LZ = TRAIN && Cf::LAZY_OK;
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
+  if constexpr (LZ) {
+    if (a.lazy)
+      for (int i = tid; i < 4 * FN_C; i += FN_NT) {
+        const int op = i / FN_C, c = i - op * FN_C;
+        float sc = 1.f, sh = 0.f;
+        if (a.lazy >> op & 1) {
+          if (a.ost[op]) { BnLive bn; bn.stats = a.ost[op]; bn.gamma = a.oga[op]; bn.beta = a.obe[op]; bn.inv_count = a.oic[op]; bn.C = FN_C; bn.eps = 1e-3f;
+                           bn_live_coef(bn, c, sc, sh); }
+          else { sc = a.osc[op][c]; sh = a.osh[op][c]; }
+        }
+        sAf[(op * 2) * FN_C + c] = sc; sAf[(op * 2 + 1) * FN_C + c] = sh;
+      }
+  }
   int bid = blockIdx.x;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
@@ -287,6 +350,9 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     }
     constexpr int n2 = (MODE & 3) ? 1 : 0;             // operand order (in0, in1, up, pool): in1 and up never occur together
     const float wp_ = (MODE & 4) ? w[1 + n2] : 0.f;
+    const bool lz = LZ && a.lazy != 0;                 // block-uniform
+    if (lz) __syncthreads();                           // the coefficient table is complete (the operand loads above are in flight meanwhile)
+    constexpr int OP1 = (MODE & 1) ? 1 : 2;            // which operand v1 holds
 #pragma unroll
     for (int i0 = 0; i0 < NI; i0 += 3) {               // the pooled operand's 3x3 windows of three items are gathered together (27 loads in flight)
       float4 m[3];
@@ -297,7 +363,11 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
         if (i < NI && (MODE & 4) && ok[i]) {
           const int it = tid + i * FN_NT;
           const int p = it / FN_Q, q = it - p * FN_Q;
-          m[u] = pool_window(a.pl, b, oh0 - 1 + p / 10, ow0 - 1 + p % 10, q * 4, a.PH, a.PW, a.C, a.pad_t, a.pad_l);
+          if (lz && (a.lazy & 8))
+            m[u] = pool_window(a.pl, b, oh0 - 1 + p / 10, ow0 - 1 + p % 10, q * 4, a.PH, a.PW, a.C, a.pad_t, a.pad_l, true,
+                               *reinterpret_cast<const float4*>(&sAf[6 * FN_C + q * 4]), *reinterpret_cast<const float4*>(&sAf[7 * FN_C + q * 4]));
+          else
+            m[u] = pool_window(a.pl, b, oh0 - 1 + p / 10, ow0 - 1 + p % 10, q * 4, a.PH, a.PW, a.C, a.pad_t, a.pad_l);
         }
       }
 #pragma unroll
@@ -309,6 +379,11 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
         const int p = it / FN_Q, q = it - p * FN_Q;
         float4 v = make_float4(0, 0, 0, 0);
         if (ok[i]) {
+          if (lz) {
+            v0[i] = fuse_aff4(v0[i], *reinterpret_cast<const float4*>(&sAf[q * 4]), *reinterpret_cast<const float4*>(&sAf[FN_C + q * 4]));
+            if (n2) v1[i] = fuse_aff4(v1[i], *reinterpret_cast<const float4*>(&sAf[(2 * OP1) * FN_C + q * 4]),
+                                      *reinterpret_cast<const float4*>(&sAf[(2 * OP1 + 1) * FN_C + q * 4]));
+          }
           v.x = w[0] * v0[i].x; v.y = w[0] * v0[i].y; v.z = w[0] * v0[i].z; v.w = w[0] * v0[i].w;
           if (n2) { v.x += w[1] * v1[i].x; v.y += w[1] * v1[i].y; v.z += w[1] * v1[i].z; v.w += w[1] * v1[i].w; }
           if (MODE & 4) { v.x += wp_ * m[u].x; v.y += wp_ * m[u].y; v.z += wp_ * m[u].z; v.w += wp_ * m[u].w; }
@@ -451,11 +526,61 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
 // Whole TRAINABLE-net BiFPN node forward (train mode): z[B*H*W, C] = dw3x3(swish(fuse(operands))) · w_pw[C,C]ᵀ + bias (raw, pre-BatchNorm),
 // stats[2C] (+)= [sum z, sum z^2] (the BatchNorm's batch statistics), zd[B*H*W, C] = the depthwise output (kept for the backward).  One
 // launch instead of mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd(stats) on the student's forward chain.
+// host arrays [4] in operand order (in0, in1, up, pool); a null entry = that operand is a plain tensor
+static int fuse_fill_lazy_fwd(FuseArgs& a, const void* op_stats4, const void* op_gamma4, const void* op_beta4, const void* op_count4) {
+  if (!op_stats4) return MMD_OK;
+  if (!op_gamma4 || !op_beta4 || !op_count4) return MMD_EINVAL;
+  const double* const* st = (const double* const*)op_stats4;
+  const float* const* ga = (const float* const*)op_gamma4;
+  const float* const* be = (const float* const*)op_beta4;
+  const long long* cn = (const long long*)op_count4;
+  const float* ops[4] = {a.in0, a.in1, a.up, a.pl};
+  for (int i = 0; i < 4; ++i) {
+    if (!st[i]) continue;
+    if (!ops[i] || !ga[i] || !be[i] || cn[i] <= 0) return MMD_EINVAL;
+    a.ost[i] = st[i]; a.oga[i] = ga[i]; a.obe[i] = be[i]; a.oic[i] = 1.0 / (double)cn[i]; a.lazy |= 1 << i;
+  }
+  return MMD_OK;
+}
+static int fuse_fill_lazy_bwd(FuseArgs& a, const void* op_scale4, const void* op_shift4) {
+  if (!op_scale4) return MMD_OK;
+  if (!op_shift4) return MMD_EINVAL;
+  const float* const* sc = (const float* const*)op_scale4;
+  const float* const* sh = (const float* const*)op_shift4;
+  const float* ops[4] = {a.in0, a.in1, a.up, a.pl};
+  for (int i = 0; i < 4; ++i) {
+    if (!sc[i]) continue;
+    if (!ops[i] || !sh[i]) return MMD_EINVAL;
+    a.osc[i] = sc[i]; a.osh[i] = sh[i]; a.lazy |= 1 << i;
+  }
+  return MMD_OK;
+}
+static int node_fwd_fused_train_impl(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
+                                     const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats,
+                                     int B, int H, int W, int C, const void* op_stats4, const void* op_gamma4, const void* op_beta4,
+                                     const void* op_count4, hipStream_t stream);
 extern "C" int mmd_bifpn_node_fwd_fused_train(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
                                               const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats,
                                               int B, int H, int W, int C, hipStream_t stream) {
+  return node_fwd_fused_train_impl(in0, in1, up, pool, theta, w_dw, w_pw, bias, z, zd, stats, B, H, W, C, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// Round 4, "lazy" operands: operand i is the RAW 1x1-conv output of its producer and its train-mode BatchNorm (no activation) is applied
+// while it is loaded, from the live batch sums op_stats4[i] (+ op_gamma4[i], op_beta4[i], op_count4[i] rows) - host arrays of 4 entries in
+// operand order (in0, in1, up, pool), null entry = plain tensor.  The producer node then needs no mmd_affine_act launch.  C <= 160.
+extern "C" int mmd_bifpn_node_fwd_fused_train_lz(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
+                                                 const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats,
+                                                 int B, int H, int W, int C, const void* op_stats4, const void* op_gamma4,
+                                                 const void* op_beta4, const void* op_count4, hipStream_t stream) {
+  return node_fwd_fused_train_impl(in0, in1, up, pool, theta, w_dw, w_pw, bias, z, zd, stats, B, H, W, C, op_stats4, op_gamma4, op_beta4, op_count4, stream);
+}
+static int node_fwd_fused_train_impl(const float* in0, const float* in1, const float* up, const float* pool, const float* theta,
+                                     const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats,
+                                     int B, int H, int W, int C, const void* op_stats4, const void* op_gamma4, const void* op_beta4,
+                                     const void* op_count4, hipStream_t stream) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (!rc) rc = fuse_fill_lazy_fwd(a, op_stats4, op_gamma4, op_beta4, op_count4);
+  if (a.lazy && C > 160) return MMD_EINVAL;
   if (rc || !w_dw || !w_pw || !z || !zd || !stats || !mmd_bifpn_node_fused_supported(C) || (in1 && up)) return MMD_EINVAL;
   const int th = cdiv(H, 8), tw = cdiv(W, 8);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
@@ -555,6 +680,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   __shared__ float sW[9 * 64];
   __shared__ float sred[4 * 3];
   __shared__ float sBn[4 * 2 * 4 * 64];            // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel]
+  __shared__ float sCo[8 * 64];                    // lazy operands' (scale, shift) of this block's channel chunk
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
@@ -565,6 +691,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
   const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  if (a.lazy) fuse_coef_fill(a, c0, sCo);          // (complete behind the staging barrier below)
   const bool cok = c < a.C;
   const int oh0 = th * TH, ow0 = tw * TW;
   for (int i = tid; i < 9 * 16; i += 256) {        // flipped taps: the transpose of a stride-1 SAME correlation
@@ -603,6 +730,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
   float d[3] = {0.f, 0.f, 0.f};
   const int oh = oh0 + orow;
+  const FuseCoef fco{sCo, c4};                     // lazy operands: the finalized BatchNorm coefficients of the block's channel chunk (LDS)
   float4 gq[R], fq[R];
   // BatchNorm-backward sums of the totals written below (x0 / x1 / xu.z != nullptr: this launch is the last contribution to that operand's
   // gradient, the operand is a BatchNorm output; replaces the mmd_bn_bwd_reduce launch of the operand's node)
@@ -621,7 +749,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     gq[o] = make_float4(0, 0, 0, 0); fq[o] = make_float4(0, 0, 0, 0);
     if (cok && oh < a.H && ow < a.W) {
       float4 t[4];
-      float4 sv = fuse_presum<MODE>(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3]);
+      float4 sv = fuse_presum<MODE>(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3], a.lazy ? &fco : nullptr);
       const size_t off = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
       if (dwg) fq[o] = make_float4(mmd_swish(sv.x), mmd_swish(sv.y), mmd_swish(sv.z), mmd_swish(sv.w));      // the node's fused activation
       float4 g = acc[o];
@@ -644,7 +772,8 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       }
       if ((MODE & 4) && dpl) {
         int arg[4];
-        pool_window_arg(a.pl, b, oh, ow, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, arg);
+        if (a.lazy & 8) pool_window_arg(a.pl, b, oh, ow, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, arg, true, fco.sc(3), fco.sh(3));
+        else pool_window_arg(a.pl, b, oh, ow, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, arg);
         const float wp = w[1 + ((MODE & 1) ? 1 : 0) + ((MODE & 2) ? 1 : 0)];
         const float gv[4] = {g.x * wp, g.y * wp, g.z * wp, g.w * wp};
         const float muv[4] = {mup.x, mup.y, mup.z, mup.w}, isv[4] = {isp.x, isp.y, isp.z, isp.w};
@@ -760,9 +889,11 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
                             const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
                             int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
                             float* dw_grad, BnSumDst x0, BnSumDst x1, BnSumDst xu, hipStream_t stream,
-                            float* dpl = nullptr, BnSumDst xp = BnSumDst{}, int own = 0) {
+                            float* dpl = nullptr, BnSumDst xp = BnSumDst{}, int own = 0, const void* op_scale4 = nullptr,
+                            const void* op_shift4 = nullptr) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
+  if (!rc) rc = fuse_fill_lazy_bwd(a, op_scale4, op_shift4);
   if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
   if ((dpl && !pool) || (xp.z && (!dpl || !xp.mean || !xp.invstd || !xp.sums))) return MMD_EINVAL;
   if ((x0.z && (!d0 || !x0.mean || !x0.invstd || !x0.sums)) || (x1.z && (!d1 || !x1.mean || !x1.invstd || !x1.sums)) ||
@@ -820,6 +951,23 @@ extern "C" int mmd_bifpn_node_dw_bwd3(const float* in0, const float* in1, const 
   return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
                           BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
                           dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own);
+}
+
+// mmd_bifpn_node_dw_bwd3 with "lazy" operands (round 4): operand i holds the RAW BatchNorm input and is read as z_i * op_scale4[i] +
+// op_shift4[i] (the finalized coefficients; host arrays of 4 entries in operand order, null entry = plain tensor) wherever the launch
+// needs the operand's VALUE - the fused activation, the fusion-weight dot products, the pool window's arg-max.  Gradients and BatchNorm
+// sums are unchanged (they are w.r.t. the BatchNorm OUTPUT; z0 / z1 / zu / zp are the raw tensors themselves).
+extern "C" int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, const float* up, const float* pool,
+                                         const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
+                                         int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                         float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0,
+                                         const float* z1, const float* mean1, const float* invstd1, double* sums1,
+                                         const float* zu, const float* meanu, const float* invstdu, double* sumsu,
+                                         float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own,
+                                         const void* op_scale4, const void* op_shift4, hipStream_t stream) {
+  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
+                          BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
+                          dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own, op_scale4, op_shift4);
 }
 
 // d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   

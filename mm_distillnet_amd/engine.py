@@ -119,6 +119,10 @@ SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))
 # round 4: backward of the thin-input high-resolution expand convs (BatchNorm-0 backward, input gradient, weight gradient) in one pass over
 # the 6x expanded gradient (csrc/mbconv_bwd_fused.hip): dz0 is neither stored nor read back, and the layer leaves the grouped weight-gradient
 # launch at the exposed end of the backward.  Taken for layers with at least this many rows (MMD_NO_MBW=1: the two-GEMM form, for A/B timing)
+# round 4: "lazy" BiFPN operands of the trainable net - a node's / down-channel conv's train-mode BatchNorm is applied by the CONSUMING node
+# kernels while they load the operand (forward: from the live batch sums; backward: finalized coefficients) instead of by an mmd_affine_act
+# launch behind every producer: 40 launches less on the student's forward chain (MMD_NO_LAZY_NODE=1: the materialising form, for A/B timing)
+LAZY_NODE = not os.environ.get("MMD_NO_LAZY_NODE")
 MBW_FUSED = not os.environ.get("MMD_NO_MBW")
 MBW_MIN_ROWS = int(os.environ.get("MMD_MBW_MIN_ROWS", "32768"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
@@ -190,6 +194,7 @@ class Net:
         # next unit consumes the given tensor instead of this net's own (tests/test_gpu_net.py::test_teacher_forced_units_bf16)
         self.probe: Optional[Dict[str, torch.Tensor]] = None
         self.force_out: Optional[Dict[str, torch.Tensor]] = None
+        self._lazy = False                     # this forward runs the BiFPN with lazy (consumer-applied) BatchNorms
 
     def _tf(self, name: str, t: torch.Tensor):
         if self.probe is not None:
@@ -510,11 +515,23 @@ class Net:
             y = self._pw(zdf, f"{name}.pointwise_conv.conv.weight", W, bias=bias, out_aff=(b["fscale"], b["fshift"]), y=y)
         return Feat(y, x.B, x.H, x.W, W)
 
-    def _down_channel(self, name: str, x: Feat, train: bool, tape: dict) -> Feat:
+    def _down_channel(self, name: str, x: Feat, train: bool, tape: dict, lazy: bool = False) -> Feat:
         ps = self.ps
         W = self.spec.fpn_w
         bias = ps.w(f"{name}.0.conv.bias")
         rec = {"x": x}
+        if train and lazy:
+            # lazy output: the raw conv output + its BatchNorm as a pending transform the consuming node kernels apply (no affine launch)
+            st = self._bn_stats(f"{name}.1", True)
+            z = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, stats=st)
+            a = self._bn_aff(f"{name}.1", True, st, x.M)
+            rec.update(z=z, bn=a)
+            tape[name] = rec
+            self._use(x)
+            self._bnout[z.data_ptr()] = (z, a[2], a[3], W, None, 0)
+            out = Feat(z, x.B, x.H, x.W, W, a[0], a[1], NONE, a[4])
+            rec["out"] = out
+            return out
         if train:
             st = self._bn_stats(f"{name}.1", True)
             z = self._pw(x, f"{name}.0.conv.weight", W, bias=bias, stats=st)
@@ -567,21 +584,36 @@ class Net:
             bn_name = f"{name}.bn"
             st = self._bn_stats(bn_name, True)
             z, zd = self._alloc(in0.M, W), self._alloc(in0.M, W)
-            call("mmd_bifpn_node_fwd_fused_train", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-                 self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
-                 self.ps.w(f"{name}.pointwise_conv.conv.bias"), z, zd, st, in0.B, in0.H, in0.W, W)
+            ops = (in0, in1, up, pl)
+            lz = [o is not None and o.bn is not None for o in ops]          # operands whose BatchNorm is still pending (lazy producers)
+            args = (in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                    self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
+                    self.ps.w(f"{name}.pointwise_conv.conv.bias"), z, zd, st, in0.B, in0.H, in0.W, W)
+            if any(lz):
+                assert self._lazy and all(o.act == NONE for o, l in zip(ops, lz) if l)
+                vp = ctypes.c_void_p
+                pick = lambda k: (vp * 4)(*[(o.bn[k].data_ptr() if l else None) for o, l in zip(ops, lz)])
+                cnt = (ctypes.c_longlong * 4)(*[(int(o.bn[3]) if l else 0) for o, l in zip(ops, lz)])
+                call("mmd_bifpn_node_fwd_fused_train_lz", *args, pick(0), pick(1), pick(2), cnt)
+            else:
+                call("mmd_bifpn_node_fwd_fused_train", *args)
             a = self._bn_aff(bn_name, True, st, in0.M)
-            if y is None:
-                y = self._alloc(in0.M, W)
-            call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, in0.M, W)
-            for operand in (in0, in1, up, pl):
+            for operand in ops:
                 if operand is not None:
                     self._use(operand)
             if pl is not None:
                 self._linear.add(pl.z.data_ptr())
             zdf = Feat(zd, in0.B, in0.H, in0.W, W)
-            out = Feat(y, in0.B, in0.H, in0.W, W)
-            self._bnout[y.data_ptr()] = (z, a[2], a[3], W, None, 0)
+            if self._lazy and y is None:
+                # lazy output (every cell but the last, whose outputs the heads and the MTA loss read): no affine launch
+                out = Feat(z, in0.B, in0.H, in0.W, W, a[0], a[1], NONE, a[4])
+                self._bnout[z.data_ptr()] = (z, a[2], a[3], W, None, 0)
+            else:
+                if y is None:
+                    y = self._alloc(in0.M, W)
+                call("mmd_affine_act", z, None, None, a[4][0], a[4][1], a[4][2], a[4][3], NONE, None, 0, None, y, in0.M, W)
+                out = Feat(y, in0.B, in0.H, in0.W, W)
+                self._bnout[y.data_ptr()] = (z, a[2], a[3], W, None, 0)
             tape.setdefault(cell + ".nodes", []).append({"in0": in0, "in1": in1, "up": up, "pl": pl, "theta": theta, "f": zdf, "conv": conv,
                                                          "zd": zdf, "z": z, "bn": a, "out": out})
             return out
@@ -606,16 +638,22 @@ class Net:
 
     def _bifpn(self, taps: List[Feat], train: bool, tape: dict) -> List[Feat]:
         feats: List[Feat] = list(taps)
+        # lazy operands need every node on the whole-node train kernel (widths <= 160), the scatter form of the pooled operand's gradient
+        # (the gather launch reads operand values) and no test hooks that read / overwrite materialised outputs
+        self._lazy = (train and LAZY_NODE and self.FUSE_NODE_TRAIN and self.NODE_WG and FOLD_SUMS and POOL_SCATTER and self.ps.flat.is_cuda
+                      and self.probe is None and self.force_out is None and self.spec.fpn_w <= 160
+                      and _lib.LIB.load().mmd_bifpn_node_fused_supported(self.spec.fpn_w) == 1)
+        lz = self._lazy
         for c in range(self.spec.fpn_cells):
             cell = f"bifpn.{c}"
             if c == 0:
                 p3, p4, p5 = feats
-                c6 = self._down_channel(f"{cell}.p5_to_p6", p5, train, tape)
+                c6 = self._down_channel(f"{cell}.p5_to_p6", p5, train, tape)         # (max-pooled by its own launch: materialised)
                 p6_in = self._pool(c6)
                 p7_in = self._pool(p6_in)
-                p3_in = self._down_channel(f"{cell}.p3_down_channel", p3, train, tape)
-                p4_in = self._down_channel(f"{cell}.p4_down_channel", p4, train, tape)
-                p5_in = self._down_channel(f"{cell}.p5_down_channel", p5, train, tape)
+                p3_in = self._down_channel(f"{cell}.p3_down_channel", p3, train, tape, lazy=lz)
+                p4_in = self._down_channel(f"{cell}.p4_down_channel", p4, train, tape, lazy=lz)
+                p5_in = self._down_channel(f"{cell}.p5_down_channel", p5, train, tape, lazy=lz)
                 if train:
                     tape[cell + ".first"] = {"c6": c6, "p6_in": p6_in, "p7_in": p7_in}
             else:
@@ -634,8 +672,8 @@ class Net:
             p4_up = self._node(cell, "conv4_up", "p4_w1", p4_in, None, p5_up, None, train, tape)
             p3_out = self._node(cell, "conv3_up", "p3_w1", p3_in, None, p4_up, None, train, tape, y=ov[0])
             if c == 0:
-                p4_in = self._down_channel(f"{cell}.p4_down_channel_2", taps[1], train, tape)
-                p5_in = self._down_channel(f"{cell}.p5_down_channel_2", taps[2], train, tape)
+                p4_in = self._down_channel(f"{cell}.p4_down_channel_2", taps[1], train, tape, lazy=lz)
+                p5_in = self._down_channel(f"{cell}.p5_down_channel_2", taps[2], train, tape, lazy=lz)
             p4_out = self._node(cell, "conv4_down", "p4_w2", p4_in, p4_up, None, p3_out, train, tape, y=ov[1])
             p5_out = self._node(cell, "conv5_down", "p5_w2", p5_in, p5_up, None, p4_out, train, tape, y=ov[2])
             p6_out = self._node(cell, "conv6_down", "p6_w2", p6_in, p6_up, None, p5_out, train, tape, y=ov[3])
@@ -1170,6 +1208,24 @@ class Net:
                 wdot = wdot_all[4 * node_i:4 * node_i + 4]
                 theta_desc.append((ps.entries[f"{cell}.{rec['theta']}"].off, nth))
                 node_i += 1
+                lzb = [o is not None and o.bn is not None for o in (in0, in1, up, pl)]
+                if any(lzb):
+                    # lazy operands: their values are read as z * scale + shift (finalized coefficients) inside the launch
+                    assert scatter or pl is None
+                    dplargs = (None, None, None, None, None)
+                    if scatter:
+                        sl, xs = self._contrib(pl, True)
+                        if sl.t is None:
+                            sl.t = self._zalloc((pl.M, W))
+                        dplargs = (sl.t, *xsn(xs))
+                    vp = ctypes.c_void_p
+                    ops_ = (in0, in1, up, pl)
+                    scs = (vp * 4)(*[(o.scale.data_ptr() if l else None) for o, l in zip(ops_, lzb)])
+                    shs = (vp * 4)(*[(o.shift.data_ptr() if l else None) for o, l in zip(ops_, lzb)])
+                    call("mmd_bifpn_node_dw_bwd3_lz", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                         ps.w(f"{name}.depthwise_conv.conv.weight"), dzd, None, wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
+                         ps.g(f"{name}.depthwise_conv.conv.weight") if self.NODE_WG else None, *xsargs, *dplargs, own, scs, shs)
+                    continue
                 if scatter or own:
                     # scatter: the pooled operand's gradient leaves this launch too - added to each window's arg-max with atomics, on top of the
                     # earlier contributions (or of zeros: a zero-initialised arena buffer when this is the first one); own: an operand that is

@@ -1770,3 +1770,71 @@ def test_bifpn_node_dw_bwd3_pooled_scatter_and_linear_sums(mode, H, W, C):
     _sums_close(x0[3], _bn_sums_ref(d0.cpu() - base0, x0[0], x0[1], x0[2]), "linear sums of d0's share (own)")
     if in1 is not None:
         _sums_close(x1[3], _bn_sums_ref(d1.cpu() - base1, x1[0], x1[1], x1[2]), "linear sums of d1's share (own)")
+
+
+@pytest.mark.parametrize("mode,H,W,C,lazy", [("td", 8, 8, 112, 0b101), ("bu", 16, 12, 112, 0b1011), ("p7", 4, 4, 112, 0b1001), ("bu", 32, 32, 112, 0b1010),
+                                             ("td", 16, 16, 64, 0b100), ("bu", 6, 10, 160, 0b1011)])
+def test_bifpn_lazy_operands(mode, H, W, C, lazy):
+    """Round 4: "lazy" BiFPN operands - the train-mode BatchNorm of a producer applied by the consuming node kernels while they load the
+    operand (forward: coefficients from the live batch sums; backward: the finalized ones), instead of an mmd_affine_act launch per
+    producer.  mmd_bifpn_node_fwd_fused_train_lz / mmd_bifpn_node_dw_bwd3_lz on RAW operands against the plain entry points on operands
+    transformed beforehand (by mmd_affine_act from the same sums, i.e. what the engine materialised until now).  lazy: bit i = operand i
+    (in0, in1, up, pool) carries a transform; the others are plain tensors."""
+    import ctypes
+    torch.manual_seed(H * W + C + lazy)
+    B = 2
+    M = B * H * W
+    shapes = {0: M, 1: M if mode == "bu" else 0, 2: M // 4 if mode == "td" else 0, 3: 4 * M if mode in ("bu", "p7") else 0}
+    raw, stats, gam, bet, sc, sh, ymat = {}, {}, {}, {}, {}, {}, {}
+    for i, rows in shapes.items():
+        if not rows:
+            raw[i] = None
+            continue
+        z = torch.randn(rows, C) * 1.7 + 0.4 - (1.0 if i == 3 else 0.0)
+        raw[i] = g(z)
+        if lazy >> i & 1:
+            st = torch.cat([z.double().sum(0), (z.double() ** 2).sum(0)]).to(DEV)
+            ga, be = g(torch.randn(C) * 0.8), g(torch.randn(C) * 0.3)           # gamma of either sign: the pool's max must be taken AFTER the transform
+            y = torch.empty(rows, C, device=DEV)
+            call("mmd_affine_act", raw[i], None, None, st, ga, be, rows, 0, None, 0, None, y, rows, C)
+            mean = st[:C] / rows
+            var = st[C:] / rows - mean * mean
+            s_ = (ga.double() / torch.sqrt(var + 1e-3)).float()
+            stats[i], gam[i], bet[i], ymat[i] = st, ga, be, y
+            sc[i], sh[i] = s_, (be.double() - mean * s_.double()).float()
+        else:
+            ymat[i] = raw[i]
+    theta = g(torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3]))
+    wd = g(torch.randn(9, C) / 3)
+    wp = g(torch.randn(C, C) / math.sqrt(C)); bias = g(torch.randn(C) * 0.1)
+    vp = ctypes.c_void_p
+    arr = lambda d: (vp * 4)(*[(d[i].data_ptr() if i in d else None) for i in range(4)])
+    cnt = (ctypes.c_longlong * 4)(*[(shapes[i] if i in stats else 0) for i in range(4)])
+    # ---- forward
+    z_ref = torch.empty(M, C, device=DEV); zd_ref = torch.empty(M, C, device=DEV); st_ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bifpn_node_fwd_fused_train", ymat[0], ymat.get(1), ymat.get(2), ymat.get(3), theta, wd, wp, bias, z_ref, zd_ref, st_ref, B, H, W, C)
+    z = torch.full((M, C), float("nan"), device=DEV); zd = torch.full((M, C), float("nan"), device=DEV)
+    st = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bifpn_node_fwd_fused_train_lz", raw[0], raw[1], raw[2], raw[3], theta, wd, wp, bias, z, zd, st, B, H, W, C,
+         arr(stats), arr(gam), arr(bet), cnt)
+    close(zd, zd_ref, 2e-5, 1e-6, "depthwise output, lazy vs materialised operands")
+    close(z, z_ref, 2e-5, 1e-6, "node output, lazy vs materialised operands")
+    close(st, st_ref, 1e-5, 1e-5, "BatchNorm sums")
+    # ---- backward (scatter form for the pooled operand)
+    dzd = g(torch.randn(M, C))
+    has1, hasu, hasp = raw[1] is not None, raw[2] is not None, raw[3] is not None
+
+    def run(entry, ops, extra):
+        wdot = torch.zeros(4, device=DEV); dwg = torch.zeros(9, C, device=DEV)
+        d0 = torch.zeros(M, C, device=DEV)
+        d1 = torch.zeros(M, C, device=DEV) if has1 else None
+        du = torch.zeros(M // 4, C, device=DEV) if hasu else None
+        dp = torch.zeros(4 * M, C, device=DEV) if hasp else None
+        call(entry, ops[0], ops[1], ops[2], ops[3], theta, wd, dzd, None, wdot, B, H, W, C, d0, 0, d1, 0, du, 0, dwg,
+             None, None, None, None, None, None, None, None, None, None, None, None, dp, None, None, None, None, 0, *extra)
+        return wdot, dwg, d0, d1, du, dp
+    ref = run("mmd_bifpn_node_dw_bwd3", [ymat[0], ymat.get(1), ymat.get(2), ymat.get(3)], ())
+    got = run("mmd_bifpn_node_dw_bwd3_lz", [raw[0], raw[1], raw[2], raw[3]], (arr(sc), arr(sh)))
+    for a_, b_, what in zip(got, ref, ("wdot", "depthwise weight gradient", "d in0", "d in1", "d up", "d pool (scatter)")):
+        if a_ is not None:
+            close(a_, b_, 2e-4 if what == "wdot" else 3e-5, 1e-5 if what == "wdot" else 1e-6, what)

@@ -125,6 +125,29 @@ def all_fwd():
 
 timeit("student + 3 teachers forward, 4 streams", cap(all_fwd))
 
+
+def fwd_k(k):
+    def f():
+        main = torch.cuda.current_stream()
+        ev = main.record_event()
+        student_fwd()
+        for i, (mod, net) in enumerate(tn[:k]):
+            side = eng.side_streams[i]
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                net.begin_step()
+                net.forward(eng.static[mod], train=False)
+        for side in eng.side_streams[:k]:
+            main.wait_stream(side)
+    return f
+
+
+# is the forward phase bound by the student's chain (flat in k) or by the chip's throughput (linear in k)?
+for k in (1, 2):
+    timeit("student + %d teacher(s) forward" % k, cap(fwd_k(k)))
+if os.environ.get("MMD_DIAG_FWD_ONLY"):
+    sys.exit(0)
+
 # student-only step: teachers replaced by their cached outputs
 eng.step_body(eng.static, ds)
 torch.cuda.synchronize()
