@@ -299,19 +299,6 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
-  if constexpr (LZ) {
-    if (a.lazy)
-      for (int i = tid; i < 4 * FN_C; i += FN_NT) {
-        const int op = i / FN_C, c = i - op * FN_C;
-        float sc = 1.f, sh = 0.f;
-        if (a.lazy >> op & 1) {
-          if (a.ost[op]) { BnLive bn; bn.stats = a.ost[op]; bn.gamma = a.oga[op]; bn.beta = a.obe[op]; bn.inv_count = a.oic[op]; bn.C = FN_C; bn.eps = 1e-3f;
-                           bn_live_coef(bn, c, sc, sh); }
-          else { sc = a.osc[op][c]; sh = a.osh[op][c]; }
-        }
-        sAf[(op * 2) * FN_C + c] = sc; sAf[(op * 2 + 1) * FN_C + c] = sh;
-      }
-  }
   int bid = blockIdx.x;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
@@ -351,7 +338,23 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     constexpr int n2 = (MODE & 3) ? 1 : 0;             // operand order (in0, in1, up, pool): in1 and up never occur together
     const float wp_ = (MODE & 4) ? w[1 + n2] : 0.f;
     const bool lz = LZ && a.lazy != 0;                 // block-uniform
-    if (lz) __syncthreads();                           // the coefficient table is complete (the operand loads above are in flight meanwhile)
+    if constexpr (LZ) {
+      if (lz) {
+        // the lazy operands' coefficient table - filled HERE, behind the operand loads issued above, so that its own dependent loads
+        // (batch sums -> coefficients) overlap them instead of preceding them on the block's critical path
+        for (int i = tid; i < 4 * FN_C; i += FN_NT) {
+          const int op = i / FN_C, c = i - op * FN_C;
+          float sc = 1.f, sh = 0.f;
+          if (a.lazy >> op & 1) {
+            if (a.ost[op]) { BnLive bn; bn.stats = a.ost[op]; bn.gamma = a.oga[op]; bn.beta = a.obe[op]; bn.inv_count = a.oic[op]; bn.C = FN_C; bn.eps = 1e-3f;
+                             bn_live_coef(bn, c, sc, sh); }
+            else { sc = a.osc[op][c]; sh = a.osh[op][c]; }
+          }
+          sAf[(op * 2) * FN_C + c] = sc; sAf[(op * 2 + 1) * FN_C + c] = sh;
+        }
+        __syncthreads();
+      }
+    }
     constexpr int OP1 = (MODE & 1) ? 1 : 2;            // which operand v1 holds
 #pragma unroll
     for (int i0 = 0; i0 < NI; i0 += 3) {               // the pooled operand's 3x3 windows of three items are gathered together (27 loads in flight)
