@@ -151,6 +151,16 @@ int mmd_chan_pool(const float* z, const float* scale, const float* shift, const 
 // Squeeze-excite FCs: gate = sigmoid(We*swish(Wr*pooled+br)+be) (src/YetAnotherEfficientNet.py:471-474).
 int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
 
+// Round 4, grouped frozen nets: several frozen nets of ONE architecture (the three teachers) evaluated as one batch of n_groups x
+// images_per_group images - a launch covers the same layer of every net and each workgroup picks its net's parameters by the image it
+// works on: group g = image / images_per_group reads its weights g * w_stride floats and its folded BatchNorm coefficients g * bn_stride
+// floats behind the pointers passed in (the nets' flat parameter / coefficient buffers are laid out alike, a constant stride apart).
+// mmd_set_group applies to the launches issued after it on this library instance until cleared with n_groups <= 1; honoured by the frozen
+// forward entry points mmd_pwconv_fwd / mmd_pwconv_fwd_pyr (LDS-tiled kernels; every group's rows are whole 128-row tiles),
+// mmd_dwconv_fwd, mmd_dwconv3_pyr (forward), mmd_mbconv_expand_dw_fwd, mmd_se_fc_fwd and mmd_bifpn_node_fwd_fused; they return -22
+// for a launch form the mode does not cover (statistics, live BatchNorm prologues, bf16 storage).
+int mmd_set_group(int n_groups, int images_per_group, long long w_stride, long long bn_stride);
+
 // One pass over (z1, g1): out5[5][B][C] += (sum g1*swish(u), sum g1*swish'(u), sum g1*swish'(u)*xhat, sum swish'(u), sum swish'(u)*xhat)
 // per (image, channel): d(gate) for the SE backward plus the partials of the BatchNorm-1 backward sums (autograd of
 // src/YetAnotherEfficientNet.py:466-476), so the expanded tensor is not read again by a BN reduce pass.

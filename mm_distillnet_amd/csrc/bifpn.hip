@@ -21,6 +21,7 @@ struct FuseArgs {
   const double* ost[4]; const float* oga[4]; const float* obe[4]; double oic[4];
   const float* osc[4]; const float* osh[4];
   int lazy;
+  int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup): whole-node eval kernel only
 };
 // per-block coefficient table of the lazy operands in LDS: tab[(2 op + {0 scale, 1 shift}) * 64 + channel of the block's 64-channel chunk];
 // a thread reads its quad where it needs it (kept out of registers: the node backward kernel runs at 190-240 VGPRs as it is)
@@ -303,6 +304,11 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid, oh0 = th * 8, ow0 = tw * 8;
+  if (!TRAIN && a.g_images) {      // grouped frozen nets: this image's net
+    const size_t gw = (size_t)(b / a.g_images) * a.g_w, gb = (size_t)(b / a.g_images) * a.g_bn;
+    wdw += gw; wpw += gw; if (bias) bias += gw; scale += gb; shift += gb;
+    fuse_weights(a.theta + gw, a.ntheta, w);
+  }
   // the 1x1 weights of the whole node, in flight while phases 0 and 1 run
   constexpr int NW4 = FN_C * FN_Q, WPT = PARK ? (NW4 + FN_NT - 1) / FN_NT : 1;
   float4 wreg[WPT];
@@ -500,6 +506,11 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (rc || !w_dw || !w_pw || !scale || !shift || !y || !mmd_bifpn_node_fused_supported(C) || (in1 && up)) return MMD_EINVAL;      // (no BiFPN node fuses in1 AND up)
   const int th = cdiv(H, 8), tw = cdiv(W, 8);
+  if (mmd_group_on()) {
+    const MmdGroup& gr = mmd_group();
+    if (B != gr.n * gr.images) return MMD_EINVAL;
+    a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
+  }
   mmd_prof_tag(MMD_FAM_MBX, "node H%lld C%lld ops%lld", H, C, a.ntheta, 0);
   mmd_prof_begin(MMD_FAM_MBX, stream);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);

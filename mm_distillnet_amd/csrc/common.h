@@ -173,6 +173,16 @@ __device__ __forceinline__ int mmd_xcd_swizzle(int bid, int nblk) {
   return (bid & 7) * cpx + (bid >> 3);
 }
 
+// ---- grouped frozen nets (round 4) ------------------------------------------------------------------------------------------------
+// Several frozen nets of one architecture (the three teachers) evaluated as ONE batch of n_groups x images_per_group images: a launch covers
+// the same layer of every net, and each workgroup picks its net's parameters by the image it works on - group g = image / images_per_group
+// reads its weights g * w_stride floats behind the first net's (all nets' flat parameter buffers are laid out alike, w_stride apart) and its
+// folded BatchNorm coefficients g * bn_stride floats behind.  The host sets the group for the launches it issues next (mmd_set_group) and
+// clears it again (n_groups = 1); only the frozen-forward entry points read it.  A row tile / slab never straddles two groups (host-checked).
+struct MmdGroup { int n; int images; long long w_stride; long long bn_stride; };
+const MmdGroup& mmd_group();           // elt.hip
+static inline bool mmd_group_on() { return mmd_group().n > 1; }
+
 static inline int mmd_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMD_OK : MMD_ELAUNCH;

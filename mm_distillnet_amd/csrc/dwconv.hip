@@ -39,6 +39,7 @@ struct DwArgs {
   const float* q_z; const float* q_gate; const float* q_add; const float* q_scale; const float* q_shift; const float* q_mean;
   const float* q_invstd; const double* q_sums; double q_inv_count; float* q_dgamma; float* q_dbeta;
   int x16, y16, bz16, qz16;      // bf16 storage (common.h w16) of x, y, bz, q_z - tile kernel only
+  int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup): image b reads group b / g_images' taps and folded coefficients
 };
 
 // LANES = float4 lanes per pixel (16 -> 64-channel chunks; 8 / 4 -> 32- / 16-channel chunks for the thin early layers,
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
+  const size_t gw = a.g_images ? (size_t)(b / a.g_images) * a.g_w : 0, gb = a.g_images ? (size_t)(b / a.g_images) * a.g_bn : 0;
   const int c0 = cc * CC, c4 = (tid & (LANES - 1)) * 4, c = c0 + c4;
   const bool cok = c < a.C;
   const int oh0 = th * Cf::TH, ow0 = tw * Cf::TW;
@@ -190,14 +192,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     BnLive bn = a.in_bn;
     const long long lo = (long long)lev * a.lev_stride;
     if (bn.stats) { bn.stats += 2 * lo; bn.gamma += lo; bn.beta += lo; if (a.pyr.n) bn.inv_count = 1.0 / ((double)a.B * H * W); }
-    dw_in_coef(a.in_scale ? a.in_scale + lo : nullptr, a.in_scale ? a.in_shift + lo : nullptr, bn, c, cok, v);
+    dw_in_coef(a.in_scale ? a.in_scale + gb + lo : nullptr, a.in_scale ? a.in_shift + gb + lo : nullptr, bn, c, cok, v);
   }
   float* const yout = a.y + ro;
 
   for (int i = tid; i < K * K * LANES; i += 256) {
     int tap = i / LANES, q = (i % LANES) * 4;
     int src = a.flip ? (K * K - 1 - tap) : tap;
-    float4 wv = (c0 + q < a.C) ? mmd_ld4(a.w + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
+    float4 wv = (c0 + q < a.C) ? mmd_ld4(a.w + gw + (size_t)src * a.C + c0 + q) : make_float4(0, 0, 0, 0);
     *reinterpret_cast<float4*>(&sW[tap * CC + q]) = wv;
   }
   if constexpr (PRO == 2) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   }
   constexpr bool E_BZ = EPI == 2 || EPI == 4, E_ST = EPI == 1 || EPI == 4, E_OUT = EPI == 3 || EPI == 4;
   float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
-  if (E_OUT && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
+  if (E_OUT && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + gb + c); osh = mmd_ld4(a.out_shift + gb + c); }
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
   float4 bsc, bsh, bmu, bis;
   if (E_BZ && a.bz && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
@@ -436,22 +438,23 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
   const int cb = bid % colblocks; bid /= colblocks;
   const int rb = bid % rowblocks; bid /= rowblocks;
   const int b = bid, c0 = cc * CC, c = c0 + c4;
+  const size_t gw = a.g_images ? (size_t)(b / a.g_images) * a.g_w : 0, gb = a.g_images ? (size_t)(b / a.g_images) * a.g_bn : 0;
   const bool cok = c < a.C;
   const int C = a.C;
   const int ow0 = (cb * (256 / LW) + strip) * R, oh0 = rb * gm.rh, oh1 = min(oh0 + gm.rh, H);
   float4 wt[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wt[t] = cok ? mmd_ld4(a.w + (size_t)(a.flip ? 8 - t : t) * C + c) : make_float4(0, 0, 0, 0);
+  for (int t = 0; t < 9; ++t) wt[t] = cok ? mmd_ld4(a.w + gw + (size_t)(a.flip ? 8 - t : t) * C + c) : make_float4(0, 0, 0, 0);
   DwView v;
   v.act = a.in_act;
   if (PRO) {
     BnLive bn = a.in_bn;
     const long long lo = (long long)lev * a.lev_stride;
     if (bn.stats) { bn.stats += 2 * lo; bn.gamma += lo; bn.beta += lo; if (a.pyr.n) bn.inv_count = 1.0 / ((double)a.B * H * W); }
-    dw_in_coef(a.in_scale ? a.in_scale + lo : nullptr, a.in_scale ? a.in_shift + lo : nullptr, bn, c, cok, v);
+    dw_in_coef(a.in_scale ? a.in_scale + gb + lo : nullptr, a.in_scale ? a.in_shift + gb + lo : nullptr, bn, c, cok, v);
   }
   float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
-  if (EPI == 3 && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + c); osh = mmd_ld4(a.out_shift + c); }
+  if (EPI == 3 && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + gb + c); osh = mmd_ld4(a.out_shift + gb + c); }
   float4 bsc, bsh, bmu, bis;
   if (EPI == 2 && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
   const float* const xb = a.x + ro + (size_t)b * H * W * C + (cok ? c : 0);
@@ -689,6 +692,11 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
   a.stats = stats; a.pool = pool; a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
   a.stats_ws = stats_ws; a.ws_slots = ws_slots;
+  if (mmd_group_on()) {      // grouped frozen nets (common.h MmdGroup): image b reads group b / images' taps and folded coefficients
+    const MmdGroup& gr = mmd_group();
+    if (B != gr.n * gr.images || stats || in_stats) return MMD_EINVAL;
+    a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
+  }
   mmd_prof_tag(MMD_FAM_DW, "dw H%lld C%lld k%lld s%lld", H, C, k, stride);
   mmd_prof_begin(MMD_FAM_DW, stream);
   int rc = 1;
@@ -759,6 +767,11 @@ extern "C" int mmd_dwconv3_pyr(const float* x, const float* w, float* y, const i
   a.x = x; a.w = w; a.y = y; a.B = a.pyr.B; a.C = C; a.pad_t = 1; a.pad_l = 1; a.flip = flip;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act; a.in_bn = mmd_make_bn(in_stats, in_gamma, in_beta, 1, C);
   a.lev_stride = lev_stride; a.cchunks = cdiv(C, 64);
+  if (mmd_group_on()) {
+    const MmdGroup& gr = mmd_group();
+    if (a.B != gr.n * gr.images || flip || dw_grad || in_stats) return MMD_EINVAL;
+    a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
+  }
   int nb = 0;
   for (int l = 0; l < a.pyr.n; ++l) {
     a.pyr.blk0[l] = nb;

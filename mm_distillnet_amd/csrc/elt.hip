@@ -282,11 +282,24 @@ extern "C" int mmd_chan_pool_bwd(const float* z, const float* scale, const float
 // Two small launches with enough blocks to fill the chip (one block per image was 50 us per call):
 //   hidden: one wave per (image, j): hpre[b,j] = wr[j,:].pooled[b,:] + br[j]        (coalesced over C)
 //   gate  : one wave per 16 channels: gate[b,c] = sigmoid(we[c,:].swish(hpre[b,:]) + be[c])   (coalesced over S)
+static MmdGroup g_group{1, 0, 0, 0};
+const MmdGroup& mmd_group() { return g_group; }
+// Grouped frozen nets (common.h MmdGroup): the launches issued after this call cover n_groups nets x images_per_group images each;
+// n_groups <= 1 switches the mode off.  Host-side state of the issuing thread's library instance (captured into a graph by value).
+extern "C" int mmd_set_group(int n_groups, int images_per_group, long long w_stride, long long bn_stride) {
+  if (n_groups <= 1) { g_group = MmdGroup{1, 0, 0, 0}; return MMD_OK; }
+  if (images_per_group <= 0 || w_stride <= 0 || bn_stride <= 0 || (w_stride & 3) || (bn_stride & 3)) return MMD_EINVAL;
+  g_group = MmdGroup{n_groups, images_per_group, w_stride, bn_stride};
+  return MMD_OK;
+}
+
 __global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
-                                                        const float* __restrict__ br, float* __restrict__ hpre, int C, int S) {
+                                                        const float* __restrict__ br, float* __restrict__ hpre, int C, int S,
+                                                        int g_images, long long g_w) {
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.y * 4 + wave;
   if (j >= S) return;
+  if (g_images) { const size_t o = (size_t)(b / g_images) * g_w; wr += o; br += o; }
   const float* p = pooled + (size_t)b * C;
   const float* w = wr + (size_t)j * C;
   float acc = 0.f;
@@ -298,9 +311,11 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict_
   if (lane == 0) hpre[(size_t)b * S + j] = acc + br[j];
 }
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hpre, const float* __restrict__ wet,
-                                                      const float* __restrict__ be, float* __restrict__ gate, int C, int S) {
+                                                      const float* __restrict__ be, float* __restrict__ gate, int C, int S,
+                                                      int g_images, long long g_w) {
   __shared__ float sh[256];
   const int b = blockIdx.x;
+  if (g_images) { const size_t o = (size_t)(b / g_images) * g_w; wet += o; be += o; }
   for (int j = threadIdx.x; j < S; j += 256) sh[j] = mmd_swish(hpre[(size_t)b * S + j]);
   __syncthreads();
   const int c = blockIdx.y * 256 + threadIdx.x;
@@ -312,8 +327,11 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
                              float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
   if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256) return MMD_EINVAL;
-  hipLaunchKernelGGL(se_hidden_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, hpre, we, be, gate, C, S);
+  const MmdGroup& gr = mmd_group();
+  const int gi = gr.n > 1 ? gr.images : 0;
+  if (gi && B != gr.n * gr.images) return MMD_EINVAL;
+  hipLaunchKernelGGL(se_hidden_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S, gi, gr.w_stride);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, hpre, we, be, gate, C, S, gi, gr.w_stride);
   return mmd_check_launch();
 }
 

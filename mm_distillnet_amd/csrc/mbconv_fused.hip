@@ -28,6 +28,7 @@ struct MbxArgs {
   float* y; float* pool; float pool_scale;
   int B, H, W, Cin, C, OH, OW, pad_t, pad_l, tiles_h, tiles_w, cchunks;
   int y16;      // y is a bf16 array (common.h w16)
+  int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup)
 };
 
 template <int K, int S> struct MbxCfg;
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
   const int tw = bid % a.tiles_w; bid /= a.tiles_w;
   const int th = bid % a.tiles_h; bid /= a.tiles_h;
   const int b = bid, c0 = cc * CC;
+  if (a.g_images) {      // this image's net: its parameter set
+    const size_t gw = (size_t)(b / a.g_images) * a.g_w, gb = (size_t)(b / a.g_images) * a.g_bn;
+    a.w0 += gw; a.wd += gw; a.sc0 += gb; a.sh0 += gb; a.sc1 += gb; a.sh1 += gb;
+  }
   const int oh0 = th * TH, ow0 = tw * TW, ih0 = oh0 * S - a.pad_t, iw0 = ow0 * S - a.pad_l;
   const int H = a.H, W = a.W, Cin = a.Cin;
 
@@ -242,6 +247,11 @@ static int mbx_impl(const float* x, const float* w_expand, const float* scale0, 
   a.pad_t = mbx_same_pad_lo(H, k, stride, &a.OH); a.pad_l = mbx_same_pad_lo(W, k, stride, &a.OW);
   a.pool_scale = 1.0f / (float)((long long)a.OH * a.OW);
   a.y16 = y16;
+  if (mmd_group_on()) {
+    const MmdGroup& gr = mmd_group();
+    if (B != gr.n * gr.images || y16) return MMD_EINVAL;
+    a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
+  }
   mmd_prof_tag(MMD_FAM_MBX, "mbx H%lld K%lld N%lld k%lld", H, Cin, Cmid, k * 10 + stride);
   mmd_prof_begin(MMD_FAM_MBX, stream);
   int rc;

@@ -77,6 +77,9 @@ struct PwArgs {
   // bf16 storage ("w16", common.h): which tensors of the launch are bf16 arrays - the A operand x, the output y, and for the
   // BatchNorm-backward operand launches the second A tensor bb.z, the stored dz (bb.dz_out) and the pooled pass' z (p5.z)
   int x16, y16, z16, dz16, p5z16;
+  // grouped frozen nets (common.h MmdGroup): g_images != 0 -> the row tile's group g = image / g_images reads w / bias g * g_w floats and
+  // out_scale / out_shift g * g_bn floats behind the given pointers (LDS-tiled kernels only)
+  int g_images; long long g_w, g_bn;
 };
 
 

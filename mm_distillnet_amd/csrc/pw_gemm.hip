@@ -136,12 +136,15 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
     }
   }
+  // grouped frozen nets: this row tile's group (a tile never straddles two groups: host-checked) selects the parameter set
+  size_t gw = 0, gb = 0;
+  if (a.g_images) { const int gi = ((m0 - srow0) / rpi) / a.g_images; gw = (size_t)gi * a.g_w; gb = (size_t)gi * a.g_bn; }
   const float* wrow[NB]; bool wok[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     int col = n0 + lrow + i * 32;
     wok[i] = col < a.N;
-    wrow[i] = a.w + (size_t)(wok[i] ? col : 0) * a.K;
+    wrow[i] = a.w + gw + (size_t)(wok[i] ? col : 0) * a.K;
   }
 
   f32x16 acc[NS];
@@ -300,8 +303,8 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   const bool cok = col < a.N;              // N % 4 == 0: a column group is all-valid or all-out
   float4 b4 = make_float4(0, 0, 0, 0), osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
   if (cok) {
-    if (a.bias) b4 = mmd_ld4(a.bias + col);
-    if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
+    if (a.bias) b4 = mmd_ld4(a.bias + gw + col);
+    if (a.out_scale) { osc = mmd_ld4(a.out_scale + gb + col); osh = mmd_ld4(a.out_shift + gb + col); }
   }
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
   float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
@@ -452,12 +455,14 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
     }
   }
+  size_t gw = 0, gb = 0;      // grouped frozen nets: the tile's parameter set
+  if (a.g_images) { const int gi = ((m0 - srow0) / rpi) / a.g_images; gw = (size_t)gi * a.g_w; gb = (size_t)gi * a.g_bn; }
   const float* wrow[8]; bool wok[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     int col = n0 + lrow + i * 8;
     wok[i] = col < a.N;
-    wrow[i] = a.w + (size_t)(wok[i] ? col : 0) * a.K;
+    wrow[i] = a.w + gw + (size_t)(wok[i] ? col : 0) * a.K;
   }
   f32x16 acc[2];
 #pragma unroll
@@ -591,8 +596,8 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   const bool cok = col < a.N;
   float4 b4 = make_float4(0, 0, 0, 0), osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
   if (cok) {
-    if (a.bias) b4 = mmd_ld4(a.bias + col);
-    if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
+    if (a.bias) b4 = mmd_ld4(a.bias + gw + col);
+    if (a.out_scale) { osc = mmd_ld4(a.out_scale + gb + col); osh = mmd_ld4(a.out_shift + gb + col); }
   }
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
   float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
@@ -982,11 +987,25 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   static const int sq_tiles = getenv("MMD_SQ_TILES") ? atoi(getenv("MMD_SQ_TILES")) : 800;
   static const int sq_min = getenv("MMD_SQ_MIN") ? atoi(getenv("MMD_SQ_MIN")) : 160;
   const bool w16 = a.x16 || a.y16 || a.z16 || a.dz16 || a.p5z16;      // bf16 storage: the LDS-tiled kernels only
-  if (!w16 && pw_rows_try(a, stream) == 1) {
+  // grouped frozen nets (common.h MmdGroup): plain forward launches only, on the LDS-tiled kernels; every group's rows must be whole tiles
+  const MmdGroup& gr = mmd_group();
+  const bool grouped = gr.n > 1;
+  if (grouped) {
+    if (w16 || a.bb.z || a.st.Cin || a.stats || a.in_bn.stats || a.in_scale) return MMD_EINVAL;
+    const int imgs = gr.n * gr.images;
+    if (a.pyr.n) {
+      if (a.pyr.B != imgs) return MMD_EINVAL;
+      for (int l = 0; l < a.pyr.n; ++l) if (((long long)gr.images * a.pyr.H[l] * a.pyr.W[l]) % PW_BM) return MMD_EINVAL;
+    } else {
+      if (a.rows_per_image <= 0 || (long long)imgs * a.rows_per_image != M || ((long long)gr.images * a.rows_per_image) % PW_BM) return MMD_EINVAL;
+    }
+    a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
+  }
+  if (!w16 && !grouped && pw_rows_try(a, stream) == 1) {
     // thin-K row-slab kernel (pw_rows.hip) took the launch
-  } else if (!w16 && pw_longk_try(a, stream) == 1) {
+  } else if (!w16 && !grouped && pw_longk_try(a, stream) == 1) {
     // long-K small-M kernel with the LDS-DMA pipelined K loop (pw_longk.hip)
-  } else if (use_stream && !w16 && K <= 128 && big_tiles >= 160) {
+  } else if (use_stream && !w16 && !grouped && K <= 128 && big_tiles >= 160) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
     else pw_stream_launch<2, 2>(a, stream);

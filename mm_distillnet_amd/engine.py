@@ -127,9 +127,30 @@ MBW_FUSED = not os.environ.get("MMD_NO_MBW")
 MBW_MIN_ROWS = int(os.environ.get("MMD_MBW_MIN_ROWS", "32768"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
 
+def pack_nets(nets: List["Net"]) -> bool:
+    """Lay the parameter stores of several frozen nets of one body architecture out at a constant stride inside shared buffers, so that
+    they can be evaluated as ONE batch with per-group parameters (Net.forward(pack=...), csrc/common.h MmdGroup).  The nets must have been
+    built with a common `stem_slot` (their stems may differ in input channels).  -> False when the stores do not line up."""
+    p0 = nets[0].ps
+    for n in nets[1:]:
+        q = n.ps
+        if n.trainable or q.n_params != p0.n_params or q.bn_total != p0.bn_total or q.order != p0.order or q.bn_off != p0.bn_off:
+            return False
+        if any(q.entries[k].off != p0.entries[k].off or (q.entries[k].native != p0.entries[k].native and q.entries[k].kind != "stem") for k in q.order):
+            return False
+    dev = p0.flat.device
+    G = len(nets)
+    flat = torch.zeros(G, p0.n_params, device=dev)
+    fsc, fsh = torch.zeros(G, p0.bn_total, device=dev), torch.zeros(G, p0.bn_total, device=dev)
+    for gi, n in enumerate(nets):
+        flat[gi].copy_(n.ps.flat); fsc[gi].copy_(n.ps.fold_scale); fsh[gi].copy_(n.ps.fold_shift)
+        n.ps.flat, n.ps.fold_scale, n.ps.fold_shift = flat[gi], fsc[gi], fsh[gi]      # (ParamStore derives every view from these on the fly)
+    return True
+
+
 class Net:
     def __init__(self, spec: NetSpec, device, trainable: bool, arena: Optional[Arena] = None,
-                 zarena: Optional[Arena] = None, precision: str = "fp32"):
+                 zarena: Optional[Arena] = None, precision: str = "fp32", stem_slot: int = 0):
         if precision not in ("fp32", "bf16", "bf16_hbm"):
             raise ValueError(f"Unsupported precision {precision}")
         # "bf16" = mixed precision: the 1x1-conv GEMMs (forward, input- and weight-gradient) feed the bf16 MFMA, fp32
@@ -142,7 +163,10 @@ class Net:
         self.spec = spec
         self.device = device
         self.trainable = trainable
-        self.ps = ParamStore(spec, device, with_grads=trainable)
+        self.ps = ParamStore(spec, device, with_grads=trainable, stem_slot=stem_slot)
+        # grouped frozen nets (round 4, csrc/common.h MmdGroup): during a pack forward (n_groups, images_per_group, w_stride, bn_stride) -
+        # every supported launch then covers the same layer of all the pack's nets, each workgroup reading its own net's parameters
+        self._grp: Optional[tuple] = None
         self.arena = arena or Arena(device)
         self.zarena = zarena or Arena(device, 64 << 20, zero_new=True)       # per-step accumulators, zeroed in one memset
         self.bn_momentum = BN_MOMENTUM
@@ -206,6 +230,18 @@ class Net:
         if self._counting:
             k = f.z.data_ptr()
             self._uses[k] = self._uses.get(k, 0) + 1
+
+    def _c(self, name: str, *args):
+        """call() for the frozen-forward entry points that honour the group mode: inside a pack forward the group is set around the launch."""
+        if self._grp is None:
+            return call(name, *args)
+        dll = _lib.LIB.load()
+        if dll.mmd_set_group(*self._grp) != 0:
+            raise RuntimeError("mmd_set_group refused %r" % (self._grp,))
+        try:
+            return call(name, *args)
+        finally:
+            dll.mmd_set_group(1, 0, 0, 0)
 
     # ------------------------------------------------------------------ parameters
     def load_state(self, state):
@@ -308,7 +344,7 @@ class Net:
         if x.w16 or y16:
             call("mmd_pwconv_fwd_w16", *args, 1, (1 if x.w16 else 0) | (2 if y16 else 0))
         else:
-            call("mmd_pwconv_fwd" + self._sfx, *args)
+            self._c("mmd_pwconv_fwd" + self._sfx, *args)
         return y
 
     def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None, y16=False):
@@ -320,7 +356,7 @@ class Net:
         if x.w16 or y16:
             call("mmd_dwconv_fwd_w16", *args, (1 if x.w16 else 0) | (2 if y16 else 0))
         else:
-            call("mmd_dwconv_fwd", *args)
+            self._c("mmd_dwconv_fwd", *args)
         return y, OH, OW
 
     def anchors(self, image_size: int) -> torch.Tensor:
@@ -347,15 +383,33 @@ class Net:
         return self._anchors[image_size]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, train: bool = False, drop_scale: Optional[torch.Tensor] = None,
-                raw_logits: bool = False):
+    def forward(self, x, train: bool = False, drop_scale: Optional[torch.Tensor] = None,
+                raw_logits: bool = False, pack: Optional[list] = None):
         """x: [B,Cin,S,S] NCHW fp32 on device.  drop_scale: [n_skip_blocks, B] = mask/keep (train only).
         Returns cls [B,A,NC] (probabilities; pre-sigmoid logits with raw_logits=True, a calibration aid), reg [B,A,4],
         features: list of 5 Feat (NHWC rows)."""
         if train and not self.trainable:
             raise RuntimeError("train-mode forward on a frozen (teacher) net")
         spec, ps = self.spec, self.ps
-        B, Cin, S, _ = x.shape
+        if pack is not None:
+            # pack forward: `pack` = the frozen nets evaluated together (this one first), x = their inputs [Bg, Cin_g, S, S] in the same order.
+            # Everything behind the stems runs ONCE over the G x Bg images with per-group parameters (pack_nets laid the stores out alike)
+            assert not train and pack[0] is self and len(pack) == len(x) and len(pack) > 1
+            Bg, S = x[0].shape[0], x[0].shape[2]
+            assert all(xi.shape[0] == Bg and xi.shape[2] == S for xi in x)
+            self._grp = (len(pack), Bg, ps.n_params, ps.bn_total)
+            try:
+                return self._forward(x, train, drop_scale, raw_logits, pack)
+            finally:
+                self._grp = None
+        return self._forward(x, train, drop_scale, raw_logits, None)
+
+    def _forward(self, x, train, drop_scale, raw_logits, pack):
+        spec, ps = self.spec, self.ps
+        if pack is not None:
+            B, S = x[0].shape[0] * len(pack), x[0].shape[2]
+        else:
+            B, Cin, S, _ = x.shape
         tape = self.tape if train else {}
         self._counting = train
         if train:
@@ -374,6 +428,14 @@ class Net:
                  *self._stats_ws(st, B * OH * OH, spec.stem_out))
             cur = Feat(z, B, OH, OH, spec.stem_out, sc, sh, SWISH, live)
             tape["stem"] = (x, cur, mu, istd)
+        elif pack is not None:
+            # the stems differ (input channels): one launch per net, each writing its images' rows of the shared stem output
+            Bg, rows = x[0].shape[0], x[0].shape[0] * OH * OH
+            for gi, (net, xg) in enumerate(zip(pack, x)):
+                b0 = net.ps.bn(f"{P}._bn0")
+                call("mmd_stem_conv_fwd", xg, net.ps.w(f"{P}._conv_stem.conv.weight"), z[gi * rows:(gi + 1) * rows], Bg, xg.shape[1], S, S,
+                     net.ps.stem_kp, spec.stem_out, b0["fscale"], b0["fshift"], SWISH, None, None, 0)
+            cur = Feat(z, B, OH, OH, spec.stem_out)
         else:
             # frozen net: the folded BN + swish ride in the producer's epilogue (once per element) instead of the depthwise
             # prologue, which would redo them for every halo pixel (1.6x for 3x3, 2.25x for 5x5 tiles)
@@ -441,14 +503,14 @@ class Net:
                 if fused_front:
                     b0 = ps.bn(f"{q}._bn0")
                     a1v = self._alloc16(M1, blk.cmid) if wide else self._alloc(M1, blk.cmid)
-                    call("mmd_mbconv_expand_dw_fwd_w16" if wide else "mmd_mbconv_expand_dw_fwd", inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
+                    self._c("mmd_mbconv_expand_dw_fwd_w16" if wide else "mmd_mbconv_expand_dw_fwd", inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
                          ps.w(f"{q}._depthwise_conv.conv.weight"), b1["fscale"], b1["fshift"], a1v, pooled, B, inp.H, inp.W, inp.C,
                          blk.cmid, blk.kernel, blk.stride)
                 else:
                     a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
                                          out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled, y16=wide)
                 f1 = Feat(a1v, B, H1, W1, blk.cmid, w16=wide)
-                call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
+                self._c("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 b2 = ps.bn(f"{q}._bn2")
                 y = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, gate=gate,
                              out_aff=(b2["fscale"], b2["fshift"]), residual=res)
@@ -572,7 +634,7 @@ class Net:
             b = self.ps.bn(f"{name}.bn")
             if y is None:
                 y = self._alloc(in0.M, in0.C)
-            call("mmd_bifpn_node_fwd_fused", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+            self._c("mmd_bifpn_node_fwd_fused", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
                  self.ps.w(f"{name}.depthwise_conv.conv.weight"), self.ps.w(f"{name}.pointwise_conv.conv.weight"),
                  self.ps.w(f"{name}.pointwise_conv.conv.bias"), b["fscale"], b["fshift"], y, in0.B, in0.H, in0.W, in0.C)
             return Feat(y, in0.B, in0.H, in0.W, in0.C)
@@ -720,11 +782,11 @@ class Net:
             cname = f"{hname}.conv_list.{i}"
             o = off0 + i * C
             zd = self._alloc_pyr(pyr, C)
-            call("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
+            self._c("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
                  None, None, None, NONE, None, None, None, None)
             z = self._alloc_pyr(pyr, C)
             st = self.stats_flat[2 * o:] if train else None
-            call("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
+            self._c("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
                  ps.w(f"{cname}.pointwise_conv.conv.bias"), NONE, st, lev_stride, 0, None)
             if train:
                 for lvl in range(5):
@@ -736,14 +798,14 @@ class Net:
             layers.append({"x": cur, "x_off": None if i == 0 else off0 + (i - 1) * C, "zd": zd, "z": z, "off": o})
             cur, cur_xf = z, nxt_xf
         zd = self._alloc_pyr(pyr, C)
-        call("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
+        self._c("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
              None, None, None, NONE, None, None, None, None)
         aoff, yoff = 0, []
         for (h, w) in pyr["sizes"]:
             yoff.append(aoff * per_anchor)
             aoff += h * w * spec.num_anchors
         yoff_c = (ctypes.c_longlong * 5)(*yoff)
-        call("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, desc, C, nout,
+        self._c("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, desc, C, nout,
              ps.w(f"{hname}.header.pointwise_conv.conv.bias"), out_act, None, 0, A * per_anchor, yoff_c)
         if train:
             tape[hname] = {"layers": layers, "hx": cur, "hx_off": off0 + (nl - 1) * C, "hzd": zd, "yoff": yoff,

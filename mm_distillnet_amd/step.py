@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from .arch import NetSpec, make_spec
-from .engine import Net, Feat, NONE, SWISH
+from .engine import Net, Feat, NONE, SWISH, pack_nets
 from .store import Arena
 
 call = _lib.call
@@ -65,8 +65,17 @@ class DistillEngine:
         self.world_size = world_size
         self.pg = process_group
         self.student = Net(student_spec, device, trainable=True, precision=cfg.precision)
-        self.teachers: Dict[str, Net] = {m: Net(teacher_specs[m], device, trainable=False, precision=cfg.precision)
+        # (a common stem slot lines the teachers' parameter layouts up behind their stems: the pack mode below)
+        slot = max(s.stem_out * ((s.in_channels * 9 + 3) // 4 * 4) for s in teacher_specs.values())
+        self.teachers: Dict[str, Net] = {m: Net(teacher_specs[m], device, trainable=False, precision=cfg.precision, stem_slot=slot)
                                          for m in TEACHER_ORDER if m in teacher_specs}
+        # Round 4, teacher pack: the frozen teachers share one body architecture, so each layer of all of them runs as ONE launch over
+        # 3 x B images with per-group weights instead of three launches on three streams (fewer, fatter launches beside the student's
+        # chain: tools/dev/diag_phases.py proxy - student forward + a frozen net at batch 3B 7.28 ms against 8.41 with three nets on three
+        # streams).  MMD_NO_PACK=1: one net per stream, the round-3 schedule
+        tl = list(self.teachers.values())
+        self.pack = (len(tl) > 1 and cfg.precision != "bf16_hbm" and not os.environ.get("MMD_NO_PACK") and str(device).startswith("cuda")
+                     and pack_nets(tl))
         ps = self.student.ps
         n = ps.n_params
         self.exp_avg = torch.zeros(n, device=device)
@@ -263,6 +272,7 @@ class DistillEngine:
             merged = st._alloc(*audio.shape)
             call("mmd_audio_merge01", audio, merged, audio[0].numel(), B)
             audio = merged
+        st.mark_block, st.mark_event = int(os.environ.get("MMD_PACK_STAGGER", "-1")), None      # (dev: hold the teacher pack until the student passed block k)
         cls_s, reg_s, feats_s = st.forward(audio, train=train, drop_scale=drop_scale if train else None)
         A = cls_s.shape[1]
         self._caps(A)
@@ -300,7 +310,36 @@ class DistillEngine:
         s2 = [b.idx for b in next(iter(self.teachers.values())).spec.blocks if b.stride == 2]
         stagger = int(os.environ.get("MMD_STAGGER", str(s2[1] if len(s2) > 1 else -1)))
         prev_net = None
+        # teacher pack (round 4): every layer of all the frozen teachers as ONE launch over G x B images with per-group weights, on one side
+        # stream.  Needs whole 128-row tiles per group on every pyramid level (the smallest, S/128 squared, decides) and no per-teacher
+        # feature surgery (the augmented variant averages images 0 / 1 of each teacher's maps)
+        G = len(self.teachers)
+        use_pack = bool(self.pack and G > 1 and not aug and (B * (S // 128) ** 2) % 128 == 0 and S % 128 == 0)
+        if use_pack:
+            nets = list(self.teachers.values())
+            net0 = nets[0]
+            side = self.side_streams[0] if concurrent else main_stream
+            if concurrent:
+                side.wait_event(fork_event)
+                if st.mark_event is not None:
+                    side.wait_event(st.mark_event)
+            with torch.cuda.stream(side):
+                net0.begin_step()
+                cls_p, reg_p, feats_p = net0.forward([batch[m] for m in self.teachers], train=False, pack=nets)
+                if teacher_labels is None:
+                    rows_p, cnt_p = self._pseudo_labels(net0, cls_p, reg_p, G * B, A, S)
+                _, a_lv = self._attention(net0)
+            for gi in range(G):
+                if teacher_labels is not None:
+                    r, c = teacher_labels[gi]
+                else:
+                    r, c = rows_p[gi * B:(gi + 1) * B], cnt_p[gi * B:(gi + 1) * B]
+                rows_t.append(r); cnt_t.append(c)
+                att_t.append([a_lv[l][gi * B * f.H * f.W:(gi + 1) * B * f.H * f.W] for l, f in enumerate(feats_p)])
+            passes = [p_ for p_ in passes if p_[3] is not None]      # (the KD-list variant's extra RGB pass still runs on its own)
         for pi, (mod, net, si, xin) in enumerate(passes):
+            if use_pack:
+                pi = G + pi
             ti = pi
             side = self.side_streams[si] if concurrent else main_stream
             if concurrent and xin is None:
@@ -346,7 +385,7 @@ class DistillEngine:
         call("mmd_focal_loss", cls_s, reg_s, st.anchors(S), boxes, nbox, G, B, A, nc, assign, npos, acc, main, dcls, dreg,
              float(cfg.w_main), 1, self.head_active if train else self.ws.alloc((1,), torch.int32))
         # backward + optimizer
-        if train:
+        if train and not os.environ.get("MMD_DEV_NO_BWD"):      # (MMD_DEV_NO_BWD=1: timing experiment - forward + losses only)
             call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
             st.backward(dcls, dreg, dfe, stop_before=self.ar_split, dfeat_pyr=d_all)
         self.out = {"reg": main[0:1], "cls": main[1:2], "kd": kd, "boxes": boxes, "nbox": nbox,

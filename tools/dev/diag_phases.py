@@ -22,6 +22,9 @@ eng = DistillEngine(sspec, specs, dev, StepConfig(image_size=S))
 eng.load(sstate, tstates)
 batch = {k: v.to(dev) for k, v in batch_cpu.items()}
 eng.capture(batch)
+for _n in [eng.student] + list(eng.teachers.values()):      # the phase graphs below allocate beyond what the step's graph froze
+    _n.arena.frozen = False; _n.zarena.frozen = False
+eng.ws.frozen = False
 
 
 def timeit(name, g, n=10):
@@ -145,6 +148,50 @@ def fwd_k(k):
 # is the forward phase bound by the student's chain (flat in k) or by the chip's throughput (linear in k)?
 for k in (1, 2):
     timeit("student + %d teacher(s) forward" % k, cap(fwd_k(k)))
+# proxy for a cross-teacher BATCHED pack (one launch per layer over 3 x B images, per-group weights): the same kernels on one frozen net at
+# batch 3B - same work and launch count as a pack would have, weights shared instead of per group
+if os.environ.get("MMD_DIAG_PACK"):
+    from mm_distillnet_amd.engine import Net
+    net24 = Net(specs["rgb"], dev, trainable=False)
+    net24.load_state(tstates["rgb"])
+    x24 = torch.cat([eng.static["rgb"]] * 3, 0).contiguous()
+
+    def pack_fwd():
+        net24.begin_step()
+        net24.forward(x24, train=False)
+
+    timeit("one frozen net at batch 3B (pack proxy)", cap(pack_fwd))
+
+    def student_and_pack():
+        main = torch.cuda.current_stream()
+        ev = main.record_event()
+        student_fwd()
+        side = eng.side_streams[0]
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            pack_fwd()
+        main.wait_stream(side)
+
+    timeit("student + frozen net at batch 3B, 2 streams", cap(student_and_pack))
+if getattr(eng, "pack", False):
+    def real_pack():
+        nets = [n for _, n in tn]
+        nets[0].begin_step()
+        nets[0].forward([eng.static[m] for m, _ in tn], train=False, pack=nets)
+
+    timeit("teacher pack (3 nets, one launch per layer)", cap(real_pack))
+
+    def student_and_real_pack():
+        main = torch.cuda.current_stream()
+        ev = main.record_event()
+        student_fwd()
+        side = eng.side_streams[0]
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            real_pack()
+        main.wait_stream(side)
+
+    timeit("student + teacher pack, 2 streams", cap(student_and_real_pack))
 if os.environ.get("MMD_DIAG_FWD_ONLY"):
     sys.exit(0)
 
