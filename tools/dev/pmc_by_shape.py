@@ -4,7 +4,7 @@ bytes - one line per pw_dispatch, in launch order).  FETCH_SIZE doubled (gfx950 
 Usage: pmc_by_shape.py <fetch counter_collection.csv> <write counter_collection.csv> <prof dump csv>"""
 import collections, csv, sys
 
-KEYS = ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel")
+KEYS = ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel")
 
 
 def seq(path):

@@ -3,7 +3,7 @@ per kernel family, with the gfx950 FETCH_SIZE correction (x2 for wide coalesced 
 Usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv>"""
 import collections, csv, sys
 
-FAM = {"pw_gemm": ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel"),
+FAM = {"pw_gemm": ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel"),
        "pw_wgrad": ("pw_wgrad_kernel", "wgrad_grouped_kernel", "wgrad_fold_kernel"),
        "dw_fwd": ("dw_fwd_kernel", "fuse_dw_fwd_kernel", "dw3_rows_kernel"), "dw_bwd": ("dw_wgrad_kernel", "dw_bwd_data_s2_kernel", "dw3_wgrad_rows_kernel"),
        "bn_bwd": ("bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"), "mbx": ("mbx_kernel", "bifpn_node_fused_kernel")}
