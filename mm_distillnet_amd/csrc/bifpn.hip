@@ -677,13 +677,25 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 // Fused node backward: the depthwise 3x3 input gradient  df = dwconv^T(dzd, w)  is computed from an LDS tile of dzd (8x8
 // pixels + halo, 64-channel chunk) and fed straight into the fusion backward above - one launch instead of two and no df
 // round trip through HBM (mirror of fuse_dw_fwd_kernel; 40 launches on the backward's serial chain).
-template <int MODE>
+// GEMM = true (round 4, "whole-node backward"): the launch also runs the node's 1x1 conv's input gradient, which used to be a launch of its
+// own in front of this one (mmd_pwconv_bwd_data_bn on the skinny GEMM kernel: 40 launches of 8-25 us on the backward's serial chain).  The
+// block evaluates the node's BatchNorm backward dz = a1 g + a2 (z - mu) + a3 on its 10x10-pixel halo tile for ALL channels into LDS
+// ([112][C + 4], dynamic), multiplies it by W[:, chunk] on v_mfma_f32_16x16x4_f32 (wave w owns 16 channels of the block's 64-channel chunk,
+// all 7 pixel tiles; its 28 B values per lane come straight from L2 and stay in registers) and writes the dzd tile into sIn - where the
+// plain form stages it from HBM.  The halo is recomputed by the neighbouring blocks (1.56x of a 2.5 MFLOP product); dzd never exists in
+// HBM.  The chunk-0 blocks store dz (interior pixels) for the conv's weight-gradient GEMM; block 0 adds dgamma / dbeta.
+struct NodeGemm {
+  const float* g; const float* z; const float* scale; const float* mean; const float* invstd; const double* sums; double inv_count;
+  const float* w;          // the 1x1 conv's weight [C out][C in] (native layout): dzd[p, c] = sum_n dz[p, n] w[n, c]
+  float* dz_out; float* dgamma; float* dbeta;
+};
+template <int MODE, bool GEMM = false>
 __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
                                                          float* __restrict__ dup, int acc_up, float* __restrict__ dwg,
                                                          int tiles_h, int tiles_w, int cchunks, BnSumDst x0, BnSumDst x1, BnSumDst xu,
-                                                         float* dpl, BnSumDst xp, int own) {
+                                                         float* dpl, BnSumDst xp, int own, NodeGemm ng) {
   // dpl (MODE & 4): the POOLED operand's gradient [B, 2H, 2W, C], scattered from here - every output pixel adds w_pool * g to the arg-max
   // element of its 3x3 window with fp32 atomics (dpl holds zeros or the earlier contributions) - instead of materialising dx for a gather
   // launch over the 4x larger source map (mmd_maxpool_same_bwd_acc: 22 launches of ~22 us per D2 step).  A scattered gradient has no last
@@ -713,11 +725,77 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     float4 wv = (c0 + q < a.C) ? mmd_ld4(wdw + (size_t)(8 - tap) * a.C + c0 + q) : make_float4(0, 0, 0, 0);
     *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
   }
+  if constexpr (GEMM) {
+    extern __shared__ float sDyn[];
+    const int C = a.C, LDZ = C + 4, NQ = C >> 2;
+    float* const sDz = sDyn;                        // [112 pixel rows (100 used)][LDZ]
+    float* const sCf = sDyn + 112 * LDZ;            // [4][C]: a1, a2, a3, mu of the BatchNorm backward
+    for (int n = tid; n < C; n += 256) {
+      const float m1 = (float)(ng.sums[n] * ng.inv_count), m2 = (float)(ng.sums[C + n] * ng.inv_count);
+      const float sc = ng.scale[n];
+      sCf[n] = sc; sCf[C + n] = -sc * ng.invstd[n] * m2; sCf[2 * C + n] = -sc * m1; sCf[3 * C + n] = ng.mean[n];
+    }
+    if (ng.dgamma && blockIdx.x == 0)
+      for (int n = tid; n < C; n += 256) { ng.dgamma[n] += (float)ng.sums[C + n]; ng.dbeta[n] += (float)ng.sums[n]; }
+    // the wave's B operand: w[n = 16 kk + 4 g + j][c = c0 + 16 wave + r], kk = 0 .. C / 16 - 1 (at most 14 k groups: C <= 224)
+    const int lane = tid & 63, r = lane & 15, gq = lane >> 4, wv_ = tid >> 6;
+    const int cb = c0 + wv_ * 16 + r;
+    const bool cvalid = cb < C;
+    float bw[14][4];
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bw[kk][j] = (kk * 16 < C && cvalid) ? ng.w[(size_t)(kk * 16 + 4 * gq + j) * C + cb] : 0.f;
+    __syncthreads();                                // coefficients visible
+    for (int it = tid; it < IH * IW * NQ; it += 256) {
+      const int pp = it / NQ, q = it - pp * NQ;
+      const int ih = oh0 - 1 + pp / IW, iw = ow0 - 1 + pp % IW;
+      float4 d = make_float4(0, 0, 0, 0);
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+        const size_t off = (((size_t)b * a.H + ih) * a.W + iw) * C + q * 4;
+        const float4 gv = mmd_ld4(ng.g + off), zv = mmd_ld4(ng.z + off);
+        const float4 a1 = *reinterpret_cast<const float4*>(&sCf[q * 4]), a2 = *reinterpret_cast<const float4*>(&sCf[C + q * 4]);
+        const float4 a3 = *reinterpret_cast<const float4*>(&sCf[2 * C + q * 4]), mu = *reinterpret_cast<const float4*>(&sCf[3 * C + q * 4]);
+        d.x = a1.x * gv.x + a2.x * (zv.x - mu.x) + a3.x; d.y = a1.y * gv.y + a2.y * (zv.y - mu.y) + a3.y;
+        d.z = a1.z * gv.z + a2.z * (zv.z - mu.z) + a3.z; d.w = a1.w * gv.w + a2.w * (zv.w - mu.w) + a3.w;
+        const int py = pp / IW, px = pp % IW;      // interior pixels, once per tile: the stored dz the weight-gradient GEMM reads
+        if (cc == 0 && ng.dz_out && py >= 1 && py <= TH && px >= 1 && px <= TW) mmd_st4(ng.dz_out + off, d);
+      }
+      *reinterpret_cast<float4*>(&sDz[pp * LDZ + q * 4]) = d;      // pixels outside the image: dz = 0 -> dzd = 0 (what the plain form stages)
+    }
+    __syncthreads();
+    // dzd tile: 7 pixel tiles x this wave's 16 channels
+    f32x4 acc7[7];
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt) acc7[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkk = C >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+      if (kk < nkk) {
+#pragma unroll
+        for (int mt = 0; mt < 7; ++mt) {
+          const float4 av = *reinterpret_cast<const float4*>(&sDz[(mt * 16 + r) * LDZ + kk * 16 + 4 * gq]);
+          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bw[kk][0], acc7[mt], 0, 0, 0);
+          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bw[kk][1], acc7[mt], 0, 0, 0);
+          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bw[kk][2], acc7[mt], 0, 0, 0);
+          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bw[kk][3], acc7[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 7; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pp = mt * 16 + 4 * gq + i;
+        if (pp < IH * IW) sIn[pp * 64 + wv_ * 16 + r] = cvalid ? acc7[mt][i] : 0.f;
+      }
+  } else {
   for (int p = tid >> 4; p < IH * IW; p += 16) {
     const int ih = oh0 - 1 + p / IW, iw = ow0 - 1 + p % IW;
     float4 v = make_float4(0, 0, 0, 0);
     if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = mmd_ld4(dzd + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
     *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+  }
   }
   __syncthreads();
   const int p = tid >> 4;
@@ -904,11 +982,14 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
                             int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
                             float* dw_grad, BnSumDst x0, BnSumDst x1, BnSumDst xu, hipStream_t stream,
                             float* dpl = nullptr, BnSumDst xp = BnSumDst{}, int own = 0, const void* op_scale4 = nullptr,
-                            const void* op_shift4 = nullptr) {
+                            const void* op_shift4 = nullptr, const NodeGemm* ng = nullptr) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (!rc) rc = fuse_fill_lazy_bwd(a, op_scale4, op_shift4);
-  if (rc || !w_dw || !dzd || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
+  if (rc || !w_dw || (!dzd && !ng) || !wdot || (!dx && !d0) || (d1 && !in1) || (dup && !up)) return MMD_EINVAL;
+  if (ng && (!ng->g || !ng->z || !ng->scale || !ng->mean || !ng->invstd || !ng->sums || !ng->w || (C & 15) || C > 224 ||
+             (ng->dgamma == nullptr) != (ng->dbeta == nullptr)))
+    return MMD_EINVAL;
   if ((dpl && !pool) || (xp.z && (!dpl || !xp.mean || !xp.invstd || !xp.sums))) return MMD_EINVAL;
   if ((x0.z && (!d0 || !x0.mean || !x0.invstd || !x0.sums)) || (x1.z && (!d1 || !x1.mean || !x1.invstd || !x1.sums)) ||
       (xu.z && (!dup || !xu.mean || !xu.invstd || !xu.sums)))
@@ -916,7 +997,17 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
-#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own)
+  if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
+    const size_t lds = (size_t)(112 * (C + 4) + 4 * C) * sizeof(float);
+#define MMD_NODE_BWD_G(M) do { static bool attr = false; \
+      if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr = true; } \
+      hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
+    if (mode == 2) MMD_NODE_BWD_G(2); else if (mode == 5) MMD_NODE_BWD_G(5); else if (mode == 4) MMD_NODE_BWD_G(4); else return MMD_EINVAL;
+#undef MMD_NODE_BWD_G
+    return mmd_check_launch();
+  }
+  const NodeGemm ng0{};
+#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, ng0)
   switch (mode) {          // the operand sets of BiFPN._forward_fast_attention: (in, up), (in, td, pool), (in, pool); others through the generic forms
     case 2: MMD_NODE_BWD(2); break;
     case 5: MMD_NODE_BWD(5); break;
@@ -982,6 +1073,29 @@ extern "C" int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, con
   return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, dzd, dx, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
                           BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
                           dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own, op_scale4, op_shift4);
+}
+
+// Whole-node backward (round 4): mmd_bifpn_node_dw_bwd3_lz with the node's 1x1 conv's input gradient inside the launch - dzd is not an
+// argument but computed per tile as BnBwd(g, z) . w_pw, with g the gradient w.r.t. the node's BatchNorm output, z its raw 1x1 output,
+// (scale, mean, invstd) of that BatchNorm, sums = [sum g, sum g xhat] over `count` rows, w_pw [C, C] the conv's weight.  dz_out [B*H*W, C]
+// receives the evaluated BatchNorm backward (the conv's weight-gradient GEMM reads it), dgamma / dbeta (+)= the sums.  Replaces
+// mmd_pwconv_bwd_data_bn + mmd_bifpn_node_dw_bwd3(_lz): one launch per node on the backward's chain instead of two.  C % 16 == 0, C <= 224.
+extern "C" int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const float* up, const float* pool,
+                                       const float* theta, const float* w_dw, float* wdot, int B,
+                                       int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                       float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0,
+                                       const float* z1, const float* mean1, const float* invstd1, double* sums1,
+                                       const float* zu, const float* meanu, const float* invstdu, double* sumsu,
+                                       float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own,
+                                       const void* op_scale4, const void* op_shift4,
+                                       const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd,
+                                       const double* bn_sums, long long count, const float* w_pw, float* dz_out, float* dgamma, float* dbeta,
+                                       hipStream_t stream) {
+  if (count <= 0) return MMD_EINVAL;
+  NodeGemm ng{g, z, bn_scale, bn_mean, bn_invstd, bn_sums, 1.0 / (double)count, w_pw, dz_out, dgamma, dbeta};
+  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, nullptr, nullptr, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
+                          BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
+                          dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own, op_scale4, op_shift4, &ng);
 }
 
 // d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   

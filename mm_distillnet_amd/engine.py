@@ -123,6 +123,9 @@ SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))
 # kernels while they load the operand (forward: from the live batch sums; backward: finalized coefficients) instead of by an mmd_affine_act
 # launch behind every producer: 40 launches less on the student's forward chain (MMD_NO_LAZY_NODE=1: the materialising form, for A/B timing)
 LAZY_NODE = not os.environ.get("MMD_NO_LAZY_NODE")
+# round 4: whole-node BiFPN backward - the node's 1x1 conv's input gradient (BatchNorm backward in its operand prologue) runs inside the node
+# backward launch (mmd_bifpn_node_bwd_full) instead of as a GEMM launch in front of it: 40 launches off the backward's serial chain
+NODE_BWD_FULL = not os.environ.get("MMD_NO_NODE_BWD_FULL")
 MBW_FUSED = not os.environ.get("MMD_NO_MBW")
 MBW_MIN_ROWS = int(os.environ.get("MMD_MBW_MIN_ROWS", "32768"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
@@ -1230,11 +1233,14 @@ class Net:
                 W = out.C
                 dz = self._bn_bwd(s.t, rec["z"], rec["bn"], f"{name}.bn", NONE, out.M, W, lazy=True,
                                   sums=s.sums if s.have_sums else None)
-                dzd = self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
+                in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
+                mode_ = (1 if in1 is not None else 0) | (2 if up is not None else 0) | (4 if pl is not None else 0)
+                full = (NODE_BWD_FULL and isinstance(dz, LazyDz) and ps.flat.is_cuda and self.NODE_WG and W % 16 == 0 and W <= 224 and mode_ in (2, 5, 4)
+                        and self.precision == "fp32" and (pl is None or (POOL_SCATTER and FOLD_SUMS)))
+                dzd = None if full else self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
                 # the depthwise weight gradient and the depthwise input gradient both come out of the fusion-backward launch below
                 if not self.NODE_WG:
                     self._dw_bwd(dzd, rec["f"], f"{name}.depthwise_conv.conv.weight", 3, 1, want_dx=False)
-                in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
                 th = ps.w(f"{cell}.{rec['theta']}")
                 nth = th.numel()
                 # gradients of the same-resolution operands (in0, in1) come straight out of the fuse backward launch; dx is
@@ -1271,6 +1277,29 @@ class Net:
                 theta_desc.append((ps.entries[f"{cell}.{rec['theta']}"].off, nth))
                 node_i += 1
                 lzb = [o is not None and o.bn is not None for o in (in0, in1, up, pl)]
+                if full:
+                    # whole-node backward: BatchNorm backward of the node + its 1x1 conv's input gradient + depthwise / fusion backward in ONE
+                    # launch; the evaluated dz is stored once for the conv's weight-gradient GEMM (grouped flush)
+                    dplargs = (None, None, None, None, None)
+                    if scatter:
+                        sl, xs = self._contrib(pl, True)
+                        if sl.t is None:
+                            sl.t = self._zalloc((pl.M, W))
+                        dplargs = (sl.t, *xsn(xs))
+                    vp = ctypes.c_void_p
+                    ops_ = (in0, in1, up, pl)
+                    scs = (vp * 4)(*[(o.scale.data_ptr() if l else None) for o, l in zip(ops_, lzb)])
+                    shs = (vp * 4)(*[(o.shift.data_ptr() if l else None) for o, l in zip(ops_, lzb)])
+                    L, bq = dz, ps.bn(dz.bn_name)
+                    wkey = f"{name}.pointwise_conv.conv.weight"
+                    dzm = self._alloc(out.M, W)
+                    call("mmd_bifpn_node_bwd_full", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                         ps.w(f"{name}.depthwise_conv.conv.weight"), wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
+                         ps.g(f"{name}.depthwise_conv.conv.weight"), *xsargs, *dplargs, own, scs if any(lzb) else None, shs if any(lzb) else None,
+                         L.g, L.z, L.aff[0], L.aff[2], L.aff[3], L.sums, L.count, ps.w(wkey), dzm, bq["dgamma"], bq["dbeta"])
+                    zdf = rec["zd"]
+                    self._pw_wgrad(dzm, zdf.z, ps.g(wkey), out.M, W, W, None, None, NONE, None, zdf.H * zdf.W)
+                    continue
                 if any(lzb):
                     # lazy operands: their values are read as z * scale + shift (finalized coefficients) inside the launch
                     assert scatter or pl is None

@@ -1838,3 +1838,45 @@ def test_bifpn_lazy_operands(mode, H, W, C, lazy):
     for a_, b_, what in zip(got, ref, ("wdot", "depthwise weight gradient", "d in0", "d in1", "d up", "d pool (scatter)")):
         if a_ is not None:
             close(a_, b_, 2e-4 if what == "wdot" else 3e-5, 1e-5 if what == "wdot" else 1e-6, what)
+
+
+@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 112), ("p7", 4, 4, 112), ("td", 32, 32, 112), ("bu", 6, 10, 64), ("td", 16, 16, 224), ("bu", 64, 64, 112)])
+def test_bifpn_node_bwd_full(mode, H, W, C):
+    """Round 4, whole-node backward: mmd_bifpn_node_bwd_full (the node's BatchNorm backward + 1x1 conv input gradient inside the node
+    backward launch) against the two launches it replaces - mmd_pwconv_bwd_data_bn, then mmd_bifpn_node_dw_bwd3 on its dzd: operand
+    gradients, fusion-weight dot products, depthwise weight gradient, pooled operand's scattered gradient, the stored dz, dgamma / dbeta."""
+    torch.manual_seed(H + W + C)
+    B = 2
+    M = B * H * W
+    has1, hasu, hasp = mode == "bu", mode == "td", mode in ("bu", "p7")
+    in0 = g(torch.randn(M, C)); in1 = g(torch.randn(M, C)) if has1 else None
+    up = g(torch.randn(M // 4, C)) if hasu else None
+    pl = g(torch.randn(4 * M, C) - 1.0) if hasp else None
+    theta = g(torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3]))
+    wd = g(torch.randn(9, C) / 3)
+    wp = torch.randn(C, C) / math.sqrt(C)
+    gg, zz = g(torch.randn(M, C)), g(torch.randn(M, C) * 1.2 + 0.1)
+    sc, sh, mu, istd = (g(t) for t in (torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.2, torch.rand(C) + 0.5))
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", gg, zz, sc, sh, mu, istd, 0, None, None, None, H * W, None, sums, M, C, None, 0)
+    # the two launches
+    dzd = torch.empty(M, C, device=DEV); dzm_r = torch.empty(M, C, device=DEV)
+    dga_r = torch.zeros(C, device=DEV); dbe_r = torch.zeros(C, device=DEV)
+    call("mmd_pwconv_bwd_data_bn", gg, zz, g(wp.t()), dzd, M, C, C, sc, sh, mu, istd, sums, M, 0, None, H * W, dzm_r, dga_r, dbe_r)
+
+    def outs():
+        return (torch.zeros(4, device=DEV), torch.zeros(9, C, device=DEV), torch.zeros(M, C, device=DEV),
+                torch.zeros(M, C, device=DEV) if has1 else None, torch.zeros(M // 4, C, device=DEV) if hasu else None,
+                torch.zeros(4 * M, C, device=DEV) if hasp else None)
+    wdot, dwg, d0, d1, du, dp = outs()
+    none12 = (None,) * 12
+    call("mmd_bifpn_node_dw_bwd3", in0, in1, up, pl, theta, wd, dzd, None, wdot, B, H, W, C, d0, 0, d1, 0, du, 0, dwg, *none12, dp, None, None, None, None, 0)
+    wdot2, dwg2, e0, e1, eu, ep = outs()
+    dzm = torch.full((M, C), float("nan"), device=DEV); dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
+    call("mmd_bifpn_node_bwd_full", in0, in1, up, pl, theta, wd, wdot2, B, H, W, C, e0, 0, e1, 0, eu, 0, dwg2, *none12, ep, None, None, None, None, 0,
+         None, None, gg, zz, sc, mu, istd, sums, M, g(wp), dzm, dga, dbe)
+    close(dzm, dzm_r, 1e-6, 1e-7, "stored dz")
+    assert torch.equal(dga, dga_r) and torch.equal(dbe, dbe_r)
+    for a_, b_, what in zip((wdot2, dwg2, e0, e1, eu, ep), (wdot, dwg, d0, d1, du, dp), ("wdot", "depthwise weight gradient", "d in0", "d in1", "d up", "d pool")):
+        if a_ is not None:
+            close(a_, b_, 3e-4 if what == "wdot" else 5e-5, 1e-4 if what == "wdot" else 2e-6, what)
