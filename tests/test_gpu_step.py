@@ -275,7 +275,11 @@ def test_d4_768_step_vs_oracle(B):
             rt = 2e-3 if same else 0.25
             print("D4/768 %s replay vs eager at B = %d: labels %s, reg %.6f / %.6f cls %.6f / %.6f" % (
                 precision, B, "equal" if same else "differ (integer truncation)", orp["reg"].item(), le[0], orp["cls"].item(), le[1]))
-            assert abs(orp["reg"].item() - le[0]) <= rt * abs(le[0]) and abs(orp["cls"].item() - le[1]) <= rt * abs(le[1])
+            # (classification loss with other labels: these random-weight D4 students saturate, every anchor whose assignment changes moves the
+            # focal sum by ~10 - measured 54 .. 112 over repeated eager bf16 steps of ONE state, tools/dev/diag_d4_labels.py - so only its order
+            # of magnitude is checked then)
+            assert abs(orp["reg"].item() - le[0]) <= rt * abs(le[0])
+            assert abs(orp["cls"].item() - le[1]) <= rt * abs(le[1]) if same else 0.4 < orp["cls"].item() / le[1] < 2.5
             np.testing.assert_allclose(orp["kd"].cpu().numpy(), le[2], rtol=2e-2 if same else 0.5, atol=1e-4)
             assert torch.isfinite(eng_b.student.ps.grad).all() and torch.isfinite(eng_b.student.ps.flat).all()
             del eng_b
