@@ -239,6 +239,9 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph
+    if os.environ.get("MMD_SERIAL"):      # (dev: the whole step as ONE chain - teachers, weight gradients and the regressor branch in line -
+        eng.concurrent_teachers = False   #  so that a kernel trace shows every launch alone, in order: tools/dev/trace_chain.py)
+        os.environ["MMD_NO_WG"] = "1"; os.environ["MMD_NO_SIDE"] = "1"
     log("engine loaded")
     if use_graph:
         eng.capture(batch)

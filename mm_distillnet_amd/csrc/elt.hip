@@ -8,6 +8,16 @@
 #include <cstdlib>
 
 #define ROWS_PER_BLOCK 256
+// Rows per block of the row-streaming elementwise / reduce kernels.  256 rows (16 loop trips per thread, four loads in flight at a time) suit
+// the chip-filling tensors; on the small maps the launch is a handful of blocks whose time is those four dependent batches of loads, so
+// they take 64 rows - one batch, every load of the thread in flight at once - on four times as many blocks.
+// (reducing kernels end in same-address f64 atomics, ~17 ns apiece: they keep the row-block count per channel <= 64)
+static inline int elt_rows_per_block(long long M, int C, bool reduces = false) {
+  const long long blocks = (long long)cdiv(C, 64) * cdiv(M, ROWS_PER_BLOCK);
+  int rpb = blocks >= 1024 ? ROWS_PER_BLOCK : (blocks >= 256 ? 128 : 64);
+  while (reduces && rpb < ROWS_PER_BLOCK && cdiv(M, rpb) > 64) rpb *= 2;
+  return rpb;
+}
 
 __device__ __forceinline__ float4 red_rowgroups(float4 v) {
   v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
@@ -113,15 +123,16 @@ extern "C" int mmd_bn_fold(const float* gamma, const float* beta, const float* r
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, BnLive bn, int act,
                                                          const float* __restrict__ rowscale, int rows_per_image,
-                                                         const float* __restrict__ res, float* __restrict__ y, int M, int C) {
+                                                         const float* __restrict__ res, float* __restrict__ y, int M, int C,
+                                                         int rpb) {
   const int tid = threadIdx.x;
   const int c = blockIdx.x * 64 + (tid & 15) * 4;
   if (c >= C) return;
   float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
   if (bn.stats) bn_live_coef4(bn, c, sc, sh);
   else if (scale) { sc = mmd_ld4(scale + c); sh = mmd_ld4(shift + c); }
-  const int r0 = blockIdx.y * ROWS_PER_BLOCK;
-  const int r1 = min(M, r0 + ROWS_PER_BLOCK);
+  const int r0 = blockIdx.y * rpb;
+  const int r1 = min(M, r0 + rpb);
 #pragma unroll 4
   for (int row = r0 + (tid >> 4); row < r1; row += 16) {
     size_t off = (size_t)row * C + c;
@@ -143,8 +154,9 @@ extern "C" int mmd_affine_act(const float* z, const float* scale, const float* s
   if (in_stats && (scale || !in_gamma || !in_beta || in_count <= 0)) return MMD_EINVAL;
   mmd_prof_tag(MMD_FAM_ELT, "affine M%lld C%lld r%lld", M, C, (long long)(res?1:0), 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
-  hipLaunchKernelGGL(affine_act_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, z, scale, shift,
-                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, rowscale, rows_per_image, res, y, M, C);
+  const int rpb = elt_rows_per_block(M, C);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(cdiv(C, 64), cdiv(M, rpb)), dim3(256), 0, stream, z, scale, shift,
+                     mmd_make_bn(in_stats, in_gamma, in_beta, in_count, C), act, rowscale, rows_per_image, res, y, M, C, rpb);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * (res ? 3 : 2));
   return mmd_check_launch();
 }
@@ -601,8 +613,9 @@ extern "C" int mmd_bn_bwd_reduce(const float* g_in, const float* z, const float*
   mmd_prof_tag(MMD_FAM_ELT, "bnred M%lld C%lld o%lld", M, C, (long long)(g_out?1:0), 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
   const bool slotted = stats_ws && ws_slots > 1 && cdiv(M, ROWS_PER_BLOCK) > MMD_STATS_DEPTH;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g_in, z, scale,
-                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C, Pyr{}, 0, ROWS_PER_BLOCK,
+  const int rpb = elt_rows_per_block(M, C, true);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, rpb)), dim3(256), 0, stream, g_in, z, scale,
+                     shift, mean, invstd, act, mul_bc, mul_b, add_bc, rows_per_image, g_out, sums, M, C, Pyr{}, 0, rpb,
                      slotted ? stats_ws : nullptr, ws_slots);
   if (slotted) mmd_stats_fold(sums, stats_ws, ws_slots, 2 * C, stream);
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * (g_out ? 3 : 2));
@@ -667,8 +680,9 @@ extern "C" int mmd_bn_bwd_apply(const float* g, const float* z, const float* mea
   if ((mul_bc || mul_b || add_bc) && rows_per_image <= 0) return MMD_EINVAL;
   mmd_prof_tag(MMD_FAM_ELT, "bnapp M%lld C%lld", M, C, 0, 0);
   mmd_prof_begin(MMD_FAM_ELT, stream);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, ROWS_PER_BLOCK)), dim3(256), 0, stream, g, z, mean,
-                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C, Pyr{}, 0, ROWS_PER_BLOCK,
+  const int rpb = elt_rows_per_block(M, C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(C, 64), cdiv(M, rpb)), dim3(256), 0, stream, g, z, mean,
+                     invstd, gamma, sums, (double)count, dz, dgamma, dbeta, M, C, Pyr{}, 0, rpb,
                      BnBwdMod{scale, shift, act, mul_bc, mul_b, add_bc, rows_per_image});
   mmd_prof_end(MMD_FAM_ELT, stream, 0.0, 4.0 * M * (double)C * 3);
   return mmd_check_launch();

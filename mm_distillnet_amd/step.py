@@ -315,8 +315,9 @@ class DistillEngine:
         # feature surgery (the augmented variant averages images 0 / 1 of each teacher's maps)
         G = len(self.teachers)
         use_pack = bool(self.pack and G > 1 and not aug and (B * (S // 128) ** 2) % 128 == 0 and S % 128 == 0)
+        npk = min(G, max(2, int(os.environ.get("MMD_PACK_SPLIT", G))))      # (dev: pack the first npk teachers, the others on their own streams)
         if use_pack:
-            nets = list(self.teachers.values())
+            nets = list(self.teachers.values())[:npk]
             net0 = nets[0]
             side = self.side_streams[0] if concurrent else main_stream
             if concurrent:
@@ -325,22 +326,20 @@ class DistillEngine:
                     side.wait_event(st.mark_event)
             with torch.cuda.stream(side):
                 net0.begin_step()
-                cls_p, reg_p, feats_p = net0.forward([batch[m] for m in self.teachers], train=False, pack=nets)
+                cls_p, reg_p, feats_p = net0.forward([batch[m] for m in list(self.teachers)[:npk]], train=False, pack=nets)
                 if teacher_labels is None:
-                    rows_p, cnt_p = self._pseudo_labels(net0, cls_p, reg_p, G * B, A, S)
+                    rows_p, cnt_p = self._pseudo_labels(net0, cls_p, reg_p, npk * B, A, S)
                 _, a_lv = self._attention(net0)
-            for gi in range(G):
+            for gi in range(npk):
                 if teacher_labels is not None:
                     r, c = teacher_labels[gi]
                 else:
                     r, c = rows_p[gi * B:(gi + 1) * B], cnt_p[gi * B:(gi + 1) * B]
                 rows_t.append(r); cnt_t.append(c)
                 att_t.append([a_lv[l][gi * B * f.H * f.W:(gi + 1) * B * f.H * f.W] for l, f in enumerate(feats_p)])
-            passes = [p_ for p_ in passes if p_[3] is not None]      # (the KD-list variant's extra RGB pass still runs on its own)
+            passes = [p_ for p_ in passes if p_[3] is not None or p_[2] >= npk]      # (the KD-list variant's extra RGB pass still runs on its own)
         for pi, (mod, net, si, xin) in enumerate(passes):
-            if use_pack:
-                pi = G + pi
-            ti = pi
+            ti = si if xin is None else G
             side = self.side_streams[si] if concurrent else main_stream
             if concurrent and xin is None:
                 side.wait_event(fork_event)
