@@ -684,6 +684,16 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 // all 7 pixel tiles; its 28 B values per lane come straight from L2 and stay in registers) and writes the dzd tile into sIn - where the
 // plain form stages it from HBM.  The halo is recomputed by the neighbouring blocks (1.56x of a 2.5 MFLOP product); dzd never exists in
 // HBM.  The chunk-0 blocks store dz (interior pixels) for the conv's weight-gradient GEMM; block 0 adds dgamma / dbeta.
+// -DMMD_NODE_TIMING (dev build, tools/dev/node_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock at the phase boundaries
+#ifdef MMD_NODE_TIMING
+__device__ unsigned long long g_node_t[16];
+#define NODE_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); g_node_t[i] = wall_clock64(); } } while (0)
+extern "C" int mmd_node_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_node_t), sizeof(g_node_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define NODE_T(i)
+#endif
 struct NodeGemm {
   const float* g; const float* z; const float* scale; const float* mean; const float* invstd; const double* sums; double inv_count;
   const float* w;          // the 1x1 conv's weight [C out][C in] (native layout): dzd[p, c] = sum_n dz[p, n] w[n, c]
@@ -708,6 +718,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   __shared__ float sBn[4 * 2 * 4 * 64];            // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel]
   __shared__ float sCo[8 * 64];                    // lazy operands' (scale, shift) of this block's channel chunk
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
+  NODE_T(0);
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
@@ -746,24 +757,51 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     for (int kk = 0; kk < 14; ++kk)
 #pragma unroll
       for (int j = 0; j < 4; ++j) bw[kk][j] = (kk * 16 < C && cvalid) ? ng.w[(size_t)(kk * 16 + 4 * gq + j) * C + cb] : 0.f;
-    __syncthreads();                                // coefficients visible
-    for (int it = tid; it < IH * IW * NQ; it += 256) {
-      const int pp = it / NQ, q = it - pp * NQ;
-      const int ih = oh0 - 1 + pp / IW, iw = ow0 - 1 + pp % IW;
-      float4 d = make_float4(0, 0, 0, 0);
-      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-        const size_t off = (((size_t)b * a.H + ih) * a.W + iw) * C + q * 4;
-        const float4 gv = mmd_ld4(ng.g + off), zv = mmd_ld4(ng.z + off);
-        const float4 a1 = *reinterpret_cast<const float4*>(&sCf[q * 4]), a2 = *reinterpret_cast<const float4*>(&sCf[C + q * 4]);
-        const float4 a3 = *reinterpret_cast<const float4*>(&sCf[2 * C + q * 4]), mu = *reinterpret_cast<const float4*>(&sCf[3 * C + q * 4]);
-        d.x = a1.x * gv.x + a2.x * (zv.x - mu.x) + a3.x; d.y = a1.y * gv.y + a2.y * (zv.y - mu.y) + a3.y;
-        d.z = a1.z * gv.z + a2.z * (zv.z - mu.z) + a3.z; d.w = a1.w * gv.w + a2.w * (zv.w - mu.w) + a3.w;
-        const int py = pp / IW, px = pp % IW;      // interior pixels, once per tile: the stored dz the weight-gradient GEMM reads
-        if (cc == 0 && ng.dz_out && py >= 1 && py <= TH && px >= 1 && px <= TW) mmd_st4(ng.dz_out + off, d);
+    // dz tile: U items (pixel, channel quad) per trip, all of a trip's loads in flight together; the FIRST trip is issued before the
+    // coefficient barrier, so its round trip overlaps the one of the batch sums / weights above (C = 112: two trips in all, one exposed)
+    constexpr int U = 6;
+    const int TOT = IH * IW * NQ;
+    float4 gv[U], zv[U];
+    size_t off[U];
+    int ppv[U], qv[U];
+    bool ok[U];
+    auto issue = [&](int it0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * 256;
+        const int pp = it / NQ, q = it - pp * NQ;
+        const int ih = oh0 - 1 + pp / IW, iw = ow0 - 1 + pp % IW;
+        ppv[u] = pp; qv[u] = q;
+        ok[u] = it < TOT && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        off[u] = (((size_t)b * a.H + ih) * a.W + iw) * C + q * 4;
+        if (ok[u]) { gv[u] = mmd_ld4(ng.g + off[u]); zv[u] = mmd_ld4(ng.z + off[u]); }
       }
-      *reinterpret_cast<float4*>(&sDz[pp * LDZ + q * 4]) = d;      // pixels outside the image: dz = 0 -> dzd = 0 (what the plain form stages)
-    }
+    };
+    auto finish = [&](int it0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (it0 + u * 256 < TOT) {
+          const int pp = ppv[u], q = qv[u];
+          float4 d = make_float4(0, 0, 0, 0);
+          if (ok[u]) {
+            const float4 a1 = *reinterpret_cast<const float4*>(&sCf[q * 4]), a2 = *reinterpret_cast<const float4*>(&sCf[C + q * 4]);
+            const float4 a3 = *reinterpret_cast<const float4*>(&sCf[2 * C + q * 4]), mu = *reinterpret_cast<const float4*>(&sCf[3 * C + q * 4]);
+            d.x = a1.x * gv[u].x + a2.x * (zv[u].x - mu.x) + a3.x; d.y = a1.y * gv[u].y + a2.y * (zv[u].y - mu.y) + a3.y;
+            d.z = a1.z * gv[u].z + a2.z * (zv[u].z - mu.z) + a3.z; d.w = a1.w * gv[u].w + a2.w * (zv[u].w - mu.w) + a3.w;
+            const int py = pp / IW, px = pp % IW;      // interior pixels, once per tile: the stored dz the weight-gradient GEMM reads
+            if (cc == 0 && ng.dz_out && py >= 1 && py <= TH && px >= 1 && px <= TW) mmd_st4(ng.dz_out + off[u], d);
+          }
+          *reinterpret_cast<float4*>(&sDz[pp * LDZ + q * 4]) = d;      // pixels outside the image: dz = 0 -> dzd = 0 (what the plain form stages)
+        }
+      }
+    };
+    issue(tid);
+    __syncthreads();                                // coefficients visible
+    NODE_T(1);
+    finish(tid);
+    for (int it0 = tid + 256 * U; it0 < TOT; it0 += 256 * U) { issue(it0); finish(it0); }
     __syncthreads();
+    NODE_T(2);
     // dzd tile: 7 pixel tiles x this wave's 16 channels
     f32x4 acc7[7];
 #pragma unroll
@@ -798,6 +836,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
   }
   __syncthreads();
+  NODE_T(3);
   const int p = tid >> 4;
   const int orow = p / (TW / R);
   const int ocol0 = (p % (TW / R)) * R;
@@ -820,6 +859,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       }
     }
   }
+  NODE_T(4);
   float d[3] = {0.f, 0.f, 0.f};
   const int oh = oh0 + orow;
   const FuseCoef fco{sCo, c4};                     // lazy operands: the finalized BatchNorm coefficients of the block's channel chunk (LDS)
@@ -835,60 +875,153 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     if ((MODE & 1) && x1.z) { mu1 = mmd_ld4(x1.mean + c); is1 = mmd_ld4(x1.invstd + c); }
     if ((MODE & 2) && xu.z) { muu = mmd_ld4(xu.mean + c); isu = mmd_ld4(xu.invstd + c); }
   }
+  // The thread's four pixels in two pairs: every global load of a pair - operands, the pooled operand's 3x3 windows (loaded ONCE: value,
+  // arg-max and the raw element at the arg-max come from the same registers), the running gradients, the BatchNorm inputs of the sums -
+  // is issued before anything of the pair is consumed: one round trip per pair where the pixel-by-pixel form took three per pixel
+  // (18 of the 35 us of a pooled-operand node on the small maps, tools/dev/node_phases.py)
+  constexpr int NWIN = (MODE & 4) ? 9 : 1;
 #pragma unroll
-  for (int o = 0; o < R; ++o) {
-    const int ow = ow0 + ocol0 + o;
-    gq[o] = make_float4(0, 0, 0, 0); fq[o] = make_float4(0, 0, 0, 0);
-    if (cok && oh < a.H && ow < a.W) {
-      float4 t[4];
-      float4 sv = fuse_presum<MODE>(a, w, b, oh, ow, c, &t[0], &t[1], &t[2], &t[3], a.lazy ? &fco : nullptr);
-      const size_t off = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
-      if (dwg) fq[o] = make_float4(mmd_swish(sv.x), mmd_swish(sv.y), mmd_swish(sv.z), mmd_swish(sv.w));      // the node's fused activation
-      float4 g = acc[o];
-      g.x *= mmd_swish_grad(sv.x); g.y *= mmd_swish_grad(sv.y); g.z *= mmd_swish_grad(sv.z); g.w *= mmd_swish_grad(sv.w);
-      gq[o] = g;
-      if (dx) mmd_st4(dx + off, g);
-      if (d0) {
-        float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
-        const float4 mine = v;
-        if (acc0) { float4 q = mmd_ld4(d0 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        mmd_st4(d0 + off, v);
-        if (x0.z) bnsum_acc4(x0, off, (own & 1) ? mine : v, mu0, is0, bs0, bq0);
-      }
-      if (d1) {
-        float4 v = make_float4(g.x * w[1], g.y * w[1], g.z * w[1], g.w * w[1]);
-        const float4 mine = v;
-        if (acc1) { float4 q = mmd_ld4(d1 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-        mmd_st4(d1 + off, v);
-        if ((MODE & 1) && x1.z) bnsum_acc4(x1, off, (own & 2) ? mine : v, mu1, is1, bs1, bq1);
-      }
-      if ((MODE & 4) && dpl) {
-        int arg[4];
-        if (a.lazy & 8) pool_window_arg(a.pl, b, oh, ow, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, arg, true, fco.sc(3), fco.sh(3));
-        else pool_window_arg(a.pl, b, oh, ow, c, a.PH, a.PW, a.C, a.pad_t, a.pad_l, arg);
-        const float wp = w[1 + ((MODE & 1) ? 1 : 0) + ((MODE & 2) ? 1 : 0)];
-        const float gv[4] = {g.x * wp, g.y * wp, g.z * wp, g.w * wp};
-        const float muv[4] = {mup.x, mup.y, mup.z, mup.w}, isv[4] = {isp.x, isp.y, isp.z, isp.w};
-        float sv[4] = {0.f, 0.f, 0.f, 0.f}, qv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int h2 = 0; h2 < R; h2 += 2) {
+    float4 r0[2], r1[2], ru[2], qd0[2], qd1[2], zb0[2], zb1[2], win[2][NWIN];
+    unsigned inb[2] = {0u, 0u};
+    bool okp[2];
+    size_t offp[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (arg[q] >= 0) {
-            const int yy = oh * 2 - a.pad_t + arg[q] / 3, xx = ow * 2 - a.pad_l + arg[q] % 3;
-            const size_t so = (((size_t)b * a.PH + yy) * a.PW + xx) * a.C + c + q;
-            atomicAdd(&dpl[so], gv[q]);
-            if (xp.z) { sv[q] = gv[q]; qv[q] = gv[q] * (xp.z[so] - muv[q]) * isv[q]; }
+    for (int oo = 0; oo < 2; ++oo) {
+      const int ow = ow0 + ocol0 + h2 + oo;
+      okp[oo] = cok && oh < a.H && ow < a.W;
+      offp[oo] = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
+      r0[oo] = r1[oo] = ru[oo] = qd0[oo] = qd1[oo] = zb0[oo] = zb1[oo] = z4;
+      if (okp[oo]) {
+        r0[oo] = mmd_ld4(a.in0 + offp[oo]);
+        if (MODE & 1) r1[oo] = mmd_ld4(a.in1 + offp[oo]);
+        if (MODE & 2) ru[oo] = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (oh >> 1)) * (a.W >> 1) + (ow >> 1)) * a.C + c);
+        if (MODE & 4) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int y = oh * 2 - a.pad_t + i;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int x = ow * 2 - a.pad_l + j;
+              win[oo][i * 3 + j] = z4;
+              if (y >= 0 && y < a.PH && x >= 0 && x < a.PW) {
+                win[oo][i * 3 + j] = mmd_ld4(a.pl + (((size_t)b * a.PH + y) * a.PW + x) * a.C + c);
+                inb[oo] |= 1u << (i * 3 + j);
+              }
+            }
           }
         }
-        bsp.x += sv[0]; bsp.y += sv[1]; bsp.z += sv[2]; bsp.w += sv[3];
-        bqp.x += qv[0]; bqp.y += qv[1]; bqp.z += qv[2]; bqp.w += qv[3];
+        if (d0 && acc0) qd0[oo] = mmd_ld4(d0 + offp[oo]);
+        if (d1 && acc1) qd1[oo] = mmd_ld4(d1 + offp[oo]);
+        if (d0 && x0.z) zb0[oo] = (x0.z == a.in0) ? r0[oo] : mmd_ld4(x0.z + offp[oo]);      // (a lazy operand IS its BatchNorm's input)
+        if ((MODE & 1) && d1 && x1.z) zb1[oo] = (x1.z == a.in1) ? r1[oo] : mmd_ld4(x1.z + offp[oo]);
       }
-      int wi = 0;
-      d[wi++] += g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
-      if (MODE & 1) d[wi++] += g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
-      if (MODE & 2) d[wi++] += g.x * t[2].x + g.y * t[2].y + g.z * t[2].z + g.w * t[2].w;
-      if (MODE & 4) d[wi++] += g.x * t[3].x + g.y * t[3].y + g.z * t[3].z + g.w * t[3].w;
     }
+    NODE_T(9 + h2);
+#pragma unroll
+    for (int oo = 0; oo < 2; ++oo) {
+      const int o = h2 + oo;
+      const int ow = ow0 + ocol0 + o;
+      gq[o] = z4; fq[o] = z4;
+      if (okp[oo]) {
+        const size_t off = offp[oo];
+        float4 t[4];
+        float4 sv = z4;
+        int wi = 0;
+        {
+          float4 v = r0[oo];
+          if (a.lazy) v = fuse_aff4(v, fco.sc(0), fco.sh(0));
+          t[0] = v; sv.x += w[wi] * v.x; sv.y += w[wi] * v.y; sv.z += w[wi] * v.z; sv.w += w[wi] * v.w; ++wi;
+        }
+        if (MODE & 1) {
+          float4 v = r1[oo];
+          if (a.lazy) v = fuse_aff4(v, fco.sc(1), fco.sh(1));
+          t[1] = v; sv.x += w[wi] * v.x; sv.y += w[wi] * v.y; sv.z += w[wi] * v.z; sv.w += w[wi] * v.w; ++wi;
+        }
+        if (MODE & 2) {
+          float4 v = ru[oo];
+          if (a.lazy) v = fuse_aff4(v, fco.sc(2), fco.sh(2));
+          t[2] = v; sv.x += w[wi] * v.x; sv.y += w[wi] * v.y; sv.z += w[wi] * v.z; sv.w += w[wi] * v.w; ++wi;
+        }
+        int arg[4] = {-1, -1, -1, -1};
+        float praw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE & 4) {
+          // value = max over the window with the zero padding taking part; arg = tap of the FIRST maximum in row-major order, -1 when a
+          // padding element wins (pool_window / pool_window_arg above, from one set of loads)
+          const bool paff = (a.lazy & 8) != 0;
+          const float4 psc = a.lazy ? fco.sc(3) : make_float4(1, 1, 1, 1), psh = a.lazy ? fco.sh(3) : z4;
+          float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const bool in = (inb[oo] >> tap) & 1u;
+            const float4 raw = win[oo][tap];
+            float4 v = raw;
+            if (in && paff) v = fuse_aff4(v, psc, psh);
+            const float vv[4] = {v.x, v.y, v.z, v.w}, rv[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (vv[q] > best[q]) { best[q] = vv[q]; arg[q] = in ? tap : -1; praw[q] = rv[q]; }
+          }
+          const float4 v = make_float4(best[0], best[1], best[2], best[3]);
+          t[3] = v; sv.x += w[wi] * v.x; sv.y += w[wi] * v.y; sv.z += w[wi] * v.z; sv.w += w[wi] * v.w; ++wi;
+        }
+        if (dwg) fq[o] = make_float4(mmd_swish(sv.x), mmd_swish(sv.y), mmd_swish(sv.z), mmd_swish(sv.w));      // the node's fused activation
+        float4 g = acc[o];
+        g.x *= mmd_swish_grad(sv.x); g.y *= mmd_swish_grad(sv.y); g.z *= mmd_swish_grad(sv.z); g.w *= mmd_swish_grad(sv.w);
+        gq[o] = g;
+        if (dx) mmd_st4(dx + off, g);
+        if (d0) {
+          float4 v = make_float4(g.x * w[0], g.y * w[0], g.z * w[0], g.w * w[0]);
+          const float4 mine = v;
+          if (acc0) { const float4 q = qd0[oo]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          mmd_st4(d0 + off, v);
+          if (x0.z) {
+            const float4 gs = (own & 1) ? mine : v, zz = zb0[oo];
+            bs0.x += gs.x; bs0.y += gs.y; bs0.z += gs.z; bs0.w += gs.w;
+            bq0.x += gs.x * (zz.x - mu0.x) * is0.x; bq0.y += gs.y * (zz.y - mu0.y) * is0.y;
+            bq0.z += gs.z * (zz.z - mu0.z) * is0.z; bq0.w += gs.w * (zz.w - mu0.w) * is0.w;
+          }
+        }
+        if (d1) {
+          float4 v = make_float4(g.x * w[1], g.y * w[1], g.z * w[1], g.w * w[1]);
+          const float4 mine = v;
+          if (acc1) { const float4 q = qd1[oo]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          mmd_st4(d1 + off, v);
+          if ((MODE & 1) && x1.z) {
+            const float4 gs = (own & 2) ? mine : v, zz = zb1[oo];
+            bs1.x += gs.x; bs1.y += gs.y; bs1.z += gs.z; bs1.w += gs.w;
+            bq1.x += gs.x * (zz.x - mu1.x) * is1.x; bq1.y += gs.y * (zz.y - mu1.y) * is1.y;
+            bq1.z += gs.z * (zz.z - mu1.z) * is1.z; bq1.w += gs.w * (zz.w - mu1.w) * is1.w;
+          }
+        }
+        if ((MODE & 4) && dpl) {
+          const float wp = w[1 + ((MODE & 1) ? 1 : 0) + ((MODE & 2) ? 1 : 0)];
+          const float gv[4] = {g.x * wp, g.y * wp, g.z * wp, g.w * wp};
+          const float muv[4] = {mup.x, mup.y, mup.z, mup.w}, isv[4] = {isp.x, isp.y, isp.z, isp.w};
+          const bool zsame = xp.z == a.pl;          // a lazy pooled operand is its BatchNorm's input: the arg-max element is in registers
+          float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (arg[q] >= 0) {
+              const int yy = oh * 2 - a.pad_t + arg[q] / 3, xx = ow * 2 - a.pad_l + arg[q] % 3;
+              const size_t so = (((size_t)b * a.PH + yy) * a.PW + xx) * a.C + c + q;
+              atomicAdd(&dpl[so], gv[q]);
+              if (xp.z) { s4[q] = gv[q]; q4[q] = gv[q] * ((zsame ? praw[q] : xp.z[so]) - muv[q]) * isv[q]; }
+            }
+          }
+          bsp.x += s4[0]; bsp.y += s4[1]; bsp.z += s4[2]; bsp.w += s4[3];
+          bqp.x += q4[0]; bqp.y += q4[1]; bqp.z += q4[2]; bqp.w += q4[3];
+        }
+        int wj = 0;
+        d[wj++] += g.x * t[0].x + g.y * t[0].y + g.z * t[0].z + g.w * t[0].w;
+        if (MODE & 1) d[wj++] += g.x * t[1].x + g.y * t[1].y + g.z * t[1].z + g.w * t[1].w;
+        if (MODE & 2) d[wj++] += g.x * t[2].x + g.y * t[2].y + g.z * t[2].z + g.w * t[2].w;
+        if (MODE & 4) d[wj++] += g.x * t[3].x + g.y * t[3].y + g.z * t[3].z + g.w * t[3].w;
+      }
+    }
+    NODE_T(10 + h2);
   }
+  NODE_T(5);
   const int wave = tid >> 6, lane = tid & 63;
   if ((MODE & 2) && dup) {
     // gradient of the nearest-upsampled operand: w_up * (sum over the 2x2 block).  A thread holds 4 pixels of one row (two
@@ -947,7 +1080,9 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         }
     }
   }
+  NODE_T(6);
   __syncthreads();                                  // sred / sBn complete; every read of the dzd tile done
+  NODE_T(7);
   if (tid < a.ntheta) atomicAdd(&wdot[tid], sred[tid] + sred[3 + tid] + sred[6 + tid] + sred[9 + tid]);
   if (tid < 128 && c0 + (tid & 63) < a.C) {         // threads 0..63: sum g, 64..127: sum g*xhat
     const int q = tid & 63, hq = tid >> 6;
@@ -976,6 +1111,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         atomicAdd(&dwg[(size_t)(8 - t) * a.C + c0 + q], sRedW[(0 * 9 + t) * 64 + q] + sRedW[(1 * 9 + t) * 64 + q] + sRedW[(2 * 9 + t) * 64 + q] + sRedW[(3 * 9 + t) * 64 + q]);
     }
   }
+  NODE_T(8);
 }
 static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up, const float* pool,
                             const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
