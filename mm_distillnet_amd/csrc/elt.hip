@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict_
   const float* p = pooled + (size_t)b * C;
   const float* w = wr + (size_t)j * C;
   float acc = 0.f;
+#pragma unroll 4
   for (int c = lane * 4; c < C; c += 256) {
     float4 a = mmd_ld4(p + c), q = mmd_ld4(w + c);
     acc += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   float acc = be[c];
+#pragma unroll 8
   for (int j = 0; j < S; ++j) acc += wet[(size_t)j * C + c] * sh[j];      // wet [S][C]: coalesced over c
   gate[(size_t)b * C + c] = mmd_sigmoid(acc);
 }
@@ -354,12 +356,17 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* __restrict__
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.y * 4 + wave;
   if (j >= S) return;
+  // channel quads, four trips' loads in flight together: the launch is ~100 waves of a few KB each - its time is its dependent round trips
+  const float* gp = gate + (size_t)b * C;
+  const float* dp = dgate + (size_t)b * C;
+  const float* wp = wet + (size_t)j * C;
   float acc = 0.f;
-  for (int c = lane; c < C; c += 64) {
-    float g = gate[(size_t)b * C + c];
-    float d = dgate[(size_t)b * C + c] * g * (1.f - g);
-    if (j == 0) dpe[(size_t)b * C + c] = d;
-    acc += wet[(size_t)j * C + c] * d;
+#pragma unroll 4
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 g = mmd_ld4(gp + c), dg = mmd_ld4(dp + c), w = mmd_ld4(wp + c);
+    const float4 d = make_float4(dg.x * g.x * (1.f - g.x), dg.y * g.y * (1.f - g.y), dg.z * g.z * (1.f - g.z), dg.w * g.w * (1.f - g.w));
+    if (j == 0) mmd_st4(dpe + (size_t)b * C + c, d);
+    acc += w.x * d.x + w.y * d.y + w.z * d.z + w.w * d.w;
   }
   acc = wave_sum(acc);
   if (lane == 0) dh[(size_t)b * S + j] = acc;
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* __restrict__
   const int c = blockIdx.y * 256 + tid;
   if (c >= C) return;
   float acc = 0.f;
+#pragma unroll 8
   for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sd[j];
   const float dp = acc * dpool_scale;
   dpooled[(size_t)b * C + c] = dp;
@@ -428,7 +436,7 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
                              int C, int S, const float* pool5, double* bn_sums, hipStream_t stream) {
   if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dh_zeroed || !dpooled) return MMD_EINVAL;
   if (dwr && (!dbr || !dwe || !dbe)) return MMD_EINVAL;         // dwr == NULL: weight gradients left to mmd_se_fc_wgrad
-  if (B <= 0 || C <= 0 || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
+  if (B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
   hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, dgate, gate, we, dpe_ws, dh_zeroed, C, S);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dh_zeroed, hpre, wr, dpr_ws, dpooled,
                      dpool_scale, C, S, gate, pool5, bn_sums, B);
@@ -472,6 +480,7 @@ __global__ __launch_bounds__(256) void se_bwd_ab_kernel(const float* __restrict_
   const int c = blockIdx.y * 256 + tid;
   if (c >= C) return;
   float acc = 0.f;
+#pragma unroll 8
   for (int j = 0; j < S; ++j) acc += wr[(size_t)j * C + c] * sd[j];
   const float dp = acc * dpool_scale;
   dpooled[(size_t)b * C + c] = dp;

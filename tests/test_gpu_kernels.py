@@ -507,14 +507,18 @@ def test_se_path(C, S):
     dpe3, dpr3, dpooled3 = torch.empty(B, C, device=DEV), torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
     sums3 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     call("mmd_se_fc_bwd_fused", pool5[0], dg, dh, g(wr), wet, dpe3, dpr3, dpooled3, 1.0 / HW, B, C, S, pool5, sums3)
-    assert torch.equal(dpe3, dpe) and torch.equal(dpr3, dpr) and torch.equal(dpooled3, dpooled2)
+    # (the hidden gradient's dot product runs over channel quads in the two-launch form and over single channels in the fused one: equal up
+    #  to the summation order)
+    assert torch.equal(dpe3, dpe)
+    close(dpr3, dpr, 1e-5, 1e-6); close(dpooled3, dpooled2, 1e-5, 1e-6)
     close(sums3, sums2, 1e-6, 1e-7, "BN-1 sums of the fused launch")
     g3 = [torch.zeros_like(t) for t in (gwr, gbr, gwe, gbe)]
     g4 = [torch.ones_like(t) for t in (gwr, gbr, gwe, gbe)]          # a second "block" (same operands) accumulating onto ones
     tab = torch.tensor([[t.data_ptr() for t in (dpe3, dpr3, dh, dpool, *gs)] + [C, S] for gs in (g3, g4)], dtype=torch.int64, device=DEV)
     call("mmd_se_fc_wgrad_batched", tab, 2, C * S, B)
     for a_, b_, c_ in zip(g3, g4, g2):
-        assert torch.equal(a_, c_) and torch.allclose(b_, c_ + 1, rtol=0, atol=1e-6)
+        close(a_, c_, 1e-5, 1e-6)       # (computed from dpr3, which equals dpr up to the summation order - see above)
+        assert torch.allclose(b_, a_ + 1, rtol=0, atol=1e-6)
 
 
 def test_colsum_slice_sigmoid():
