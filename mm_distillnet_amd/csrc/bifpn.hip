@@ -715,7 +715,11 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   __shared__ float sIn[IH * IW * 64];
   __shared__ float sW[9 * 64];
   __shared__ float sred[4 * 3];
-  __shared__ float sBn[4 * 2 * 4 * 64];            // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel]
+  // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel].  GEMM form: they live in the dz
+  // tile's place (dead behind the MFMA phase) - with the 100-row tile that brings the block to 78 KB, two blocks per CU on the large maps
+  extern __shared__ float sDyn[];
+  __shared__ float sBnS[GEMM ? 4 : 4 * 2 * 4 * 64];
+  float* const sBn = GEMM ? sDyn : sBnS;
   __shared__ float sCo[8 * 64];                    // lazy operands' (scale, shift) of this block's channel chunk
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   NODE_T(0);
@@ -737,10 +741,9 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
   }
   if constexpr (GEMM) {
-    extern __shared__ float sDyn[];
     const int C = a.C, LDZ = C + 4, NQ = C >> 2;
-    float* const sDz = sDyn;                        // [112 pixel rows (100 used)][LDZ]
-    float* const sCf = sDyn + 112 * LDZ;            // [4][C]: a1, a2, a3, mu of the BatchNorm backward
+    float* const sDz = sDyn;                        // [100 pixel rows][LDZ] (the seventh 16-row MFMA tile re-reads row 99 for its rows 100 .. 111)
+    float* const sCf = sDyn + IH * IW * LDZ;        // [4][C]: a1, a2, a3, mu of the BatchNorm backward
     for (int n = tid; n < C; n += 256) {
       const float m1 = (float)(ng.sums[n] * ng.inv_count), m2 = (float)(ng.sums[C + n] * ng.inv_count);
       const float sc = ng.scale[n];
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       if (kk < nkk) {
 #pragma unroll
         for (int mt = 0; mt < 7; ++mt) {
-          const float4 av = *reinterpret_cast<const float4*>(&sDz[(mt * 16 + r) * LDZ + kk * 16 + 4 * gq]);
+          const float4 av = *reinterpret_cast<const float4*>(&sDz[min(mt * 16 + r, IH * IW - 1) * LDZ + kk * 16 + 4 * gq]);
           acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bw[kk][0], acc7[mt], 0, 0, 0);
           acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bw[kk][1], acc7[mt], 0, 0, 0);
           acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bw[kk][2], acc7[mt], 0, 0, 0);
@@ -1134,7 +1137,7 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
-    const size_t lds = (size_t)(112 * (C + 4) + 4 * C) * sizeof(float);
+    const size_t lds = (size_t)(100 * (C + 4) + 4 * C) * sizeof(float);
 #define MMD_NODE_BWD_G(M) do { static bool attr = false; \
       if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr = true; } \
       hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
