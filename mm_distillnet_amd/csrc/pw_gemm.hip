@@ -1018,7 +1018,9 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
 #define SK_PICK(P, F) (a.bf16 ? pw_gemm_skinny_kernel<true, P, F> : pw_gemm_skinny_kernel<false, P, F>)
     // (PF = 2 instantiates and runs, but hipcc drains both register stages before each LDS store - its waitcnt pass counts down to
     // vmcnt(0) across the per-lane masking branches - so it measured 1 % slower than PF = 1; see profiles/r01_notes.md)
-    sk = pro == 1 ? SK_PICK(1, 1) : pro == 3 ? SK_PICK(3, 1) : pro == 4 ? SK_PICK(4, 1) : SK_PICK(0, 1);
+    static const int sk_pf2 = getenv("MMD_SK_PF2") ? atoi(getenv("MMD_SK_PF2")) : 0;      // (dev: bit 0 = BatchNorm-backward operand launches, bit 1 = the others, with two register stages)
+    sk = pro == 1 ? ((sk_pf2 & 1) ? SK_PICK(1, 2) : SK_PICK(1, 1)) : pro == 3 ? SK_PICK(3, 1) : pro == 4 ? SK_PICK(4, 1)
+       : ((sk_pf2 & 2) ? SK_PICK(0, 2) : SK_PICK(0, 1));
 #undef SK_PICK
     hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), 0, stream, a);
   } else {
