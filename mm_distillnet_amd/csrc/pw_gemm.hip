@@ -414,6 +414,14 @@ static void (*pw_pick_lean(int nkl, int bf))(PwArgs) {
 #define SK_BK 128
 #define SK_LD 132
 
+// -DMMD_KSTAMPS (dev build, tools/dev/skinny_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock along the K loop
+#ifdef MMD_KSTAMPS
+__device__ unsigned long long g_kst[128];
+#define MMD_KT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 128) g_kst[i] = wall_clock64(); } while (0)
+extern "C" int mmd_k_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kst), sizeof(g_kst)) == hipSuccess ? 0 : -1; }
+#else
+#define MMD_KT(i)
+#endif
 // PF = register prefetch depth.  The skinny launches have at most one or two blocks per CU, so nothing but the block itself hides
 // its load latency: with PF = 2 the loads of K steps t+1 and t+2 are in flight while step t is multiplied (two register stages,
 // ~250 VGPRs - occupancy is irrelevant at these grid sizes).
@@ -562,6 +570,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   };
 
   const int nk = (a.K + SK_BK - 1) / SK_BK;
+  MMD_KT(0);
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
     if (s < nk) gload(s * SK_BK, st[s]);
@@ -572,16 +581,24 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     for (int s = 0; s < PF; ++s) {
       const int kt = kt0 + s;
       if (kt < nk) {                               // block-uniform
+#ifdef MMD_KSTAMPS
+        __builtin_amdgcn_s_waitcnt(0); MMD_KT(64 + kt);      // (dev build only: the step's loads have landed)
+#endif
         lstore(st[s]);
+        MMD_KT(1 + 4 * kt);
         __syncthreads();
+        MMD_KT(2 + 4 * kt);
         if (kt + PF < nk) gload((kt + PF) * SK_BK, st[s]);
         if constexpr (PF > 1) __builtin_amdgcn_sched_barrier(0);
         mma();
+        MMD_KT(3 + 4 * kt);
         __syncthreads();
+        MMD_KT(4 + 4 * kt);
       }
     }
   }
   // ---- cross-wave K reduction through LDS: part[wave][row][col], row-major 32 x 64
+  MMD_KT(120);
   float* part = sB;
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -679,6 +696,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       atomicAdd(&stats[a.N + n0 + tid], (double)q2);
     }
   }
+  MMD_KT(121);
 }
 
 // ------------------------------------------------------------------------------------------
