@@ -155,6 +155,14 @@ __device__ __forceinline__ void dw_stage_input_bnbwd(const DwArgs& a, float* sIn
 // WG (with EPI 2): the weight gradient of the forward conv out of the same launch - the dY tile is in LDS, the forward input a0 = swish(u)
 // is recomputed for the BatchNorm sums anyway; k*k float4 sums per thread, one block reduction, k*k*CC atomics per block.  A depthwise
 // weight-gradient launch is a leaf whose kernel time the saturated chip pays in full (profiles/r02_notes.md).
+// -DMMD_DWSTAMPS (dev build, tools/dev/dw_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock at the phase boundaries
+#ifdef MMD_DWSTAMPS
+__device__ unsigned long long g_dwst[16];
+#define MMD_DT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dwst[i] = wall_clock64(); } while (0)
+extern "C" int mmd_dw_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dwst), sizeof(g_dwst)) == hipSuccess ? 0 : -1; }
+#else
+#define MMD_DT(i)
+#endif
 template <int K, int S, int LANES = 16, int PRO = 1, int EPI = 4, bool WG = false>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   using Cf = DwCfg<K, S, LANES>;
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   __shared__ float sW[K * K * CC];
   __shared__ float sRed[2 * 4 * CC];
   const int tid = threadIdx.x;
+  MMD_DT(0);
   // XCD-aware order: blocks are dealt round-robin to the 8 XCDs; remap so that each XCD's L2 sees a contiguous run of tiles
   // (neighbouring tiles share halo rows / columns)
   int bid = (a.pyr.n || a.noswz) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
@@ -211,7 +220,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   } else {
     dw_stage_input<K, S, LANES, PRO != 0>(v, sIn, b, oh0 * S - a.pad_t, ow0 * S - a.pad_l, c0, tid);
   }
+  MMD_DT(1);
   __syncthreads();
+  MMD_DT(2);
 
   const int p = tid / LANES;
   const int orow = p / (Cf::TW / Cf::R);
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       }
     }
   }
+  MMD_DT(3);
   constexpr bool E_BZ = EPI == 2 || EPI == 4, E_ST = EPI == 1 || EPI == 4, E_OUT = EPI == 3 || EPI == 4;
   float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
   if (E_OUT && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + gb + c); osh = mmd_ld4(a.out_shift + gb + c); }
@@ -277,6 +289,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       mmd_stw4(yout, (((size_t)b * OH + oh) * OW + ow) * a.C + c, t, a.y16);
     }
   }
+  MMD_DT(4);
   if (((E_ST || E_BZ) && a.stats) || (E_OUT && a.pool)) {
     // reduce over the 4 pixel-groups of a wave (lanes l, l^16, l^32, l^48 share c4), then over 4 waves in LDS
     auto red4 = [](float4 v) {       // lanes l, l^LANES, l^2LANES, ... of a wave share the channel group
@@ -313,6 +326,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       }
     }
   }
+  MMD_DT(5);
   if constexpr (WG) {
     static_assert(S == 1 && Cf::IH * Cf::IW >= 4 * K * K, "weight-gradient reduction aliases the input tile");
     // dw[i][j] += sum_q a0[q] * dY[q - (i - p, j - p)]: the launch's (flipped-tap) window of dY around q, read once more from the LDS tile
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
           dwa[i * K + j].z += fq[o].z * in[o + j].z; dwa[i * K + j].w += fq[o].w * in[o + j].w;
         }
     }
+    MMD_DT(6);
     __syncthreads();                                  // every read of the tile is done: reduce in its place
     float* sRedW = sIn;                               // [4 waves][K*K][CC]
     const int wave = tid >> 6, lane = tid & 63;
@@ -352,6 +367,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
         atomicAdd(&a.dwg[(size_t)(K * K - 1 - t) * a.C + c0 + q], sRedW[(0 * K * K + t) * CC + q] + sRedW[(1 * K * K + t) * CC + q] +
                                                                     sRedW[(2 * K * K + t) * CC + q] + sRedW[(3 * K * K + t) * CC + q]);
     }
+    MMD_DT(7);
   }
 }
 
@@ -368,7 +384,7 @@ static int dw_fwd_launch(DwArgs& a, hipStream_t st) {
   const int epi = (a.stats && out) ? 4 : (a.bz ? 2 : (a.stats ? 1 : (out ? 3 : 0)));
   const dim3 grid((unsigned)nb), blk(256);
 #define MMD_DW_TILE(P, E) hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, P, E>), grid, blk, 0, st, a)
-  if constexpr (S == 1 && LANES == 16) {
+  if constexpr (S == 1 && LANES >= 8) {
     if (a.q_z) {        // BatchNorm-1 backward evaluated in the prologue (MBConv input gradient; always with the BatchNorm-0 sums + weight gradient)
       if (!(a.dwg && epi == 2 && !pro)) return MMD_EINVAL;
       hipLaunchKernelGGL((dw_fwd_kernel<K, S, LANES, 2, 2, true>), grid, blk, 0, st, a); goto launched;
@@ -387,15 +403,25 @@ launched:
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * a.C, st);
   return mmd_check_launch();
 }
+// Channel chunk of the tile kernel: 64 channels (16 float4 lanes per pixel).  32-channel chunks where 64-channel ones pad the width by 10 %
+// or more beyond what 32-channel ones do - C = 144 (192 against 160 lanes' worth of loads, FMAs and stores per pixel) and C = 288, the stride-1
+// blocks of the 128^2 / 64^2 stages - measured no better (round 4: 16.01 - 16.07 against 15.94 - 16.00 ms/step: two outputs per thread reuse
+// less of the LDS window than four); MMD_DW_LANES=8 forces them (4 / 8 / 16 for 3x3).
+static int dw_lanes_for(int C) {
+  static const int force = getenv("MMD_DW_LANES") ? atoi(getenv("MMD_DW_LANES")) : 0;
+  (void)C;
+  return force == 8 ? 8 : 16;
+}
 // 3x3 / stride 1: narrow channel chunks when C is small (thin 256x256 layers of the backbone)
 static int dw_fwd_launch_31(DwArgs& a, hipStream_t st) {
   static const int force = getenv("MMD_DW_LANES") ? atoi(getenv("MMD_DW_LANES")) : 0;
   if (force == 4) return dw_fwd_launch<3, 1, 4>(a, st);
-  if (force == 8) return dw_fwd_launch<3, 1, 8>(a, st);
-  if (force == 16) return dw_fwd_launch<3, 1, 16>(a, st);
-  if (a.C <= 16) return dw_fwd_launch<3, 1, 4>(a, st);
-  if (a.C <= 32) return dw_fwd_launch<3, 1, 8>(a, st);
-  return dw_fwd_launch<3, 1, 16>(a, st);
+  if (a.C <= 16 && !force) return dw_fwd_launch<3, 1, 4>(a, st);
+  if (a.C <= 32 && !force) return dw_fwd_launch<3, 1, 8>(a, st);
+  return dw_lanes_for(a.C) == 8 ? dw_fwd_launch<3, 1, 8>(a, st) : dw_fwd_launch<3, 1, 16>(a, st);
+}
+static int dw_fwd_launch_51(DwArgs& a, hipStream_t st) {
+  return dw_lanes_for(a.C) == 8 ? dw_fwd_launch<5, 1, 8>(a, st) : dw_fwd_launch<5, 1, 16>(a, st);
 }
 
 // ---- 3x3 / stride 1 as a row-streaming register window -------------------------------------------------------------------
@@ -704,7 +730,7 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
   if (rc != 1) {}
   else if (k == 3 && stride == 1) rc = dw_fwd_launch_31(a, stream);
   else if (k == 3) rc = dw_fwd_launch<3, 2>(a, stream);
-  else if (stride == 1) rc = dw_fwd_launch<5, 1>(a, stream);
+  else if (stride == 1) rc = dw_fwd_launch_51(a, stream);
   else rc = dw_fwd_launch<5, 2>(a, stream);
   mmd_prof_end(MMD_FAM_DW, stream, 2.0 * B * a.OH * a.OW * (double)C * k * k,
                4.0 * ((double)B * H * W * C + (double)B * a.OH * a.OW * C));
@@ -876,7 +902,7 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
     }
     a.dwg = dw_grad;
     rc = (k == 3 && !dw_grad) ? dw3_rows_launch(a, stream) : 1;      // (the row-streaming kernel has no weight-gradient form)
-    if (rc == 1) rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch<5, 1>(a, stream);
+    if (rc == 1) rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch_51(a, stream);
   } else {
     size_t total = (size_t)B * H * W * (C >> 2);
     if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_kernel<3>, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, 0);
@@ -933,7 +959,8 @@ extern "C" int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, con
   a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1; a.qz16 = (w16 >> 2) & 1; a.bz16 = (w16 >> 3) & 1;
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd1 H%lld C%lld k%lld s%lld", H, C, k, 1);
   mmd_prof_begin(MMD_FAM_DW_BWD, stream);
-  const int rc = (k == 3) ? dw_fwd_launch<3, 1, 16>(a, stream) : dw_fwd_launch<5, 1, 16>(a, stream);
+  const int rc = (k == 3) ? (dw_lanes_for(C) == 8 ? dw_fwd_launch<3, 1, 8>(a, stream) : dw_fwd_launch<3, 1, 16>(a, stream))
+                          : (dw_lanes_for(C) == 8 ? dw_fwd_launch<5, 1, 8>(a, stream) : dw_fwd_launch<5, 1, 16>(a, stream));
   mmd_prof_end(MMD_FAM_DW_BWD, stream, 2.0 * B * OH * OW * (double)C * k * k, 4.0 * 4 * (double)B * H * W * C);
   return rc;
 }
