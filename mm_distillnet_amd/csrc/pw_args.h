@@ -24,6 +24,21 @@ __device__ __forceinline__ void bn_bwd_coef(const BnBwdOp& b, int c, float& a1, 
   a2 = -a1 * is * m2; a3 = -a1 * m1;
 }
 struct BnBwdCoef4 { float4 a1, a2, a3, mu, sh; };
+// The coefficients of all K channels, once per block, in LDS: tab[5][K] (K % 4 == 0).  The GEMM kernels used to evaluate them per K step
+// and thread from the batch sums (8 double loads + 12 float loads + ~45 VALU instructions per 4 channels, every row group of a step
+// repeating the same channels): their BatchNorm-backward operand launches are instruction-bound (tools/dev/skinny_phases.py).
+__device__ __forceinline__ void bn_bwd_tab_fill(const BnBwdOp& b, int K, float* tab, int tid, int nthreads) {
+  for (int c = tid; c < K; c += nthreads) {
+    float a1, a2, a3, mu, sh;
+    bn_bwd_coef(b, c, a1, a2, a3, mu, sh);
+    tab[c] = a1; tab[K + c] = a2; tab[2 * K + c] = a3; tab[3 * K + c] = mu; tab[4 * K + c] = sh;
+  }
+}
+__device__ __forceinline__ void bn_bwd_tab4(const float* tab, int K, int c, BnBwdCoef4& o) {
+  o.a1 = *reinterpret_cast<const float4*>(tab + c); o.a2 = *reinterpret_cast<const float4*>(tab + K + c);
+  o.a3 = *reinterpret_cast<const float4*>(tab + 2 * K + c); o.mu = *reinterpret_cast<const float4*>(tab + 3 * K + c);
+  o.sh = *reinterpret_cast<const float4*>(tab + 4 * K + c);
+}
 __device__ __forceinline__ void bn_bwd_coef4(const BnBwdOp& b, int c, BnBwdCoef4& o) {
   bn_bwd_coef(b, c, o.a1.x, o.a2.x, o.a3.x, o.mu.x, o.sh.x); bn_bwd_coef(b, c + 1, o.a1.y, o.a2.y, o.a3.y, o.mu.y, o.sh.y);
   bn_bwd_coef(b, c + 2, o.a1.z, o.a2.z, o.a3.z, o.mu.z, o.sh.z); bn_bwd_coef(b, c + 3, o.a1.w, o.a2.w, o.a3.w, o.mu.w, o.sh.w);
@@ -80,6 +95,7 @@ struct PwArgs {
   // grouped frozen nets (common.h MmdGroup): g_images != 0 -> the row tile's group g = image / g_images reads w / bias g * g_w floats and
   // out_scale / out_shift g * g_bn floats behind the given pointers (LDS-tiled kernels only)
   int g_images; long long g_w, g_bn;
+  int bq_lds;      // BatchNorm-backward operand launches: the per-channel coefficients come from a per-block LDS table (5 x K floats of dynamic LDS)
 };
 
 

@@ -158,9 +158,11 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   bool kok;
   unsigned smask = 0;                     // PRO == 2: validity bit per (row slot, element), applied in lstore
   int kcur = 0;                           // PRO == 1: k of the staged group (for the dz side output)
+  extern __shared__ float sBqTab[];       // PRO == 1 with a.bq_lds: [5][K] BatchNorm-backward coefficients (pw_args.h)
   if constexpr (PRO == 1) {
     if (a.bb.dgamma && t == 0)
       for (int c = tid; c < a.K; c += 256) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
+    if (a.bq_lds) { bn_bwd_tab_fill(a.bb, a.K, sBqTab, tid, 256); __syncthreads(); }
   }
   auto gload = [&](int k0) {
     // every load is unconditional on a clamped (always valid) address and masked afterwards: guarded loads compile to a
@@ -188,7 +190,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       }
     } else if constexpr (PRO == 1) {
       kcur = kc;
-      bn_bwd_coef4(a.bb, kc, bq);
+      if (!a.bq_lds) bn_bwd_coef4(a.bb, kc, bq);
 #pragma unroll
       for (int i = 0; i < NA; ++i) { ra[i] = mmd_ldw4(xrow[i], kc, a.x16); rg[i] = mmd_ldw4(grow[i], kc, a.z16); }
     } else if constexpr (PRO == 3) {
@@ -210,6 +212,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     for (int i = 0; i < NB; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
   };
   auto lstore = [&]() {
+    if constexpr (PRO == 1) { if (a.bq_lds) bn_bwd_tab4(sBqTab, a.K, kcur, bq); }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
@@ -404,6 +407,23 @@ static void (*pw_pick_lean(int nkl, int bf))(PwArgs) {
        : nkl == 3 ? pw_gemm_kernel_lean<BM_T, BN_T, 3, false, PRO, WAVES> : pw_gemm_kernel_lean<BM_T, BN_T, 4, false, PRO, WAVES>;
 }
 
+// BatchNorm-backward operand launches: dynamic LDS bytes of the per-block coefficient table (sets a.bq_lds), 0 when the table is off (not such
+// a launch, MMD_NO_BQ_LDS, or the table would not fit beside `static_bytes` of the kernel's own tiles).
+#include <unordered_set>
+static size_t pw_bq_lds(PwArgs& a, const void* kern, size_t static_bytes) {
+  static const int off = getenv("MMD_NO_BQ_LDS") ? 1 : 0;
+  a.bq_lds = 0;
+  if (!a.bb.z || off || (a.K & 3)) return 0;
+  const size_t bytes = (size_t)5 * a.K * sizeof(float);
+  if (static_bytes + bytes > 150 * 1024) return 0;
+  if (static_bytes + bytes > 64 * 1024) {         // beyond the default per-block limit: raise it once per kernel
+    static std::unordered_set<const void*> raised;
+    if (!raised.count(kern)) { hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); raised.insert(kern); }
+  }
+  a.bq_lds = 1;
+  return bytes;
+}
+
 // ------------------------------------------------------------------------------------------
 // "Skinny" variant for layers whose 128x64 tiling gives too few blocks (deep 16x16 / 32x32 stages, BiFPN and
 // head layers): block tile 32(M) x 64(N); the four waves split K (wave w owns k in [32w,32w+32) of every
@@ -477,9 +497,11 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+  extern __shared__ float sBqTabS[];      // PRO == 1 with a.bq_lds: [5][K] BatchNorm-backward coefficients (pw_args.h)
   if constexpr (PRO == 1) {
     if (a.bb.dgamma && t == 0)
       for (int c = tid; c < a.K; c += 256) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
+    if (a.bq_lds) { bn_bwd_tab_fill(a.bb, a.K, sBqTabS, tid, 256); __syncthreads(); }
   }
 
   struct Stage { float4 ra[4], rg[4], rb[8], rsc, rsh; BnBwdCoef4 bq; bool kok; int kc; };
@@ -492,7 +514,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     const int kc = s.kok ? k : 0;
     s.kc = kc;
     if constexpr (PRO == 1) {
-      bn_bwd_coef4(a.bb, kc, s.bq);
+      if (!a.bq_lds) bn_bwd_coef4(a.bb, kc, s.bq);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s.ra[i] = mmd_ldw4(xrow[i], kc, a.x16); s.rg[i] = mmd_ldw4(grow[i], kc, a.z16); }
     } else if constexpr (PRO == 3) {
@@ -514,11 +536,13 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     for (int i = 0; i < 8; ++i) s.rb[i] = mmd_ld4(wrow[i] + kc);
   };
   auto lstore = [&](const Stage& s) {
+    BnBwdCoef4 bqs;
+    if constexpr (PRO == 1) { if (a.bq_lds) bn_bwd_tab4(sBqTabS, a.K, s.kc, bqs); else bqs = s.bq; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = s.ra[i];
       if constexpr (PRO == 1) {
-        v = bn_bwd_eval4(v, s.rg[i], rowsc[i], a.bb.act, s.bq);
+        v = bn_bwd_eval4(v, s.rg[i], rowsc[i], a.bb.act, bqs);
         if (a.bb.dz_out && tn == 0 && s.kok && rok[i]) mmd_stw4(a.bb.dz_out, (size_t)(m0 + lrow + i * 8) * a.K + s.kc, v, a.dz16);
       } else if constexpr (PRO == 3) {
       } else if constexpr (PRO == 4) {
@@ -1040,7 +1064,11 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     sk = pro == 1 ? ((sk_pf2 & 1) ? SK_PICK(1, 2) : SK_PICK(1, 1)) : pro == 3 ? SK_PICK(3, 1) : pro == 4 ? SK_PICK(4, 1)
        : ((sk_pf2 & 2) ? SK_PICK(0, 2) : SK_PICK(0, 1));
 #undef SK_PICK
-    hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), 0, stream, a);
+    // (the per-block coefficient table of the BatchNorm-backward operand launches pays on the tiled kernels below - 25 launches, -8 % - and
+    //  not here: 19 launches 641 -> 659 us per step; MMD_SK_BQ_LDS=1 switches it on)
+    static const int sk_tab = getenv("MMD_SK_BQ_LDS") ? 1 : 0;
+    const size_t bql = sk_tab ? pw_bq_lds(a, (const void*)sk, 58 * 1024) : 0;      // (sets a.bq_lds: before `a` is copied into the launch)
+    hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), bql, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
     // plain A operand (no producer transform, no gate) or gate only: register-lean variants at a higher occupancy
@@ -1070,7 +1098,8 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
       kern = plain ? pw_pick_lean<128, 64, 3, 5>(nkl, a.bf16) : gated ? pw_pick_lean<128, 64, 4, 5>(nkl, a.bf16) : pw_pick<128, 64, 0>(nkl, a.bf16);
     }
     a.nblk = ntm * a.ntn;
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), 0, stream, a);
+    const size_t bql = pw_bq_lds(a, (const void*)kern, 28 * 1024);     // (sets a.bq_lds: before `a` is copied into the launch)
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), bql, stream, a);
   }
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * N, stream);
   // algorithmic bytes of the launch's contract: A, B, Y once each, plus what the fused prologue / epilogue jobs move by definition - the
