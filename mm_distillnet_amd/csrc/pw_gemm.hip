@@ -415,7 +415,9 @@ static size_t pw_bq_lds(PwArgs& a, const void* kern, size_t static_bytes) {
   a.bq_lds = 0;
   if (!a.bb.z || off || (a.K & 3)) return 0;
   const size_t bytes = (size_t)5 * a.K * sizeof(float);
-  if (static_bytes + bytes > 150 * 1024) return 0;
+  // (the tiled kernels hide their latencies behind 3 - 4 co-resident blocks per CU: the table may not push a block beyond 48 KB)
+  static const size_t cap = getenv("MMD_BQ_LDS_CAP_KB") ? (size_t)atoi(getenv("MMD_BQ_LDS_CAP_KB")) * 1024 : 48 * 1024;
+  if (static_bytes + bytes > cap) return 0;
   if (static_bytes + bytes > 64 * 1024) {         // beyond the default per-block limit: raise it once per kernel
     static std::unordered_set<const void*> raised;
     if (!raised.count(kern)) { hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); raised.insert(kern); }
