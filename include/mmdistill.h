@@ -198,6 +198,13 @@ int mmd_colsum(const float* a, float* out, int M, int C, hipStream_t stream);
 
 // Stem 3x3/s2 TF-SAME conv lowered to rows [B*OH*OW, Kp] (src/YetAnotherEfficientNet.py:519,603); the GEMM is mmd_pwconv_fwd.
 int mmd_stem_im2col(const float* x, float* col, int B, int Cin, int H, int W, int Kp, hipStream_t stream);
+// Weight gradient of the stem conv without the im2col matrix (round 4; csrc/stem_wgrad.hip): dw [Cout, Kp] (+)= sum over the output pixels of
+// dz[(b, oh, ow)][co] * x[b][ci][2 oh + i - pad_t][2 ow + j - pad_l] at column ci*9 + i*3 + j - autograd of Conv2dStaticSamePadding(Cin, Cout, 3, stride=2)
+// (src/YetAnotherEfficientNet.py:519-523, 597-604; padding :27-65).  x [B, Cin, H, W] NCHW, dz [B*OH*OW, Cout] rows.  ws: mmd_stem_wgrad_ws_floats(Cout)
+// floats of scratch (per-block partials, folded in a fixed order).  _supported -> 1 for Cin <= 8, Kp <= 80, Cout <= 48, ceil(W/2) % 64 == 0.
+int mmd_stem_conv_bwd_weight_supported(int Cin, int H, int W, int Kp, int Cout);
+int mmd_stem_wgrad_ws_floats(int Cout);
+int mmd_stem_conv_bwd_weight(const float* x, const float* dz, float* dw, float* ws, int B, int Cin, int H, int W, int Kp, int Cout, hipStream_t stream);
 
 // dlogit = dprob * p * (1-p) (classifier sigmoid, src/YetAnotherEfficientDet.py:529).
 int mmd_sigmoid_bwd(const float* dprob, const float* prob, float* dlogit, long long n, hipStream_t stream);

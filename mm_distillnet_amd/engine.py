@@ -116,6 +116,8 @@ SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
 # both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
 # (S*C MACs, serial per wave) - measured 17.0 -> 17.7 ms/step against the two wide launches; off unless MMD_SE_FUSED=1
 SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))
+# stem weight gradient straight from the NCHW image (mmd_stem_conv_bwd_weight) instead of im2col + a GEMM item of the last grouped flush
+STEM_WG_DIRECT = not os.environ.get("MMD_NO_STEM_WG_DIRECT")
 # round 4: backward of the thin-input high-resolution expand convs (BatchNorm-0 backward, input gradient, weight gradient) in one pass over
 # the 6x expanded gradient (csrc/mbconv_bwd_fused.hip): dz0 is neither stored nor read back, and the layer leaves the grouped weight-gradient
 # launch at the exposed end of the backward.  Taken for layers with at least this many rows (MMD_NO_MBW=1: the two-GEMM form, for A/B timing)
@@ -1505,11 +1507,30 @@ class Net:
         stem_sums = self._bw["stem_sums"]
         ximg, stem, mu, istd = tape["stem"]
         s = self._slot(stem)
+        Bi, Cin, Hi, Wi = ximg.shape
+        dll = _lib.LIB.load() if ps.flat.is_cuda else None
+        direct = bool(STEM_WG_DIRECT and dll is not None and self.precision == "fp32"
+                      and dll.mmd_stem_conv_bwd_weight_supported(Cin, Hi, Wi, ps.stem_kp, stem.C) == 1)
+        if direct:
+            # the last grouped flush (the thin 256^2 layers of blocks 0 - 2) starts NOW, beside the stem's BatchNorm backward, and the stem's
+            # own weight gradient runs beside it on the second side stream: the step's exposed tail is the longer of the two, not their sum
+            self._wg_flush()
         dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
-        with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
-            col = self._alloc(stem.M, ps.stem_kp)
-            call("mmd_stem_im2col", ximg, col, ximg.shape[0], ximg.shape[1], ximg.shape[2], ximg.shape[3], ps.stem_kp)
-        self._pw_wgrad(dz, col, ps.g(f"{P}._conv_stem.conv.weight"), stem.M, ps.stem_kp, stem.C)
-        self._wg_flush()
+        if direct:
+            # no im2col matrix (168 MB at 512^2 x 8 channels): the patches are gathered from the image rows while the dz tile is multiplied
+            ws = self._alloc(int(dll.mmd_stem_wgrad_ws_floats(stem.C)))
+            main_stream = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_event(main_stream.record_event())
+            with torch.cuda.stream(self._side):
+                call("mmd_stem_conv_bwd_weight", ximg, dz, ps.g(f"{P}._conv_stem.conv.weight"), ws, Bi, Cin, Hi, Wi, ps.stem_kp, stem.C)
+            main_stream.wait_stream(self._side)
+        else:
+            with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
+                col = self._alloc(stem.M, ps.stem_kp)
+                call("mmd_stem_im2col", ximg, col, Bi, Cin, Hi, Wi, ps.stem_kp)
+            self._pw_wgrad(dz, col, ps.g(f"{P}._conv_stem.conv.weight"), stem.M, ps.stem_kp, stem.C)
+            self._wg_flush()
         if self._wg is not None:
             torch.cuda.current_stream().wait_stream(self._wg)

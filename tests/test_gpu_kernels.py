@@ -563,6 +563,39 @@ def test_stem_im2col(cin, S):
     close(y2.view(B, OH, OH, 32), nhwc(swish(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))), 2e-4, 1e-5, "direct stem conv + BN + swish")
 
 
+@pytest.mark.parametrize("cin,S,cout,B", [(8, 128, 32, 3), (3, 256, 32, 2), (1, 128, 48, 2), (8, 255, 40, 1)])
+def test_stem_conv_bwd_weight_direct(cin, S, cout, B):
+    """mmd_stem_conv_bwd_weight (round 4: the stem's weight gradient straight from the NCHW image, no im2col matrix) against torch autograd of
+    the TF-SAME 3x3 / stride-2 conv in float64, and against the path it replaces (mmd_stem_im2col + the weight-gradient GEMM); accumulates
+    into dw; odd image sizes (one more padded row / column) included."""
+    torch.manual_seed(cin * S + cout)
+    x = torch.randn(B, cin, S, S)
+    OH = (S + 1) // 2
+    Kp = (cin * 9 + 3) // 4 * 4
+    M = B * OH * OH
+    dz = torch.randn(M, cout)
+    dll = _lib.LIB.load()
+    assert dll.mmd_stem_conv_bwd_weight_supported(cin, S, S, Kp, cout) == 1
+    assert dll.mmd_stem_conv_bwd_weight_supported(cin, 100, 100, Kp, cout) == 0          # 50 output columns: not whole 64-pixel tiles
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(same_pad(x.double(), 3, 2), w, stride=2)                 # [B, cout, OH, OH]
+    (y * dz.double().view(B, OH, OH, cout).permute(0, 3, 1, 2)).sum().backward()
+    ref = torch.zeros(cout, Kp, dtype=torch.float64); ref[:, :cin * 9] = w.grad.reshape(cout, -1)
+    base = torch.randn(cout, Kp)
+    dw = g(base.clone())
+    ws = torch.empty(int(dll.mmd_stem_wgrad_ws_floats(cout)), device=DEV)
+    call("mmd_stem_conv_bwd_weight", g(x), g(dz), dw, ws, B, cin, S, S, Kp, cout)
+    got = dw.cpu().double() - base.double()
+    assert (got[:, cin * 9:] == 0).all(), "padding columns of the weight matrix receive no gradient"
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale + 1e-4, (got - ref).abs().max().item()
+    col = torch.empty(M, Kp, device=DEV)
+    call("mmd_stem_im2col", g(x), col, B, cin, S, S, Kp)
+    dw2 = torch.zeros(cout, Kp, device=DEV)
+    call("mmd_pwconv_bwd_weight", g(dz), col, dw2, M, Kp, cout, None, None, 0, None, 1)
+    assert (dw2.cpu().double() - got).abs().max().item() <= 2e-5 * scale + 1e-4
+
+
 def test_stem_conv_b4_width():
     torch.manual_seed(4)
     B, cin, S, CO = 2, 3, 20, 48
