@@ -699,7 +699,10 @@ struct NodeGemm {
   const float* w;          // the 1x1 conv's weight [C out][C in] (native layout): dzd[p, c] = sum_n dz[p, n] w[n, c]
   float* dz_out; float* dgamma; float* dbeta;
 };
-template <int MODE, bool GEMM = false>
+// NKK (GEMM form): the width in 16-channel groups as a compile-time constant (7 = D2's 112, 14 = D4's 224; 0 = read from the arguments) - the MFMA
+// loop is then straight-line code: with the run-time bound every k group sat behind its own branch, and the LDS reads of the next group
+// could not be hoisted over it
+template <int MODE, bool GEMM = false, int NKK = 0>
 __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
@@ -755,9 +758,10 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     const int lane = tid & 63, r = lane & 15, gq = lane >> 4, wv_ = tid >> 6;
     const int cb = c0 + wv_ * 16 + r;
     const bool cvalid = cb < C;
-    float bw[14][4];
+    constexpr int KKN = NKK ? NKK : 14;
+    float bw[KKN][4];
 #pragma unroll
-    for (int kk = 0; kk < 14; ++kk)
+    for (int kk = 0; kk < KKN; ++kk)
 #pragma unroll
       for (int j = 0; j < 4; ++j) bw[kk][j] = (kk * 16 < C && cvalid) ? ng.w[(size_t)(kk * 16 + 4 * gq + j) * C + cb] : 0.f;
     // dz tile: U items (pixel, channel quad) per trip, all of a trip's loads in flight together; the FIRST trip is issued before the
@@ -811,8 +815,8 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     for (int mt = 0; mt < 7; ++mt) acc7[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkk = C >> 4;
 #pragma unroll
-    for (int kk = 0; kk < 14; ++kk) {
-      if (kk < nkk) {
+    for (int kk = 0; kk < KKN; ++kk) {
+      if (NKK || kk < nkk) {
 #pragma unroll
         for (int mt = 0; mt < 7; ++mt) {
           const float4 av = *reinterpret_cast<const float4*>(&sDz[min(mt * 16 + r, IH * IW - 1) * LDZ + kk * 16 + 4 * gq]);
@@ -1138,11 +1142,13 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
     const size_t lds = (size_t)(100 * (C + 4) + 4 * C) * sizeof(float);
-#define MMD_NODE_BWD_G(M) do { static bool attr = false; \
-      if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr = true; } \
-      hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
+#define MMD_NODE_BWD_GK(M, NK) do { static bool attr = false; \
+      if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr = true; } \
+      hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true, NK>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
+#define MMD_NODE_BWD_G(M) do { if (C == 112) MMD_NODE_BWD_GK(M, 7); else if (C == 224) MMD_NODE_BWD_GK(M, 14); else MMD_NODE_BWD_GK(M, 0); } while (0)
     if (mode == 2) MMD_NODE_BWD_G(2); else if (mode == 5) MMD_NODE_BWD_G(5); else if (mode == 4) MMD_NODE_BWD_G(4); else return MMD_EINVAL;
 #undef MMD_NODE_BWD_G
+#undef MMD_NODE_BWD_GK
     return mmd_check_launch();
   }
   const NodeGemm ng0{};
