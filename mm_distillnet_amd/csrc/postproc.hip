@@ -16,13 +16,34 @@
 // teacher - stay on the one-pass kernel path.
 
 // ---- pass 1: per anchor best class/score and flags
+// A block's 256 anchors x NC class scores are one contiguous run: staged through LDS with coalesced float4 loads (row stride NC + 1:
+// conflict-free per-anchor reads).  The per-thread form read 80-byte-strided scalars: 80 us for the pack's 24 x 49104 x 20 scores (1.2 TB/s)
+// on the frozen teachers' chain, which is the forward phase's critical path (profiles/r04_notes.md section 22).
+#define PPS_MAXNC 64
 __global__ __launch_bounds__(256) void pp_score_kernel(const float* __restrict__ cls, int A, int NC, float thr,
                                                        unsigned long long valid_mask, float* __restrict__ score,
                                                        unsigned char* __restrict__ clsid, unsigned char* __restrict__ flags) {
-  const int b = blockIdx.y;
-  const int a = blockIdx.x * 256 + threadIdx.x;
+  extern __shared__ float spp[];                  // [256][NC + 1]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int a0 = blockIdx.x * 256;
+  const int na = min(256, A - a0);
+  const size_t base = ((size_t)b * A + a0) * NC;  // (16-byte aligned when 256 NC % 4 == 0: NC % 4 == 0 or handled by the scalar tail below)
+  const int total = na * NC;
+  const int ld = NC + 1;
+  if (((base | (size_t)NC) & 3) == 0) {
+    for (int e = tid * 4; e < total; e += 1024) {
+      const float4 v = mmd_ld4(cls + base + e);
+      const int r = e / NC, c = e - r * NC;         // NC % 4 == 0: the four elements lie in one row
+      float* d = &spp[r * ld + c];
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int e = tid; e < total; e += 256) { const int r = e / NC; spp[r * ld + (e - r * NC)] = cls[base + e]; }
+  }
+  __syncthreads();
+  const int a = a0 + tid;
   if (a >= A) return;
-  const float* p = cls + ((size_t)b * A + a) * NC;
+  const float* p = &spp[tid * ld];
   float best = p[0]; int bi = 0;
   for (int c = 1; c < NC; ++c) { float v = p[c]; if (v > best) { best = v; bi = c; } }
   size_t o = (size_t)b * A + a;
@@ -41,64 +62,83 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane) {      // exclusi
   for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
   return x - v;
 }
-#define PP_PER 4      // consecutive anchors per thread and sweep: 4096 anchors per barrier round instead of 1024
-__global__ __launch_bounds__(1024) void pp_compact_kernel(const float* __restrict__ reg, const float* __restrict__ anchors,
-                                                          const float* __restrict__ score, const unsigned char* __restrict__ clsid,
-                                                          const unsigned char* __restrict__ flags, int A, float image_size,
-                                                          float* __restrict__ over_scores, float* __restrict__ cand,
-                                                          int* __restrict__ n_over, int* __restrict__ n_keep, int* overflow,
-                                                          int cap) {
-  __shared__ int s_o[16], s_k[16];
-  __shared__ int base_o, base_k;
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid == 0) { base_o = 0; base_k = 0; }
-  __syncthreads();
-  for (int a0 = 0; a0 < A; a0 += 1024 * PP_PER) {
-    const int a = a0 + tid * PP_PER;
-    unsigned char f[PP_PER];
-    int co = 0, ck = 0;
+// One block per (image, chunk of 1024 anchors), 256 threads x 4 consecutive anchors (round 4; until then ONE 1024-thread block per image
+// walked the anchors in 12 barrier rounds: 49 us for 24 blocks on the teachers' chain).  The chunk's base positions in the image's two
+// ordered lists are the counts of the flags in front of it, which the block takes from the flag bytes themselves (<= 48 KB: popcounts of
+// 16-byte loads) - no workspace, no cross-block hand-off; the rows land exactly where the one-block walk put them.
+#define PP_PER 4
+#define PP_CHUNK (256 * PP_PER)
+__device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
-    for (int i = 0; i < PP_PER; ++i) {
-      f[i] = (a + i < A) ? flags[(size_t)b * A + a + i] : 0;
-      co += f[i] & 1; ck += (f[i] >> 1) & 1;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void pp_count_word(unsigned w, int& co, int& ck) { co += __popc(w & 0x01010101u); ck += __popc(w & 0x02020202u); }
+__global__ __launch_bounds__(256) void pp_compact_kernel(const float* __restrict__ reg, const float* __restrict__ anchors,
+                                                         const float* __restrict__ score, const unsigned char* __restrict__ clsid,
+                                                         const unsigned char* __restrict__ flags, int A, float image_size,
+                                                         float* __restrict__ over_scores, float* __restrict__ cand,
+                                                         int* __restrict__ n_over, int* __restrict__ n_keep, int* overflow,
+                                                         int cap) {
+  __shared__ int s_o[4], s_k[4], s_bo[4], s_bk[4];
+  const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int a0 = blockIdx.x * PP_CHUNK;
+  const unsigned char* fb = flags + (size_t)b * A;
+  // ---- flags in front of the chunk
+  int co0 = 0, ck0 = 0;
+  if ((((size_t)b * A) & 15) == 0) {
+    const uint4* f16 = reinterpret_cast<const uint4*>(fb);
+    for (int i = tid; i < a0 / 16; i += 256) {          // a0 is a multiple of 1024
+      const uint4 v = f16[i];
+      pp_count_word(v.x, co0, ck0); pp_count_word(v.y, co0, ck0); pp_count_word(v.z, co0, ck0); pp_count_word(v.w, co0, ck0);
     }
-    const int po = wave_excl_scan(co, lane), pk = wave_excl_scan(ck, lane);
-    if (lane == 63) { s_o[wave] = po + co; s_k[wave] = pk + ck; }
-    __syncthreads();
-    int wo = 0, wk = 0, to = 0, tk = 0;
-    for (int i = 0; i < 16; ++i) { if (i < wave) { wo += s_o[i]; wk += s_k[i]; } to += s_o[i]; tk += s_k[i]; }
-    const int bo = base_o, bk = base_k;
-    int pos = bo + wo + po, kp = bk + wk + pk;
-#pragma unroll
-    for (int i = 0; i < PP_PER; ++i) {
-      if (!(f[i] & 1)) continue;
-      const int ai = a + i;
-      float sc = score[(size_t)b * A + ai];
-      // only the first `cap` entries can ever be indexed (index < n_keep <= cap), so a longer list is not an error
-      if (pos < cap) over_scores[(size_t)b * cap + pos] = sc;
-      ++pos;
-      if (f[i] & 2) {
-        if (kp < cap) {
-          float4 an = mmd_ld4(anchors + (size_t)ai * 4);                 // y1,x1,y2,x2
-          float4 r = mmd_ld4(reg + ((size_t)b * A + ai) * 4);            // dy,dx,dh,dw
-          float yca = __fdiv_rn(__fadd_rn(an.x, an.z), 2.f), xca = __fdiv_rn(__fadd_rn(an.y, an.w), 2.f);
-          float ha = __fsub_rn(an.z, an.x), wa = __fsub_rn(an.w, an.y);
-          float w = __fmul_rn(expf(r.w), wa), h = __fmul_rn(expf(r.z), ha);
-          float yc = __fadd_rn(__fmul_rn(r.x, ha), yca), xc = __fadd_rn(__fmul_rn(r.y, wa), xca);
-          float x1 = __fsub_rn(xc, __fdiv_rn(w, 2.f)), y1 = __fsub_rn(yc, __fdiv_rn(h, 2.f));
-          float x2 = __fadd_rn(xc, __fdiv_rn(w, 2.f)), y2 = __fadd_rn(yc, __fdiv_rn(h, 2.f));
-          x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, image_size); y2 = fminf(y2, image_size);
-          float* o = cand + ((size_t)b * cap + kp) * 6;
-          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)clsid[(size_t)b * A + ai];
-        } else *overflow = 1;
-        ++kp;
-      }
-    }
-    __syncthreads();
-    if (tid == 0) { base_o = bo + to; base_k = bk + tk; }
-    __syncthreads();
+  } else {
+    for (int i = tid; i < a0; i += 256) { const unsigned char f = fb[i]; co0 += f & 1; ck0 += (f >> 1) & 1; }
   }
-  if (tid == 0) { n_over[b] = min(base_o, cap); n_keep[b] = min(base_k, cap); }
+  // ---- the chunk's own flags
+  const int a = a0 + tid * PP_PER;
+  unsigned char f[PP_PER];
+  int co = 0, ck = 0;
+#pragma unroll
+  for (int i = 0; i < PP_PER; ++i) {
+    f[i] = (a + i < A) ? fb[a + i] : 0;
+    co += f[i] & 1; ck += (f[i] >> 1) & 1;
+  }
+  const int po = wave_excl_scan(co, lane), pk = wave_excl_scan(ck, lane);
+  const int wb_o = wave_sum_i(co0), wb_k = wave_sum_i(ck0);
+  if (lane == 63) { s_o[wave] = po + co; s_k[wave] = pk + ck; }
+  if (lane == 0) { s_bo[wave] = wb_o; s_bk[wave] = wb_k; }
+  __syncthreads();
+  int wo = 0, wk = 0, to = 0, tk = 0, bo = 0, bk = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { if (i < wave) { wo += s_o[i]; wk += s_k[i]; } to += s_o[i]; tk += s_k[i]; bo += s_bo[i]; bk += s_bk[i]; }
+  int pos = bo + wo + po, kp = bk + wk + pk;
+#pragma unroll
+  for (int i = 0; i < PP_PER; ++i) {
+    if (!(f[i] & 1)) continue;
+    const int ai = a + i;
+    float sc = score[(size_t)b * A + ai];
+    // only the first `cap` entries can ever be indexed (index < n_keep <= cap), so a longer list is not an error
+    if (pos < cap) over_scores[(size_t)b * cap + pos] = sc;
+    ++pos;
+    if (f[i] & 2) {
+      if (kp < cap) {
+        float4 an = mmd_ld4(anchors + (size_t)ai * 4);                 // y1,x1,y2,x2
+        float4 r = mmd_ld4(reg + ((size_t)b * A + ai) * 4);            // dy,dx,dh,dw
+        float yca = __fdiv_rn(__fadd_rn(an.x, an.z), 2.f), xca = __fdiv_rn(__fadd_rn(an.y, an.w), 2.f);
+        float ha = __fsub_rn(an.z, an.x), wa = __fsub_rn(an.w, an.y);
+        float w = __fmul_rn(expf(r.w), wa), h = __fmul_rn(expf(r.z), ha);
+        float yc = __fadd_rn(__fmul_rn(r.x, ha), yca), xc = __fadd_rn(__fmul_rn(r.y, wa), xca);
+        float x1 = __fsub_rn(xc, __fdiv_rn(w, 2.f)), y1 = __fsub_rn(yc, __fdiv_rn(h, 2.f));
+        float x2 = __fadd_rn(xc, __fdiv_rn(w, 2.f)), y2 = __fadd_rn(yc, __fdiv_rn(h, 2.f));
+        x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, image_size); y2 = fminf(y2, image_size);
+        float* o = cand + ((size_t)b * cap + kp) * 6;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = sc; o[5] = (float)clsid[(size_t)b * A + ai];
+      } else *overflow = 1;
+      ++kp;
+    }
+  }
+  if (tid == 0 && a0 + PP_CHUNK >= A) { n_over[b] = min(bo + to, cap); n_keep[b] = min(bk + tk, cap); }      // the image's last chunk
 }
 
 extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float* anchors, int B, int A, int NC,
@@ -109,9 +149,9 @@ extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float
   if (!cls || !reg || !anchors || !score_ws || !clsid_ws || !flags_ws || !over_scores || !cand || !n_over || !n_keep || !overflow)
     return MMD_EINVAL;
   if (B <= 0 || A <= 0 || NC <= 0 || NC > 64 || cap <= 0) return MMD_EINVAL;
-  hipLaunchKernelGGL(pp_score_kernel, dim3(cdiv(A, 256), B), dim3(256), 0, stream, cls, A, NC, conf_threshold,
+  hipLaunchKernelGGL(pp_score_kernel, dim3(cdiv(A, 256), B), dim3(256), (size_t)256 * (NC + 1) * sizeof(float), stream, cls, A, NC, conf_threshold,
                      valid_class_mask, score_ws, clsid_ws, flags_ws);
-  hipLaunchKernelGGL(pp_compact_kernel, dim3(B), dim3(1024), 0, stream, reg, anchors, score_ws, clsid_ws, flags_ws, A,
+  hipLaunchKernelGGL(pp_compact_kernel, dim3(cdiv(A, PP_CHUNK), B), dim3(256), 0, stream, reg, anchors, score_ws, clsid_ws, flags_ws, A,
                      image_size, over_scores, cand, n_over, n_keep, overflow, cap);
   return mmd_check_launch();
 }
@@ -216,11 +256,14 @@ __global__ __launch_bounds__(1024) void pp_nms_kernel(NmsArgs a) {
     if (tid < n) myscore = row_ptr(tid)[4];
     skey[tid] = myscore; sidx[tid] = tid;
     __syncthreads();
-    // bitonic sort, descending score, ascending index on ties (1024 slots)
-    for (int k = 2; k <= PP_CAP; k <<= 1)
+    // bitonic sort, descending score, ascending index on ties, over the smallest power of two >= n (>= 64) slots: the slots past n hold
+    // -inf keys and sort behind every row; a teacher's ~100 candidates need 28 barrier stages instead of the 55 of a 1024-wide sort
+    int PS = 64;
+    while (PS < n) PS <<= 1;
+    for (int k = 2; k <= PS; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
         int ixj = tid ^ j;
-        if (ixj > tid) {
+        if (ixj > tid && ixj < PS) {
           float k0 = skey[tid], k1 = skey[ixj]; int i0 = sidx[tid], i1 = sidx[ixj];
           bool first_before = (k0 > k1) || (k0 == k1 && i0 < i1);     // "tid element sorts before ixj element"
           bool up = ((tid & k) == 0);
