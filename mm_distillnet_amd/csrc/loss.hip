@@ -122,6 +122,69 @@ __device__ __forceinline__ void mta_kl_body(const float* __restrict__ a_s, const
     else da_s[o] = accumulate ? da_s[o] + d : d;
   }
 }
+// Pairwise form (one teacher map) with both maps held in REGISTERS (HW <= 256 * MTA_RC): the generic body above re-reads them from global
+// memory in each of its ten reduction passes (45 us for the 64 x 64 level's blocks, on the critical path between forward and backward).
+// Same per-thread element order (j = tid + 256 i) and the same block reductions: the same numbers.
+#define MTA_RC 16
+__device__ __forceinline__ void mta_kl_body_cached(const float* __restrict__ a_s, const float* __restrict__ t0, int HW, int B, float T,
+                                                   float* loss, float* da_s, float gscale, int accumulate, int b, float* sm) {
+  const int tid = threadIdx.x;
+  const float* as = a_s + (size_t)b * HW;
+  const float* tp = t0 + (size_t)b * HW;
+  float ra[MTA_RC], rt[MTA_RC];
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) { const int j = tid + 256 * i; ra[i] = j < HW ? as[j] : 0.f; rt[i] = j < HW ? tp[j] : 0.f; }
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) if (tid + 256 * i < HW) acc += ra[i] * ra[i];
+  const float ns = fmaxf(sqrtf(block_sum(acc, sm, tid)), 1e-12f);
+  acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) if (tid + 256 * i < HW) acc += rt[i] * rt[i];
+  const float nk = fmaxf(sqrtf(block_sum(acc, sm, tid)), 1e-12f);
+  float ms = -INFINITY, mt = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) if (tid + 256 * i < HW) { ms = fmaxf(ms, ra[i] / ns / T); mt = fmaxf(mt, (1.f * rt[i] / nk) / T); }
+  ms = block_max(ms, sm, tid); mt = block_max(mt, sm, tid);
+  float es = 0.f, et = 0.f;
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) if (tid + 256 * i < HW) { es += __expf(ra[i] / ns / T - ms); et += __expf((1.f * rt[i] / nk) / T - mt); }
+  es = block_sum(es, sm, tid); et = block_sum(et, sm, tid);
+  float kl = 0.f, dot_gu = 0.f;
+  float ru[MTA_RC], rv[MTA_RC];
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) {
+    ru[i] = 0.f; rv[i] = 0.f;
+    if (tid + 256 * i < HW) {
+      const float u = __expf(ra[i] / ns / T - ms) / es;
+      const float v = __expf((1.f * rt[i] / nk) / T - mt) / et;
+      ru[i] = u; rv[i] = v;
+      kl += (v > 0.f ? v * __logf(v) : 0.f) - v * u;
+      dot_gu += (-v) * u;
+    }
+  }
+  kl = block_sum(kl, sm, tid); dot_gu = block_sum(dot_gu, sm, tid);
+  if (tid == 0) atomicAdd(loss, kl / (float)B);
+  if (!da_s) return;
+  float dot_ad = 0.f;
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) if (tid + 256 * i < HW) {
+    const float ah = ra[i] / ns;
+    const float dah = ru[i] * (-rv[i] - dot_gu) / T;
+    dot_ad += ah * dah;
+  }
+  dot_ad = block_sum(dot_ad, sm, tid);
+  const float sc = gscale / (float)B;
+#pragma unroll
+  for (int i = 0; i < MTA_RC; ++i) if (tid + 256 * i < HW) {
+    const float ah = ra[i] / ns;
+    const float dah = ru[i] * (-rv[i] - dot_gu) / T;
+    const float d = (dah - ah * dot_ad) / ns * sc;
+    const size_t o = (size_t)b * HW + tid + 256 * i;
+    if (accumulate == 2) atomicAdd(&da_s[o], d);
+    else da_s[o] = accumulate ? da_s[o] + d : d;
+  }
+}
 __global__ __launch_bounds__(256) void mta_kl_kernel(const float* __restrict__ a_s, const float* __restrict__ t0,
                                                      const float* __restrict__ t1, const float* __restrict__ t2, int nt,
                                                      int HW, int B, float T, float* loss, float* da_s, float gscale,
@@ -146,6 +209,8 @@ __global__ __launch_bounds__(256) void mta_kl_multi_kernel(MtaMulti m) {
   if (m.list_mode)
     mta_kl_body(m.a_s[l], m.a_t[0][l], m.nt > 1 ? m.a_t[1][l] : nullptr, m.nt > 2 ? m.a_t[2][l] : nullptr,
                 m.nt > 3 ? m.a_t[3][l] : nullptr, m.nt, m.HW[l], m.B, m.T, m.loss + l, m.da[l], m.gscale, 0, blockIdx.x, sm);
+  else if (m.HW[l] <= 256 * MTA_RC)
+    mta_kl_body_cached(m.a_s[l], m.a_t[t][l], m.HW[l], m.B, m.T, m.loss + t * nlev + l, m.da[l], m.gscale, m.nt > 1 ? 2 : 0, blockIdx.x, sm);
   else
     mta_kl_body(m.a_s[l], m.a_t[t][l], nullptr, nullptr, nullptr, 1, m.HW[l], m.B, m.T, m.loss + t * nlev + l, m.da[l], m.gscale,
                 m.nt > 1 ? 2 : 0, blockIdx.x, sm);
@@ -202,23 +267,38 @@ extern "C" int mmd_mta_attention_bwd(const float* f, const float* da, float* df,
 
 // ------------------------------------------------------------------ focal loss
 // boxes [B, maxg, 5] (x1,y1,x2,y2,label), nbox [B].  assign[b,a]: >=0 positive (box index), -1 ignore, -2 negative.
+#define FA_LDS_BOXES 1024
 __global__ __launch_bounds__(256) void focal_assign_kernel(const float* __restrict__ anchors, const float* __restrict__ boxes,
                                                            const int* __restrict__ nbox, int maxg, int A, int* __restrict__ assign,
                                                            int* npos) {
+  // the image's boxes (+ areas) staged in LDS once per block: the per-anchor loop read them as scalars from global memory, five dependent
+  // L1 round trips per box and anchor (48 us for ~70 boxes per image, on the critical path between forward and backward)
+  __shared__ float4 sbx[FA_LDS_BOXES];
+  __shared__ float sar[FA_LDS_BOXES];
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const int G = min(nbox[b], maxg);
+  const float* bx = boxes + (size_t)b * maxg * 5;
+  const int GL = min(G, FA_LDS_BOXES);
+  for (int g = threadIdx.x; g < GL; g += 256) {
+    const float x1 = bx[g * 5], y1 = bx[g * 5 + 1], x2 = bx[g * 5 + 2], y2 = bx[g * 5 + 3];
+    sbx[g] = make_float4(x1, y1, x2, y2);
+    sar[g] = (x2 - x1) * (y2 - y1);
+  }
+  __syncthreads();
   int cnt = 0;
   if (a < A && G > 0) {
     float4 an = mmd_ld4(anchors + (size_t)a * 4);     // y1,x1,y2,x2
     float aarea = (an.z - an.x) * (an.w - an.y);
     float best = -INFINITY; int bi = 0;
-    const float* bx = boxes + (size_t)b * maxg * 5;
     for (int g = 0; g < G; ++g) {
-      float x1 = bx[g * 5], y1 = bx[g * 5 + 1], x2 = bx[g * 5 + 2], y2 = bx[g * 5 + 3];
-      float area = (x2 - x1) * (y2 - y1);
+      float x1, y1, x2, y2, area;
+      if (g < GL) { const float4 q = sbx[g]; x1 = q.x; y1 = q.y; x2 = q.z; y2 = q.w; area = sar[g]; }
+      else { x1 = bx[g * 5]; y1 = bx[g * 5 + 1]; x2 = bx[g * 5 + 2]; y2 = bx[g * 5 + 3]; area = (x2 - x1) * (y2 - y1); }
       float iw = fmaxf(fminf(an.w, x2) - fmaxf(an.y, x1), 0.f);
       float ih = fmaxf(fminf(an.z, y2) - fmaxf(an.x, y1), 0.f);
+      // a disjoint pair has IoU exactly 0, which replaces `best` only while that is still -inf (the first box): skip its division
+      if (g > 0 && !(iw * ih > 0.f)) continue;
       float ua = fmaxf(aarea + area - iw * ih, 1e-8f);
       float iou = iw * ih / ua;
       if (iou > best) { best = iou; bi = g; }      // first maximum wins, like torch.max on CPU
@@ -232,6 +312,10 @@ __global__ __launch_bounds__(256) void focal_assign_kernel(const float* __restri
 }
 
 // loss sums: acc[b*2+0] += cls-sum, acc[b*2+1] += reg-sum (double).  Gradients written for every element.
+// Two passes per block of 256 anchors: (1) thread = anchor: assignment / label into LDS, smooth-L1 + its gradient; (2) every thread walks
+// float4s of the block's contiguous run of 256 x NC class probabilities (coalesced loads and stores; the per-anchor form touched 64
+// cache lines per wave instruction: 59 us for 2 x 31 MB on the critical path between forward and backward).  A thread's focal terms are
+// summed in fp32, the reduction across threads runs in fp64.
 __global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
                                                          const float* __restrict__ anchors, const float* __restrict__ boxes,
                                                          const int* __restrict__ nbox, const int* __restrict__ assign,
@@ -239,89 +323,99 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict
                                                          double* acc, float* __restrict__ dcls, float* __restrict__ dreg,
                                                          float gscale, int to_logit) {
   __shared__ double sd[8];
-  const int b = blockIdx.y;
-  const int a = blockIdx.x * 256 + threadIdx.x;
+  __shared__ short s_as[256], s_lab[256];       // per anchor: -2 negative / -1 ignore / 0 positive; label of a positive
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int a0 = blockIdx.x * 256;
+  const int a = a0 + tid;
   int total = 0;
   for (int i = 0; i < B; ++i) total += min(nbox[i], maxg);
   const int G = min(nbox[b], maxg);
   const float alpha = 0.25f;
+  const int np = G > 0 ? npos[b] : 0;
+  const float norm = G > 0 ? fmaxf((float)np, 1.f) : 1.f;     // image w/o boxes: un-normalised (reference quirk)
+  const float gs = gscale / (float)B / norm;
   double lc = 0.0, lr = 0.0;
-  if (a < A) {
-    const float* p = cls + ((size_t)b * A + a) * NC;
-    float* dp = dcls ? dcls + ((size_t)b * A + a) * NC : nullptr;
-    float* dr = dreg ? dreg + ((size_t)b * A + a) * 4 : nullptr;
-    if (total == 0) {                       // whole batch without boxes: zero loss, no gradient
-      if (dp) for (int c = 0; c < NC; ++c) dp[c] = 0.f;
-      if (dr) { dr[0] = dr[1] = dr[2] = dr[3] = 0.f; }
-    } else {
-      const int as = G > 0 ? assign[(size_t)b * A + a] : -2;
-      const int np = G > 0 ? npos[b] : 0;
-      const float norm = G > 0 ? fmaxf((float)np, 1.f) : 1.f;     // image w/o boxes: un-normalised (reference quirk)
-      const float gs = gscale / (float)B / norm;
-      int lab = -1;
-      const float* bx = boxes + ((size_t)b * maxg + (as >= 0 ? as : 0)) * 5;
-      if (as >= 0) lab = (int)bx[4];
-      auto term = [&](float raw, int c, float& gv) -> float {      // focal term of one (anchor, class) and its gradient
-        float q = fminf(fmaxf(raw, 1e-4f), 1.f - 1e-4f);
-        bool inside = raw >= 1e-4f && raw <= 1.f - 1e-4f;
-        float l = 0.f, d = 0.f;
-        if (as != -1) {
-          if (c == lab) {
-            float om = 1.f - q, lg = __logf(q);
-            l = -alpha * om * om * lg;
-            d = alpha * (2.f * om * lg - om * om / q);
-          } else {
-            float om = 1.f - q, lg = __logf(om);
-            l = -(1.f - alpha) * q * q * lg;
-            d = (1.f - alpha) * (-2.f * q * lg + q * q / om);
-          }
-        }
-        gv = inside ? d * gs : 0.f;
-        if (to_logit) gv *= raw * (1.f - raw);
-        return l;
-      };
-      if ((NC & 3) == 0) {
-        // an anchor's NC probabilities are 16-byte aligned: dwordx4 loads / stores (a per-class dword loop touches 64 cache
-        // lines per instruction); the per-anchor sum of <= NC terms in fp32, the reduction across anchors in fp64
-        float ls = 0.f;
-        for (int c = 0; c < NC; c += 4) {
-          float4 r4 = mmd_ld4(p + c), g4v;
-          ls += term(r4.x, c, g4v.x) + term(r4.y, c + 1, g4v.y) + term(r4.z, c + 2, g4v.z) + term(r4.w, c + 3, g4v.w);
-          if (dp) mmd_st4(dp + c, g4v);
-        }
-        lc = (double)ls;
-      } else {
-        for (int c = 0; c < NC; ++c) {
-          float gv;
-          lc += (double)term(p[c], c, gv);
-          if (dp) dp[c] = gv;
-        }
-      }
-      lc /= (double)norm;
+  // ---- pass 1
+  {
+    int as = -2, lab = -1;
+    if (a < A) {
+      float* dr = dreg ? dreg + ((size_t)b * A + a) * 4 : nullptr;
       float g4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (as >= 0) {
-        float4 an = mmd_ld4(anchors + (size_t)a * 4);
-        float aw = an.w - an.y, ah = an.z - an.x;
-        float acx = an.y + 0.5f * aw, acy = an.x + 0.5f * ah;
-        float gw = bx[2] - bx[0], gh = bx[3] - bx[1];
-        float gcx = bx[0] + 0.5f * gw, gcy = bx[1] + 0.5f * gh;
-        gw = fmaxf(gw, 1.f); gh = fmaxf(gh, 1.f);
-        float t[4] = {(gcy - acy) / ah, (gcx - acx) / aw, __logf(gh / ah), __logf(gw / aw)};
-        const float* r = reg + ((size_t)b * A + a) * 4;
-        const float gr = gscale / (float)B / (4.f * (float)np);
+      if (total != 0) {
+        as = G > 0 ? assign[(size_t)b * A + a] : -2;
+        if (as >= 0) {
+          const float* bx = boxes + ((size_t)b * maxg + as) * 5;
+          lab = (int)bx[4];
+          float4 an = mmd_ld4(anchors + (size_t)a * 4);
+          float aw = an.w - an.y, ah = an.z - an.x;
+          float acx = an.y + 0.5f * aw, acy = an.x + 0.5f * ah;
+          float gw = bx[2] - bx[0], gh = bx[3] - bx[1];
+          float gcx = bx[0] + 0.5f * gw, gcy = bx[1] + 0.5f * gh;
+          gw = fmaxf(gw, 1.f); gh = fmaxf(gh, 1.f);
+          float t[4] = {(gcy - acy) / ah, (gcx - acx) / aw, __logf(gh / ah), __logf(gw / aw)};
+          const float* r = reg + ((size_t)b * A + a) * 4;
+          const float gr = gscale / (float)B / (4.f * (float)np);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float diff = r[k] - t[k];
-          float ad = fabsf(diff);
-          float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-          if (ad <= 1.f / 9.f) { lr += 4.5 * (double)ad * ad; g4[k] = 9.f * ad * sgn * gr; }
-          else { lr += (double)ad - 0.5 / 9.0; g4[k] = sgn * gr; }
+          for (int k = 0; k < 4; ++k) {
+            float diff = r[k] - t[k];
+            float ad = fabsf(diff);
+            float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            if (ad <= 1.f / 9.f) { lr += 4.5 * (double)ad * ad; g4[k] = 9.f * ad * sgn * gr; }
+            else { lr += (double)ad - 0.5 / 9.0; g4[k] = sgn * gr; }
+          }
+          lr /= (4.0 * (double)np);
         }
-        lr /= (4.0 * (double)np);
       }
       if (dr) { dr[0] = g4[0]; dr[1] = g4[1]; dr[2] = g4[2]; dr[3] = g4[3]; }
     }
+    s_as[tid] = (short)(as >= 0 ? 0 : as); s_lab[tid] = (short)lab;
   }
+  __syncthreads();
+  // ---- pass 2
+  auto term = [&](float raw, int as, bool is_lab, float& gv) -> float {      // focal term of one (anchor, class) and its gradient
+    float q = fminf(fmaxf(raw, 1e-4f), 1.f - 1e-4f);
+    bool inside = raw >= 1e-4f && raw <= 1.f - 1e-4f;
+    float l = 0.f, d = 0.f;
+    if (as != -1) {
+      if (is_lab) {
+        float om = 1.f - q, lg = __logf(q);
+        l = -alpha * om * om * lg;
+        d = alpha * (2.f * om * lg - om * om / q);
+      } else {
+        float om = 1.f - q, lg = __logf(om);
+        l = -(1.f - alpha) * q * q * lg;
+        d = (1.f - alpha) * (-2.f * q * lg + q * q / om);
+      }
+    }
+    gv = inside ? d * gs : 0.f;
+    if (to_logit) gv *= raw * (1.f - raw);
+    return l;
+  };
+  const int na = min(256, A - a0);
+  const size_t base = ((size_t)b * A + a0) * NC;
+  const int run = na * NC;
+  float ls = 0.f;
+  if (total == 0) {                         // whole batch without boxes: zero loss, no gradient
+    if (dcls) for (int e = tid; e < run; e += 256) dcls[base + e] = 0.f;
+  } else if ((NC & 3) == 0) {
+    for (int e = tid * 4; e < run; e += 1024) {
+      const int r = e / NC, c = e - r * NC;                 // NC % 4 == 0: the four elements belong to one anchor
+      const int as = s_as[r], lab = s_lab[r];
+      const float4 r4 = mmd_ld4(cls + base + e);
+      float4 g4v;
+      ls += term(r4.x, as, c == lab, g4v.x) + term(r4.y, as, c + 1 == lab, g4v.y) + term(r4.z, as, c + 2 == lab, g4v.z) +
+            term(r4.w, as, c + 3 == lab, g4v.w);
+      if (dcls) mmd_st4(dcls + base + e, g4v);
+    }
+  } else {
+    for (int e = tid; e < run; e += 256) {
+      const int r = e / NC, c = e - r * NC;
+      float gv;
+      ls += term(cls[base + e], s_as[r], c == s_lab[r], gv);
+      if (dcls) dcls[base + e] = gv;
+    }
+  }
+  lc = (double)ls / (double)norm;
   lc = wave_sum_d(lc); lr = wave_sum_d(lr);
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { sd[wave * 2] = lc; sd[wave * 2 + 1] = lr; }
@@ -344,6 +438,10 @@ __global__ void focal_finalize_kernel(const double* acc, const int* nbox, int ma
   if (any_boxes && total) *any_boxes = 1;     // sticky: head parameters have received a gradient
 }
 
+__global__ void focal_zero_kernel(int* npos, double* acc, int B) {
+  for (int i = threadIdx.x; i < B; i += blockDim.x) npos[i] = 0;
+  for (int i = threadIdx.x; i < 2 * B; i += blockDim.x) acc[i] = 0.0;
+}
 // cls [B,A,NC] post-sigmoid probabilities, reg [B,A,4], anchors [A,4] (y1,x1,y2,x2).
 // workspace: assign int[B*A], npos int[B] (zeroed here), acc double[2B] (zeroed here).
 extern "C" int mmd_focal_loss(const float* cls, const float* reg, const float* anchors, const float* boxes,
@@ -352,8 +450,7 @@ extern "C" int mmd_focal_loss(const float* cls, const float* reg, const float* a
                               int to_logit, int* any_boxes, hipStream_t stream) {
   if (!cls || !reg || !anchors || !boxes || !nbox || !assign_ws || !npos_ws || !acc_ws || !loss_out) return MMD_EINVAL;
   if (B <= 0 || A <= 0 || NC <= 0 || maxg <= 0) return MMD_EINVAL;
-  mmd_zero_bytes(npos_ws, sizeof(int) * B, stream);
-  mmd_zero_bytes(acc_ws, sizeof(double) * 2 * B, stream);
+  hipLaunchKernelGGL(focal_zero_kernel, dim3(1), dim3(256), 0, stream, npos_ws, acc_ws, B);      // (one launch: both sit on the critical path)
   dim3 grid(cdiv(A, 256), B);
   hipLaunchKernelGGL(focal_assign_kernel, grid, dim3(256), 0, stream, anchors, boxes, nbox, maxg, A, assign_ws, npos_ws);
   hipLaunchKernelGGL(focal_loss_kernel, grid, dim3(256), 0, stream, cls, reg, anchors, boxes, nbox, assign_ws, npos_ws, maxg,
