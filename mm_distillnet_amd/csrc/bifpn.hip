@@ -282,14 +282,16 @@ template <int FC> struct FnCfg {
 
 // TRAIN (the student's nodes): y = the RAW 1x1-conv output z (+ bias), its per-channel sums (sum z, sum z^2: the node's train-mode BatchNorm
 // statistics) go to `stats`, and the depthwise output tile is also stored (zd_out: the 1x1 conv's weight gradient reads it in the backward).
-template <int MODE, bool TRAIN = false, int FC = 112>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
+// PK = false: the 1x1 weights are NOT parked in LDS even where they would fit (B fragments from L2 as at FC = 224): 78 KB instead of 86 KB, two
+// blocks per CU - for the chip-filling launches (the 64^2 level of the teacher pack: 1536 blocks = six rounds of one block per CU)
+template <int MODE, bool TRAIN = false, int FC = 112, bool PK = true>      // operand set: bit 0 = in1, bit 1 = up, bit 2 = pool (as fuse_presum)
 __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, float* __restrict__ y,
                                                                 int tiles_h, int tiles_w, float* __restrict__ zd_out, double* stats) {
   using Cf = FnCfg<FC>;
-  constexpr int FN_C = FC, FN_Q = Cf::Q, FN_FS = Cf::FS, FN_ZS = Cf::ZS, FN_WS = Cf::WS, FN_U = Cf::U, KR = Cf::KR, CT = Cf::CT;
-  constexpr bool PARK = Cf::PARK;
+  constexpr bool PARK = Cf::PARK && PK;
+  constexpr int FN_C = FC, FN_Q = Cf::Q, FN_FS = Cf::FS, FN_ZS = Cf::ZS, FN_WS = Cf::WS, FN_U = PARK ? Cf::U : 100 * Cf::FS, KR = Cf::KR, CT = Cf::CT;
   extern __shared__ float smem[];
   float* const sU = smem;                       // [100][FS] fused input tile | [C][WS] pointwise weights
   float* const sZ = smem + FN_U;                // [64][ZS] depthwise output tile
@@ -520,8 +522,14 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
     if (!attr) { hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<M, false, FC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
     hipLaunchKernelGGL((bifpn_node_fused_kernel<M, false, FC_>), grid, blk, FnCfg<FC_>::lds(false), stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw, nullptr, nullptr); \
     rc = MMD_OK; } while (0)
+#define MMD_NODE_FWD_NP(M, FC_) do { static bool attr = false; \
+    if (!attr) { hipFuncSetAttribute((const void*)bifpn_node_fused_kernel<M, false, FC_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    hipLaunchKernelGGL((bifpn_node_fused_kernel<M, false, FC_, false>), grid, blk, (size_t)(100 * FnCfg<FC_>::FS + 64 * FnCfg<FC_>::ZS + 9 * FC_) * sizeof(float), stream, a, w_dw, w_pw, bias, scale, shift, y, th, tw, nullptr, nullptr); \
+    rc = MMD_OK; } while (0)
+  static const int nopark_min = getenv("MMD_NODE_NOPARK_MIN") ? atoi(getenv("MMD_NODE_NOPARK_MIN")) : 1024;
 #define MMD_NODE_FWD_C(FC_) do { \
-    if (mode == 2) MMD_NODE_FWD(2, FC_);            /* (in, up): top-down nodes */ \
+    if (mode == 2 && FC_ == 112 && (int)grid.x >= nopark_min) MMD_NODE_FWD_NP(2, 112); \
+    else if (mode == 2) MMD_NODE_FWD(2, FC_);            /* (in, up): top-down nodes */ \
     else if (mode == 5) MMD_NODE_FWD(5, FC_);       /* (in, td, pool): bottom-up nodes */ \
     else if (mode == 4) MMD_NODE_FWD(4, FC_);       /* (in, pool): p7_out */ \
     else if (mode == 1) MMD_NODE_FWD(1, FC_); } while (0)
@@ -530,6 +538,7 @@ extern "C" int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, cons
   else if (C == 160) MMD_NODE_FWD_C(160);
   else MMD_NODE_FWD_C(64);
 #undef MMD_NODE_FWD_C
+#undef MMD_NODE_FWD_NP
 #undef MMD_NODE_FWD
   if (rc) return rc;
   const double rows = (double)B * H * W;
