@@ -205,6 +205,9 @@ int mmd_stem_im2col(const float* x, float* col, int B, int Cin, int H, int W, in
 int mmd_stem_conv_bwd_weight_supported(int Cin, int H, int W, int Kp, int Cout);
 int mmd_stem_wgrad_ws_floats(int Cout);
 int mmd_stem_conv_bwd_weight(const float* x, const float* dz, float* dw, float* ws, int B, int Cin, int H, int W, int Kp, int Cout, hipStream_t stream);
+// ... with the stem BatchNorm(+swish) backward in the prologue: dz = BnBwd(g, z) is evaluated while the tile is staged (never a tensor), dgamma /
+// dbeta (+)= sums - autograd of `_bn0` + swish behind the stem conv (src/YetAnotherEfficientNet.py:523-524); arguments as mmd_pwconv_bwd_data_bn.
+int mmd_stem_conv_bwd_weight_bn(const float* x, const float* g, const float* z, float* dw, float* ws, int B, int Cin, int H, int W, int Kp, int Cout, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, float* dgamma, float* dbeta, hipStream_t stream);
 
 // dlogit = dprob * p * (1-p) (classifier sigmoid, src/YetAnotherEfficientDet.py:529).
 int mmd_sigmoid_bwd(const float* dprob, const float* prob, float* dlogit, long long n, hipStream_t stream);

@@ -16,6 +16,7 @@
 // tiny launch adds the slots into dW in a fixed order (deterministic, no same-address atomics).
 // HBM: x once (~1.5x through the shared rows of neighbouring output rows: L2) + dz once - 0.13 GB instead of 0.64 GB for the student's stem.
 #include "common.h"
+#include "pw_args.h"
 
 #define SW_TM 64            // output pixels per tile
 #define SW_XW 132           // LDS row stride of the input rows (130 used)
@@ -31,9 +32,13 @@ extern "C" int mmd_sw_stamps(unsigned long long* out) { return hipMemcpyFromSymb
 #else
 #define MMD_ST(i)
 #endif
-template <int COT>          // 16-row tiles of dW: Cout <= 16 * COT
+// BNP: dz is not a tensor - the stem's BatchNorm(+swish) backward is evaluated from (g = dz argument, bb.z) while the tile is staged (the
+// coefficients of a thread's channel quads do not depend on the tile: registers), as in the 1x1 convs' BatchNorm-backward operand launches;
+// block 0 adds dgamma / dbeta.  Saves the mmd_bn_bwd_apply launch at the very end of the backward and its [M, Cout] write + read.
+template <int COT, bool BNP = false>          // 16-row tiles of dW: Cout <= 16 * COT
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ ws, int B,
-                                                        int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l, int Cout, int ntiles) {
+                                                        int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l, int Cout, int ntiles,
+                                                        BnBwdOp bb = BnBwdOp{}) {
   constexpr int NT = COT * SW_KT;                  // output tiles of the block
   constexpr int TPW = (NT + 3) / 4;                // ... per wave
   constexpr int NXR = 13;                          // x elements per thread and tile: ceil(8 * 3 * 130 / 256)
@@ -81,7 +86,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     zp[k] = e / zq; zc[k] = (e - zp[k] * zq) * 4;
   }
   float xr[NXR];
-  float4 zr[NZR];
+  float4 zr[NZR], gr[BNP ? NZR : 1];
+  BnBwdCoef4 bq[BNP ? NZR : 1];
+  if constexpr (BNP) {
+#pragma unroll
+    for (int k = 0; k < NZR; ++k) bn_bwd_coef4(bb, min(zc[k], Cout - 4), bq[k]);
+    if (bb.dgamma && blockIdx.x == 0)
+      for (int c = tid; c < Cout; c += 256) { bb.dgamma[c] += (float)bb.sums[Cout + c]; bb.dbeta[c] += (float)bb.sums[c]; }
+  }
   // every load is unconditional on a clamped (always valid) address and masked afterwards (a guarded load is a branch + a full drain)
   auto gload = [&](int tile) {
     const int owt = tile % tpr; int q = tile / tpr;
@@ -100,6 +112,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     for (int k = 0; k < NZR; ++k) {
       const float4 v = mmd_ld4(zb0 + min(zp[k], SW_TM - 1) * Cout + zc[k]);
       zr[k] = (zp[k] < SW_TM) ? v : make_float4(0, 0, 0, 0);
+      if constexpr (BNP) gr[k] = mmd_ld4(bb.z + (zb0 - dz) + min(zp[k], SW_TM - 1) * Cout + zc[k]);
     }
   };
   auto lstore = [&]() {
@@ -108,7 +121,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       if (xv[k]) sX[xs[k]] = xr[k];
 #pragma unroll
     for (int k = 0; k < NZR; ++k)
-      if (zp[k] < SW_TM) *reinterpret_cast<float4*>(&sDz[zp[k] * SW_LDZ + zc[k]]) = zr[k];
+      if (zp[k] < SW_TM) {
+        float4 v = zr[k];
+        if constexpr (BNP) v = bn_bwd_eval4(v, gr[k], 1.f, bb.act, bq[k]);
+        *reinterpret_cast<float4*>(&sDz[zp[k] * SW_LDZ + zc[k]]) = v;
+      }
   };
   // dz columns past Cout (Cout < 16 COT) are never staged: zero them once
   for (int i = tid; i < SW_TM * SW_LDZ; i += 256) sDz[i] = 0.f;
@@ -182,8 +199,8 @@ extern "C" int mmd_stem_conv_bwd_weight_supported(int Cin, int H, int W, int Kp,
 extern "C" int mmd_stem_wgrad_ws_floats(int Cout) { return SW_BLOCKS_MAX * (16 * ((Cout + 15) / 16)) * (16 * SW_KT); }
 
 // dw [Cout, Kp] (+)= the stem conv's weight gradient from the NCHW image x [B, Cin, H, W] and dz [B*OH*OW, Cout] (OH = ceil(H/2), OW = ceil(W/2)).
-extern "C" int mmd_stem_conv_bwd_weight(const float* x, const float* dz, float* dw, float* ws, int B, int Cin, int H, int W, int Kp, int Cout,
-                                        hipStream_t stream) {
+static int stem_wgrad_impl(const float* x, const float* dz, float* dw, float* ws, int B, int Cin, int H, int W, int Kp, int Cout, const BnBwdOp* bb,
+                           hipStream_t stream) {
   if (!x || !dz || !dw || !ws || B <= 0 || !mmd_stem_conv_bwd_weight_supported(Cin, H, W, Kp, Cout)) return MMD_EINVAL;
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   int eh = (OH - 1) * 2 - H + 3, ew = (OW - 1) * 2 - W + 3;
@@ -193,11 +210,28 @@ extern "C" int mmd_stem_conv_bwd_weight(const float* x, const float* dz, float* 
   const int cot = (Cout + 15) / 16;
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "stemwg B%lld Cin%lld H%lld Co%lld", B, Cin, H, Cout);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
-  if (cot == 1) hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, dz, ws, B, Cin, H, W, OH, OW, eh / 2, ew / 2, Cout, ntiles);
-  else if (cot == 2) hipLaunchKernelGGL(stem_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, stream, x, dz, ws, B, Cin, H, W, OH, OW, eh / 2, ew / 2, Cout, ntiles);
-  else hipLaunchKernelGGL(stem_wgrad_kernel<3>, dim3(blocks), dim3(256), 0, stream, x, dz, ws, B, Cin, H, W, OH, OW, eh / 2, ew / 2, Cout, ntiles);
+#define MMD_SW(COT_) do { \
+    if (bb) hipLaunchKernelGGL((stem_wgrad_kernel<COT_, true>), dim3(blocks), dim3(256), 0, stream, x, dz, ws, B, Cin, H, W, OH, OW, eh / 2, ew / 2, Cout, ntiles, *bb); \
+    else hipLaunchKernelGGL((stem_wgrad_kernel<COT_, false>), dim3(blocks), dim3(256), 0, stream, x, dz, ws, B, Cin, H, W, OH, OW, eh / 2, ew / 2, Cout, ntiles, BnBwdOp{}); } while (0)
+  if (cot == 1) MMD_SW(1); else if (cot == 2) MMD_SW(2); else MMD_SW(3);
+#undef MMD_SW
   hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(cdiv(Cout * Kp, 16)), dim3(256), 0, stream, ws, dw, blocks, 16 * cot * 16 * SW_KT, Cout, Kp);
   const double M = (double)B * OH * OW;
-  mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * Cout * Cin * 9, 4.0 * ((double)B * Cin * H * W + M * Cout));
+  mmd_prof_end(MMD_FAM_PW_WGRAD, stream, 2.0 * M * Cout * Cin * 9, 4.0 * ((double)B * Cin * H * W + M * Cout * (bb ? 2 : 1)));
   return mmd_check_launch();
+}
+extern "C" int mmd_stem_conv_bwd_weight(const float* x, const float* dz, float* dw, float* ws, int B, int Cin, int H, int W, int Kp, int Cout,
+                                        hipStream_t stream) {
+  return stem_wgrad_impl(x, dz, dw, ws, B, Cin, H, W, Kp, Cout, nullptr, stream);
+}
+// The same with the stem's BatchNorm(+act) backward evaluated while the dz tile is staged: dz = BnBwd(g, z) (coefficients as in
+// mmd_pwconv_bwd_data_bn: scale, shift, mean, invstd of the BatchNorm, sums = [sum g', sum g' xhat] over `count` rows), dgamma / dbeta (+)= the sums.
+extern "C" int mmd_stem_conv_bwd_weight_bn(const float* x, const float* g, const float* z, float* dw, float* ws, int B, int Cin, int H, int W, int Kp,
+                                           int Cout, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                           const double* sums, long long count, int act, float* dgamma, float* dbeta, hipStream_t stream) {
+  if (!g || !z || !scale || !shift || !mean || !invstd || !sums || count <= 0 || (dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  BnBwdOp bb{};
+  bb.z = z; bb.scale = scale; bb.shift = shift; bb.mean = mean; bb.invstd = invstd; bb.sums = sums; bb.inv_count = 1.0 / (double)count;
+  bb.C = Cout; bb.act = act; bb.mul_b = nullptr; bb.rows_per_image = 1; bb.dz_out = nullptr; bb.dgamma = dgamma; bb.dbeta = dbeta;
+  return stem_wgrad_impl(x, g, dw, ws, B, Cin, H, W, Kp, Cout, &bb, stream);
 }

@@ -1515,18 +1515,25 @@ class Net:
             # the last grouped flush (the thin 256^2 layers of blocks 0 - 2) starts NOW, beside the stem's BatchNorm backward, and the stem's
             # own weight gradient runs beside it on the second side stream: the step's exposed tail is the longer of the two, not their sum
             self._wg_flush()
-        dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
         if direct:
-            # no im2col matrix (168 MB at 512^2 x 8 channels): the patches are gathered from the image rows while the dz tile is multiplied
+            # no im2col matrix (168 MB at 512^2 x 8 channels): the patches are gathered from the image rows while the dz tile is multiplied -
+            # and no dz tensor either: the stem BatchNorm's backward is evaluated while that tile is staged (mmd_stem_conv_bwd_weight_bn)
+            if stem_sums is None:
+                stem_sums = self._zalloc((2 * stem.C,), torch.float64)
+                call("mmd_bn_bwd_reduce", s.t, stem.z, stem.scale, stem.shift, mu, istd, SWISH, None, None, None, 0, None, stem_sums, stem.M, stem.C,
+                     *self._stats_ws(stem_sums, stem.M, stem.C))
+            b0 = ps.bn(f"{P}._bn0")
             ws = self._alloc(int(dll.mmd_stem_wgrad_ws_floats(stem.C)))
             main_stream = torch.cuda.current_stream()
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_event(main_stream.record_event())
             with torch.cuda.stream(self._side):
-                call("mmd_stem_conv_bwd_weight", ximg, dz, ps.g(f"{P}._conv_stem.conv.weight"), ws, Bi, Cin, Hi, Wi, ps.stem_kp, stem.C)
+                call("mmd_stem_conv_bwd_weight_bn", ximg, s.t, stem.z, ps.g(f"{P}._conv_stem.conv.weight"), ws, Bi, Cin, Hi, Wi, ps.stem_kp, stem.C,
+                     stem.scale, stem.shift, mu, istd, stem_sums, stem.M, SWISH, b0["dgamma"], b0["dbeta"])
             main_stream.wait_stream(self._side)
         else:
+            dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
             with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path
                 col = self._alloc(stem.M, ps.stem_kp)
                 call("mmd_stem_im2col", ximg, col, Bi, Cin, Hi, Wi, ps.stem_kp)

@@ -594,6 +594,20 @@ def test_stem_conv_bwd_weight_direct(cin, S, cout, B):
     dw2 = torch.zeros(cout, Kp, device=DEV)
     call("mmd_pwconv_bwd_weight", g(dz), col, dw2, M, Kp, cout, None, None, 0, None, 1)
     assert (dw2.cpu().double() - got).abs().max().item() <= 2e-5 * scale + 1e-4
+    # the BatchNorm(+swish) backward in the prologue (no dz tensor) against mmd_bn_bwd_apply -> the plain form
+    gq, zq = g(torch.randn(M, cout)), g(torch.randn(M, cout) * 1.2 + 0.1)
+    isd, gam = torch.rand(cout) + 0.5, torch.rand(cout) + 0.5
+    sc_, sh_, mu_, is_ = g(gam * isd), g(torch.randn(cout) * 0.1), g(torch.randn(cout) * 0.2), g(isd)
+    sums = torch.zeros(2 * cout, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", gq, zq, sc_, sh_, mu_, is_, 1, None, None, None, 0, None, sums, M, cout, None, 0)
+    dzq = torch.empty(M, cout, device=DEV); dga, dbe = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+    call("mmd_bn_bwd_apply", gq, zq, mu_, is_, g(gam), sums, M, dzq, dga, dbe, M, cout, sc_, sh_, 1, None, None, None, 0)
+    dwa = torch.zeros(cout, Kp, device=DEV)
+    call("mmd_stem_conv_bwd_weight", g(x), dzq, dwa, ws, B, cin, S, S, Kp, cout)
+    dwb = torch.zeros(cout, Kp, device=DEV); dga2, dbe2 = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+    call("mmd_stem_conv_bwd_weight_bn", g(x), gq, zq, dwb, ws, B, cin, S, S, Kp, cout, sc_, sh_, mu_, is_, sums, M, 1, dga2, dbe2)
+    close(dwb, dwa, 5e-5, 1e-4, "stem weight gradient with the BatchNorm backward in the prologue")
+    assert torch.equal(dga2, dga) and torch.equal(dbe2, dbe)
 
 
 def test_stem_conv_b4_width():
