@@ -1509,7 +1509,8 @@ class Net:
         s = self._slot(stem)
         Bi, Cin, Hi, Wi = ximg.shape
         dll = _lib.LIB.load() if ps.flat.is_cuda else None
-        direct = bool(STEM_WG_DIRECT and dll is not None and self.precision == "fp32"
+        # (every precision mode: the bf16 rule rounds the operands of the 1x1 convs only - the stem is a 3x3 conv and stays fp32)
+        direct = bool(STEM_WG_DIRECT and dll is not None
                       and dll.mmd_stem_conv_bwd_weight_supported(Cin, Hi, Wi, ps.stem_kp, stem.C) == 1)
         if direct:
             # the last grouped flush (the thin 256^2 layers of blocks 0 - 2) starts NOW, beside the stem's BatchNorm backward, and the stem's
