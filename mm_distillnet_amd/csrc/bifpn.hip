@@ -58,20 +58,30 @@ __device__ __forceinline__ void fuse_weights(const float* theta, int n, float* w
 __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int b, int oh, int ow, int c, int PH, int PW,
                                               int C, int pad_t, int pad_l, bool aff = false, float4 sc = make_float4(1, 1, 1, 1),
                                               float4 sh = make_float4(0, 0, 0, 0)) {
-  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  // every tap is loaded unconditionally from a clamped (always valid) address and masked afterwards: a guarded load is a branch of its
+  // own with a full wait behind it - nine dependent round trips per window instead of one (the pooled-operand nodes spent 14 us of a 22 us
+  // block there, tools/dev/node_fwd_phases.py)
+  float4 v[9];
+  bool in[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    int y = oh * 2 - pad_t + i;
+    const int y = oh * 2 - pad_t + i;
+    const int yc = min(max(y, 0), PH - 1);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      int x = ow * 2 - pad_l + j;
-      float4 v = make_float4(0, 0, 0, 0);   // zero padding takes part in the max
-      if (y >= 0 && y < PH && x >= 0 && x < PW) {
-        v = mmd_ld4(src + (((size_t)b * PH + y) * PW + x) * C + c);
-        if (aff) v = fuse_aff4(v, sc, sh);
-      }
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      const int x = ow * 2 - pad_l + j;
+      const int xc = min(max(x, 0), PW - 1);
+      in[i * 3 + j] = y >= 0 && y < PH && x >= 0 && x < PW;
+      v[i * 3 + j] = mmd_ld4(src + (((size_t)b * PH + yc) * PW + xc) * C + c);
     }
+  }
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float4 u = v[t];
+    if (aff) u = fuse_aff4(u, sc, sh);
+    if (!in[t]) u = make_float4(0, 0, 0, 0);   // zero padding takes part in the max
+    m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
   }
   return m;
 }
@@ -255,6 +265,16 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
   return mmd_check_launch();
 }
 
+// -DMMD_NODE_TIMING (dev build, tools/dev/node_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock at the phase boundaries
+#ifdef MMD_NODE_TIMING
+__device__ unsigned long long g_node_t[16];
+#define NODE_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); g_node_t[i] = wall_clock64(); } } while (0)
+extern "C" int mmd_node_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_node_t), sizeof(g_node_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define NODE_T(i)
+#endif
 // ---- whole BiFPN node of a FROZEN net in one kernel ---------------------------------------------------------------------------
 //   y = BN_folded( pw( dw3x3( swish( sum_i w_i * operand_i ) ) ) + bias )      SeparableConvBlock(norm=True, activation=False) after the
 // fast-attention fusion (src/YetAnotherEfficientDet.py:150-185, 338-390), eval mode.  The two-kernel path writes the depthwise output,
@@ -299,6 +319,7 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   float* const sSt = sWd + 9 * FN_C;            // TRAIN: [2][C] block sums
   float* const sAf = sSt + 2 * FN_C;            // TRAIN, lazy operands: [4 operands][scale | shift][C]
   constexpr bool LZ = TRAIN && Cf::LAZY_OK;
+  NODE_T(0);
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
@@ -404,7 +425,9 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
       }
     }
   }
+  NODE_T(1);
   __syncthreads();
+  NODE_T(2);
   // ---- phase 1
   for (int it = tid; it < 64 * FN_Q; it += FN_NT) {
     const int p = it / FN_Q, q = it - p * FN_Q;
@@ -424,7 +447,9 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
       if (oh < a.H && ow < a.W) mmd_st4(zd_out + (((size_t)b * a.H + oh) * a.W + ow) * FN_C + q * 4, acc);
     }
   }
+  NODE_T(3);
   __syncthreads();                                   // every read of the input tile is done: park the 1x1 weights in its place
+  NODE_T(4);
   if constexpr (PARK) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -433,6 +458,7 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     }
     __syncthreads();
   }
+  NODE_T(5);
   // ---- phase 2
   const int lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -491,10 +517,12 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
       if (g == 0) { atomicAdd(&sSt[n], s1); atomicAdd(&sSt[FN_C + n], s2); }
     }
   }
+  NODE_T(6);
   if (TRAIN) {
     __syncthreads();
     for (int i = tid; i < 2 * FN_C; i += FN_NT) atomicAdd(&stats[i], (double)sSt[i]);
   }
+  NODE_T(7);
 }
 
 // 1 when mmd_bifpn_node_fwd_fused has a kernel for this width (the caller keeps mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd otherwise)
@@ -693,16 +721,6 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 // all 7 pixel tiles; its 28 B values per lane come straight from L2 and stay in registers) and writes the dzd tile into sIn - where the
 // plain form stages it from HBM.  The halo is recomputed by the neighbouring blocks (1.56x of a 2.5 MFLOP product); dzd never exists in
 // HBM.  The chunk-0 blocks store dz (interior pixels) for the conv's weight-gradient GEMM; block 0 adds dgamma / dbeta.
-// -DMMD_NODE_TIMING (dev build, tools/dev/node_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock at the phase boundaries
-#ifdef MMD_NODE_TIMING
-__device__ unsigned long long g_node_t[16];
-#define NODE_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); g_node_t[i] = wall_clock64(); } } while (0)
-extern "C" int mmd_node_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_node_t), sizeof(g_node_t)) == hipSuccess ? 0 : -1;
-}
-#else
-#define NODE_T(i)
-#endif
 struct NodeGemm {
   const float* g; const float* z; const float* scale; const float* mean; const float* invstd; const double* sums; double inv_count;
   const float* w;          // the 1x1 conv's weight [C out][C in] (native layout): dzd[p, c] = sum_n dz[p, n] w[n, c]
@@ -919,11 +937,11 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
               const int x = ow * 2 - a.pad_l + j;
-              win[oo][i * 3 + j] = z4;
-              if (y >= 0 && y < a.PH && x >= 0 && x < a.PW) {
-                win[oo][i * 3 + j] = mmd_ld4(a.pl + (((size_t)b * a.PH + y) * a.PW + x) * a.C + c);
-                inb[oo] |= 1u << (i * 3 + j);
-              }
+              // (unconditional load from a clamped address, masked afterwards: a guarded load is a branch with a full wait behind it)
+              const bool inw = y >= 0 && y < a.PH && x >= 0 && x < a.PW;
+              const float4 wv = mmd_ld4(a.pl + (((size_t)b * a.PH + min(max(y, 0), a.PH - 1)) * a.PW + min(max(x, 0), a.PW - 1)) * a.C + c);
+              win[oo][i * 3 + j] = inw ? wv : z4;
+              if (inw) inb[oo] |= 1u << (i * 3 + j);
             }
           }
         }
