@@ -62,7 +62,7 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
   // own with a full wait behind it - nine dependent round trips per window instead of one (the pooled-operand nodes spent 14 us of a 22 us
   // block there, tools/dev/node_fwd_phases.py)
   float4 v[9];
-  bool in[9];
+  unsigned in = 0u;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int y = oh * 2 - pad_t + i;
@@ -71,7 +71,7 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
     for (int j = 0; j < 3; ++j) {
       const int x = ow * 2 - pad_l + j;
       const int xc = min(max(x, 0), PW - 1);
-      in[i * 3 + j] = y >= 0 && y < PH && x >= 0 && x < PW;
+      if (y >= 0 && y < PH && x >= 0 && x < PW) in |= 1u << (i * 3 + j);
       v[i * 3 + j] = mmd_ld4(src + (((size_t)b * PH + yc) * PW + xc) * C + c);
     }
   }
@@ -80,7 +80,7 @@ __device__ __forceinline__ float4 pool_window(const float* __restrict__ src, int
   for (int t = 0; t < 9; ++t) {
     float4 u = v[t];
     if (aff) u = fuse_aff4(u, sc, sh);
-    if (!in[t]) u = make_float4(0, 0, 0, 0);   // zero padding takes part in the max
+    if (!((in >> t) & 1u)) u = make_float4(0, 0, 0, 0);   // zero padding takes part in the max
     m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
   }
   return m;
@@ -807,8 +807,8 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         const int ih = oh0 - 1 + pp / IW, iw = ow0 - 1 + pp % IW;
         ppv[u] = pp; qv[u] = q;
         ok[u] = it < TOT && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        off[u] = (((size_t)b * a.H + ih) * a.W + iw) * C + q * 4;
-        if (ok[u]) { gv[u] = mmd_ld4(ng.g + off[u]); zv[u] = mmd_ld4(ng.z + off[u]); }
+        off[u] = (((size_t)b * a.H + min(max(ih, 0), a.H - 1)) * a.W + min(max(iw, 0), a.W - 1)) * C + min(q, NQ - 1) * 4;
+        gv[u] = mmd_ld4(ng.g + off[u]); zv[u] = mmd_ld4(ng.z + off[u]);      // unconditional (clamped address), masked by ok[] below
       }
     };
     auto finish = [&](int it0) {
