@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
   const int ow0 = (cb * (256 / LW) + strip) * R, oh0 = rb * gm.rh, oh1 = min(oh0 + gm.rh, H);
   float4 wt[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wt[t] = cok ? mmd_ld4(a.w + gw + (size_t)(a.flip ? 8 - t : t) * C + c) : make_float4(0, 0, 0, 0);
+  for (int t = 0; t < 9; ++t) wt[t] = mmd_ld4(a.w + gw + (size_t)(a.flip ? 8 - t : t) * C + (cok ? c : 0));      // (lanes past C never store)
   DwView v;
   v.act = a.in_act;
   if (PRO) {
@@ -485,24 +485,32 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
   if (EPI == 2 && cok) { bsc = mmd_ld4(a.bscale + c); bsh = mmd_ld4(a.bshift + c); bmu = mmd_ld4(a.bmean + c); bis = mmd_ld4(a.binvstd + c); }
   const float* const xb = a.x + ro + (size_t)b * H * W * C + (cok ? c : 0);
   const size_t ob = ro + (size_t)b * H * W * C + c;
-  bool colok[R + 2];
+  // Row loads are unconditional from clamped coordinates and masked afterwards (a guarded load compiles to a branch with a full
+  // wait per load: R + 2 dependent round trips per row), and issued one row ahead of their use.
+  unsigned colok = 0;
+  int colo[R + 2];
 #pragma unroll
-  for (int q = 0; q < R + 2; ++q) { const int iw = ow0 - 1 + q; colok[q] = cok && iw >= 0 && iw < W; }
-
-  auto load_row = [&](int ih, float4 (&dst)[R + 2]) {
-    const bool rok = ih >= 0 && ih < H;
-    const float* p = xb + ((long long)min(max(ih, 0), H - 1) * W + (ow0 - 1)) * C;
+  for (int q = 0; q < R + 2; ++q) {
+    const int iw = ow0 - 1 + q;
+    if (cok && iw >= 0 && iw < W) colok |= 1u << q;
+    colo[q] = min(max(iw, 0), W - 1) * C;
+  }
+  auto issue_row = [&](int ih, float4 (&dst)[R + 2]) {
+    const float* p = xb + (long long)min(max(ih, 0), H - 1) * W * C;
+#pragma unroll
+    for (int q = 0; q < R + 2; ++q) dst[q] = mmd_ld4(p + colo[q]);
+  };
+  auto finish_row = [&](int ih, float4 (&dst)[R + 2]) {
+    const unsigned m = (ih >= 0 && ih < H) ? colok : 0u;
 #pragma unroll
     for (int q = 0; q < R + 2; ++q) {
-      float4 u = make_float4(0, 0, 0, 0);
-      if (rok && colok[q]) {
-        u = mmd_ld4(p + q * C);
-        if (PRO) {
-          if (v.xf) { u.x = u.x * v.sc.x + v.sh.x; u.y = u.y * v.sc.y + v.sh.y; u.z = u.z * v.sc.z + v.sh.z; u.w = u.w * v.sc.w + v.sh.w; }
-          if (v.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
-        }
+      float4 u = dst[q];
+      if (PRO) {
+        if (v.xf) { u.x = u.x * v.sc.x + v.sh.x; u.y = u.y * v.sc.y + v.sh.y; u.z = u.z * v.sc.z + v.sh.z; u.w = u.w * v.sc.w + v.sh.w; }
+        if (v.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
       }
-      dst[q] = u;
+      const bool ok = (m >> q) & 1u;
+      dst[q] = make_float4(ok ? u.x : 0.f, ok ? u.y : 0.f, ok ? u.z : 0.f, ok ? u.w : 0.f);
     }
   };
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
@@ -516,13 +524,22 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
     if (a.bscale && cok) { gsc = mmd_ld4(a.bscale + lo + c); gsh = mmd_ld4(a.bshift + lo + c); }
     if (a.stats && cok) { gmu = mmd_ld4(a.bmean + lo + c); gis = mmd_ld4(a.binvstd + lo + c); }
   }
-  auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2]) {
+  // the `bz` row of an output row (EPI 2 / WG) travels with the input rows: loaded unconditionally one row ahead (issue_z)
+  constexpr bool ZROW = EPI == 2 || WG;
+  auto issue_z = [&](int oh, float4 (&dst)[ZROW ? R : 1]) {
+    if constexpr (ZROW) {
+      const float* p = a.bz + ro + (size_t)b * H * W * C + (cok ? c : 0) + (size_t)min(oh, H - 1) * W * C;
+#pragma unroll
+      for (int o = 0; o < R; ++o) dst[o] = mmd_ld4(p + colo[o + 1]);
+    }
+  };
+  auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2], const float4 (&zr)[ZROW ? R : 1]) {
     if constexpr (WG) {
 #pragma unroll
       for (int o = 0; o < R; ++o) {
         const int ow = ow0 + o;
         if (cok && ow < W) {
-          float4 f = mmd_ld4(a.bz + ob + ((size_t)oh * W + ow) * C);
+          float4 f = zr[o];
           if (a.bscale) { f.x = f.x * gsc.x + gsh.x; f.y = f.y * gsc.y + gsh.y; f.z = f.z * gsc.z + gsh.z; f.w = f.w * gsc.w + gsh.w; }
           if (a.wg_act == MMD_ACT_SWISH) { f.x = mmd_swish(f.x); f.y = mmd_swish(f.y); f.z = mmd_swish(f.z); f.w = mmd_swish(f.w); }
 #pragma unroll
@@ -551,7 +568,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
       if (cok && ow < W) {
         const size_t off = ob + ((size_t)oh * W + ow) * C;
         if (EPI == 2) {
-          const float4 zz = mmd_ld4(a.bz + off);
+          const float4 zz = zr[ZROW ? o : 0];
           float4 gg;
           gg.x = acc.x * mmd_swish_grad(zz.x * bsc.x + bsh.x); gg.y = acc.y * mmd_swish_grad(zz.y * bsc.y + bsh.y);
           gg.z = acc.z * mmd_swish_grad(zz.z * bsc.z + bsh.z); gg.w = acc.w * mmd_swish_grad(zz.w * bsc.w + bsh.w);
@@ -562,8 +579,8 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
           s.x += acc.x; s.y += acc.y; s.z += acc.z; s.w += acc.w;
           ss.x += acc.x * acc.x; ss.y += acc.y * acc.y; ss.z += acc.z * acc.z; ss.w += acc.w * acc.w;
         }
-        if (WG && a.stats) {      // sums of the BatchNorm(+swish) backward that consumes this launch's output (x's producer BN): x is re-read from L1
-          const float4 zz = mmd_ld4(a.bz + off);
+        if (WG && a.stats) {      // sums of the BatchNorm(+swish) backward that consumes this launch's output (x's producer BN)
+          const float4 zz = zr[ZROW ? o : 0];
           float4 gg;
           gg.x = acc.x * mmd_swish_grad(zz.x * gsc.x + gsh.x); gg.y = acc.y * mmd_swish_grad(zz.y * gsc.y + gsh.y);
           gg.z = acc.z * mmd_swish_grad(zz.z * gsc.z + gsh.z); gg.w = acc.w * mmd_swish_grad(zz.w * gsc.w + gsh.w);
@@ -582,14 +599,15 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
     }
   };
 
-  float4 w0[R + 2], w1[R + 2], w2[R + 2];
-  load_row(oh0 - 1, w0);
-  load_row(oh0, w1);
-  for (int oh = oh0; oh < oh1; oh += 3) {
-    load_row(oh + 1, w2);
-    out_row(oh, w0, w1, w2);
-    if (oh + 1 < oh1) { load_row(oh + 2, w0); out_row(oh + 1, w1, w2, w0); }
-    if (oh + 2 < oh1) { load_row(oh + 3, w1); out_row(oh + 2, w2, w0, w1); }
+  // four row buffers: three hold the window, the fourth receives the next row while the current output row is computed
+  float4 w0[R + 2], w1[R + 2], w2[R + 2], w3[R + 2], za[ZROW ? R : 1], zb[ZROW ? R : 1];
+  issue_row(oh0 - 1, w0); issue_row(oh0, w1); issue_row(oh0 + 1, w2); issue_z(oh0, za);
+  finish_row(oh0 - 1, w0); finish_row(oh0, w1);
+  for (int oh = oh0; oh < oh1; oh += 4) {
+    issue_row(oh + 2, w3); issue_z(oh + 1, zb); finish_row(oh + 1, w2); out_row(oh, w0, w1, w2, za);
+    if (oh + 1 < oh1) { issue_row(oh + 3, w0); issue_z(oh + 2, za); finish_row(oh + 2, w3); out_row(oh + 1, w1, w2, w3, zb); }
+    if (oh + 2 < oh1) { issue_row(oh + 4, w1); issue_z(oh + 3, zb); finish_row(oh + 3, w0); out_row(oh + 2, w2, w3, w0, za); }
+    if (oh + 3 < oh1) { issue_row(oh + 5, w2); issue_z(oh + 4, za); finish_row(oh + 4, w1); out_row(oh + 3, w3, w0, w1, zb); }
   }
   if ((EPI == 1 || EPI == 2) || (WG && a.stats) || (EPI == 3 && a.pool)) {      // lanes l, l^LW, l^2LW, ... of a wave share the channel quad; then the 4 waves through LDS
     auto red = [](float4 x) {
@@ -1089,33 +1107,48 @@ __global__ __launch_bounds__(256) void dw3_wgrad_rows_kernel(DwWgArgs a, DwRowsG
   if (PRO) { BnLive none{}; dw_in_coef(a.in_scale, a.in_shift, none, c, cok, v); }
   const float* const xb = a.x + (size_t)b * H * W * C + (cok ? c : 0);
   const float* const gb = a.dy + (size_t)b * H * W * C + (cok ? c : 0);
-  bool colok[R + 2];
+  // unconditional, clamped, masked row loads issued one row ahead: as in dw3_rows_kernel
+  unsigned colok = 0;
+  int colo[R + 2];
 #pragma unroll
-  for (int q = 0; q < R + 2; ++q) { const int iw = ow0 - 1 + q; colok[q] = cok && iw >= 0 && iw < W; }
-  auto load_row = [&](int ih, float4 (&dst)[R + 2]) {
-    const bool rok = ih >= 0 && ih < H;
-    const float* p = xb + ((long long)min(max(ih, 0), H - 1) * W + (ow0 - 1)) * C;
+  for (int q = 0; q < R + 2; ++q) {
+    const int iw = ow0 - 1 + q;
+    if (cok && iw >= 0 && iw < W) colok |= 1u << q;
+    colo[q] = min(max(iw, 0), W - 1) * C;
+  }
+  auto issue_row = [&](int ih, float4 (&dst)[R + 2]) {
+    const float* p = xb + (long long)min(max(ih, 0), H - 1) * W * C;
+#pragma unroll
+    for (int q = 0; q < R + 2; ++q) dst[q] = mmd_ld4(p + colo[q]);
+  };
+  auto finish_row = [&](int ih, float4 (&dst)[R + 2]) {
+    const unsigned m = (ih >= 0 && ih < H) ? colok : 0u;
 #pragma unroll
     for (int q = 0; q < R + 2; ++q) {
-      float4 u = make_float4(0, 0, 0, 0);
-      if (rok && colok[q]) {
-        u = mmd_ld4(p + q * C);
-        if (PRO) {
-          if (v.xf) { u.x = u.x * v.sc.x + v.sh.x; u.y = u.y * v.sc.y + v.sh.y; u.z = u.z * v.sc.z + v.sh.z; u.w = u.w * v.sc.w + v.sh.w; }
-          if (v.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
-        }
+      float4 u = dst[q];
+      if (PRO) {
+        if (v.xf) { u.x = u.x * v.sc.x + v.sh.x; u.y = u.y * v.sc.y + v.sh.y; u.z = u.z * v.sc.z + v.sh.z; u.w = u.w * v.sc.w + v.sh.w; }
+        if (v.act == MMD_ACT_SWISH) { u.x = mmd_swish(u.x); u.y = mmd_swish(u.y); u.z = mmd_swish(u.z); u.w = mmd_swish(u.w); }
       }
-      dst[q] = u;
+      const bool ok = (m >> q) & 1u;
+      dst[q] = make_float4(ok ? u.x : 0.f, ok ? u.y : 0.f, ok ? u.z : 0.f, ok ? u.w : 0.f);
     }
+  };
+  auto issue_g = [&](int oh, float4 (&dst)[R]) {
+    const float* p = gb + (long long)min(oh, H - 1) * W * C;
+#pragma unroll
+    for (int o = 0; o < R; ++o) dst[o] = mmd_ld4(p + colo[o + 1]);
   };
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
-  auto out_row = [&](int oh, const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2]) {
+  auto out_row = [&](const float4 (&r0)[R + 2], const float4 (&r1)[R + 2], const float4 (&r2)[R + 2], const float4 (&gr)[R]) {
     float4 g[R];
-    const float* p = gb + ((long long)oh * W + ow0) * C;
 #pragma unroll
-    for (int o = 0; o < R; ++o) g[o] = colok[o + 1] ? mmd_ld4(p + o * C) : make_float4(0, 0, 0, 0);
+    for (int o = 0; o < R; ++o) {
+      const bool ok = (colok >> (o + 1)) & 1u;
+      g[o] = make_float4(ok ? gr[o].x : 0.f, ok ? gr[o].y : 0.f, ok ? gr[o].z : 0.f, ok ? gr[o].w : 0.f);
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -1125,14 +1158,14 @@ __global__ __launch_bounds__(256) void dw3_wgrad_rows_kernel(DwWgArgs a, DwRowsG
         acc[6 + j].x += g[o].x * r2[o + j].x; acc[6 + j].y += g[o].y * r2[o + j].y; acc[6 + j].z += g[o].z * r2[o + j].z; acc[6 + j].w += g[o].w * r2[o + j].w;
       }
   };
-  float4 w0[R + 2], w1[R + 2], w2[R + 2];
-  load_row(oh0 - 1, w0);
-  load_row(oh0, w1);
-  for (int oh = oh0; oh < oh1; oh += 3) {
-    load_row(oh + 1, w2);
-    out_row(oh, w0, w1, w2);
-    if (oh + 1 < oh1) { load_row(oh + 2, w0); out_row(oh + 1, w1, w2, w0); }
-    if (oh + 2 < oh1) { load_row(oh + 3, w1); out_row(oh + 2, w2, w0, w1); }
+  float4 w0[R + 2], w1[R + 2], w2[R + 2], w3[R + 2], za[R], zb[R];
+  issue_row(oh0 - 1, w0); issue_row(oh0, w1); issue_row(oh0 + 1, w2); issue_g(oh0, za);
+  finish_row(oh0 - 1, w0); finish_row(oh0, w1);
+  for (int oh = oh0; oh < oh1; oh += 4) {
+    issue_row(oh + 2, w3); issue_g(oh + 1, zb); finish_row(oh + 1, w2); out_row(w0, w1, w2, za);
+    if (oh + 1 < oh1) { issue_row(oh + 3, w0); issue_g(oh + 2, za); finish_row(oh + 2, w3); out_row(w1, w2, w3, zb); }
+    if (oh + 2 < oh1) { issue_row(oh + 4, w1); issue_g(oh + 3, zb); finish_row(oh + 3, w0); out_row(w2, w3, w0, za); }
+    if (oh + 3 < oh1) { issue_row(oh + 5, w2); issue_g(oh + 4, za); finish_row(oh + 4, w1); out_row(w3, w0, w1, zb); }
   }
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
