@@ -204,6 +204,21 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     dw_in_coef(a.in_scale ? a.in_scale + gb + lo : nullptr, a.in_scale ? a.in_shift + gb + lo : nullptr, bn, c, cok, v);
   }
   float* const yout = a.y + ro;
+  constexpr bool E_BZ = EPI == 2 || EPI == 4, E_ST = EPI == 1 || EPI == 4, E_OUT = EPI == 3 || EPI == 4;
+  const int p = tid / LANES;
+  const int orow = p / (Cf::TW / Cf::R);
+  const int ocol0 = (p % (Cf::TW / Cf::R)) * Cf::R;
+  // the epilogue's `bz` values: loaded first, unconditionally from clamped positions (behind the staging loads they would be R dependent
+  // round trips at the end of the block: 3.4 of a block's 19 us, profiles/r04_dw_bwd_phases.txt)
+  constexpr bool Z_PRE = EPI == 2;       // (the run-time-mode body EPI 4 loads them in place: 14 more live registers cost it a block per CU)
+  float4 zq[Z_PRE ? Cf::R : 1];
+  if constexpr (Z_PRE) {
+    if (a.bz) {
+      const size_t zrow = ((size_t)b * OH + min(oh0 + orow, OH - 1)) * OW;
+#pragma unroll
+      for (int o = 0; o < Cf::R; ++o) zq[o] = mmd_ldw4(a.bz, (zrow + min(ow0 + ocol0 + o, OW - 1)) * a.C + (cok ? c : 0), a.bz16);
+    }
+  }
 
   for (int i = tid; i < K * K * LANES; i += 256) {
     int tap = i / LANES, q = (i % LANES) * 4;
@@ -224,9 +239,6 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   __syncthreads();
   MMD_DT(2);
 
-  const int p = tid / LANES;
-  const int orow = p / (Cf::TW / Cf::R);
-  const int ocol0 = (p % (Cf::TW / Cf::R)) * Cf::R;
   float4 acc[Cf::R];
 #pragma unroll
   for (int o = 0; o < Cf::R; ++o) acc[o] = make_float4(0, 0, 0, 0);
@@ -249,7 +261,6 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
   }
   MMD_DT(3);
-  constexpr bool E_BZ = EPI == 2 || EPI == 4, E_ST = EPI == 1 || EPI == 4, E_OUT = EPI == 3 || EPI == 4;
   float4 osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
   if (E_OUT && a.out_scale && cok) { osc = mmd_ld4(a.out_scale + gb + c); osh = mmd_ld4(a.out_shift + gb + c); }
   float4 s = make_float4(0, 0, 0, 0), ss = make_float4(0, 0, 0, 0), pl = make_float4(0, 0, 0, 0);
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     if (cok && oh < OH && ow < OW) {
       float4 v = acc[o];
       if (E_BZ && a.bz) {
-        const float4 zz = mmd_ldw4(a.bz, (((size_t)b * OH + oh) * OW + ow) * a.C + c, a.bz16);
+        const float4 zz = Z_PRE ? zq[Z_PRE ? o : 0] : mmd_ldw4(a.bz, (((size_t)b * OH + oh) * OW + ow) * a.C + c, a.bz16);
         if (WG) fq[o] = make_float4(mmd_swish(zz.x * bsc.x + bsh.x), mmd_swish(zz.y * bsc.y + bsh.y), mmd_swish(zz.z * bsc.z + bsh.z),
                                     mmd_swish(zz.w * bsc.w + bsh.w));
         float4 gg;
@@ -329,10 +340,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   MMD_DT(5);
   if constexpr (WG) {
     static_assert(S == 1 && Cf::IH * Cf::IW >= 4 * K * K, "weight-gradient reduction aliases the input tile");
-    // dw[i][j] += sum_q a0[q] * dY[q - (i - p, j - p)]: the launch's (flipped-tap) window of dY around q, read once more from the LDS tile
-    float4 dwa[K * K];
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) dwa[t] = make_float4(0, 0, 0, 0);
+    // dw[i][j] += sum_q a0[q] * dY[q - (i - p, j - p)]: the launch's (flipped-tap) window of dY around q, read once more from the LDS tile.
+    // One tap row at a time: k float4 sums, butterfly-reduced over the wave's NG = 64 / LANES pixel groups (every lane then holds the
+    // wave's sum), and pixel group i % NG keeps row i - ceil(k / NG) x k float4 per lane instead of k*k (100 VGPRs at k = 5, which held
+    // the launch at two blocks per CU).
+    constexpr int NG = 64 / LANES, NK = (K + NG - 1) / NG;
+    const int lane = tid & 63, grp = lane / LANES, wave = tid >> 6;
+    float4 keep[NK][K];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       float4 in[Cf::SEG];
@@ -340,25 +354,29 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
 #pragma unroll
       for (int q = 0; q < Cf::SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * CC);
 #pragma unroll
-      for (int j = 0; j < K; ++j)
+      for (int j = 0; j < K; ++j) {
+        float4 v = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int o = 0; o < Cf::R; ++o) {
-          dwa[i * K + j].x += fq[o].x * in[o + j].x; dwa[i * K + j].y += fq[o].y * in[o + j].y;
-          dwa[i * K + j].z += fq[o].z * in[o + j].z; dwa[i * K + j].w += fq[o].w * in[o + j].w;
+          v.x += fq[o].x * in[o + j].x; v.y += fq[o].y * in[o + j].y; v.z += fq[o].z * in[o + j].z; v.w += fq[o].w * in[o + j].w;
         }
+#pragma unroll
+        for (int o = LANES; o < 64; o <<= 1) {
+          v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+        }
+        if (grp == i % NG) keep[i / NG][j] = v;
+      }
     }
     MMD_DT(6);
     __syncthreads();                                  // every read of the tile is done: reduce in its place
     float* sRedW = sIn;                               // [4 waves][K*K][CC]
-    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-      float4 v = dwa[t];
+    for (int r = 0; r < NK; ++r) {
+      const int i = r * NG + grp;
+      if (i < K) {
 #pragma unroll
-      for (int o = LANES; o < 64; o <<= 1) {
-        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+        for (int j = 0; j < K; ++j) *reinterpret_cast<float4*>(&sRedW[(wave * K * K + i * K + j) * CC + c4]) = keep[r][j];
       }
-      if (lane < LANES) *reinterpret_cast<float4*>(&sRedW[(wave * K * K + t) * CC + c4]) = v;
     }
     __syncthreads();
     for (int i = tid; i < K * K * CC; i += 256) {
