@@ -342,7 +342,23 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
       wreg[i] = idx < NW4 ? mmd_ld4(wpw + (size_t)idx * 4) : make_float4(0, 0, 0, 0);
     }
   }
-  for (int i = tid; i < 9 * FN_Q; i += FN_NT) *reinterpret_cast<float4*>(&sWd[i * 4]) = mmd_ld4(wdw + (size_t)i * 4);
+  // depthwise taps and the epilogue coefficients of the wave's column tiles: loaded here, used (LDS store / epilogue) only after the
+  // operand loads of phase 0 are in flight - a store or a guarded `bias ? bias[n] : 0` right here is a full wait in front of them
+  static_assert(9 * FN_Q <= 2 * FN_NT, "two tap quads per thread");
+  const float4 wd0 = mmd_ld4(wdw + (size_t)min(tid, 9 * FN_Q - 1) * 4), wd1 = mmd_ld4(wdw + (size_t)min(tid + FN_NT, 9 * FN_Q - 1) * 4);
+  constexpr int NJ = (CT + 1) / 2;               // column tiles per wave
+  float ebi[NJ], esc[NJ], esh[NJ];               // epilogue coefficients of the wave's column tiles (ct = (wave >> 2) + 2 j)
+  {
+    const int wv = tid >> 6, r_ = tid & 15;
+    const float* const bsrc = bias ? bias : wdw;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = min(((wv >> 2) + 2 * j) * 16 + r_, FN_C - 1);
+      const float t = bsrc[n];
+      ebi[j] = bias ? t : 0.f;
+      if (!TRAIN) { esc[j] = scale[n]; esh[j] = shift[n]; } else { esc[j] = 1.f; esh[j] = 0.f; }
+    }
+  }
   if (TRAIN) for (int i = tid; i < 2 * FN_C; i += FN_NT) sSt[i] = 0.f;
   // ---- phase 0: every global load of the thread's (pixel, quad) items is issued before the first use (one block per CU: nothing else
   // would hide six dependent load latencies); the pooled operand's 3x3 window is gathered in the second pass
@@ -367,6 +383,8 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
     constexpr int n2 = (MODE & 3) ? 1 : 0;             // operand order (in0, in1, up, pool): in1 and up never occur together
     const float wp_ = (MODE & 4) ? w[1 + n2] : 0.f;
     const bool lz = LZ && a.lazy != 0;                 // block-uniform
+    if (tid < 9 * FN_Q) *reinterpret_cast<float4*>(&sWd[tid * 4]) = wd0;
+    if (tid + FN_NT < 9 * FN_Q) *reinterpret_cast<float4*>(&sWd[(tid + FN_NT) * 4]) = wd1;
     if constexpr (LZ) {
       if (lz) {
         // the lazy operands' coefficient table - filled HERE, behind the operand loads issued above, so that its own dependent loads
@@ -463,14 +481,6 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   const int lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave & 3;
-  constexpr int NJ = (CT + 1) / 2;               // column tiles per wave
-  float ebi[NJ], esc[NJ], esh[NJ];               // epilogue coefficients of the wave's column tiles (ct = (wave >> 2) + 2 j)
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = min(((wave >> 2) + 2 * j) * 16 + r, FN_C - 1);
-    ebi[j] = bias ? bias[n] : 0.f;
-    if (!TRAIN) { esc[j] = scale[n]; esh[j] = shift[n]; } else { esc[j] = 1.f; esh[j] = 0.f; }
-  }
   float af[KR];
   {
     const float* ap = &sZ[(rt * 16 + r) * FN_ZS + g * KR];
@@ -753,8 +763,6 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   __shared__ float sCo[8 * 64];                    // lazy operands' (scale, shift) of this block's channel chunk
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   NODE_T(0);
-  float w[3];
-  fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int cc = bid % cchunks; bid /= cchunks;
@@ -762,25 +770,40 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
   const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
-  if (a.lazy) fuse_coef_fill(a, c0, sCo);          // (complete behind the staging barrier below)
   const bool cok = c < a.C;
   const int oh0 = th * TH, ow0 = tw * TW;
-  for (int i = tid; i < 9 * 16; i += 256) {        // flipped taps: the transpose of a stride-1 SAME correlation
-    int tap = i >> 4, q = (i & 15) * 4;
-    float4 wv = (c0 + q < a.C) ? mmd_ld4(wdw + (size_t)(8 - tap) * a.C + c0 + q) : make_float4(0, 0, 0, 0);
-    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
+  // ---- head: everything the block needs before its first barrier (lazy operands' coefficients, flipped taps, the BatchNorm backward's
+  // coefficient sources) is LOADED here and stored to LDS behind the loads of the 1x1 weights and of the dz tile's first trip: as four
+  // load -> LDS-store groups in a row they were four dependent round trips, 4.5 of a block's 19 us (profiles/r04_node_bwd_phases_after.txt)
+  const int hop = __builtin_amdgcn_readfirstlane(tid >> 6), hcl = tid & 63;      // lazy table: this thread's (operand, channel)
+  const bool hlz = (a.lazy >> hop) & 1, hlive = hlz && a.ost[hop];      // (live batch statistics: the forward form; the backward passes finalized coefficients)
+  const int hlc = min(c0 + hcl, a.C - 1);
+  // unconditional loads (stand-in address when the operand carries no finalized coefficients): a value loaded inside a branch is waited for at the join
+  float hsc = ((hlz && !hlive) ? a.osc[hop] : wdw)[(hlz && !hlive) ? hlc : 0], hsh = ((hlz && !hlive) ? a.osh[hop] : wdw)[(hlz && !hlive) ? hlc : 0];
+  const int ti = min(tid, 9 * 16 - 1), ttap = ti >> 4, tq = (ti & 15) * 4;      // flipped taps: the transpose of a stride-1 SAME correlation
+  const bool tok = c0 + tq < a.C;
+  const float4 twv = mmd_ld4(wdw + (size_t)(8 - ttap) * a.C + (tok ? c0 + tq : 0));
+  double hs0 = 0, hs1 = 0;
+  float hscl = 0.f, hinv = 0.f, hmu = 0.f;
+  if constexpr (GEMM) {
+    const int n = min(tid, a.C - 1);
+    hs0 = ng.sums[n]; hs1 = ng.sums[a.C + n]; hscl = ng.scale[n]; hinv = ng.invstd[n]; hmu = ng.mean[n];
   }
+  auto head_store = [&]() {
+    if (tid < 9 * 16) *reinterpret_cast<float4*>(&sW[ttap * 64 + tq]) = tok ? twv : make_float4(0, 0, 0, 0);
+    if (a.lazy) {
+      if (hlive) {
+        BnLive bn; bn.stats = a.ost[hop]; bn.gamma = a.oga[hop]; bn.beta = a.obe[hop]; bn.inv_count = a.oic[hop]; bn.C = a.C; bn.eps = 1e-3f;
+        bn_live_coef(bn, hlc, hsc, hsh);
+      }
+      const bool in = hlz && c0 + hcl < a.C;
+      sCo[(2 * hop) * 64 + hcl] = in ? hsc : 1.f; sCo[(2 * hop + 1) * 64 + hcl] = in ? hsh : 0.f;
+    }
+  };
   if constexpr (GEMM) {
     const int C = a.C, LDZ = C + 4, NQ = C >> 2;
     float* const sDz = sDyn;                        // [100 pixel rows][LDZ] (the seventh 16-row MFMA tile re-reads row 99 for its rows 100 .. 111)
     float* const sCf = sDyn + IH * IW * LDZ;        // [4][C]: a1, a2, a3, mu of the BatchNorm backward
-    for (int n = tid; n < C; n += 256) {
-      const float m1 = (float)(ng.sums[n] * ng.inv_count), m2 = (float)(ng.sums[C + n] * ng.inv_count);
-      const float sc = ng.scale[n];
-      sCf[n] = sc; sCf[C + n] = -sc * ng.invstd[n] * m2; sCf[2 * C + n] = -sc * m1; sCf[3 * C + n] = ng.mean[n];
-    }
-    if (ng.dgamma && blockIdx.x == 0)
-      for (int n = tid; n < C; n += 256) { ng.dgamma[n] += (float)ng.sums[C + n]; ng.dbeta[n] += (float)ng.sums[n]; }
     // the wave's B operand: w[n = 16 kk + 4 g + j][c = c0 + 16 wave + r], kk = 0 .. C / 16 - 1 (at most 14 k groups: C <= 224)
     const int lane = tid & 63, r = lane & 15, gq = lane >> 4, wv_ = tid >> 6;
     const int cb = c0 + wv_ * 16 + r;
@@ -830,8 +853,20 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       }
     };
     issue(tid);
+    head_store();
+    if (tid < C) {
+      const float m1 = (float)(hs0 * ng.inv_count), m2 = (float)(hs1 * ng.inv_count);
+      sCf[tid] = hscl; sCf[C + tid] = -hscl * hinv * m2; sCf[2 * C + tid] = -hscl * m1; sCf[3 * C + tid] = hmu;
+    }
+    for (int n = tid + 256; n < C; n += 256) {      // (C > 256 only)
+      const float m1 = (float)(ng.sums[n] * ng.inv_count), m2 = (float)(ng.sums[C + n] * ng.inv_count);
+      const float sc = ng.scale[n];
+      sCf[n] = sc; sCf[C + n] = -sc * ng.invstd[n] * m2; sCf[2 * C + n] = -sc * m1; sCf[3 * C + n] = ng.mean[n];
+    }
     __syncthreads();                                // coefficients visible
     NODE_T(1);
+    if (ng.dgamma && blockIdx.x == 0)
+      for (int n = tid; n < C; n += 256) { ng.dgamma[n] += (float)ng.sums[C + n]; ng.dbeta[n] += (float)ng.sums[n]; }
     finish(tid);
     for (int it0 = tid + 256 * U; it0 < TOT; it0 += 256 * U) { issue(it0); finish(it0); }
     __syncthreads();
@@ -862,6 +897,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         if (pp < IH * IW) sIn[pp * 64 + wv_ * 16 + r] = cvalid ? acc7[mt][i] : 0.f;
       }
   } else {
+  head_store();
   for (int p = tid >> 4; p < IH * IW; p += 16) {
     const int ih = oh0 - 1 + p / IW, iw = ow0 - 1 + p % IW;
     float4 v = make_float4(0, 0, 0, 0);
@@ -871,6 +907,8 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
   __syncthreads();
   NODE_T(3);
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
   const int p = tid >> 4;
   const int orow = p / (TW / R);
   const int ocol0 = (p % (TW / R)) * R;
