@@ -182,23 +182,67 @@ __global__ __launch_bounds__(256) void fuse_dw_fwd_kernel(FuseArgs a, const floa
   const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
   const bool cok = c < a.C;
   const int oh0 = th * TH, ow0 = tw * TW;
-  for (int i = tid; i < 9 * 16; i += 256) {
-    int tap = i >> 4, q = (i & 15) * 4;
-    float4 wv = (c0 + q < a.C) ? mmd_ld4(wdw + (size_t)tap * a.C + c0 + q) : make_float4(0, 0, 0, 0);
-    *reinterpret_cast<float4*>(&sW[tap * 64 + q]) = wv;
-  }
-  for (int p = tid >> 4; p < IH * IW; p += 16) {
+  // staging: every operand load of the thread's seven tile pixels is issued before the first use, unconditionally from clamped coordinates
+  // (masked afterwards) - as a guarded load -> fuse -> LDS-store loop each pixel was a dependent round trip of its own (two with a pooled
+  // operand); the pooled operand's 3x3 windows follow three pixels at a time
+  constexpr int NST = (IH * IW + 15) / 16;
+  const bool has1 = a.in1 != nullptr, hasu = a.up != nullptr, hasp = a.pl != nullptr;      // block-uniform
+  const int cs = cok ? c : 0;
+  const int ti = min(tid, 9 * 16 - 1), ttap = ti >> 4, tq = (ti & 15) * 4;
+  const bool tok = c0 + tq < a.C;
+  const float4 twv = mmd_ld4(wdw + (size_t)ttap * a.C + (tok ? c0 + tq : 0));
+  float4 v0[NST], v1[NST];
+  unsigned okm = 0u;
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int p = (tid >> 4) + 16 * i;
     const int ih = oh0 - 1 + p / IW, iw = ow0 - 1 + p % IW;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-      float4 t0, t1, t2, t3;
-      v = fuse_presum(a, w, b, ih, iw, c, &t0, &t1, &t2, &t3);
-      v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w);
-      const int py = p / IW, px = p % IW;
-      if (f_out && py >= 1 && py <= TH && px >= 1 && px <= TW)
-        mmd_st4(f_out + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c, v);
+    if (cok && p < IH * IW && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) okm |= 1u << i;
+    const int ihc = min(max(ih, 0), a.H - 1), iwc = min(max(iw, 0), a.W - 1);
+    const size_t off = (((size_t)b * a.H + ihc) * a.W + iwc) * a.C + cs;
+    v0[i] = mmd_ld4(a.in0 + off);
+    v1[i] = make_float4(0, 0, 0, 0);
+    if (has1) v1[i] = mmd_ld4(a.in1 + off);
+    else if (hasu) v1[i] = mmd_ld4(a.up + (((size_t)b * (a.H >> 1) + (ihc >> 1)) * (a.W >> 1) + (iwc >> 1)) * a.C + cs);
+  }
+  if (tid < 9 * 16) *reinterpret_cast<float4*>(&sW[ttap * 64 + tq]) = tok ? twv : make_float4(0, 0, 0, 0);
+  const float w1 = (has1 || hasu) ? w[1] : 0.f, wp = hasp ? w[(has1 || hasu) ? 2 : 1] : 0.f;
+#pragma unroll
+  for (int i0 = 0; i0 < NST; i0 += 3) {
+    float4 m[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = i0 + u;
+      m[u] = make_float4(0, 0, 0, 0);
+      if (i < NST && hasp) {
+        const int p = (tid >> 4) + 16 * i;
+        const int ihc = min(max(oh0 - 1 + p / IW, 0), a.H - 1), iwc = min(max(ow0 - 1 + p % IW, 0), a.W - 1);
+        m[u] = pool_window(a.pl, b, ihc, iwc, cs, a.PH, a.PW, a.C, a.pad_t, a.pad_l);
+      }
     }
-    *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = i0 + u;
+      if (i >= NST) break;
+      const int p = (tid >> 4) + 16 * i;
+      if (p >= IH * IW) break;
+      // (the summation order and contraction of fuse_presum: the two-launch path's f is bit-identical)
+      auto mix = [&](float x0, float x1, float xm) {
+        float t = w[0] * x0;
+        if (has1 || hasu) t = __fmaf_rn(w1, x1, t);
+        if (hasp) t = __fmaf_rn(wp, xm, t);
+        return t;
+      };
+      float4 v;
+      v.x = mix(v0[i].x, v1[i].x, m[u].x); v.y = mix(v0[i].y, v1[i].y, m[u].y);
+      v.z = mix(v0[i].z, v1[i].z, m[u].z); v.w = mix(v0[i].w, v1[i].w, m[u].w);
+      const bool ok = (okm >> i) & 1u;
+      v.x = ok ? mmd_swish(v.x) : 0.f; v.y = ok ? mmd_swish(v.y) : 0.f; v.z = ok ? mmd_swish(v.z) : 0.f; v.w = ok ? mmd_swish(v.w) : 0.f;
+      const int py = p / IW, px = p % IW;
+      if (ok && f_out && py >= 1 && py <= TH && px >= 1 && px <= TW)
+        mmd_st4(f_out + (((size_t)b * a.H + oh0 - 1 + py) * a.W + ow0 - 1 + px) * a.C + c, v);
+      *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+    }
   }
   __syncthreads();
   const int p = tid >> 4;
@@ -897,12 +941,24 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
         if (pp < IH * IW) sIn[pp * 64 + wv_ * 16 + r] = cvalid ? acc7[mt][i] : 0.f;
       }
   } else {
-  head_store();
-  for (int p = tid >> 4; p < IH * IW; p += 16) {
+  // the dzd tile: all seven loads of a thread in flight together (unconditional, clamped addresses, masked) - guarded they were seven
+  // load -> LDS-store round trips in a row
+  constexpr int NST = (IH * IW + 15) / 16;
+  float4 sv[NST];
+  unsigned sok = 0u;
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int p = (tid >> 4) + 16 * i;
     const int ih = oh0 - 1 + p / IW, iw = ow0 - 1 + p % IW;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (cok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = mmd_ld4(dzd + (((size_t)b * a.H + ih) * a.W + iw) * a.C + c);
-    *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = v;
+    if (cok && p < IH * IW && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) sok |= 1u << i;
+    sv[i] = mmd_ld4(dzd + (((size_t)b * a.H + min(max(ih, 0), a.H - 1)) * a.W + min(max(iw, 0), a.W - 1)) * a.C + (cok ? c : 0));
+  }
+  head_store();
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int p = (tid >> 4) + 16 * i;
+    const bool ok = (sok >> i) & 1u;
+    if (p < IH * IW) *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = make_float4(ok ? sv[i].x : 0.f, ok ? sv[i].y : 0.f, ok ? sv[i].z : 0.f, ok ? sv[i].w : 0.f);
   }
   }
   __syncthreads();

@@ -1284,7 +1284,7 @@ def test_pwconv_bwd_bn_prologue(M, K, N, act, rowscale, sfx):
     close(dbe, beta.grad, 5e-4, 5e-4 * max(beta.grad.abs().max().item(), 1.0), "dbeta")
 
 
-@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 48), ("p7", 4, 4, 112), ("td", 6, 10, 224)])
+@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 12, 48), ("p7", 4, 4, 112), ("td", 6, 10, 224), ("m6", 8, 8, 112)])
 def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
     """Fused node backward (depthwise input gradient from an LDS tile + fusion backward) against the two launches it
     replaces: same dx, same operand gradients (written and accumulated), same theta dot products."""
@@ -1292,9 +1292,9 @@ def test_bifpn_node_dw_bwd_fused(mode, H, W, C):
     B = 2
     in0 = torch.randn(B * H * W, C)
     in1 = torch.randn(B * H * W, C) if mode == "bu" else None
-    up = torch.randn(B * (H // 2) * (W // 2), C) if mode == "td" else None
-    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7") else None
-    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3])
+    up = torch.randn(B * (H // 2) * (W // 2), C) if mode in ("td", "m6") else None        # ("m6": up-sampled + pooled operand, an operand
+    pl = torch.randn(B * 4 * H * W, C) - 1.0 if mode in ("bu", "p7", "m6") else None      #  set the BiFPN never builds - the generic instantiation)
+    theta = torch.tensor([0.7, 1.3, 0.4][:3 if mode in ("bu", "m6") else 2])
     wd = torch.randn(9, C) / 3
     dzd = torch.randn(B * H * W, C)
     gp = lambda t: g(t) if t is not None else None
