@@ -214,6 +214,10 @@ int mmd_sigmoid_bwd(const float* dprob, const float* prob, float* dlogit, long l
 
 // Copy one pyramid level out of a concatenated [B, A_total, C] head tensor.
 int mmd_slice_rows(const float* src, float* dst, int B, int rows, int N, long long batch_stride, long long offset, hipStream_t stream);
+// ... every level in one launch, into the level-major pyramid matrix the head backward works on (the split the reference's per-level loop
+// implies, src/YetAnotherEfficientDet.py:470-480 / 520-530 run backwards): dst[row0[l] + b * HW_l + r, :] = src[b * batch_stride + offsets[l] + r * N ...];
+// pyr_desc as for mmd_dwconv3_pyr, offsets = one host value per level.
+int mmd_slice_rows_pyr(const float* src, float* dst, const int* pyr_desc, int N, long long batch_stride, const long long* offsets, hipStream_t stream);
 
 // MTALoss.at without the normalisation: a[b,j] = mean_c f^p (src/loss/MTALoss.py:76-77).
 int mmd_mta_attention(const float* f, float* a, int rows, int C, float p, hipStream_t stream);

@@ -779,6 +779,45 @@ extern "C" int mmd_slice_rows(const float* src, float* dst, int B, int rows, int
   return mmd_check_launch();
 }
 
+// every level of the pyramid in one launch (five launches of 5 - 12 us at the head of the backward's serial chain otherwise):
+// dst[row0[l] + b * HW_l + r, :] = src[b * bstride + off[l] + r * N ...]
+struct SliceOff { long long v[MMD_MAX_LEV]; };
+__global__ __launch_bounds__(256) void slice_rows_pyr_kernel(const float* __restrict__ src, float* __restrict__ dst, Pyr p, int N,
+                                                             long long bstride, SliceOff off, int vec) {
+  // one thread per `vec` consecutive floats of a destination row block (vec = 2 when every slice start and N are even)
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * vec;
+  const size_t total = (size_t)p.row0[p.n] * N;
+  if (i >= total) return;
+  const int row = (int)(i / N);
+  const int l = pyr_level_of_row(p, row);
+  long long o = off.v[0]; int r0 = 0, hw = p.H[0] * p.W[0];
+#pragma unroll
+  for (int k = 1; k < MMD_MAX_LEV; ++k) if (k == l) { o = off.v[k]; r0 = p.row0[k]; hw = p.H[k] * p.W[k]; }
+  const size_t rel = i - (size_t)r0 * N;                 // offset inside the level's [B][HW][N] block
+  const size_t per = (size_t)hw * N;
+  const int b = (int)(rel / per);
+  if (b >= p.B) {                                        // the level's padding rows (levels start at multiples of 128 rows)
+    if (vec == 2) *reinterpret_cast<float2*>(dst + i) = make_float2(0.f, 0.f); else dst[i] = 0.f;
+    return;
+  }
+  const float* s = src + (size_t)b * bstride + o + (rel - (size_t)b * per);
+  if (vec == 2) *reinterpret_cast<float2*>(dst + i) = *reinterpret_cast<const float2*>(s);
+  else dst[i] = *s;
+}
+extern "C" int mmd_slice_rows_pyr(const float* src, float* dst, const int* pyr_desc, int N, long long batch_stride,
+                                  const long long* offsets, hipStream_t stream) {
+  if (!src || !dst || !pyr_desc || !offsets || N <= 0) return MMD_EINVAL;
+  Pyr p;
+  if (mmd_make_pyr(p, pyr_desc)) return MMD_EINVAL;
+  SliceOff off{};
+  bool even = !(N & 1) && !(batch_stride & 1);
+  for (int l = 0; l < p.n; ++l) { off.v[l] = offsets[l]; even = even && !(offsets[l] & 1); }
+  const int vec = even ? 2 : 1;
+  const size_t n = (size_t)p.row0[p.n] * N / vec;
+  hipLaunchKernelGGL(slice_rows_pyr_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, src, dst, p, N, batch_stride, off, vec);
+  return mmd_check_launch();
+}
+
 // BN(+swish) backward over a whole pyramid in one launch each (per-level BN parameters lev_stride channels apart)
 extern "C" int mmd_bn_bwd_reduce_pyr(const float* g_in, const float* z, const float* scale, const float* shift,
                                      const float* mean, const float* invstd, int act, const int* pyr_desc,

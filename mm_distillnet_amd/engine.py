@@ -1125,8 +1125,7 @@ class Net:
         nout = spec.num_anchors * per_anchor
         ls = rec["lev_stride"]
         dy = self._alloc_pyr(pyr, nout)
-        for lvl, (h, w) in enumerate(pyr["sizes"]):
-            call("mmd_slice_rows", dout, dy[pyr["row0"][lvl]:], pyr["B"], h * w, nout, A * per_anchor, rec["yoff"][lvl])
+        call("mmd_slice_rows_pyr", dout, dy, desc, nout, A * per_anchor, (ctypes.c_longlong * len(rec["yoff"]))(*[int(v) for v in rec["yoff"]]))
         hw_key = f"{hname}.header.pointwise_conv.conv.weight"
         self._leaf(lambda dy=dy, gb=ps.g(f"{hname}.header.pointwise_conv.conv.bias"): call("mmd_colsum", dy, gb, Mt, nout))
         self._pw_wgrad(dy, rec["hzd"], ps.g(hw_key), Mt, C, nout)

@@ -1,5 +1,6 @@
 """GPU parity: every HIP entry point (through the C ABI) against a plain PyTorch-CPU fp32 reference of the
 same op (autograd supplies the backward references).  Tolerances are fp32: rtol 1e-4..1e-3 as stated per test."""
+import ctypes
 import math
 
 import numpy as np
@@ -532,6 +533,26 @@ def test_colsum_slice_sigmoid():
     dst = torch.empty(B * rows, N, device=DEV)
     call("mmd_slice_rows", g(src), dst, B, rows, N, At * 4, 20)
     close(dst.view(B, rows * N), src[:, 20:20 + rows * N])
+    # every pyramid level in one launch (levels start at multiples of 128 rows; the padding rows come out as zeros)
+    for N in (36, 9):                                    # even (float2 copies) and odd row widths
+        sizes = [(8, 8), (4, 4), (2, 2)]
+        B = 3
+        A = sum(h * w for h, w in sizes)
+        src = torch.randn(B, A * N)
+        flat = [len(sizes), B] + [v for hw in sizes for v in hw]
+        desc = (ctypes.c_int * len(flat))(*flat)
+        row0 = [0]
+        for h, w in sizes:
+            row0.append(row0[-1] + (B * h * w + 127) // 128 * 128)
+        offs, o = [], 0
+        for h, w in sizes:
+            offs.append(o); o += h * w * N
+        dst = torch.full((row0[-1], N), 7.0, device=DEV)
+        call("mmd_slice_rows_pyr", g(src), dst, desc, N, A * N, (ctypes.c_longlong * len(offs))(*offs))
+        for l, (h, w) in enumerate(sizes):
+            got = dst[row0[l]:row0[l] + B * h * w].cpu().view(B, h * w * N)
+            assert torch.equal(got, src[:, offs[l]:offs[l] + h * w * N])
+            assert torch.count_nonzero(dst[row0[l] + B * h * w:row0[l + 1]]) == 0
     p, dp = torch.rand(1000), torch.randn(1000)
     dl = torch.empty(1000, device=DEV)
     call("mmd_sigmoid_bwd", g(dp), g(p), dl, 1000)
