@@ -128,6 +128,10 @@ LAZY_NODE = not os.environ.get("MMD_NO_LAZY_NODE")
 # round 4: whole-node BiFPN backward - the node's 1x1 conv's input gradient (BatchNorm backward in its operand prologue) runs inside the node
 # backward launch (mmd_bifpn_node_bwd_full) instead of as a GEMM launch in front of it: 40 launches off the backward's serial chain
 NODE_BWD_FULL = not os.environ.get("MMD_NO_NODE_BWD_FULL")
+# bf16 modes: the whole-node backward (whose 1x1 input-gradient product runs exact fp32 MFMA - closer to the fp32 reference than the mode's
+# operand-rounding rule asks for, like the whole-node forward) up to width 160; D2 bf16 13.48 -> 13.25 ms/step, D4 (224) 49.9 -> 52.2: there
+# the bf16 GEMM + two-launch form stays
+NODE_FULL_BF16 = not os.environ.get("MMD_NO_NODE_FULL_BF16")
 MBW_FUSED = not os.environ.get("MMD_NO_MBW")
 MBW_MIN_ROWS = int(os.environ.get("MMD_MBW_MIN_ROWS", "32768"))      # squeeze-excite backward: one data-gradient launch per block, one weight-gradient launch per segment
 
@@ -1237,7 +1241,7 @@ class Net:
                 in0, in1, up, pl = rec["in0"], rec["in1"], rec["up"], rec["pl"]
                 mode_ = (1 if in1 is not None else 0) | (2 if up is not None else 0) | (4 if pl is not None else 0)
                 full = (NODE_BWD_FULL and isinstance(dz, LazyDz) and ps.flat.is_cuda and self.NODE_WG and W % 16 == 0 and W <= 224 and mode_ in (2, 5, 4)
-                        and self.precision == "fp32" and (pl is None or (POOL_SCATTER and FOLD_SUMS)))
+                        and (self.precision == "fp32" or (W <= 160 and NODE_FULL_BF16)) and (pl is None or (POOL_SCATTER and FOLD_SUMS)))
                 dzd = None if full else self._pw_bwd(dz, rec["zd"], f"{name}.pointwise_conv.conv.weight", W, None, True)
                 # the depthwise weight gradient and the depthwise input gradient both come out of the fusion-backward launch below
                 if not self.NODE_WG:
