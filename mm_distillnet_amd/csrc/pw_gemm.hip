@@ -1078,7 +1078,10 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     const bool noxf = lean_on && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
     const bool plain = noxf && !a.gate, gated = noxf && a.gate;
     // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
-    static const int bn32_gain = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 10;
+    // (bf16 operands: the A tile's conversion and L2 re-reads per column tile outweigh the padded MFMA work sooner - D4's N = 224 nodes on four
+    // 64-wide tiles instead of seven 32-wide ones: config 5 49.9 -> 49.5 ms/step)
+    static const int bn32_gain_env = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 0;
+    const int bn32_gain = bn32_gain_env ? bn32_gain_env : (a.bf16 ? 20 : 10);
     const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
     void (*kern)(PwArgs);
     if ((!a.bb.z && (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles)))) ||
