@@ -47,9 +47,14 @@ WG_DEFER = WG_GROUP and bool(os.environ.get("MMD_WG_DEFER"))
 # flush the grouped launch every WG_CHUNK recorded layers.  D2 records 99 layers per backward: 60 (round 2) = two launches, the second - every backbone layer below block 19 - alone at
 # the very end of the backward (0.93 ms exposed); 45 = three, the last one only blocks 4..0 + stem while the second overlaps the high-resolution blocks' main chain
 # (round 3, alternating runs: 16.52 / 16.81 -> 16.55 / 16.66 ms/step, medians 16.65 -> 16.47; 50: 16.70 / 16.82, 80: 16.99 / 17.01; round 2: 30 / 15 layers 20.5 / 20.8 vs 19.7 for 60)
-WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "45"))
+# round 4 (alternating runs, four rounds): 45: 15.02 - 15.08, 46: 15.17 - 15.25, 47: 14.87 - 14.94, 48 / 49: 14.97 - 15.01 ms/step - the last flush is the step's exposed
+# tail (rocprofv3: ~0.45 ms behind the main chain's last kernel at 45), 47 leaves it the two 256^2 project convs only; D4 and the bf16 modes do not care
+WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "47"))
 WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "4096"))      # rows per item: 4096 x (64x64 tile) measured best (1.33 ms per step vs 2.58 at 256)
 WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "4096"))
+# rows per item of a segment's LAST flush: it runs alone at the end of the backward (the thin 256^2 / 128^2 layers: 416 items of 4096 rows =
+# 1.6 rounds of one block per CU, 278 us exposed); shorter items balance and keep more loads in flight
+WG_ROWS_FINAL = int(os.environ.get("MMD_WG_ROWS_FINAL", "4096"))
 # grid of a flush that runs BESIDE the backward's main chain (every flush but the last of a segment).  A chip-filling grid of these long-running
 # blocks starves the chain's kernels of CU slots (round 4 trace: the two M131072 K24 N144 input-gradient GEMMs next to the second flush took
 # 380 us apiece against 77 us alone); a thin persistent grid leaves the chain its slots and has ~2 ms of backward left to finish in
@@ -128,6 +133,7 @@ LAZY_NODE = not os.environ.get("MMD_NO_LAZY_NODE")
 # round 4: whole-node BiFPN backward - the node's 1x1 conv's input gradient (BatchNorm backward in its operand prologue) runs inside the node
 # backward launch (mmd_bifpn_node_bwd_full) instead of as a GEMM launch in front of it: 40 launches off the backward's serial chain
 NODE_BWD_FULL = not os.environ.get("MMD_NO_NODE_BWD_FULL")
+STEM_WG_SIDE = bool(os.environ.get("MMD_STEM_WG_SIDE"))      # (dev: the stem's weight gradient on the second side stream, the earlier placement)
 # bf16 modes: the whole-node backward (whose 1x1 input-gradient product runs exact fp32 MFMA - closer to the fp32 reference than the mode's
 # operand-rounding rule asks for, like the whole-node forward) up to width 160; D2 bf16 13.48 -> 13.25 ms/step, D4 (224) 49.9 -> 52.2: there
 # the bf16 GEMM + two-launch form stays
@@ -866,7 +872,10 @@ class Net:
         """Weight-gradient kernels are leaves of the backward graph (only the optimizer reads them), so they are
         issued on their own stream - a parallel branch of the captured graph - ordered after everything the
         current stream has enqueued so far; backward() joins the stream at its end.  Arena buffers are never
-        reused within a step, so the only ordering needed is producer -> wgrad."""
+        reused within a step, so the only ordering needed is producer -> wgrad.
+        (Round 4: the small leaves - depthwise / squeeze-excite / bias gradients - on a stream of their own, so that they do not queue behind a
+        grouped flush's ~0.9 ms kernel, measured WORSE, all of them or only the last few: 14.72 - 14.89 -> 14.88 - 15.02 ms/step - one more
+        branch beside the main chain costs more than the 0.1 ms the last two leaves wait.)"""
         if not self.ps.flat.is_cuda or os.environ.get("MMD_NO_WG"):
             yield
             return
@@ -948,7 +957,7 @@ class Net:
                 arr[i].in_scale, arr[i].in_shift, arr[i].gate = ptr(a) or None, ptr(b) or None, ptr(gt) or None
                 arr[i].M, arr[i].K, arr[i].N, arr[i].in_act, arr[i].rows_per_image = M, K, N, act, max(int(rpi), 1)
             ni, nt, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
-            rc = _lib.LIB.load().mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), n, WG_ROWS, ctypes.cast(ctypes.pointer(ni), ctypes.c_void_p),
+            rc = _lib.LIB.load().mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), n, WG_ROWS_FINAL if final else WG_ROWS, ctypes.cast(ctypes.pointer(ni), ctypes.c_void_p),
                                                 ctypes.cast(ctypes.pointer(nt), ctypes.c_void_p), ctypes.cast(ctypes.pointer(wsf), ctypes.c_void_p))
             if rc != 0:
                 raise RuntimeError(f"mmd_wgrad_plan failed with status {rc}")
@@ -1528,14 +1537,20 @@ class Net:
                      *self._stats_ws(stem_sums, stem.M, stem.C))
             b0 = ps.bn(f"{P}._bn0")
             ws = self._alloc(int(dll.mmd_stem_wgrad_ws_floats(stem.C)))
-            main_stream = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_event(main_stream.record_event())
-            with torch.cuda.stream(self._side):
+            if STEM_WG_SIDE:
+                main_stream = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_event(main_stream.record_event())
+                with torch.cuda.stream(self._side):
+                    call("mmd_stem_conv_bwd_weight_bn", ximg, s.t, stem.z, ps.g(f"{P}._conv_stem.conv.weight"), ws, Bi, Cin, Hi, Wi, ps.stem_kp, stem.C,
+                         stem.scale, stem.shift, mu, istd, stem_sums, stem.M, SWISH, b0["dgamma"], b0["dbeta"])
+                main_stream.wait_stream(self._side)
+            else:
+                # on the MAIN stream, whose chain ends here: in the captured graph the side-stream branch came out serialised BEHIND the grouped
+                # flush (rocprofv3 trace: flush 278 us -> fold 46 -> stem 78 -> fold 12, all exposed), the main branch runs beside it
                 call("mmd_stem_conv_bwd_weight_bn", ximg, s.t, stem.z, ps.g(f"{P}._conv_stem.conv.weight"), ws, Bi, Cin, Hi, Wi, ps.stem_kp, stem.C,
                      stem.scale, stem.shift, mu, istd, stem_sums, stem.M, SWISH, b0["dgamma"], b0["dbeta"])
-            main_stream.wait_stream(self._side)
         else:
             dz = self._bn_bwd(s.t, stem.z, (stem.scale, stem.shift, mu, istd), f"{P}._bn0", SWISH, stem.M, stem.C, sums=stem_sums)
             with self._wgrad_stream():          # im2col of the input image + weight-gradient GEMM, both off the critical path

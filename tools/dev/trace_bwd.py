@@ -37,3 +37,9 @@ for k in sorted(b):
     tot = sum(b[k].values())
     print("%5.1f ms busy %3d%% n=%3d  %s" % (k * 0.5, tot / 5000, sum(1 for r in seg if (int(r["Start_Timestamp"]) - t0) // 500000 == k),
                                    ", ".join("%s %.0f" % (n_, v / 1e3) for n_, v in b[k].most_common(3))))
+# the tail: the last launches in front of the optimizer (what the step's end waits for), times relative to the segment's end
+t1 = int(seg[-1]["End_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in seg)
+print("tail (us before the backward's end): start  end  queue  kernel")
+for r in sorted(seg, key=lambda r: int(r["End_Timestamp"]))[-28:]:
+    print("  %8.1f %8.1f  q%-3s %s" % ((int(r["Start_Timestamp"]) - t1) / 1e3, (int(r["End_Timestamp"]) - t1) / 1e3,
+                                      r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][:60]))
