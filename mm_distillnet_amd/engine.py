@@ -50,6 +50,8 @@ WG_DEFER = WG_GROUP and bool(os.environ.get("MMD_WG_DEFER"))
 # round 4 (alternating runs, four rounds): 45: 15.02 - 15.08, 46: 15.17 - 15.25, 47: 14.87 - 14.94, 48 / 49: 14.97 - 15.01 ms/step - the last flush is the step's exposed
 # tail (rocprofv3: ~0.45 ms behind the main chain's last kernel at 45), 47 leaves it the two 256^2 project convs only; D4 and the bf16 modes do not care
 WG_CHUNK = int(os.environ.get("MMD_WG_CHUNK", "47"))
+# (dev) explicit flush points instead of the fixed stride: "47,80,94" = flush when the 47th, 80th, 94th layer of the backward has been recorded
+WG_POINTS = frozenset(int(v) for v in os.environ.get("MMD_WG_POINTS", "").split(",") if v.strip())
 WG_ROWS = int(os.environ.get("MMD_WG_ROWS", "4096"))      # rows per item: 4096 x (64x64 tile) measured best (1.33 ms per step vs 2.58 at 256)
 WG_BLOCKS = int(os.environ.get("MMD_WG_GRID", "4096"))
 # rows per item of a segment's LAST flush: it runs alone at the end of the backward (the thin 256^2 / 128^2 layers: 416 items of 4096 rows =
@@ -218,6 +220,7 @@ class Net:
         self._wg = None           # weight-gradient stream: nothing downstream of a wgrad until the optimizer
         self.mark_block, self.mark_event = -1, None
         self._wg_pending: list = []          # deferred 1x1-conv weight gradients of the current backward segment
+        self._wg_count = 0                   # layers recorded so far in this backward
         self._leaf_pending: list = []        # other deferred leaves (closures), issued by _wg_flush
         self._wg_plans: Dict[tuple, dict] = {}  # (segment index, operand signature) -> planned table (built once: arena addresses repeat every step)
         self._wg_segment = 0
@@ -908,7 +911,11 @@ class Net:
                     call("mmd_pwconv_bwd_weight" + self._sfx, dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi)
             return
         self._wg_pending.append((dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi))
-        if WG_CHUNK > 0 and len(self._wg_pending) >= WG_CHUNK:
+        self._wg_count += 1
+        if WG_POINTS:
+            if self._wg_count in WG_POINTS:
+                self._wg_flush(final=False)
+        elif WG_CHUNK > 0 and len(self._wg_pending) >= WG_CHUNK:
             self._wg_flush(final=False)
 
     def _group_bf16(self) -> bool:
@@ -1189,6 +1196,7 @@ class Net:
         slots: Dict[int, GradSlot] = {}
         self._bw = {"slots": slots, "stem_sums": None}
         self._wg_pending, self._leaf_pending, self._wg_segment, self._se_wg = [], [], 0, []
+        self._wg_count = 0
         slot = self._slot
         fold_heads = FOLD_SUMS and ps.flat.is_cuda and (dfeat_pyr is not None or all(d is None for d in dfeats))
         if not fold_heads:
