@@ -742,7 +742,7 @@ class Net:
             if last:    # final outputs land in ONE pyramid row buffer so the shared-weight heads run all levels per launch
                 sizes = [(p3_in.H, p3_in.W), (p4_in.H, p4_in.W), (p5_in.H, p5_in.W), (p6_in.H, p6_in.W), (p7_in.H, p7_in.W)]
                 pyr = self._make_pyr(p3_in.B, sizes)
-                fcat = self._alloc_pyr(pyr, p3_in.C)
+                fcat = self._alloc_pyr(pyr, p3_in.C, train)
                 ov = [fcat[pyr["row0"][l]:pyr["row0"][l] + pyr["rows"][l]] for l in range(5)]
                 self._pyr, self._fcat = pyr, fcat
             else:
@@ -772,9 +772,11 @@ class Net:
         return {"desc": (ctypes.c_int * len(flat))(*flat), "row0": row0, "rows": rows, "sizes": sizes, "B": B,
                 "total": row0[-1], "padded": row0[-1] != sum(rows)}
 
-    def _alloc_pyr(self, pyr, C: int) -> torch.Tensor:
+    def _alloc_pyr(self, pyr, C: int, zero_pad: bool = True) -> torch.Tensor:
+        """zero_pad=False: a frozen net's tensor - nothing multiplies its padding rows into a sum (no weight gradients, no batch statistics), whatever
+        they hold stays in the padding rows of its consumers' outputs (D4 / 768^2, whose 6^2 level is padded: 40 fill launches less on the pack's chain)."""
         t = self._alloc(pyr["total"], C)
-        if pyr["padded"]:          # padding rows are multiplied in the weight-gradient GEMMs: they must be zeros, not stale bits
+        if pyr["padded"] and zero_pad:          # padding rows are multiplied in the weight-gradient GEMMs: they must be zeros, not stale bits
             for l in range(len(pyr["rows"])):       # (only the pad rows: a whole-buffer memset per pyramid tensor cost 1.8 ms/step at 768)
                 lo, hi = pyr["row0"][l] + pyr["rows"][l], pyr["row0"][l + 1]
                 if hi > lo:
@@ -799,10 +801,10 @@ class Net:
         for i in range(nl):
             cname = f"{hname}.conv_list.{i}"
             o = off0 + i * C
-            zd = self._alloc_pyr(pyr, C)
+            zd = self._alloc_pyr(pyr, C, train)
             self._c("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
                  None, None, None, NONE, None, None, None, None)
-            z = self._alloc_pyr(pyr, C)
+            z = self._alloc_pyr(pyr, C, train)
             st = self.stats_flat[2 * o:] if train else None
             self._c("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
                  ps.w(f"{cname}.pointwise_conv.conv.bias"), NONE, st, lev_stride, 0, None)
@@ -815,7 +817,7 @@ class Net:
                 nxt_xf = (ps.fold_scale[o:], ps.fold_shift[o:], SWISH, None, None, None)
             layers.append({"x": cur, "x_off": None if i == 0 else off0 + (i - 1) * C, "zd": zd, "z": z, "off": o})
             cur, cur_xf = z, nxt_xf
-        zd = self._alloc_pyr(pyr, C)
+        zd = self._alloc_pyr(pyr, C, train)
         self._c("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
              None, None, None, NONE, None, None, None, None)
         aoff, yoff = 0, []
