@@ -1146,12 +1146,12 @@ class Net:
         rec = tape[hname]
         nout = spec.num_anchors * per_anchor
         ls = rec["lev_stride"]
-        dy = self._alloc_pyr(pyr, nout)
+        dy = self._alloc_pyr(pyr, nout, False)          # (the slice launch writes the padding rows itself; the plain input-gradient GEMMs below write every row)
         call("mmd_slice_rows_pyr", dout, dy, desc, nout, A * per_anchor, (ctypes.c_longlong * len(rec["yoff"]))(*[int(v) for v in rec["yoff"]]))
         hw_key = f"{hname}.header.pointwise_conv.conv.weight"
         self._leaf(lambda dy=dy, gb=ps.g(f"{hname}.header.pointwise_conv.conv.bias"): call("mmd_colsum", dy, gb, Mt, nout))
         self._pw_wgrad(dy, rec["hzd"], ps.g(hw_key), Mt, C, nout)
-        dzd = self._alloc_pyr(pyr, C)
+        dzd = self._alloc_pyr(pyr, C, False)
         call("mmd_pwconv_bwd_data" + self._sfx, dy, ps.w_t(hw_key), dzd, Mt, C, nout, 0)
         xo = rec["hx_off"]
         # the depthwise weight gradient rides in the (flipped) input-gradient launch: a leaf launch's kernel time is paid in full; so do
@@ -1175,7 +1175,7 @@ class Net:
                  SWISH)
             wkey = f"{cname}.pointwise_conv.conv.weight"
             self._pw_wgrad(dz, L["zd"], ps.g(wkey), Mt, C, C)
-            dzd = self._alloc_pyr(pyr, C)
+            dzd = self._alloc_pyr(pyr, C, False)
             call("mmd_pwconv_bwd_data" + self._sfx, dz, ps.w_t(wkey), dzd, Mt, C, C, 0)
             xo = L["x_off"]
             g = self._alloc_pyr(pyr, C)
