@@ -917,7 +917,9 @@ class Net:
         if WG_POINTS:
             if self._wg_count in WG_POINTS:
                 self._wg_flush(final=False)
-        elif WG_CHUNK > 0 and len(self._wg_pending) >= WG_CHUNK:
+        elif WG_CHUNK > 0 and self._wg_count % WG_CHUNK == 0:
+            # (counted over the whole backward, not per segment: the split backward of the data-parallel step then flushes at the same layers as
+            # the one-segment form - its second segment's 11 layers would otherwise all sit in the exposed last flush)
             self._wg_flush(final=False)
 
     def _group_bf16(self) -> bool:
