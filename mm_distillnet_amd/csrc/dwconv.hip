@@ -1223,7 +1223,10 @@ static int dw3_wgrad_rows_go(DwWgArgs& a, bool pro, hipStream_t st) {
 // is what wastes the thin layer), so only the 16-channel-chunk form is used.
 static int dw3_wgrad_rows_launch(DwWgArgs& a, hipStream_t st) {
   static const int mode = getenv("MMD_DW_ROWS") ? atoi(getenv("MMD_DW_ROWS")) : 1;
-  if (!mode || a.C > 16 || a.W < 256) return 1;
+  // (C in (16, 32] - block 0's depthwise conv on the stem's 256^2 x 32 output, the last leaf of the step's tail - as 32-channel chunks: the
+  // tile kernel's 64-channel chunk leaves half of its lanes idle there)
+  if (!mode || a.C > 32 || a.W < 256) return 1;
+  if (a.C > 16) return dw3_wgrad_rows_go<4, 8>(a, a.in_scale || a.in_act != MMD_ACT_NONE, st);
   return dw3_wgrad_rows_go<4, 4>(a, a.in_scale || a.in_act != MMD_ACT_NONE, st);
 }
 

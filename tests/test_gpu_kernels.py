@@ -299,7 +299,9 @@ def test_pwconv_bwd(M, K, N):
                                         (3, 1, 4, 4, 112), (5, 2, 32, 32, 240), (3, 2, 9, 7, 16),
                                         # 3x3 / s1 wide enough for the row-streaming kernel: 4 / 2 / 1 columns per thread, 64- / 32- / 16-channel chunks
                                         (3, 1, 24, 70, 80), (3, 1, 18, 40, 64), (3, 1, 9, 20, 72), (3, 1, 10, 130, 32), (3, 1, 6, 260, 16),
-                                        (3, 1, 67, 64, 144)])
+                                        (3, 1, 67, 64, 144),
+                                        # weight gradient on the row-streaming window as 32-channel chunks (16 < C <= 32, W >= 256)
+                                        (3, 1, 6, 260, 32), (3, 1, 9, 264, 24)])
 def test_dwconv(k, s, H, W, C):
     torch.manual_seed(k * 100 + s * 10 + C)
     B = 2
