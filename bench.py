@@ -141,6 +141,38 @@ def cpu_baseline(sstate, tstates, S, sample_b, coef=2):
 _T0 = time.time()
 
 
+def launch_ranks(args, argv=None, runner=None):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher - it starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process (one rank per GPU,
+    the reference's `train.py:296-313` mp.spawn shape), lets rank 0's single JSON line through on stdout and returns the child's exit
+    status.  Nothing here touches the GPU (no HIP call before the child exists, and no exec).  Returns None when this process is a rank
+    itself; a rank whose WORLD_SIZE disagrees with --gpus refuses with exit status 2 instead of printing a line for the wrong N."""
+    import subprocess
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s: start one rank per GPU (python -m torch.distributed.run --nproc-per-node %d "
+                  "bench.py --gpus %d ...) or run `python bench.py --gpus %d` and let it start them" % (
+                      args.gpus, world_env, args.gpus, args.gpus, args.gpus), file=sys.stderr, flush=True)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    log("launcher: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    return (runner or subprocess.run)(cmd, env=env).returncode
+
+
 def log(msg):
     print("[bench %6.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -160,6 +192,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU baseline's batch (0 = the per-GPU batch)")
     args = ap.parse_args()
+    rc = launch_ranks(args)
+    if rc is not None:
+        sys.exit(rc)
     # stdout carries exactly ONE line, the JSON record: RCCL prints its version banner to stdout when a communicator comes up, so
     # file descriptor 1 points at stderr for the whole run and the record goes out through a saved duplicate at the end
     sys.stdout.flush()

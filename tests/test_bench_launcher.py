@@ -1,0 +1,69 @@
+"""CPU: `python bench.py --gpus N` starts N ranks as a child process before anything touches the GPU (BASELINE configs[3]: the
+reference starts one process per GPU itself, /root/reference/train.py:296-313), and a rank whose WORLD_SIZE disagrees with
+--gpus refuses instead of printing a record for the wrong N."""
+import argparse
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _Done:
+    def __init__(self, rc):
+        self.returncode = rc
+
+
+def test_launcher_builds_one_rank_per_gpu(monkeypatch):
+    bench = _bench()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    seen = {}
+
+    def runner(cmd, env):
+        seen["cmd"], seen["env"] = cmd, env
+        return _Done(7)
+
+    rc = bench.launch_ranks(argparse.Namespace(gpus=4), argv=["--gpus", "4", "--steps", "5", "--warmup", "2"], runner=runner)
+    assert rc == 7                                   # the child's status is the launcher's status
+    cmd = seen["cmd"]
+    assert cmd[:4] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_single_gpu_and_ranks_do_not_launch(monkeypatch):
+    bench = _bench()
+
+    def runner(cmd, env):
+        raise AssertionError("must not start a child")
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.launch_ranks(argparse.Namespace(gpus=1), argv=[], runner=runner) is None
+    monkeypatch.setenv("WORLD_SIZE", "8")            # a rank started by torch.distributed.run
+    assert bench.launch_ranks(argparse.Namespace(gpus=8), argv=[], runner=runner) is None
+    monkeypatch.setenv("WORLD_SIZE", "2")            # --gpus and the launcher disagree: refuse loudly
+    assert bench.launch_ranks(argparse.Namespace(gpus=8), argv=[], runner=runner) == 2
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert bench.launch_ranks(argparse.Namespace(gpus=1), argv=[], runner=runner) is None
+
+
+def test_mismatch_exits_nonzero_before_any_gpu_call():
+    """the real entry point, no GPU in this container: the refusal must come before torch.cuda.set_device"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, p.stderr[-2000:]
+    assert p.stdout.strip() == ""
+    assert "WORLD_SIZE=2" in p.stderr
