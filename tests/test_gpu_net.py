@@ -545,3 +545,62 @@ def test_teacher_pack_matches_separate_nets():
     nets[0].begin_step()
     with pytest.raises(RuntimeError):
         nets[0].forward([x[:2] for x in xs], train=False, pack=nets)
+
+
+# ---- D4 (BASELINE configs[4]) against fixtures made by the reference's own D4 classes (tools/oracle/make_golden.py golden_net_d4)
+@pytest.mark.parametrize("mod,cin,seed", [("rgb", 3, 41), ("thermal", 1, 42), ("audio", 8, 43)])
+def test_net_d4_768_eval_golden(golden_dir, mod, cin, seed):
+    gold = np.load(os.path.join(golden_dir, f"net_d4_768_eval_{mod}.npz"))
+    spec, st = make_state(4, cin, seed, mod)
+    net = Net(spec, DEV, trainable=False)
+    net.load_state(st)
+    x = synth_inputs(1, 768, seed=44)[mod]
+    net.begin_step()
+    cls, reg, feats = net.forward(x.to(DEV), train=False)
+    torch.cuda.synchronize()
+    assert tuple(cls.shape) == (1, 110484, 20)
+    a = net.anchors(768).cpu()
+    np.testing.assert_array_equal(a[::997].numpy(), gold["anchors.sample"])
+    check_summary(gold, "anchors", a, 1e-6, 1e-7)
+    check_summary(gold, "cls", cls, 1e-3, 1e-4); check_summary(gold, "reg", reg, 1e-3, 1e-4)
+    for i, u in enumerate(feats):
+        check_summary(gold, f"feat{i}", feat_nchw(u).contiguous(), 1e-3, 1e-4)
+
+
+def test_net_d4_train_fwd_bwd_golden(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "net_d4_256_train_audio.npz"))
+    spec, st = make_state(4, 8, 43, "audio")
+    x = synth_inputs(2, 256, seed=45)["audio"]
+    masks = {int(b): torch.from_numpy(m) for b, m in zip(gold["drop_blocks"], gold["drop_masks"])}
+    net = Net(spec, DEV, trainable=True)
+    net.load_state(st)
+    skip = [b for b in spec.blocks if b.skip]
+    ds = torch.stack([masks[b.idx] / (1.0 - b.drop_rate) for b in skip]).to(DEV)
+    net.begin_step()
+    cls, reg, feats = net.forward(x.to(DEV), train=True, drop_scale=ds)
+    check_summary(gold, "cls", cls, 1e-3, 1e-4); check_summary(gold, "reg", reg, 1e-3, 1e-4)
+    for i, u in enumerate(feats):
+        check_summary(gold, f"feat{i}", feat_nchw(u).contiguous(), 1e-3, 1e-4)
+    loss = cls.sum() * 0.01 + (reg ** 2).mean() + sum((u.z ** 2).mean() for u in feats)
+    assert abs(loss.item() - float(gold["loss"])) < 1e-3 * abs(float(gold["loss"]))
+    dcls = (0.01 * cls * (1 - cls)).contiguous()
+    dreg = (2.0 * reg / reg.numel()).contiguous()
+    dfe = [(2.0 * u.z / u.z.numel()).contiguous() for u in feats]
+    net.ps.grad.zero_()
+    net.backward(dcls, dreg, dfe)
+    torch.cuda.synchronize()
+    grads = net.ps.export_grads()
+    ex = net.ps.export_state()
+    for k in gold.files:
+        if k.startswith("stat.") and k.endswith(".head"):
+            name = k[5:-5]
+            check_summary(gold, "stat." + name, ex[name], 1e-4, 1e-5)
+        if k.startswith("gradnorm."):
+            top = k[len("gradnorm."):]
+            tot = sum(float(grads[n].double().pow(2).sum()) for n in grads
+                      if (".".join(n.split(".")[:2]) if n.startswith("bifpn") else n.split(".")[0]) == top)
+            assert abs(tot ** 0.5 - float(gold[k])) <= 1e-2 * float(gold[k]), (top, tot ** 0.5, float(gold[k]))
+        if k.startswith("grad.") and k.endswith(".head"):
+            name = k[5:-5]
+            check_summary(gold, "grad." + name, grads[name], 2e-2, 1e-3)
+    assert int(ex["backbone_net.model._bn0.num_batches_tracked"]) == int(gold["nbt"])

@@ -627,3 +627,66 @@ def test_full_size_step_graph_vs_oracle(teach):
         # (worst case: an element whose gradient is ~eps gets +lr on one side and -lr on the other)
         assert worst <= 2.05 * lr * (step + 1) and close_frac / n_el >= (0.99 if same else 0.95)
     assert eng.adam_main[0].item() == 2.0
+
+
+# ---- D4 step against the reference's own ModelWithNMSLoss built from D4 nets (tools/oracle/make_golden.py golden_step_d4)
+D4_STEP_MODS = {"rgb": (3, 51), "depth": (3, 52), "thermal": (1, 53)}
+
+
+def build_d4_golden(S=256):
+    teachers = {k: make_state(4, cin, seed, k, cls_bias=-2.0) for k, (cin, seed) in D4_STEP_MODS.items()}
+    spec_s, st_s = make_state(4, 8, 54, "audio")
+    eng = DistillEngine(spec_s, {k: v[0] for k, v in teachers.items()}, DEV, StepConfig(image_size=S))
+    eng.load(st_s, {k: v[1] for k, v in teachers.items()})
+    return eng, spec_s
+
+
+@pytest.mark.parametrize("own_labels", [False, True])
+def test_step_d4_golden(golden_dir, own_labels):
+    """BASELINE configs[4]'s architecture through the whole step, against a fixture made by the REFERENCE's D4 classes (not by the
+    oracle): 3 frozen D4 teachers + the D4 student at 256^2, B = 2.  own_labels False: the teachers' pseudo-label rows come from the
+    reference run - losses 2e-4, gradients 2e-3, Adam 1e-5 as for D2; True: the GPU teachers' own decode + NMS - rows within 1 px,
+    losses 2e-2."""
+    gold = np.load(os.path.join(golden_dir, "step_d4_256_pairwise.npz"))
+    S, B = 256, 2
+    eng, spec = build_d4_golden(S)
+    batch = {k: v.to(DEV) for k, v in synth_inputs(B, S, seed=71).items()}
+    ds = drop_scale_from(gold, spec)
+    if own_labels:
+        out = eng.step_body(batch, ds)
+    else:
+        A = eng.student.anchors(S).shape[0]
+        labels = eng.labels_from_rows([[gold[f"teacher{ti}_img{i}"] for i in range(B)] for ti in range(3)], A)
+        out = eng.step_body(batch, ds, teacher_labels=labels)
+    torch.cuda.synchronize()
+    eng.check_overflow()
+    if own_labels:
+        tot = hit = 0
+        for ti in range(3):
+            for i in range(B):
+                ref = gold[f"teacher{ti}_img{i}"]
+                n = int(out["cnt_t"][ti][i].item())
+                got = out["rows_t"][ti][i, :n].cpu().numpy()
+                assert abs(n - ref.shape[0]) <= max(2, 0.05 * ref.shape[0]), (ti, i, n, ref.shape[0])
+                for r in ref:
+                    tot += 1
+                    hit += bool(n and (np.abs(got[:, :4] - r[:4]).max(1) <= 1.0).any())
+        assert hit >= 0.95 * tot, (hit, tot)
+    lt = 2e-2 if own_labels else 2e-4
+    np.testing.assert_allclose(out["reg"].cpu().numpy(), gold["reg"], rtol=lt)
+    np.testing.assert_allclose(out["cls"].cpu().numpy(), gold["cls"], rtol=lt)
+    np.testing.assert_allclose(out["kd"].cpu().numpy(), gold["kd"].reshape(out["kd"].shape), rtol=1e-4, atol=1e-5)
+    loss = 1.0 * (out["reg"].item() + out["cls"].item()) + 0.005 * out["kd"].sum().item()
+    assert abs(loss - float(gold["loss"])) < lt * abs(float(gold["loss"]))
+    if own_labels:
+        grad_checks(gold, eng.student.ps.export_grads(), 2e-2, 3e-2, 2e-3)
+    else:
+        grad_checks(gold, eng.student.ps.export_grads(), 2e-3, 2e-3, 2e-3)
+    eng.optimizer_body()
+    torch.cuda.synchronize()
+    params = eng.student.ps.export_state()
+    if not own_labels:
+        for k in gold.files:
+            if k.startswith("adam.") and k.endswith(".head"):
+                name = k[5:-5]
+                check_summary(gold, "adam." + name, params[name], 1e-5, 1e-4)

@@ -213,3 +213,88 @@ def test_validate_and_predictions_golden(golden_dir):
     np.testing.assert_allclose(reg_t / N, g["scalar.Test/Regression_loss"], rtol=1e-5)
     np.testing.assert_allclose(cls_t / N, g["scalar.Test/Class_loss"], rtol=1e-5)
     np.testing.assert_allclose(kd_t / N, g["scalar.Test/KD"], rtol=1e-5)
+
+
+# ---- BASELINE configs[4]'s architecture (D4) pinned on the reference's own classes: tools/oracle/make_golden.py golden_net_d4 / golden_step_d4
+D4_MODS = [("rgb", 3, 41), ("thermal", 1, 42), ("audio", 8, 43)]
+
+
+@pytest.mark.parametrize("mod,cin,seed", D4_MODS)
+def test_net_d4_768_eval(golden_dir, mod, cin, seed):
+    """`YetAnotherEfficientDet(compound_coef=4, in_channels=c)` in eval mode at 768^2, B = 1 (src/YetAnotherEfficientDet.py:608-629:
+    fpn width 224, 7 cells, 4 head layers, backbone b4) - the oracle's D4 tables against the reference's, not against D2's."""
+    g = np.load(os.path.join(golden_dir, f"net_d4_768_eval_{mod}.npz"))
+    spec, st = make_state(4, cin, seed, mod)
+    x = synth_inputs(1, 768, seed=44)[mod]
+    with torch.no_grad():
+        (c, r, a), f = O.forward(st, x, 4, False)
+    assert c.shape == (1, 110484, 20) and [tuple(u.shape[1:]) for u in f] == [(224, 96, 96), (224, 48, 48), (224, 24, 24), (224, 12, 12), (224, 6, 6)]
+    check_summary(g, "cls", c); check_summary(g, "reg", r); check_summary(g, "anchors", a, 1e-6, 1e-7)
+    np.testing.assert_array_equal(a[0, ::997].numpy(), g["anchors.sample"])
+    for i, u in enumerate(f):
+        check_summary(g, f"feat{i}", u)
+
+
+def test_net_d4_train_fwd_bwd(golden_dir):
+    g = np.load(os.path.join(golden_dir, "net_d4_256_train_audio.npz"))
+    spec, st = make_state(4, 8, 43, "audio")
+    st = grad_state(st)
+    x = synth_inputs(2, 256, seed=45)["audio"]
+    assert [b.idx for b in spec.blocks if b.skip] == [int(b) for b in g["drop_blocks"]]
+    masks = {int(b): torch.from_numpy(m) for b, m in zip(g["drop_blocks"], g["drop_masks"])}
+    (c, r, a), f = O.forward(st, x, 4, True, masks)
+    loss = c.sum() * 0.01 + (r ** 2).mean() + sum((u ** 2).mean() for u in f)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    check_summary(g, "cls", c); check_summary(g, "reg", r)
+    gn = {}
+    for k, v in st.items():
+        if v.requires_grad and v.grad is not None:
+            top = ".".join(k.split(".")[:2]) if k.startswith("bifpn") else k.split(".")[0]
+            gn[top] = gn.get(top, 0.0) + float(v.grad.double().pow(2).sum())
+    for k in g.files:
+        if k.startswith("gradnorm."):
+            assert abs(gn[k[9:]] ** 0.5 - float(g[k])) <= 2e-3 * float(g[k]), (k, gn[k[9:]] ** 0.5, float(g[k]))
+        if k.startswith("grad.") and k.endswith(".head"):
+            name = k[5:-5]
+            check_summary(g, "grad." + name, st[name].grad, 2e-3, 1e-4)
+        if k.startswith("stat.") and k.endswith(".head"):
+            name = k[5:-5]
+            check_summary(g, "stat." + name, st[name], 1e-5, 1e-6)
+    assert int(st["backbone_net.model._bn0.num_batches_tracked"]) == int(g["nbt"])
+
+
+D4_STEP_MODS = {"rgb": (3, 51), "depth": (3, 52), "thermal": (1, 53)}
+
+
+def test_step_d4(golden_dir):
+    """the reference's `ModelWithNMSLoss` built from D4 nets directly (256^2, B = 2): pseudo-label rows bit for bit, losses, gradients, Adam"""
+    g = np.load(os.path.join(golden_dir, "step_d4_256_pairwise.npz"))
+    S, B = 256, 2
+    teachers = {k: make_state(4, cin, seed, k, cls_bias=-2.0)[1] for k, (cin, seed) in D4_STEP_MODS.items()}
+    _, st = make_state(4, 8, 54, "audio")
+    st = grad_state(st)
+    batch = synth_inputs(B, S, seed=71)
+    masks = {int(b): torch.from_numpy(m) for b, m in zip(g["drop_blocks"], g["drop_masks"])}
+    out = ST.distill_forward(st, teachers, batch, S, 4, masks)
+    for ti in range(3):
+        for i in range(B):
+            np.testing.assert_array_equal(out["per_teacher"][ti][i].reshape(-1, 6), g[f"teacher{ti}_img{i}"])
+    np.testing.assert_allclose(out["reg"].detach().numpy(), g["reg"], rtol=1e-4)
+    np.testing.assert_allclose(out["cls"].detach().numpy(), g["cls"], rtol=1e-4)
+    np.testing.assert_allclose(torch.stack(out["kd"]).detach().numpy(), g["kd"], rtol=1e-5)
+    loss = ST.total_loss(out)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    params = {k: v for k, v in st.items() if v.requires_grad}
+    grads = {k: v.grad for k, v in params.items() if v.grad is not None}
+    for k in g.files:
+        if k.startswith("grad.") and k.endswith(".head"):
+            name = k[5:-5]
+            check_summary(g, "grad." + name, grads[name], 2e-3, 1e-4)
+    with torch.no_grad():
+        ST.adam_step(params, grads, {})
+    for k in g.files:
+        if k.startswith("adam.") and k.endswith(".head"):
+            name = k[5:-5]
+            check_summary(g, "adam." + name, params[name], 1e-5, 1e-6)

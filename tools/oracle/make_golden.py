@@ -334,6 +334,134 @@ def golden_step():
               [d[f"teacher{t}_img{i}"].shape[0] for t in range(len(per)) for i in range(B)])
 
 
+D4_MODS = [("rgb", 3, 41), ("thermal", 1, 42), ("audio", 8, 43)]
+
+
+def golden_net_d4():
+    """BASELINE configs[4]'s architecture pinned on the reference's own classes ("D4@768 B = 1"): the reference builds
+    `YetAnotherEfficientDet(compound_coef=4, in_channels=c)` from the tables at src/YetAnotherEfficientDet.py:608-629 (fpn width 224,
+    7 BiFPN cells, 4 head layers, backbone b4); only `load_model` hard-codes D2, so the nets are constructed directly.
+    (1) eval forward at 768^2, B = 1, in_channels 3 / 1 / 8; (2) train-mode forward + backward at 256^2, B = 2, with recorded
+    drop-connect masks, running-stat update included."""
+    S = 768
+    for mod, cin, seed in D4_MODS:
+        spec, st = make_state(4, cin, seed, mod)
+        x = synth_inputs(1, S, seed=44)[mod]
+        m = ref_model(4, cin, st).eval()
+        d = {}
+        with torch.no_grad():
+            (c, r, a), f = m(x)
+        put(d, "cls", c); put(d, "reg", r); put(d, "anchors", a)
+        d["anchors.sample"] = a[0, ::997].numpy()
+        for i, u in enumerate(f):
+            put(d, f"feat{i}", u)
+        np.savez(os.path.join(OUT, f"net_d4_768_eval_{mod}.npz"), **d)
+        print("net d4 eval", mod, tuple(c.shape), d["cls.sum"], d["reg.l2"], [tuple(u.shape) for u in f])
+    S, B = 256, 2
+    spec, st = make_state(4, 8, 43, "audio")
+    x = synth_inputs(B, S, seed=45)["audio"]
+    dc = MaskedDropConnect(17)
+    REN.drop_connect = dc
+    m = ref_model(4, 8, st).train()
+    (c, r, a), f = m(x)
+    loss = c.sum() * 0.01 + (r ** 2).mean() + sum((u ** 2).mean() for u in f)
+    loss.backward()
+    d = {"loss": np.float64(loss.item())}
+    put(d, "cls", c); put(d, "reg", r)
+    for i, u in enumerate(f):
+        put(d, f"feat{i}", u)
+    d["drop_masks"] = torch.stack(dc.calls).numpy()
+    d["drop_blocks"] = np.array([b.idx for b in spec.blocks if b.skip], dtype=np.int64)
+    assert d["drop_masks"].shape[0] == d["drop_blocks"].shape[0], (d["drop_masks"].shape, d["drop_blocks"].shape)
+    sd = m.state_dict()
+    named = dict(m.named_parameters())
+    gn = {}
+    for k, p in named.items():
+        top = ".".join(k.split(".")[:2]) if k.startswith("bifpn") else k.split(".")[0]
+        gn[top] = gn.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    for k, v in gn.items():
+        d[f"gradnorm.{k}"] = np.float64(v ** 0.5)
+    for k in ["backbone_net.model._conv_stem.conv.weight", "backbone_net.model._blocks.7._depthwise_conv.conv.weight",
+              "backbone_net.model._blocks.13._se_reduce.conv.weight", "backbone_net.model._blocks.31._bn2.weight",
+              "backbone_net.model._blocks.30._expand_conv.conv.weight",
+              "bifpn.0.p4_w2", "bifpn.6.conv5_down.depthwise_conv.conv.weight", "bifpn.0.p5_to_p6.0.conv.weight",
+              "bifpn.3.conv6_up.pointwise_conv.conv.weight",
+              "regressor.header.pointwise_conv.conv.bias", "classifier.conv_list.3.pointwise_conv.conv.weight",
+              "classifier.bn_list.4.3.weight"]:
+        put(d, "grad." + k, named[k].grad)
+    for k in ["backbone_net.model._bn0.running_mean", "backbone_net.model._blocks.20._bn1.running_var",
+              "bifpn.5.conv4_up.bn.running_var", "regressor.bn_list.4.3.running_mean"]:
+        put(d, "stat." + k, sd[k])
+    d["nbt"] = np.int64(sd["backbone_net.model._bn0.num_batches_tracked"].item())
+    np.savez(os.path.join(OUT, "net_d4_256_train_audio.npz"), **d)
+    print("net d4 train", d["loss"], {k: round(float(v), 5) for k, v in d.items() if k.startswith("gradnorm.")})
+
+
+def golden_step_d4():
+    """A whole `ModelWithNMSLoss` step (src/optimization/train_methods.py:425-560) on D4 nets built directly - three frozen D4 teachers
+    and the 8-channel D4 student at 256^2, B = 2: losses, gradients, one Adam step, the teachers' pseudo-label rows."""
+    tm = refshim.load_train_methods()
+    S, B = 256, 2
+    mods = {"rgb": (3, 51), "depth": (3, 52), "thermal": (1, 53)}
+    bias = {"rgb": -2.0, "depth": -2.0, "thermal": -2.0}
+    states = {k: make_state(4, cin, seed, k, cls_bias=bias[k])[1] for k, (cin, seed) in mods.items()}
+    spec, st_s = make_state(4, 8, 54, "audio")
+    batch = synth_inputs(B, S, seed=71)
+    teachers = torch.nn.ModuleDict()
+    for k in ("rgb", "depth", "thermal"):
+        teachers[k] = ref_model(4, mods[k][0], states[k])
+    teachers.eval()
+    for p_ in teachers.parameters():
+        p_.requires_grad = False
+    dc = MaskedDropConnect(19)
+    REN.drop_connect = dc
+    student = ref_model(4, 8, st_s).train()
+    model = tm.ModelWithNMSLoss(student, teachers, YetAnotherFocalLoss(), None, MTALoss(T="9", p="2"),
+                                cfg(S, "YetAnotherEfficientDet_D4"), VALID)
+    opt = torch.optim.Adam(student.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    opt.zero_grad()
+    res = model(batch["rgb"], batch["thermal"], batch["depth"], batch["audio"], None)
+    regl, clsl, kdl = res[0], res[1], res[2]
+    loss_main = torch.mean(torch.stack(regl)) + torch.mean(torch.stack(clsl))
+    loss = 1.0 * loss_main + 0.005 * torch.sum(torch.stack(kdl))
+    loss.backward()
+    d = {"reg": regl[0].detach().numpy(), "cls": clsl[0].detach().numpy(),
+         "kd": torch.stack(kdl).detach().numpy(), "loss": np.float64(loss.item()),
+         "drop_masks": torch.stack(dc.calls).numpy(),
+         "drop_blocks": np.array([b.idx for b in spec.blocks if b.skip], dtype=np.int64)}
+    gn = {}
+    named = dict(student.named_parameters())
+    for k, p_ in named.items():
+        if p_.grad is None:
+            continue
+        top = ".".join(k.split(".")[:2]) if k.startswith("bifpn") else k.split(".")[0]
+        gn[top] = gn.get(top, 0.0) + float(p_.grad.double().pow(2).sum())
+    for k, v in gn.items():
+        d[f"gradnorm.{k}"] = np.float64(v ** 0.5)
+    watch = ["backbone_net.model._conv_stem.conv.weight", "backbone_net.model._blocks.16._project_conv.conv.weight",
+             "bifpn.6.conv3_up.pointwise_conv.conv.weight", "classifier.header.pointwise_conv.conv.bias",
+             "regressor.header.pointwise_conv.conv.weight", "bifpn.1.p5_w2", "regressor.conv_list.3.depthwise_conv.conv.weight"]
+    for k in watch:
+        if named[k].grad is None:
+            print("no grad for", k)
+            continue
+        put(d, "grad." + k, named[k].grad)
+    opt.step()
+    for k in watch:
+        put(d, "adam." + k, named[k])
+    with torch.no_grad():
+        per = []
+        for k in ("rgb", "depth", "thermal"):
+            pred, _ = teachers[k](batch[k])
+            per.append(RU.logits_to_ground_truth(pred, None, VALID, cfg(S, "YetAnotherEfficientDet_D4"), include_scores=True))
+    for ti, lab in enumerate(per):
+        for i in range(B):
+            d[f"teacher{ti}_img{i}"] = np.asarray(lab[i], dtype=np.float32).reshape(-1, 6)
+    np.savez_compressed(os.path.join(OUT, "step_d4_256_pairwise.npz"), **d)
+    print("step d4", d["reg"], d["cls"], d["kd"].reshape(-1)[:5], d["loss"],
+          [d[f"teacher{t}_img{i}"].shape[0] for t in range(3) for i in range(B)])
+
+
 def synth_detections(seed=41, n_batches=5, bs=4, S=512):
     """Synthetic evaluation set: per image pseudo ground truth [m,5] (x1,y1,x2,y2,label) and student detections [n,6]
     (x1,y1,x2,y2,score,label) - jittered copies of some ground-truth boxes, false positives, wrong-class boxes, images with no
@@ -545,7 +673,7 @@ def golden_validate():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step", "metrics", "validate"]
+    which = sys.argv[1:] or ["keys", "net", "losses", "postproc", "step", "metrics", "validate", "net_d4", "step_d4"]
     if "metrics" in which:
         golden_metrics()
     if "validate" in which:
@@ -560,3 +688,7 @@ if __name__ == "__main__":
         golden_postproc()
     if "step" in which:
         golden_step()
+    if "net_d4" in which:
+        golden_net_d4()
+    if "step_d4" in which:
+        golden_step_d4()
