@@ -29,13 +29,13 @@ int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const float* up, c
 
 // Whole BiFPN node of a frozen net in one kernel: fusion + swish + depthwise 3x3 + 1x1 conv (w_pw [C, C] as stored upstream) + bias + folded
 // BatchNorm (SeparableConvBlock(norm=True) after BiFPN._forward_fast_attention's weighted sum, src/YetAnotherEfficientDet.py:150-185,338-390,
-// eval mode).  -22 for a width without a kernel: ask mmd_bifpn_node_fused_supported (C = 112) and keep mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd.
+// eval mode).  -22 for a width without a kernel: ask mmd_bifpn_node_fused_supported (C in {64, 112, 160, 224}: the fpn widths of D0 / D2 / D3 / D4) and keep mmd_bifpn_node_dw_fwd + mmd_pwconv_fwd.
 int mmd_bifpn_node_fused_supported(int C);
 int mmd_bifpn_node_fwd_fused(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* w_pw, const float* bias, const float* scale, const float* shift, float* y, int B, int H, int W, int C, hipStream_t stream);
 
 // The same node for the TRAINABLE net in train mode: z = the raw 1x1-conv output (+ bias), stats [2C] (+)= [sum z, sum z^2] (the batch
 // statistics of the node's BatchNorm, src/YetAnotherEfficientDet.py:171-176), zd = the depthwise output (read by the 1x1 conv's weight
-// gradient in the backward).  C == 112.
+// gradient in the backward).  C as mmd_bifpn_node_fused_supported.
 int mmd_bifpn_node_fwd_fused_train(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, const float* w_pw, const float* bias, float* z, float* zd, double* stats, int B, int H, int W, int C, hipStream_t stream);
 
 // Backward of the fusion node, part 1: dx = df*swish'(x), wdot[i] += <dx, operand_i>.
@@ -106,19 +106,22 @@ int mmd_maxpool_bwd_sums_ok(int B, int PH, int PW, int C);
 int mmd_maxpool_same_bwd_acc2(const float* src, const float* dout, float* dst, const float* theta, int ntheta, int widx, int accumulate, int B, int PH, int PW, int C, const float* z, const float* mean, const float* invstd, double* sums, hipStream_t stream);
 
 // Depthwise kxk TF-SAME conv, NHWC, fused producer BN+swish prologue, stats / eval-BN+swish / SE-pool epilogue.
+// pool [B, C] (nullable, frozen nets): the squeeze-excite average pool (src/YetAnotherEfficientNet.py:470) accumulated as 64-bit fixed-point
+// integers, pool[b, c] += round(2^36 * mean_hw y): integer atomics commute exactly, so a frozen net's outputs are bit-identical from run to
+// run (zero the array first; mmd_se_fc_fwd_q reads it back).
 // stats_ws/ws_slots (nullable/0): zeroed workspace of ws_slots*2C doubles; launches that would send > 128 blocks to one
 // BatchNorm-sum address spread their f64 atomics over the slots and fold them into `stats` (workspace left zero).
 // Replaces Conv2dStaticSamePadding(groups=C) (src/YetAnotherEfficientNet.py:433-435, src/YetAnotherEfficientDet.py:169-170) incl. F.pad (:51-65).
-int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream);
+int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, long long* pool, double* stats_ws, int ws_slots, hipStream_t stream);
 
 // Frozen-net MBConv front half in one kernel: expand 1x1 conv + folded BN0 + swish -> depthwise kxk/stride (TF-SAME) + folded BN1 + swish
-// + squeeze-excite average pool (pool[B,Cmid] +=, nullable).  The 6x expanded tensor stays in LDS (MFMA -> LDS -> depthwise).
+// + squeeze-excite average pool (pool[B,Cmid] +=, nullable; Q36 fixed-point integers as for mmd_dwconv_fwd).  The 6x expanded tensor stays in LDS (MFMA -> LDS -> depthwise).
 // w_expand [Cmid, Cin] as stored by the reference, w_dw tap-major [k*k, Cmid].  -22 for a geometry without a kernel: ask
 // mmd_mbconv_expand_dw_supported (Cin in {16,24,32,40,48,56}, Cmid % 48 == 0, k in {3,5}, stride in {1,2}) and keep mmd_pwconv_fwd +
 // mmd_dwconv_fwd otherwise.  Replaces MBConvBlock.forward's `_expand_conv`/`_bn0`/swish/`_depthwise_conv`/`_bn1`/swish/avg-pool
 // in eval mode (src/YetAnotherEfficientNet.py:450-470).
 int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stride);
-int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream);
+int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream);
 
 // Input gradient of the depthwise conv.  With bn_sums (stride 1 only) the launch also accumulates the sums of the BatchNorm(+swish)
 // backward that consumes dx: bn_sums[c] += sum dx*swish'(u), bn_sums[C+c] += sum dx*swish'(u)*xhat, u = bn_z*bn_scale+bn_shift,
@@ -156,14 +159,18 @@ int mmd_chan_pool(const float* z, const float* scale, const float* shift, const 
 
 // Squeeze-excite FCs: gate = sigmoid(We*swish(Wr*pooled+br)+be) (src/YetAnotherEfficientNet.py:471-474).
 int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
+// The frozen nets' form: pooled_q [B, C] holds the Q36 fixed-point pool sums of mmd_dwconv_fwd / mmd_mbconv_expand_dw_fwd (value = q / 2^36).
+int mmd_se_fc_fwd_q(const long long* pooled_q, const float* wr, const float* br, const float* we, const float* be, float* hpre, float* gate, int B, int C, int S, hipStream_t stream);
 
 // Round 4, grouped frozen nets: several frozen nets of ONE architecture (the three teachers) evaluated as one batch of n_groups x
 // images_per_group images - a launch covers the same layer of every net and each workgroup picks its net's parameters by the image it
 // works on: group g = image / images_per_group reads its weights g * w_stride floats and its folded BatchNorm coefficients g * bn_stride
 // floats behind the pointers passed in (the nets' flat parameter / coefficient buffers are laid out alike, a constant stride apart).
-// mmd_set_group applies to the launches issued after it on this library instance until cleared with n_groups <= 1; honoured by the frozen
+// mmd_set_group applies to the launches the CALLING HOST THREAD issues after it until cleared with n_groups <= 1 (thread-local descriptor:
+// other threads' launches never see it); clearing returns -22 when no launch issued in between read the group, i.e. an entry point
+// without a group mode ran under it (with the first net's parameters for every image).  Honoured by the frozen
 // forward entry points mmd_pwconv_fwd / mmd_pwconv_fwd_pyr (LDS-tiled kernels; every group's rows are whole 128-row tiles),
-// mmd_dwconv_fwd, mmd_dwconv3_pyr (forward), mmd_mbconv_expand_dw_fwd, mmd_se_fc_fwd and mmd_bifpn_node_fwd_fused; they return -22
+// mmd_dwconv_fwd, mmd_dwconv3_pyr (forward), mmd_mbconv_expand_dw_fwd, mmd_se_fc_fwd(_q), mmd_bifpn_node_fwd_fused and mmd_bifpn_node_dw_fwd; they return -22
 // for a launch form the mode does not cover (statistics, live BatchNorm prologues, bf16 storage).
 int mmd_set_group(int n_groups, int images_per_group, long long w_stride, long long bn_stride);
 
@@ -449,11 +456,11 @@ int mmd_comm_destroy(void* comm);
 // mmd_pwconv_fwd:            bit 0 = x, bit 1 = y (no residual / strided output with a bf16 y)
 int mmd_pwconv_fwd_w16(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, int bf16_mma, int w16, hipStream_t stream);
 // mmd_dwconv_fwd:            bit 0 = x, bit 1 = y
-int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, float* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream);
+int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, long long* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream);
 // mmd_chan_pool:             z
 int mmd_chan_pool_w16(const float* z, const float* scale, const float* shift, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g, float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream);
 // mmd_mbconv_expand_dw_fwd:  y
-int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream);
+int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream);
 // mmd_pwconv_bwd_data_bn2:   bit 0 = g, bit 1 = dx, bit 2 = z, bit 3 = dz_out, bit 4 = p5_z
 int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, int bf16_mma, int w16, hipStream_t stream);
 // mmd_dwconv_bwd_data_bn1:   bit 0 = g1, bit 1 = dx, bit 2 = z1, bit 3 = bn_z

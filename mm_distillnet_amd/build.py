@@ -41,14 +41,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     # (include/mmdistill.h is the binding contract; no kernel source includes it, so it does not date the objects)
     hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))
-    procs, objs = [], {lib: [] for lib, _, _ in VARIANTS}
+    procs, objs, stamps = [], {lib: [] for lib, _, _ in VARIANTS}, []
     for lib, odir, extra in VARIANTS:
         os.makedirs(os.path.join(PKG, odir), exist_ok=True)
         # objects are only reused when they were compiled with this exact flag list (A/B builds with MMD_EXTRA_HIPCC_FLAGS, -DMMD_NO_W16)
         stamp, want = os.path.join(PKG, odir, "flags.stamp"), _want_flags(extra)
         # (no stamp yet = objects of a tree from before the stamps: they were built with the default flags)
         same_flags = (open(stamp).read() == want) if os.path.exists(stamp) else not os.environ.get("MMD_EXTRA_HIPCC_FLAGS")
-        open(stamp, "w").write(want)
+        if not same_flags:
+            # other flags: the old objects must not survive a failed / interrupted rebuild (they would look newer than their sources)
+            for o in glob.glob(os.path.join(PKG, odir, "*.o")):
+                os.remove(o)
+            if os.path.exists(stamp):
+                os.remove(stamp)
+        stamps.append((stamp, want))
         for s in srcs:
             o = os.path.join(PKG, odir, os.path.basename(s)[:-4] + ".o")
             objs[lib].append(o)
@@ -61,6 +67,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {s}")
+    for stamp, want in stamps:      # only now: every object of the variant exists and was compiled with `want`
+        open(stamp, "w").write(want)
     for lib, _, _ in VARIANTS:
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs[lib]])
         if verbose:

@@ -21,7 +21,7 @@ struct FuseArgs {
   const double* ost[4]; const float* oga[4]; const float* obe[4]; double oic[4];
   const float* osc[4]; const float* osh[4];
   int lazy;
-  int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup): whole-node eval kernel only
+  int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup): whole-node eval kernel and fuse_dw_fwd_kernel
 };
 // per-block coefficient table of the lazy operands in LDS: tab[(2 op + {0 scale, 1 shift}) * 64 + channel of the block's 64-channel chunk];
 // a thread reads its quad where it needs it (kept out of registers: the node backward kernel runs at 190-240 VGPRs as it is)
@@ -171,14 +171,18 @@ __global__ __launch_bounds__(256) void fuse_dw_fwd_kernel(FuseArgs a, const floa
   constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
   __shared__ float sIn[IH * IW * 64];
   __shared__ float sW[9 * 64];
-  float w[3];
-  fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int cc = bid % cchunks; bid /= cchunks;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
+  if (a.g_images) {      // grouped frozen nets: this image's net (fusion weights and depthwise taps live in the flat parameter buffer)
+    const size_t gw = (size_t)(b / a.g_images) * a.g_w;
+    a.theta += gw; wdw += gw;
+  }
+  float w[3];
+  fuse_weights(a.theta, a.ntheta, w);
   const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
   const bool cok = c < a.C;
   const int oh0 = th * TH, ow0 = tw * TW;
@@ -305,6 +309,11 @@ extern "C" int mmd_bifpn_node_dw_fwd(const float* in0, const float* in1, const f
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (rc || !w_dw || !zd) return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
+  if (mmd_group_on()) {
+    const MmdGroup& gr = mmd_group();
+    if (B != gr.n * gr.images) return MMD_EINVAL;
+    a.g_images = gr.images; a.g_w = gr.w_stride;
+  }
   hipLaunchKernelGGL(fuse_dw_fwd_kernel, dim3((unsigned)(B * th * tw * cc)), dim3(256), 0, stream, a, w_dw, f_out, zd, th, tw, cc);
   return mmd_check_launch();
 }

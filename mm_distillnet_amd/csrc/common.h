@@ -179,9 +179,27 @@ __device__ __forceinline__ int mmd_xcd_swizzle(int bid, int nblk) {
 // reads its weights g * w_stride floats behind the first net's (all nets' flat parameter buffers are laid out alike, w_stride apart) and its
 // folded BatchNorm coefficients g * bn_stride floats behind.  The host sets the group for the launches it issues next (mmd_set_group) and
 // clears it again (n_groups = 1); only the frozen-forward entry points read it.  A row tile / slab never straddles two groups (host-checked).
+// Round 5: the descriptor is THREAD-LOCAL (set, launch and clear happen on the issuing host thread; another thread's launches never see it),
+// and reading it marks it "honoured": clearing a group that no launch read returns MMD_EINVAL - an entry point without a group mode was
+// issued under it and ran with the first net's parameters for every image.
 struct MmdGroup { int n; int images; long long w_stride; long long bn_stride; };
-const MmdGroup& mmd_group();           // elt.hip
+const MmdGroup& mmd_group();           // elt.hip (marks the calling thread's group as honoured)
 static inline bool mmd_group_on() { return mmd_group().n > 1; }
+
+// ---- bit-reproducible squeeze-excite pool sums of the frozen nets (round 5) ---------------------------------------------------------
+// pool[b, c] accumulates mean_hw y as a 64-bit FIXED-POINT integer (Q36: value * 2^36): every block converts its partial sum - computed
+// in a fixed order - once, and integer atomic adds commute exactly, so the pooled value and with it every output of a frozen net is
+// bit-identical from run to run whatever order the blocks arrive in (fp32 atomics made the teachers' last bits, and now and then a
+// borderline pseudo-label, differ between runs).  Resolution 1.5e-11, range +-1.3e8; mmd_se_fc_fwd_q reads it back.
+#define MMD_POOL_Q 68719476736.0
+#ifdef __HIPCC__
+__device__ __forceinline__ void mmd_pool_add(long long* p, float v, float scale) {
+  double x = (double)v * (double)scale * MMD_POOL_Q;
+  x = fmin(fmax(x, -9.0e18), 9.0e18);
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(x));
+}
+__device__ __forceinline__ float mmd_pool_get(long long q) { return (float)((double)q * (1.0 / MMD_POOL_Q)); }
+#endif
 
 static inline int mmd_check_launch() {
   hipError_t e = hipGetLastError();

@@ -21,7 +21,7 @@ struct DwArgs {
   int flip;
   const float* in_scale; const float* in_shift; int in_act; BnLive in_bn;
   const float* out_scale; const float* out_shift; int out_act;
-  double* stats; float* pool; float pool_scale;
+  double* stats; long long* pool; float pool_scale;      // pool: Q36 fixed-point sums (common.h mmd_pool_add)
   double* stats_ws; int ws_slots;            // slotted sums (common.h)
   // input-gradient launch feeding a BatchNorm(+swish) backward: stats become (sum g, sum g*xhat) with g = y * swish'(u),
   // u = bz*bscale + bshift, xhat = (bz - bmean)*binvstd, bz = the BN's forward input at the output position (y itself is stored)
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       __syncthreads();
       if (tid < CC && c0 + tid < a.C) {
         float v = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
-        atomicAdd(&a.pool[(size_t)b * a.C + c0 + tid], v * a.pool_scale);
+        mmd_pool_add(&a.pool[(size_t)b * a.C + c0 + tid], v, a.pool_scale);
       }
     }
   }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
       __syncthreads();
       if (tid < CC && c0 + tid < C) {
         const float vv = sRed[tid] + sRed[CC + tid] + sRed[2 * CC + tid] + sRed[3 * CC + tid];
-        atomicAdd(&a.pool[(size_t)b * C + c0 + tid], vv * a.pool_scale);
+        mmd_pool_add(&a.pool[(size_t)b * C + c0 + tid], vv, a.pool_scale);
       }
     }
   }
@@ -741,7 +741,7 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
                               const float* in_scale, const float* in_shift, int in_act,
                               const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                               const float* out_scale, const float* out_shift, int out_act,
-                              double* stats, float* pool, double* stats_ws, int ws_slots, hipStream_t stream) {
+                              double* stats, long long* pool, double* stats_ws, int ws_slots, hipStream_t stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -778,7 +778,7 @@ extern "C" int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int 
                                   const float* in_scale, const float* in_shift, int in_act,
                                   const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                                   const float* out_scale, const float* out_shift, int out_act,
-                                  double* stats, float* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream) {
+                                  double* stats, long long* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream) {
   if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;

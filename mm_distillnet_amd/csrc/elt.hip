@@ -294,30 +294,48 @@ extern "C" int mmd_chan_pool_bwd(const float* z, const float* scale, const float
 // Two small launches with enough blocks to fill the chip (one block per image was 50 us per call):
 //   hidden: one wave per (image, j): hpre[b,j] = wr[j,:].pooled[b,:] + br[j]        (coalesced over C)
 //   gate  : one wave per 16 channels: gate[b,c] = sigmoid(we[c,:].swish(hpre[b,:]) + be[c])   (coalesced over S)
-static MmdGroup g_group{1, 0, 0, 0};
-const MmdGroup& mmd_group() { return g_group; }
-// Grouped frozen nets (common.h MmdGroup): the launches issued after this call cover n_groups nets x images_per_group images each;
-// n_groups <= 1 switches the mode off.  Host-side state of the issuing thread's library instance (captured into a graph by value).
+static thread_local MmdGroup g_group{1, 0, 0, 0};
+static thread_local bool g_group_read = false;
+const MmdGroup& mmd_group() { g_group_read = true; return g_group; }
+// Grouped frozen nets (common.h MmdGroup): the launches the CALLING THREAD issues after this call cover n_groups nets x images_per_group
+// images each; n_groups <= 1 switches the mode off.  Thread-local host-side state (captured into a graph by value): launches of other host
+// threads never see it.  Switching a group off that no launch has read returns MMD_EINVAL: an entry point without a group mode ran under
+// it, i.e. with the first net's parameters for every image - the caller must not use that result.
 extern "C" int mmd_set_group(int n_groups, int images_per_group, long long w_stride, long long bn_stride) {
-  if (n_groups <= 1) { g_group = MmdGroup{1, 0, 0, 0}; return MMD_OK; }
+  if (n_groups <= 1) {
+    const bool unread = g_group.n > 1 && !g_group_read;
+    g_group = MmdGroup{1, 0, 0, 0};
+    return unread ? MMD_EINVAL : MMD_OK;
+  }
   if (images_per_group <= 0 || w_stride <= 0 || bn_stride <= 0 || (w_stride & 3) || (bn_stride & 3)) return MMD_EINVAL;
   g_group = MmdGroup{n_groups, images_per_group, w_stride, bn_stride};
+  g_group_read = false;
   return MMD_OK;
 }
 
-__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
+// Q: `pooled` holds the frozen nets' Q36 fixed-point pool sums (common.h mmd_pool_add) instead of floats
+template <bool Q>
+__global__ __launch_bounds__(256) void se_hidden_kernel(const void* __restrict__ pooled_, const float* __restrict__ wr,
                                                         const float* __restrict__ br, float* __restrict__ hpre, int C, int S,
                                                         int g_images, long long g_w) {
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.y * 4 + wave;
   if (j >= S) return;
   if (g_images) { const size_t o = (size_t)(b / g_images) * g_w; wr += o; br += o; }
-  const float* p = pooled + (size_t)b * C;
+  const float* p = reinterpret_cast<const float*>(pooled_) + (size_t)b * C;
+  const long long* pq = reinterpret_cast<const long long*>(pooled_) + (size_t)b * C;
   const float* w = wr + (size_t)j * C;
   float acc = 0.f;
 #pragma unroll 4
   for (int c = lane * 4; c < C; c += 256) {
-    float4 a = mmd_ld4(p + c), q = mmd_ld4(w + c);
+    float4 a;
+    if (Q) {
+      const longlong2 q0 = *reinterpret_cast<const longlong2*>(pq + c), q1 = *reinterpret_cast<const longlong2*>(pq + c + 2);
+      a = make_float4(mmd_pool_get(q0.x), mmd_pool_get(q0.y), mmd_pool_get(q1.x), mmd_pool_get(q1.y));
+    } else {
+      a = mmd_ld4(p + c);
+    }
+    const float4 q = mmd_ld4(w + c);
     acc += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
   }
   acc = wave_sum(acc);
@@ -338,15 +356,25 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   for (int j = 0; j < S; ++j) acc += wet[(size_t)j * C + c] * sh[j];      // wet [S][C]: coalesced over c
   gate[(size_t)b * C + c] = mmd_sigmoid(acc);
 }
-extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
-                             float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
+static int se_fc_fwd_impl(const void* pooled, bool q, const float* wr, const float* br, const float* we, const float* be,
+                          float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
   if (!pooled || !wr || !br || !we || !be || !hpre || !gate || B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256) return MMD_EINVAL;
   const MmdGroup& gr = mmd_group();
   const int gi = gr.n > 1 ? gr.images : 0;
   if (gi && B != gr.n * gr.images) return MMD_EINVAL;
-  hipLaunchKernelGGL(se_hidden_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S, gi, gr.w_stride);
+  if (q) hipLaunchKernelGGL(se_hidden_kernel<true>, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S, gi, gr.w_stride);
+  else hipLaunchKernelGGL(se_hidden_kernel<false>, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S, gi, gr.w_stride);
   hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, hpre, we, be, gate, C, S, gi, gr.w_stride);
   return mmd_check_launch();
+}
+extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
+                             float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
+  return se_fc_fwd_impl(pooled, false, wr, br, we, be, hpre, gate, B, C, S, stream);
+}
+// the frozen nets' form: pooled_q [B, C] = the Q36 fixed-point pool sums the depthwise / fused expand+depthwise epilogues accumulate
+extern "C" int mmd_se_fc_fwd_q(const long long* pooled_q, const float* wr, const float* br, const float* we, const float* be,
+                               float* hpre, float* gate, int B, int C, int S, hipStream_t stream) {
+  return se_fc_fwd_impl(pooled_q, true, wr, br, we, be, hpre, gate, B, C, S, stream);
 }
 
 // backward, step 1a: dpe[b,c] = dgate*gate*(1-gate) (recomputed per wave); dh[b,j] = sum_c wet[j,c]*dpe[b,c], one wave per (b,j)

@@ -25,7 +25,7 @@
 struct MbxArgs {
   const float* x; const float* w0; const float* sc0; const float* sh0;
   const float* wd; const float* sc1; const float* sh1;
-  float* y; float* pool; float pool_scale;
+  float* y; long long* pool; float pool_scale;      // pool: Q36 fixed-point sums (common.h mmd_pool_add)
   int B, H, W, Cin, C, OH, OW, pad_t, pad_l, tiles_h, tiles_w, cchunks;
   int y16;      // y is a bf16 array (common.h w16)
   int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup)
@@ -40,6 +40,7 @@ template <> struct MbxCfg<5, 2> { static constexpr int TH = 8, TW = 8, R = 1; };
 constexpr int MBX_CC = 48;      // channels per block = 3 sub-chunks of 16 (one MFMA row tile each)
 constexpr int MBX_LD = 20;      // LDS floats per pixel (16 channels + 4 pad)
 constexpr int MBX_NW = 4;       // waves per block
+static_assert(MBX_NW == 4, "the pool epilogue adds four wave slots in a fixed order");
 
 // value of the lane `ctrl` selects (0x120 + n = row_ror:n, rotation within each 16-lane row)
 template <int CTRL> __device__ __forceinline__ float mbx_dpp(float v) {
@@ -54,11 +55,11 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
   constexpr int PT = (P + 15) / 16, TPW = (PT + NW - 1) / NW;
   constexpr int NT = NW * 64, NG = NT / 4, CC = MBX_CC, LD = MBX_LD;
   constexpr int SEG = (R - 1) * S + K, NSTRIP = TH * (TW / R);
-  extern __shared__ float smem[];      // ONE array: expanded tile [16 PT][LD] | depthwise weights [K*K][CC] | pool sums [CC] | sc0 sh0 sc1 sh1 [4][CC] | W0 chunk [CC][Cin]
+  extern __shared__ float smem[];      // ONE array: expanded tile [16 PT][LD] | depthwise weights [K*K][CC] | pool sums [NW][CC] | sc0 sh0 sc1 sh1 [4][CC] | W0 chunk [CC][Cin]
   float* const sE = smem;
   float* const sW = smem + PT * 16 * LD;
   float* const sPool = sW + K * K * CC;
-  float* const sAff = sPool + CC;
+  float* const sAff = sPool + NW * CC;      // pool sums: one slot per wave, added in wave order (bit-reproducible)
   float* const sW0 = sAff + 4 * CC;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,7 +111,6 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
   for (int i = tid; i < CC * NK; i += NT)                       // [CC][Cin] is contiguous in the [Cmid][Cin] weight
     *reinterpret_cast<float4*>(&sW0[i * 4]) = mmd_ld4(a.w0 + (size_t)c0 * Cin + i * 4);
   if (tid < CC) {
-    sPool[tid] = 0.f;
     sAff[tid] = a.sc0[c0 + tid]; sAff[CC + tid] = a.sh0[c0 + tid]; sAff[2 * CC + tid] = a.sc1[c0 + tid]; sAff[3 * CC + tid] = a.sh1[c0 + tid];
   }
   __syncthreads();
@@ -188,14 +188,16 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
     if (a.pool) {                  // lanes l, l+4, l+8, l+12 of a 16-lane row share the channel quad: two DPP row rotations, then 16 lanes add to LDS
       pl.x += mbx_dpp<0x124>(pl.x); pl.y += mbx_dpp<0x124>(pl.y); pl.z += mbx_dpp<0x124>(pl.z); pl.w += mbx_dpp<0x124>(pl.w);
       pl.x += mbx_dpp<0x128>(pl.x); pl.y += mbx_dpp<0x128>(pl.y); pl.z += mbx_dpp<0x128>(pl.z); pl.w += mbx_dpp<0x128>(pl.w);
-      if ((lane & 12) == 0) {
-        float* sp = sPool + ct * 16 + c4;
-        atomicAdd(sp, pl.x); atomicAdd(sp + 1, pl.y); atomicAdd(sp + 2, pl.z); atomicAdd(sp + 3, pl.w);
-      }
+      // ... then the wave's four rows by two cross-row shuffles; lanes 0-3 store the wave's sums to ITS slot (no LDS atomics: their order
+      // across waves is not fixed, and the frozen nets must be bit-reproducible - common.h mmd_pool_add)
+      pl.x += __shfl_xor(pl.x, 16, 64); pl.y += __shfl_xor(pl.y, 16, 64); pl.z += __shfl_xor(pl.z, 16, 64); pl.w += __shfl_xor(pl.w, 16, 64);
+      pl.x += __shfl_xor(pl.x, 32, 64); pl.y += __shfl_xor(pl.y, 32, 64); pl.z += __shfl_xor(pl.z, 32, 64); pl.w += __shfl_xor(pl.w, 32, 64);
+      if (lane < 4) *reinterpret_cast<float4*>(sPool + wave * CC + ct * 16 + c4) = pl;
     }
     __syncthreads();                                           // sE is rewritten by the next sub-chunk
   }
-  if (a.pool && tid < CC) atomicAdd(&a.pool[(size_t)b * a.C + c0 + tid], sPool[tid] * a.pool_scale);
+  if (a.pool && tid < CC)      // (the last sub-chunk's barrier above orders the slot stores)
+    mmd_pool_add(&a.pool[(size_t)b * a.C + c0 + tid], ((sPool[tid] + sPool[CC + tid]) + sPool[2 * CC + tid]) + sPool[3 * CC + tid], a.pool_scale);
 }
 
 static int mbx_same_pad_lo(int n, int k, int s, int* out) {
@@ -213,7 +215,7 @@ static int mbx_launch(MbxArgs& a, hipStream_t st) {
   const long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
   if (nb > 0x7fffffffLL) return MMD_EINVAL;
   constexpr int IH = (Cf::TH - 1) * S + K, IW = (Cf::TW - 1) * S + K;
-  constexpr size_t lds = (size_t)((IH * IW + 15) / 16 * 16 * MBX_LD + K * K * MBX_CC + 5 * MBX_CC + MBX_CC * 4 * NK) * sizeof(float);
+  constexpr size_t lds = (size_t)((IH * IW + 15) / 16 * 16 * MBX_LD + K * K * MBX_CC + (4 + MBX_NW) * MBX_CC + MBX_CC * 4 * NK) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
   hipLaunchKernelGGL((mbx_kernel<NK, K, S>), dim3((unsigned)nb), dim3(MBX_NW * 64), lds, st, a);
   return mmd_check_launch();
@@ -237,7 +239,7 @@ extern "C" int mmd_mbconv_expand_dw_supported(int Cin, int Cmid, int k, int stri
 // y[B,OH,OW,Cmid] = swish(dwconv_same(swish(x[B,H,W,Cin] · w_expand[Cmid,Cin]ᵀ * scale0 + shift0), w_dw[k*k,Cmid]) * scale1 + shift1);
 // pool[B,Cmid] += mean over OH x OW of y (pool may be null).  OH = ceil(H / stride).
 static int mbx_impl(const float* x, const float* w_expand, const float* scale0, const float* shift0,
-                    const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                    const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool,
                     int B, int H, int W, int Cin, int Cmid, int k, int stride, int y16, hipStream_t stream) {
   if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !scale1 || !shift1 || !y || B <= 0 || H <= 0 || W <= 0) return MMD_EINVAL;
   if (!mmd_mbconv_expand_dw_supported(Cin, Cmid, k, stride)) return MMD_EINVAL;
@@ -268,13 +270,13 @@ static int mbx_impl(const float* x, const float* w_expand, const float* scale0, 
   return rc;
 }
 extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
-                                        const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                        const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool,
                                         int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
   return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 0, stream);
 }
 // y is stored as a bf16 array (common.h w16): the frozen nets' activated depthwise output, read back by the project conv
 extern "C" int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0,
-                                            const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                            const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool,
                                             int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
   if (true && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
   return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 1, stream);

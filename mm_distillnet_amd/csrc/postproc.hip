@@ -149,7 +149,15 @@ extern "C" int mmd_decode_filter(const float* cls, const float* reg, const float
   if (!cls || !reg || !anchors || !score_ws || !clsid_ws || !flags_ws || !over_scores || !cand || !n_over || !n_keep || !overflow)
     return MMD_EINVAL;
   if (B <= 0 || A <= 0 || NC <= 0 || NC > 64 || cap <= 0) return MMD_EINVAL;
-  hipLaunchKernelGGL(pp_score_kernel, dim3(cdiv(A, 256), B), dim3(256), (size_t)256 * (NC + 1) * sizeof(float), stream, cls, A, NC, conf_threshold,
+  const size_t score_lds = (size_t)256 * (NC + 1) * sizeof(float);
+  if (score_lds > 64 * 1024) {      // NC = 64: 66 560 B, just above the default dynamic-LDS limit (the CU has 160 KB)
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)pp_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 65 * (int)sizeof(float)) != hipSuccess) return MMD_ELAUNCH;
+      attr = true;
+    }
+  }
+  hipLaunchKernelGGL(pp_score_kernel, dim3(cdiv(A, 256), B), dim3(256), score_lds, stream, cls, A, NC, conf_threshold,
                      valid_class_mask, score_ws, clsid_ws, flags_ws);
   hipLaunchKernelGGL(pp_compact_kernel, dim3(cdiv(A, PP_CHUNK), B), dim3(256), 0, stream, reg, anchors, score_ws, clsid_ws, flags_ws, A,
                      image_size, over_scores, cand, n_over, n_keep, overflow, cap);

@@ -26,7 +26,20 @@ from .arch import NetSpec, BN_EPS, BN_MOMENTUM, pyramid_sizes
 from .store import ParamStore, Arena
 
 NONE, SWISH, SIGMOID = 0, 1, 2
-call = _lib.call
+import threading
+
+_PACK = threading.local()      # .on: this thread is inside a pack forward (Net.forward(pack=...))
+# entry points a pack forward may issue WITHOUT the group descriptor: they read no per-net parameters (or, the stems, are issued once per net)
+PACK_PLAIN_OK = frozenset({"mmd_stem_conv_fwd", "mmd_maxpool_same_fwd", "mmd_memset_async"})
+
+
+def call(name: str, *args):
+    """_lib.call, except inside a pack forward: there every launch that reads parameters must go through Net._c (group descriptor set,
+    honoured by the library or refused) - a plain launch would evaluate every net's images with the first net's weights, silently."""
+    if getattr(_PACK, "on", False) and name not in PACK_PLAIN_OK:
+        raise RuntimeError(f"{name} issued inside a pack forward without the group descriptor (engine.Net._c): it would read net 0's parameters for every image")
+    return _lib.call(name, *args)
+
 
 
 class WgLayer(ctypes.Structure):
@@ -253,13 +266,20 @@ class Net:
         """call() for the frozen-forward entry points that honour the group mode: inside a pack forward the group is set around the launch."""
         if self._grp is None:
             return call(name, *args)
+        if name.endswith("_w16"):
+            raise RuntimeError(f"{name}: the bf16-storage library has no group mode")
         dll = _lib.LIB.load()
         if dll.mmd_set_group(*self._grp) != 0:
             raise RuntimeError("mmd_set_group refused %r" % (self._grp,))
+        ok = False
         try:
-            return call(name, *args)
+            rc = _lib.call(name, *args)
+            ok = True
         finally:
-            dll.mmd_set_group(1, 0, 0, 0)
+            # -22 from the clearing call: no launch read the descriptor, i.e. `name` has no group mode and ran with net 0's parameters
+            if dll.mmd_set_group(1, 0, 0, 0) != 0 and ok:
+                raise RuntimeError(f"{name} does not honour the group descriptor (csrc/common.h MmdGroup): refused inside a pack forward")
+        return rc
 
     # ------------------------------------------------------------------ parameters
     def load_state(self, state):
@@ -416,10 +436,12 @@ class Net:
             Bg, S = x[0].shape[0], x[0].shape[2]
             assert all(xi.shape[0] == Bg and xi.shape[2] == S for xi in x)
             self._grp = (len(pack), Bg, ps.n_params, ps.bn_total)
+            _PACK.on = True
             try:
                 return self._forward(x, train, drop_scale, raw_logits, pack)
             finally:
                 self._grp = None
+                _PACK.on = False
         return self._forward(x, train, drop_scale, raw_logits, None)
 
     def _forward(self, x, train, drop_scale, raw_logits, pack):
@@ -491,7 +513,8 @@ class Net:
             res = inp.z if blk.skip else None
             H1, W1 = -(-inp.H // blk.stride), -(-inp.W // blk.stride)
             M1 = B * H1 * W1
-            pooled = self._zalloc((B, blk.cmid))
+            # (frozen nets: Q36 fixed-point integer sums - bit-reproducible whatever order the blocks' atomics arrive in, csrc/common.h mmd_pool_add)
+            pooled = self._zalloc((B, blk.cmid)) if train else self._zalloc((B, blk.cmid), torch.int64)
             hpre = self._alloc(B, blk.se)
             gate = self._alloc(B, blk.cmid)
             se_w = (ps.w(f"{q}._se_reduce.conv.weight"), ps.w(f"{q}._se_reduce.conv.bias"),
@@ -528,7 +551,7 @@ class Net:
                     a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
                                          out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled, y16=wide)
                 f1 = Feat(a1v, B, H1, W1, blk.cmid, w16=wide)
-                self._c("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
+                self._c("mmd_se_fc_fwd_q", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 b2 = ps.bn(f"{q}._bn2")
                 y = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, gate=gate,
                              out_aff=(b2["fscale"], b2["fshift"]), residual=res)
@@ -701,8 +724,8 @@ class Net:
         # (MMD_NO_NODE_WG=1: the earlier form - f written here, weight gradient by its own launch on the side stream - for A/B timing)
         f = self._alloc(in0.M, in0.C) if (train and not self.NODE_WG) else None
         zd = self._alloc(in0.M, in0.C)
-        call("mmd_bifpn_node_dw_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
-             self.ps.w(f"{cell}.{conv}.depthwise_conv.conv.weight"), f, zd, in0.B, in0.H, in0.W, in0.C)
+        self._c("mmd_bifpn_node_dw_fwd", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
+                self.ps.w(f"{cell}.{conv}.depthwise_conv.conv.weight"), f, zd, in0.B, in0.H, in0.W, in0.C)
         ff = Feat(f if f is not None else zd, in0.B, in0.H, in0.W, in0.C)
         for operand in (in0, in1, up, pl):
             if operand is not None:

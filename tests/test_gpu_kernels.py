@@ -323,8 +323,12 @@ def test_dwconv(k, s, H, W, C):
     close(stats[C:], (y.double() ** 2).sum((0, 2, 3)), 1e-4, 1e-5)
     # eval epilogue + pool
     osc, osh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
-    pool = torch.zeros(B, C, device=DEV)
-    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, g(osc), g(osh), 1, None, pool, None, 0)
+    pool_q = torch.zeros(B, C, device=DEV, dtype=torch.int64)      # Q36 fixed-point sums (bit-reproducible integer atomics)
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, g(osc), g(osh), 1, None, pool_q, None, 0)
+    pool = (pool_q.double() * 2.0 ** -36).float()
+    p1 = pool_q.clone(); pool_q.zero_()
+    call("mmd_dwconv_fwd", g(nhwc(x)), wn, yo, B, H, W, C, k, s, g(isc), g(ish), 1, None, None, None, 0, g(osc), g(osh), 1, None, pool_q, None, 0)
+    assert torch.equal(p1, pool_q), "pool sums differ between two launches"
     ye = swish(y * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1))
     close(yo.view(B, OH, OW, C), nhwc(ye), 2e-4, 1e-5, "dw eval")
     close(pool, ye.mean((2, 3)), 2e-4, 1e-5, "pool")
@@ -375,8 +379,12 @@ def test_mbconv_expand_dw_fused(cin, cmid, k, s, H, W):
     assert dll.mmd_mbconv_expand_dw_supported(cin, cmid, k, s) == 1
     xn, w0n, wdn = g(nhwc(x)), g(w0), g(wd.reshape(cmid, k * k).t())
     yo = torch.full((B * OH * OW, cmid), float("nan"), device=DEV)
-    pool = torch.zeros(B, cmid, device=DEV)
-    call("mmd_mbconv_expand_dw_fwd", xn, w0n, g(sc0), g(sh0), wdn, g(sc1), g(sh1), yo, pool, B, H, W, cin, cmid, k, s)
+    pool_q = torch.zeros(B, cmid, device=DEV, dtype=torch.int64)      # Q36 fixed-point sums (bit-reproducible integer atomics)
+    call("mmd_mbconv_expand_dw_fwd", xn, w0n, g(sc0), g(sh0), wdn, g(sc1), g(sh1), yo, pool_q, B, H, W, cin, cmid, k, s)
+    pool = (pool_q.double() * 2.0 ** -36).float()
+    p1, y1 = pool_q.clone(), yo.clone(); pool_q.zero_()
+    call("mmd_mbconv_expand_dw_fwd", xn, w0n, g(sc0), g(sh0), wdn, g(sc1), g(sh1), yo, pool_q, B, H, W, cin, cmid, k, s)
+    assert torch.equal(p1, pool_q) and torch.equal(y1, yo), "fused expand + depthwise: two launches differ"
     close(yo.view(B, OH, OW, cmid), nhwc(y), 2e-4, 1e-5, "fused expand+dw")
     close(pool, y.mean((2, 3)), 2e-4, 1e-5, "fused pool")
     # the two-kernel path of the same block
@@ -473,6 +481,10 @@ def test_se_path(C, S):
     dh, dg = torch.empty(B, S, device=DEV), torch.empty(B, C, device=DEV)
     wet = g(we.detach().t())       # engine-native [S][C]
     call("mmd_se_fc_fwd", dpool, g(wr), g(br), wet, g(be), dh, dg, B, C, S)
+    # the frozen nets' form reads the pool as Q36 fixed-point integers
+    dh_q, dg_q = torch.empty_like(dh), torch.empty_like(dg)
+    call("mmd_se_fc_fwd_q", (dpool.double() * 2.0 ** 36).round().to(torch.int64), g(wr), g(br), wet, g(be), dh_q, dg_q, B, C, S)
+    close(dh_q, dh, 1e-6, 1e-7, "hidden from Q36 pool"); close(dg_q, dg, 1e-6, 1e-7, "gate from Q36 pool")
     close(dh, hpre, 1e-4, 1e-5); close(dg, gate, 1e-4, 1e-5, "gate")
     # backward: dgate = sum_hw gout*a
     dgate = torch.zeros(B, C, device=DEV)

@@ -547,6 +547,115 @@ def test_teacher_pack_matches_separate_nets():
         nets[0].forward([x[:2] for x in xs], train=False, pack=nets)
 
 
+
+def _pack_case(coef, B, S, fuse_node=True):
+    from mm_distillnet_amd.engine import pack_nets
+    mods = {"rgb": (3, 11), "depth": (3, 14), "thermal": (1, 12)}
+    slot = 32 * 28 if coef == 2 else None
+    nets, outs, xs = [], [], []
+    for m, (cin, seed) in mods.items():
+        spec, st = make_state(coef, cin, seed, m if m != "depth" else "rgb")
+        if slot is None:
+            slot = spec.stem_out * 28
+        net = Net(spec, DEV, trainable=False, stem_slot=slot)
+        net.FUSE_NODE = fuse_node
+        net.load_state(st)
+        x = synth_inputs(B, S, seed=50 + seed)[m if m != "depth" else "rgb"].to(DEV)
+        net.begin_step()
+        c, r, f = net.forward(x, train=False)
+        outs.append((c.clone(), r.clone(), [feat_nchw(u).clone() for u in f]))
+        nets.append(net); xs.append(x)
+    assert pack_nets(nets)
+    for n in nets:
+        n.refresh()
+    return nets, xs, outs
+
+
+@pytest.mark.parametrize("coef,fuse_node", [(1, True), (2, False)])
+def test_teacher_pack_unfused_nodes(coef, fuse_node):
+    """a pack forward whose BiFPN nodes take the two-launch path - an fpn width without a whole-node kernel (D1: 88) or
+    MMD_NO_NODE_FUSE - must read every net's own fusion weights and depthwise taps (mmd_bifpn_node_dw_fwd honours the group descriptor
+    now), not net 0's: each net's slice of the packed result equals that net evaluated alone."""
+    B, S = 8, 512
+    nets, xs, outs = _pack_case(coef, B, S, fuse_node)
+    assert fuse_node is False or not nets[0]._node_fusable(Feat_like(nets[0].spec.fpn_w))
+    nets[0].begin_step()
+    c, r, f = nets[0].forward(xs, train=False, pack=nets)
+    torch.cuda.synchronize()
+    for gi, (c1, r1, f1) in enumerate(outs):
+        sl = slice(gi * B, (gi + 1) * B)
+        assert relerr(c[sl], c1) < 1e-4 and relerr(r[sl], r1) < 1e-4, (gi, relerr(c[sl], c1), relerr(r[sl], r1))
+        for u, v in zip(f, f1):
+            assert relerr(feat_nchw(u)[sl], v) < 1e-4, (gi, relerr(feat_nchw(u)[sl], v))
+
+
+class Feat_like:
+    def __init__(self, C):
+        self.C, self.M = C, 1 << 20
+
+
+def test_pack_refuses_group_unaware_launches():
+    """inside a pack forward a launch either honours the group descriptor or is refused: a plain call() of a parameter-reading entry point
+    raises on the host, and an entry point without a group mode issued through Net._c is reported by the library (mmd_set_group's clearing
+    call returns -22 when nothing read the descriptor)."""
+    import mm_distillnet_amd.engine as E
+    spec, st = make_state(2, 3, 11, "rgb")
+    net = Net(spec, DEV, trainable=False)
+    net.load_state(st)
+    x = torch.zeros(8 * 16, 16, device=DEV)
+    y = torch.empty(8 * 4, 16, device=DEV)
+    net._grp = (2, 4, net.ps.n_params, net.ps.bn_total)
+    try:
+        with pytest.raises(RuntimeError, match="does not honour the group descriptor"):
+            net._c("mmd_maxpool_same_fwd", x, y, 8, 4, 4, 16)
+        E._PACK.on = True
+        with pytest.raises(RuntimeError, match="inside a pack forward"):
+            E.call("mmd_affine_act", x, None, None, None, None, None, None, 0, None, 0, None, x, 128, 16)
+        E.call("mmd_maxpool_same_fwd", x, y, 8, 4, 4, 16)       # parameter-free: allowed
+    finally:
+        E._PACK.on = False
+        net._grp = None
+    # the descriptor is thread-local: a launch from another host thread while this one holds a group runs ungrouped
+    import threading
+    dll = E._lib.LIB.load()
+    assert dll.mmd_set_group(3, 8, 1024, 64) == 0
+    res = {}
+
+    def other():
+        res["rc_clear"] = dll.mmd_set_group(1, 0, 0, 0)          # nothing set on THIS thread: plain OK
+
+    t = threading.Thread(target=other); t.start(); t.join()
+    assert res["rc_clear"] == 0
+    assert dll.mmd_set_group(1, 0, 0, 0) == -22                  # this thread's group was never read by a launch
+    torch.cuda.synchronize()
+
+
+def test_frozen_nets_bit_reproducible():
+    """the frozen nets' squeeze-excite pool sums are integer (Q36 fixed-point) atomics and the fused expand + depthwise
+    kernel adds its waves' partials in a fixed order, so two evaluations of the teacher pack - and of a single net - on the same input give
+    bit-identical class, regression and feature tensors (fp32 atomics made last bits, and now and then a pseudo-label, differ run to run)."""
+    B, S = 8, 512
+    nets, xs, outs = _pack_case(2, B, S)
+    runs = []
+    for _ in range(3):
+        nets[0].begin_step()
+        c, r, f = nets[0].forward(xs, train=False, pack=nets)
+        torch.cuda.synchronize()
+        runs.append((c.clone(), r.clone(), [u.z.clone() for u in f]))
+    for c, r, f in runs[1:]:
+        assert torch.equal(c, runs[0][0]) and torch.equal(r, runs[0][1])
+        assert all(torch.equal(a, b) for a, b in zip(f, runs[0][2]))
+    # one net alone, twice (different tile shapes than the pack: compared with itself)
+    single = []
+    for _ in range(2):
+        nets[2].begin_step()
+        c, r, f = nets[2].forward(xs[2], train=False)
+        torch.cuda.synchronize()
+        single.append((c.clone(), r.clone(), [u.z.clone() for u in f]))
+    assert torch.equal(single[0][0], single[1][0]) and torch.equal(single[0][1], single[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(single[0][2], single[1][2]))
+
+
 # ---- D4 (BASELINE configs[4]) against fixtures made by the reference's own D4 classes (tools/oracle/make_golden.py golden_net_d4)
 @pytest.mark.parametrize("mod,cin,seed", [("rgb", 3, 41), ("thermal", 1, 42), ("audio", 8, 43)])
 def test_net_d4_768_eval_golden(golden_dir, mod, cin, seed):
