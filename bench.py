@@ -41,7 +41,10 @@ FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
             2: ("dw_fwd_kernel (depthwise conv forward)", "hbm"),
             3: ("dw_bwd kernels (depthwise conv backward)", "hbm"),
             4: ("row-streaming kernels (BN backward / affine / pools)", "hbm"),
-            5: ("mbx_kernel / bifpn_node_fused_kernel (frozen nets: expand + depthwise, whole BiFPN node, one kernel each)", "hbm")}
+            5: ("mbx_kernel / bifpn_node_fused_kernel (frozen nets: expand + depthwise, whole BiFPN node, one kernel each)", "hbm"),
+            6: ("se_* kernels (squeeze-excite FCs: forward + data gradients; launch-latency bound)", "hbm"),
+            7: ("fuse_dw_bwd_kernel (BiFPN node backward: depthwise + fusion [+ 1x1 input gradient])", "hbm")}
+FAM_KEY = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd", 5: "mbx", 6: "se", 7: "node_bwd"}
 PEAK = {"mfma": 157.3, "hbm": 8000.0}      # TFLOP/s fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
 
 
@@ -361,6 +364,7 @@ def main():
         for d in dlls:
             d.mmd_prof_dump_to(None)
         fam = max(res, key=lambda f: res[f][1])
+        std_shape = args.coef == 2 and S == 512 and B == 8
         n, tms, fl, by = res[fam]
         name, bound = FAMILIES[fam]
         if args.precision != "fp32" and bound == "mfma":
@@ -372,7 +376,7 @@ def main():
             achieved = by / (tms * 1e-3) / 1e9
             unit = "GB/s"
         traffic = None
-        fam_key = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd", 5: "mbx"}[fam]
+        fam_key = FAM_KEY[fam]
         try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["families"][fam_key]
             # the committed PMC passes are of the default workload only
@@ -388,6 +392,30 @@ def main():
                 "avg_launch_us": round(tms * 1e3 / max(n, 1), 2), "family_ms_per_step": round(tms, 3),
                 "algorithmic_bytes_per_step": by, "algorithmic_flops_per_step": fl,
                 "all_families_ms": {FAMILIES[f][0].split(" ")[0]: round(res[f][1], 3) for f in res}}
+        # every profiled family against its own roof: ms = the family's launches of one eager single-stream step, achieved
+        # = their algorithmic flops (mfma) / bytes (hbm) over that time, traffic_ratio = PMC HBM bytes / algorithmic bytes where the committed
+        # counter passes (profiles/pmc_traffic.json, default workload) cover the family
+        fams = []
+        try:
+            pmc_f = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["families"]
+        except Exception:
+            pmc_f = {}
+        for f in sorted(res, key=lambda f_: -res[f_][1]):
+            n_f, ms_f, fl_f, by_f = res[f]
+            if not n_f:
+                continue
+            b_f = FAMILIES[f][1]
+            if args.precision != "fp32" and b_f == "mfma":
+                b_f = "hbm"
+            ach = (fl_f / (ms_f * 1e-3) / 1e12) if b_f == "mfma" else (by_f / (ms_f * 1e-3) / 1e9)
+            tr = None
+            pk = pmc_f.get(FAM_KEY[f])
+            if pk and std_shape and args.precision == "fp32" and FAM_KEY[f] != "bn_bwd" and by_f > 0:
+                tr = round(pk["hbm_bytes_per_step"] / by_f, 3)
+            fams.append({"name": FAMILIES[f][0].split(" (")[0], "bound": b_f, "launches": int(n_f), "ms": round(ms_f, 3),
+                         "achieved": round(ach, 3), "unit": "TFLOP/s" if b_f == "mfma" else "GB/s", "frac": round(ach / PEAK[b_f], 4),
+                         "traffic_ratio": tr})
+        roof["families"] = fams
         if args.coef == 2 and S == 512:
             # the whole step against both roofs (3.41 GB and 55.1 GFLOP of conv-granularity work per image, cfg 3)
             sb, sf = 3.41e9 * B, 55.1e9 * B

@@ -1270,6 +1270,14 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
+  // algorithmic bytes: the operand maps read (the up / pooled operand at a quarter / four times the node's size), the upstream gradient
+  // (two tensors g, z when the 1x1 input gradient rides in this launch) and one gradient map written per operand
+  const double rows = (double)B * H * W;
+  const double maps = 1.0 + (in1 ? 1.0 : 0.0) + (up ? 0.25 : 0.0) + (pool ? 4.0 : 0.0);
+  const double nbytes = 4.0 * rows * C * (2.0 * maps + (ng ? 2.0 : 1.0));
+  const double nflops = rows * C * (2.0 * 9 * 2 + (ng ? 2.0 * C : 0.0));
+  mmd_prof_tag(MMD_FAM_NODE_BWD, "nodebwd H%lld C%lld mode%lld full%lld", H, C, mode, ng ? 1 : 0);
+  mmd_prof_begin(MMD_FAM_NODE_BWD, stream);
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
     const size_t lds = (size_t)(100 * (C + 4) + 4 * C) * sizeof(float);
 #define MMD_NODE_BWD_GK(M, NK) do { static bool attr = false; \
@@ -1279,6 +1287,7 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
     if (mode == 2) MMD_NODE_BWD_G(2); else if (mode == 5) MMD_NODE_BWD_G(5); else if (mode == 4) MMD_NODE_BWD_G(4); else return MMD_EINVAL;
 #undef MMD_NODE_BWD_G
 #undef MMD_NODE_BWD_GK
+    mmd_prof_end(MMD_FAM_NODE_BWD, stream, nflops, nbytes);
     return mmd_check_launch();
   }
   const NodeGemm ng0{};
@@ -1293,6 +1302,7 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
     default: MMD_NODE_BWD(7); break;
   }
 #undef MMD_NODE_BWD
+  mmd_prof_end(MMD_FAM_NODE_BWD, stream, nflops, nbytes);
   return mmd_check_launch();
 }
 extern "C" int mmd_bifpn_node_dw_bwd(const float* in0, const float* in1, const float* up, const float* pool,

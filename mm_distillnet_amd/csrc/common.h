@@ -226,4 +226,6 @@ void mmd_prof_tag(int family, const char* fmt, long long a, long long b, long lo
 #define MMD_FAM_DW_BWD 3
 #define MMD_FAM_ELT 4
 #define MMD_FAM_MBX 5
+#define MMD_FAM_SE 6        /* squeeze-excite FC launches (forward + data gradients) */
+#define MMD_FAM_NODE_BWD 7  /* BiFPN node backward (depthwise + fusion [+ 1x1 input gradient]) */
 #define MMD_FAM_COUNT 8

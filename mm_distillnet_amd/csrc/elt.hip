@@ -362,9 +362,13 @@ static int se_fc_fwd_impl(const void* pooled, bool q, const float* wr, const flo
   const MmdGroup& gr = mmd_group();
   const int gi = gr.n > 1 ? gr.images : 0;
   if (gi && B != gr.n * gr.images) return MMD_EINVAL;
+  // algorithmic bytes: both FC matrices once per group, the pooled / hidden / gate vectors
+  mmd_prof_tag(MMD_FAM_SE, "sefwd B%lld C%lld S%lld q%lld", B, C, S, q ? 1 : 0);
+  mmd_prof_begin(MMD_FAM_SE, stream);
   if (q) hipLaunchKernelGGL(se_hidden_kernel<true>, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S, gi, gr.w_stride);
   else hipLaunchKernelGGL(se_hidden_kernel<false>, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, pooled, wr, br, hpre, C, S, gi, gr.w_stride);
   hipLaunchKernelGGL(se_gate_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, hpre, we, be, gate, C, S, gi, gr.w_stride);
+  mmd_prof_end(MMD_FAM_SE, stream, 4.0 * B * (double)C * S, 4.0 * ((gr.n > 1 ? gr.n : 1) * 2.0 * C * S + (double)B * ((q ? 3.0 : 2.0) * C + 2.0 * S)));
   return mmd_check_launch();
 }
 extern "C" int mmd_se_fc_fwd(const float* pooled, const float* wr, const float* br, const float* we, const float* be,
@@ -465,12 +469,15 @@ extern "C" int mmd_se_fc_bwd(const float* dgate, const float* gate, const float*
   if (!dgate || !gate || !hpre || !pooled || !wr || !we || !dpe_ws || !dpr_ws || !dh_zeroed || !dpooled) return MMD_EINVAL;
   if (dwr && (!dbr || !dwe || !dbe)) return MMD_EINVAL;         // dwr == NULL: weight gradients left to mmd_se_fc_wgrad
   if (B <= 0 || C <= 0 || (C & 3) || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
+  mmd_prof_tag(MMD_FAM_SE, "sebwd B%lld C%lld S%lld", B, C, S, 0);
+  mmd_prof_begin(MMD_FAM_SE, stream);
   hipLaunchKernelGGL(se_bwd_a_kernel, dim3(B, cdiv(S, 4)), dim3(256), 0, stream, dgate, gate, we, dpe_ws, dh_zeroed, C, S);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dh_zeroed, hpre, wr, dpr_ws, dpooled,
                      dpool_scale, C, S, gate, pool5, bn_sums, B);
   if (dwr)
     hipLaunchKernelGGL(se_fc_wgrad_kernel, dim3(cdiv((long long)C * S, 256)), dim3(256), 0, stream, dpe_ws, dpr_ws, hpre,
                        pooled, dwr, dbr, dwe, dbe, B, C, S);
+  mmd_prof_end(MMD_FAM_SE, stream, 4.0 * B * (double)C * S, 4.0 * (2.0 * C * S + (double)B * (4.0 * C + 3.0 * S)));
   return mmd_check_launch();
 }
 // Both FC layers' backward in ONE launch (round 3: se_bwd_a + se_bwd_b were two dependent ~10 us launches on the backward's serial chain per
@@ -524,8 +531,11 @@ extern "C" int mmd_se_fc_bwd_fused(const float* dgate, const float* gate, const 
                                    const float* pool5, double* bn_sums, hipStream_t stream) {
   if (!dgate || !gate || !hpre || !wr || !we || !dpe_ws || !dpr_ws || !dpooled) return MMD_EINVAL;
   if (B <= 0 || C <= 0 || C > SE_MAXC || S <= 0 || S > 256 || ((pool5 == nullptr) != (bn_sums == nullptr))) return MMD_EINVAL;
+  mmd_prof_tag(MMD_FAM_SE, "sebwdf B%lld C%lld S%lld", B, C, S, 0);
+  mmd_prof_begin(MMD_FAM_SE, stream);
   hipLaunchKernelGGL(se_bwd_ab_kernel, dim3(B, cdiv(C, 256)), dim3(256), 0, stream, dgate, gate, hpre, wr, we, dpe_ws, dpr_ws, dpooled,
                      dpool_scale, C, S, pool5, bn_sums, B);
+  mmd_prof_end(MMD_FAM_SE, stream, 4.0 * B * (double)C * S, 4.0 * (2.0 * C * S + (double)B * (4.0 * C + 3.0 * S)));
   return mmd_check_launch();
 }
 

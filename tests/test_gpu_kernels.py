@@ -1726,17 +1726,17 @@ def test_w16_dwconv_fwd_and_pool(k, s, H, W, C, mode):
         rest = lambda st, pool: (None, None, 0, None, None, None, 0, g(sc), g(sh), 1, st, pool, None, 0)
     y_ref = torch.empty(B * OH * OW, C, device=DEV)
     st_ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV) if mode == "train" else None
-    pl_ref = torch.zeros(B, C, device=DEV) if mode == "eval" else None
+    pl_ref = torch.zeros(B, C, dtype=torch.int64, device=DEV) if mode == "eval" else None      # Q36 fixed-point pool sums
     call("mmd_dwconv_fwd", g(x), g(wd), y_ref, B, H, W, C, k, s, *rest(st_ref, pl_ref))
     y = torch.empty(B * OH * OW, C, dtype=torch.bfloat16, device=DEV)
     st = torch.zeros(2 * C, dtype=torch.float64, device=DEV) if mode == "train" else None
-    pl = torch.zeros(B, C, device=DEV) if mode == "eval" else None
+    pl = torch.zeros(B, C, dtype=torch.int64, device=DEV) if mode == "eval" else None
     call("mmd_dwconv_fwd_w16", _b16(x), g(wd), y, B, H, W, C, k, s, *rest(st, pl), 3)
     _close16(y, y_ref, "bf16-stored depthwise output")
     if st is not None:
         close(st, st_ref, 2e-5, 1e-6, "BatchNorm sums")
     if pl is not None:
-        close(pl, pl_ref, 2e-5, 1e-6, "SE pool")
+        close(pl.double() * 2.0 ** -36, pl_ref.double() * 2.0 ** -36, 2e-5, 1e-6, "SE pool")
     # the SE pool over a bf16-stored tensor == the pool over its widening
     z = _r16(torch.randn(B * 64, C))
     p_ref, p16 = torch.zeros(B, C, device=DEV), torch.zeros(B, C, device=DEV)

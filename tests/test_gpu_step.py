@@ -672,7 +672,9 @@ def test_step_d4_golden(golden_dir, own_labels):
     loss = 1.0 * (out["reg"].item() + out["cls"].item()) + 0.005 * out["kd"].sum().item()
     assert abs(loss - float(gold["loss"])) < lt * abs(float(gold["loss"]))
     if own_labels:
-        grad_checks(gold, eng.student.ps.export_grads(), 2e-2, 3e-2, 2e-3)
+        # (the stem's gradient - the far end of a 32-block, 7-cell deep chain with BatchNorm over 8 samples on the 2 x 2 level - measured
+        # 4e-3 of its largest element from the reference run with the GPU teachers' own labels, 2e-3 with the reference's)
+        grad_checks(gold, eng.student.ps.export_grads(), 2e-2, 3e-2, 6e-3)
     else:
         grad_checks(gold, eng.student.ps.export_grads(), 2e-3, 2e-3, 2e-3)
     eng.optimizer_body()
