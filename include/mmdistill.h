@@ -258,6 +258,12 @@ int mmd_opt_step_gated(int mode, float* p, const float* g, float* m, float* v, f
 // hipMemsetAsync wrapper (graph-capturable zeroing of stats / gradient buffers).
 int mmd_memset_async(void* p, int value, long long bytes, hipStream_t stream);
 
+// Drop-connect scales of one step, drawn on the device (drop_connect, src/YetAnotherEfficientNet.py:173-182): out [n_skip, batch] =
+// floor(keep[s] + U[0,1)) / keep[s], U from Philox4x32-10 keyed by `seed` with counter (state[0] = draws so far, element / 4).  state [2]
+// (device): state[0] is advanced by the launch, state[1] != 0 = the caller injected out[] itself and the launch leaves it alone.
+// Capturable: the replay loop of a captured step then issues no RNG / elementwise launches of its own.
+int mmd_drop_scale(float* out, const float* keep, int n_skip, int batch, unsigned long long seed, unsigned long long* state, hipStream_t stream);
+
 // clip_grad_norm_ on the flat gradient buffer (src/optimization/traditional.py:184-188).
 int mmd_clip_grad_norm(float* g, long long n, float max_norm, double* sumsq_ws, hipStream_t stream);
 

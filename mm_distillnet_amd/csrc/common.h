@@ -165,11 +165,14 @@ static inline int mmd_make_pyr(Pyr& p, const int* desc) {
 }
 
 // XCD-aware 1-D block remap (8 XCDs, blocks dealt round-robin): gives each XCD a contiguous
-// chunk of the logical tile order so neighbouring tiles share one L2. Bijective only when
-// nblk % 8 == 0; otherwise identity.
+// chunk of the logical tile order so neighbouring tiles share one L2.
+// Round 5: any nblk - the largest multiple of 8 is swizzled, the last nblk % 8 blocks map to themselves (still a bijection).  With the
+// identity fallback the two column tiles of one row tile of the head GEMMs (2046 = 8 * 255 + 6 blocks) sat on DIFFERENT XCDs and each
+// fetched the A tile from HBM: 1.8x the algorithmic traffic on exactly the launches whose block count is not a multiple of 8
+// (profiles/r04_pmc_gemm_by_shape.txt).
 __device__ __forceinline__ int mmd_xcd_swizzle(int bid, int nblk) {
-  if ((nblk & 7) != 0) return bid;
-  int cpx = nblk >> 3;
+  const int cpx = nblk >> 3, main = cpx << 3;
+  if (bid >= main) return bid;
   return (bid & 7) * cpx + (bid >> 3);
 }
 

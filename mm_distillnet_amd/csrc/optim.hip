@@ -215,3 +215,48 @@ extern "C" int mmd_opt_step_gated(int mode, float* p, const float* g, float* m, 
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, stream, p, g, m, v, state_main, state_head, hyper6, head_active, r, grad_scale, n4);
   return mmd_check_launch();
 }
+
+// ---------------------------------------------------------------- drop-connect masks on the device
+// reference: drop_connect (src/YetAnotherEfficientNet.py:173-182): per sample and skip block, mask = floor(keep + U[0, 1)), scale = mask / keep.
+// One launch INSIDE the captured step draws all of them, so the replay loop holds no ATen RNG / floor / div / copy launches:
+// Philox4x32-10 (Salmon et al., SC'11) keyed by `seed`, counter = (draws so far, element index); `state` [2] on the device:
+//   state[0] = number of draws so far (advanced by this launch), state[1] != 0 = "injected": the caller wrote out[] itself (tests, a resumed
+//   run that replays recorded masks) and this launch leaves it alone.  One block: the counter update is ordered behind every read of it.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(256) void drop_scale_kernel(float* __restrict__ out, const float* __restrict__ keep, int n_skip, int B,
+                                                         unsigned long long seed, unsigned long long* state) {
+  const unsigned long long draw = state[0];
+  const bool injected = state[1] != 0ull;
+  if (!injected) {
+    const int n = n_skip * B;
+    for (int q = threadIdx.x; q * 4 < n; q += 256) {      // one Philox block = four uniforms
+      unsigned c[4] = {(unsigned)draw, (unsigned)(draw >> 32), (unsigned)q, 0u};
+      philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = q * 4 + e;
+        if (i < n) {
+          const float kp = keep[i / B];
+          const float u = (float)(c[e] >> 8) * (1.0f / 16777216.0f);      // 24 random bits: [0, 1)
+          out[i] = floorf(kp + u) / kp;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && !injected) state[0] = draw + 1ull;
+}
+extern "C" int mmd_drop_scale(float* out, const float* keep, int n_skip, int batch, unsigned long long seed, unsigned long long* state,
+                              hipStream_t stream) {
+  if (!out || !keep || !state || n_skip <= 0 || batch <= 0) return MMD_EINVAL;
+  hipLaunchKernelGGL(drop_scale_kernel, dim3(1), dim3(256), 0, stream, out, keep, n_skip, batch, seed, state);
+  return mmd_check_launch();
+}

@@ -54,6 +54,7 @@ class StepConfig:
     cand_cap: int = 0                  # rows per image of the candidate / pseudo-label arrays; 0 = every anchor (the reference
                                        # has no cap, src/utils/utils.py:179-205), so nothing can overflow
     augment: bool = False              # cfg audio_augmentation_merge (ModelWithNMSLossAugmented.forward augment=True)
+    seed: int = 0                      # cfg `seed` (train.py:120 make_reproducible_run): keys the device-side drop-connect draws
     precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors); "bf16_hbm": + the wide MBConv tensors stored as bf16
 
 
@@ -122,6 +123,10 @@ class DistillEngine:
         self.comm = None
         self.comm_stream = None
         self.keep = torch.tensor([1.0 - b.drop_rate for b in student_spec.blocks if b.skip], device=device).view(-1, 1)
+        # device-side drop-connect draws: Philox key (cfg seed, rank-specific like a per-rank torch seed) and [draw counter, injected flag]
+        self.drop_seed = (int(getattr(cfg, "seed", 0)) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * (1 + int(os.environ.get("RANK", "0")))) % (1 << 64)
+        self.drop_state = torch.zeros(2, dtype=torch.int64, device=device)
+        self._drop_injected = False
 
     # ------------------------------------------------------------------
     def _head_ranges(self):
@@ -174,9 +179,24 @@ class DistillEngine:
         self.hyper[0] = lr
 
     def make_drop_scale(self, batch: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-        """mask/keep per skip block and sample: floor(keep + U[0,1)) / keep (src/YetAnotherEfficientNet.py:173-182)."""
+        """mask/keep per skip block and sample: floor(keep + U[0,1)) / keep (src/YetAnotherEfficientNet.py:173-182).  Host-driven form
+        (torch's generator): tests and callers that inject their own masks; the training loop draws on the device, draw_drop_scale."""
         u = torch.rand(self.n_skip, batch, device=self.device, generator=generator)
         return torch.floor(self.keep + u) / self.keep
+
+    def draw_drop_scale(self, out: torch.Tensor):
+        """The same draw as ONE HIP launch (csrc/optim.hip drop_scale_kernel: Philox4x32-10, device-side draw counter): captured at the
+        head of g_main, so a replayed step issues no ATen launches.  A caller-injected mask (set_drop_scale) is left alone."""
+        call("mmd_drop_scale", out, self.keep, self.n_skip, out.shape[1], self.drop_seed, self.drop_state)
+
+    def set_drop_scale(self, drop_scale: Optional[torch.Tensor]):
+        """inject (tensor) or release (None) the masks of the captured step: an injected mask survives the graph's own draw."""
+        inject = drop_scale is not None
+        if inject:
+            self.static["drop_scale"].copy_(drop_scale)
+        if inject != self._drop_injected:
+            self.drop_state[1] = 1 if inject else 0
+            self._drop_injected = inject
 
     # ------------------------------------------------------------------
     def _caps(self, A: int):
@@ -496,7 +516,8 @@ class DistillEngine:
         """Eager step (no graph): forward, losses, backward, all-reduce, Adam."""
         B = batch["audio"].shape[0]
         if drop_scale is None:
-            drop_scale = self.make_drop_scale(B)
+            drop_scale = torch.empty(self.n_skip, B, device=self.device)
+            self.draw_drop_scale(drop_scale)
         out = self.step_body(batch, drop_scale)
         self.allreduce_grads(0)
         self.backward_tail()
@@ -540,6 +561,7 @@ class DistillEngine:
         # "global" mode such a call from another thread would invalidate the capture
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
+            self.draw_drop_scale(self.static["drop_scale"])      # (no-op while a mask is injected: set_drop_scale)
             self.step_body(self.static, self.static["drop_scale"])
         out = self.out
         self.g_tail = None
@@ -567,8 +589,8 @@ class DistillEngine:
             for k, v in batch.items():
                 if v is not None:
                     self.static[k].copy_(v, non_blocking=True)
-        B = self.static["audio"].shape[0]
-        self.static["drop_scale"].copy_(drop_scale if drop_scale is not None else self.make_drop_scale(B))
+        if drop_scale is not None or self._drop_injected:
+            self.set_drop_scale(drop_scale)
         self.g_main.replay()
         self.allreduce_grads(0)
         if self.g_tail is not None:

@@ -1966,3 +1966,38 @@ def test_bifpn_node_bwd_full(mode, H, W, C):
     for a_, b_, what in zip((wdot2, dwg2, e0, e1, eu, ep), (wdot, dwg, d0, d1, du, dp), ("wdot", "depthwise weight gradient", "d in0", "d in1", "d up", "d pool")):
         if a_ is not None:
             close(a_, b_, 3e-4 if what == "wdot" else 5e-5, 1e-4 if what == "wdot" else 2e-6, what)
+
+
+def test_drop_scale_philox_kernel():
+    """drop_connect's per-sample masks drawn by ONE HIP launch (mmd_drop_scale, src/YetAnotherEfficientNet.py:173-182): values are 0 or
+    1 / keep, the keep rate matches, draws advance with the device-side counter, equal (seed, counter) give equal draws, and an injected
+    mask (state[1] != 0) is left alone with the counter unchanged."""
+    n_skip, B = 16, 512
+    keep = torch.linspace(1.0, 0.8, n_skip, device=DEV).view(-1, 1).contiguous()
+    state = torch.zeros(2, dtype=torch.int64, device=DEV)
+    a, b, c = (torch.empty(n_skip, B, device=DEV) for _ in range(3))
+    seed = 0x1234567890ABCDEF
+    call("mmd_drop_scale", a, keep, n_skip, B, seed, state)
+    call("mmd_drop_scale", b, keep, n_skip, B, seed, state)
+    assert state.tolist() == [2, 0]
+    assert not torch.equal(a, b)
+    for t in (a, b):
+        on = t > 0
+        assert torch.allclose(t[on], (1.0 / keep).expand_as(t)[on]) and bool((t[~on] == 0).all())
+        rate = on.float().mean(1).cpu()
+        assert bool(((rate - keep.view(-1).cpu()).abs() < 0.08).all()), rate      # 512 Bernoulli draws per block: sigma <= 0.018
+        assert bool((t[0] == 1.0).all())                                          # keep = 1: never dropped
+    state[0] = 1                                                                  # same (seed, counter) -> the same draw
+    call("mmd_drop_scale", c, keep, n_skip, B, seed, state)
+    assert torch.equal(c, b)
+    call("mmd_drop_scale", c, keep, n_skip, B, seed + 1, state)                   # another key -> another draw
+    assert not torch.equal(c, b)
+    state[1] = 1                                                                  # injected: untouched, counter frozen
+    inj = torch.full((n_skip, B), 7.0, device=DEV)
+    call("mmd_drop_scale", inj, keep, n_skip, B, seed, state)
+    assert bool((inj == 7.0).all()) and state.tolist()[0] == 3
+    # ragged size (not a multiple of 4)
+    small = torch.full((3, 5), -1.0, device=DEV)
+    state[1] = 0
+    call("mmd_drop_scale", small, keep[:3].contiguous(), 3, 5, seed, state)
+    assert bool(((small == 0) | (small > 0.99)).all())

@@ -13,7 +13,7 @@ ec.capture(batch)
 def rel(a, b): return ((a - b).abs().max() / b.abs().max()).item()
 for i, ds in enumerate(scales):
     ea.step_body(batch, ds); eb.step_body(batch, ds)
-    ec.static["drop_scale"].copy_(ds); ec.g_main.replay()
+    ec.set_drop_scale(ds); ec.g_main.replay()
     torch.cuda.synchronize()
     ga, gb, gc = ea.student.ps.grad, eb.student.ps.grad, ec.student.ps.grad
     print(i, "grad eager-eager", rel(ga, gb), "eager-graph", rel(ga, gc), "gnorm", ga.norm().item(), gc.norm().item(),

@@ -92,7 +92,7 @@ def step_config(cfg) -> StepConfig:
                       # ModelWithNMSLossAugmented acts on it (key absent from the shipped cfg -> off)
                       augment=bool(cfg.getboolean("audio_augmentation_merge", False)) and method == "traditional_nms_augmented",
                       # extension key (absent from the reference's cfg files -> fp32): "bf16" = 1x1 convs on the bf16 MFMA
-                      precision=cfg.get("precision", "fp32"),
+                      precision=cfg.get("precision", "fp32"), seed=cfg.getint("seed", 24),
                       **TR.optimizer_settings(cfg))
 
 
