@@ -43,9 +43,11 @@ struct MmdWgradLayer {
 // slab is re-read per K tile, every X slab per N tile; 6.3 GB measured), 128-wide tiles would move 3.4 GB and make the 112-wide BiFPN /
 // head layers single-tile - and measured SLOWER all the same: step 18.5 -> 20.2-20.7 ms at the same MFMA time per item, 19.2 with 4x the
 // rows per item (232 VGPRs, two waves per SIMD, a quarter of the items to balance over the chip).  The launch is not HBM-bound.
+// MMD_WG_TILE: 64 / 128 = the square forms (one tile edge for every layer); unset = the rectangular form (round 5, further down): 128-wide
+// N tiles for the layers with N > 64, 64 x 64 for the thin ones, in one launch.
 static int wg_tile() {
-  static const int t = getenv("MMD_WG_TILE") ? atoi(getenv("MMD_WG_TILE")) : 64;
-  return t == 128 ? 128 : 64;
+  static const int t = getenv("MMD_WG_TILE") ? atoi(getenv("MMD_WG_TILE")) : 0;
+  return t == 128 ? 128 : t == 64 ? 64 : 0;
 }
 
 // BF (precision "bf16": BASELINE configs[4]): both operands are rounded to bf16 (RNE) at the MFMA input, fp32 accumulate - the arithmetic of
@@ -194,6 +196,191 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   }
 }
 
+// ---- round 5: rectangular output tiles, 128 (N) x 64 (K) for the layers with N > 64 ------------------------------------------------
+// A 64 x 64 item reads rows x (64 + 64) floats for 4096 outputs: every dY slab is re-read once per K tile, every X slab once per N tile -
+// 5.1 GB of HBM traffic per step for 2.5 GB of operands at ~4.1 TB/s (profiles/r04_pmc_hbm_traffic.csv): the launch runs at what the
+// memory system delivers.  Here a layer with N > 64 takes 128-wide N tiles (per-layer tile width `pad_`, 64 or 128): an item reads rows x
+// (128 + 64) floats for 8192 outputs (21 flop per operand byte instead of 16, the X slabs re-read half as often), a wave owns two
+// 32 x 32 sub-tiles along N (32 accumulator registers; the 128 x 128 form needed 232 VGPRs and measured slower), 32 MFMAs per wave
+// between the two barriers of a 32-row step instead of 16.  Thin layers (N <= 64: the 256^2 / 128^2 project convs) keep 64 x 64 items in
+// the same launch - all four waves stay busy there.  Same table, planner, workspace scheme and split-ordered fold: bit-reproducible.
+template <bool BF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void wgrad_grouped_rect_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
+  constexpr int LDD = 128 + 4, LDX = 64 + 4;
+  __shared__ float sD[GW_BR * LDD];
+  __shared__ float sX[GW_BR * LDX];
+  __shared__ int sItem0[GW_MAXL + 1];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nl; i += 256) sItem0[i] = L[i].item0;
+  if (tid == 0) sItem0[nl] = nitems;
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int c4x = (tid & 15) * 4, lrowx = tid >> 4;      // X tile: 16 float4 per row, 16 rows per pass, 2 passes
+  int li = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    while (sItem0[li + 1] <= item) ++li;
+    li = __builtin_amdgcn_readfirstlane(li);
+    const MmdWgradLayer a = L[li];
+    const int TN = a.pad_;                                // 64 or 128 (block-uniform)
+    const bool wide = TN == 128;
+    int b = item - a.item0;
+    const int tk = b % a.ntk; b /= a.ntk;
+    const int tn = b % a.ntn; b /= a.ntn;
+    const int mbeg = b * a.mchunk;
+    const int mend = min(a.M, mbeg + a.mchunk);
+    const int n0 = tn * TN, k0 = tk * 64;
+    // dY tile: TN / 4 float4 per row -> 8 (wide) or 16 rows per pass, 4 or 2 passes
+    const int c4d = wide ? (tid & 31) * 4 : (tid & 15) * 4, lrowd = wide ? tid >> 5 : tid >> 4, rppd = wide ? 8 : 16;
+    const bool nok = (n0 + c4d) < a.N, kok = (k0 + c4x) < a.K;
+    float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
+    if (a.in_scale && kok) { xsc = mmd_ld4(a.in_scale + k0 + c4x); xsh = mmd_ld4(a.in_shift + k0 + c4x); }
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+    float4 rd[4], rx[2], rg[2]; bool rokd[4], rokx[2];
+    auto gload = [&](int mb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < 2 || wide) {
+          const int row = mb + lrowd + i * rppd;
+          rokd[i] = row < mend;
+          rd[i] = mmd_ld4(a.dy + (size_t)(rokd[i] ? row : mbeg) * a.N + (nok ? n0 + c4d : 0));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = mb + lrowx + i * 16;
+        rokx[i] = row < mend;
+        const int rc = rokx[i] ? row : mbeg;
+        rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4x : 0));
+        if (a.gate) rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4x : 0));
+      }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < 2 || wide)
+          *reinterpret_cast<float4*>(&sD[(lrowd + i * rppd) * LDD + c4d]) = (rokd[i] && nok) ? rd[i] : make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float4 v = rx[i];
+        if (a.in_scale) { v.x = v.x * xsc.x + xsh.x; v.y = v.y * xsc.y + xsh.y; v.z = v.z * xsc.z + xsh.z; v.w = v.w * xsc.w + xsh.w; }
+        if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+        if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
+        if (!(rokx[i] && kok)) v = make_float4(0, 0, 0, 0);
+        *reinterpret_cast<float4*>(&sX[(lrowx + i * 16) * LDX + c4x]) = v;
+      }
+    };
+    // this wave's n sub-tiles: 64-wide tile -> one (wn * 32), 128-wide -> two (wn * 64, wn * 64 + 32); the live ones are a prefix
+    const int nb = wide ? wn * 64 : wn * 32;
+    int nu = (n0 + nb < a.N ? 1 : 0) + ((wide && n0 + nb + 32 < a.N) ? 1 : 0);
+    int nv = (k0 + wk * 32 < a.K) ? 1 : 0;
+    nu = __builtin_amdgcn_readfirstlane(nu); nv = __builtin_amdgcn_readfirstlane(nv);
+    const float* const pd = &sD[h * LDD + nb + r];
+    const float* const px = &sX[h * LDX + wk * 32 + r];
+    auto mma = [&](auto nu_c) {
+      constexpr int NU = decltype(nu_c)::value;
+      if constexpr (BF) {
+#pragma unroll
+        for (int gq = 0; gq < GW_BR / 16; ++gq) {
+          gw_bf16x8 dv[NU];
+#pragma unroll
+          for (int u = 0; u < NU; ++u) dv[u] = gw_gather8(&sD[(gq * 16 + h * 8) * LDD + nb + u * 32 + r], LDD);
+          const gw_bf16x8 xv = gw_gather8(&sX[(gq * 16 + h * 8) * LDX + wk * 32 + r], LDX);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dv[u], xv, acc[u], 0, 0, 0);
+        }
+        return;
+      }
+#pragma unroll
+      for (int tt = 0; tt < GW_BR / 2; ++tt) {
+        float dv[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) dv[u] = pd[tt * 2 * LDD + u * 32];
+        const float xv = px[tt * 2 * LDX];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], xv, acc[u], 0, 0, 0);
+      }
+    };
+    gload(mbeg);
+    for (int mb = mbeg; mb < mend; mb += GW_BR) {
+      lstore();
+      __syncthreads();
+      if (mb + GW_BR < mend) gload(mb + GW_BR);
+      if (nv) {
+        if (nu == 2) mma(std::integral_constant<int, 2>{});
+        else if (nu == 1) mma(std::integral_constant<int, 1>{});
+      }
+      __syncthreads();
+    }
+    // partial tile [TN n][64 k] -> this item's workspace slot
+    float* out = ws + a.ws_off + (size_t)(item - a.item0) * (TN * 64);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (u == 0 || wide)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n = nb + u * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          out[n * 64 + wk * 32 + r] = acc[u][q];
+        }
+  }
+}
+
+// fold of the rectangular form: one block per output tile [TN][64] (TN = the layer's pad_), splits added in split order
+__global__ __launch_bounds__(256) void wgrad_fold_rect_kernel(const MmdWgradLayer* __restrict__ L, int nl, int ntiles, const float* __restrict__ ws) {
+  __shared__ int s_li;
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int lo = 0, hi = nl - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
+    s_li = lo;
+  }
+  __syncthreads();
+  const MmdWgradLayer a = L[s_li];
+  const int TN = a.pad_, TT = TN * 64;
+  const int t = tile - a.tile0;
+  const int tn = t / a.ntk, tk = t - tn * a.ntk;
+  const int tiles = a.ntn * a.ntk;
+  const size_t sstride = (size_t)tiles * TT;
+  const float* p = ws + a.ws_off + (size_t)t * TT + tid * 4;
+  // two passes of 4096 floats for a 128-wide tile, one for a 64-wide one; eight splits' loads in flight per round, added in split order
+  for (int half = 0; half * 4096 < TT; ++half) {
+    float4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* ph = p + half * 4096;
+    constexpr int FU = 8;
+    int sp = 0;
+    for (; sp + FU <= a.nsplit; sp += FU) {
+      float4 v[FU][4];
+#pragma unroll
+      for (int f = 0; f < FU; ++f)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[f][u] = mmd_ld4(ph + (size_t)(sp + f) * sstride + u * 1024);
+#pragma unroll
+      for (int f = 0; f < FU; ++f)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[u].x += v[f][u].x; s[u].y += v[f][u].y; s[u].z += v[f][u].z; s[u].w += v[f][u].w; }
+    }
+    for (; sp < a.nsplit; ++sp) {
+      const float* q = ph + (size_t)sp * sstride;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = mmd_ld4(q + u * 1024);
+        s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = half * 4096 + u * 1024 + tid * 4, n = tn * TN + e / 64, k = tk * 64 + e % 64;
+      if (n < a.N && k < a.K) mmd_st4(a.dw + (size_t)n * a.K + k, s[u]);
+    }
+  }
+}
+
 // one block per output tile: dW[n0.., k0..] = sum over the splits (in split order) of the partial tiles
 template <int T>
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const MmdWgradLayer* __restrict__ L, int nl, int ntiles, const float* __restrict__ ws) {
@@ -260,6 +447,21 @@ extern "C" int mmd_wgrad_plan(MmdWgradLayer* layers, int n, int rows_per_item, i
     if ((a.in_scale == nullptr) != (a.in_shift == nullptr)) return MMD_EINVAL;
     if (a.rows_per_image <= 0) a.rows_per_image = 1;
     const int T = wg_tile();
+    if (T == 0) {      // rectangular form: TN x 64 tiles, TN = 128 for N > 64; half the rows per item there (same MFMA time per item)
+      static const int rect_min = getenv("MMD_WG_RECT_MIN") ? atoi(getenv("MMD_WG_RECT_MIN")) : 65;
+      static const int rect_rows = getenv("MMD_WG_RECT_ROWS") ? atoi(getenv("MMD_WG_RECT_ROWS")) : 0;
+      const int TN = a.N >= rect_min ? 128 : 64;
+      a.ntn = cdiv(a.N, TN); a.ntk = cdiv(a.K, 64);
+      const int rpi = TN == 128 ? max(rect_rows ? rect_rows : rows_per_item / 2, GW_BR) : rows_per_item;
+      const int splits = cdiv(a.M, rpi);
+      a.mchunk = cdiv(cdiv(a.M, splits), GW_BR) * GW_BR;
+      a.nsplit = cdiv(a.M, a.mchunk);
+      a.item0 = items; a.tile0 = tiles; a.ws_off = ws; a.pad_ = TN;
+      items += a.nsplit * a.ntn * a.ntk;
+      tiles += a.ntn * a.ntk;
+      ws += (long long)a.nsplit * a.ntn * a.ntk * TN * 64;
+      continue;
+    }
     a.ntn = cdiv(a.N, T); a.ntk = cdiv(a.K, T);
     int splits = cdiv(a.M, T == 128 ? max(rows_per_item / 4, GW_BR) : rows_per_item);      // same MFMA time per item for either tile
     a.mchunk = cdiv(cdiv(a.M, splits), GW_BR) * GW_BR;
@@ -281,7 +483,11 @@ static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int
   if (blocks > n_items) blocks = n_items;
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wgrouped L%lld items%lld tiles%lld b%lld", n_layers, n_items, n_tiles, blocks);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
-  if (wg_tile() == 128) {
+  if (wg_tile() == 0) {
+    if (bf16) hipLaunchKernelGGL(wgrad_grouped_rect_kernel<true>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    else hipLaunchKernelGGL(wgrad_grouped_rect_kernel<false>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    hipLaunchKernelGGL(wgrad_fold_rect_kernel, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
+  } else if (wg_tile() == 128) {
     if (bf16) hipLaunchKernelGGL((wgrad_grouped_kernel<128, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     else hipLaunchKernelGGL((wgrad_grouped_kernel<128, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     hipLaunchKernelGGL(wgrad_fold_kernel<128>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);

@@ -291,8 +291,10 @@ def test_d4_768_step_vs_oracle(B):
             # (a sanity bound in that case - 25 %: measured 3 - 9 % - the tight statement is the equal-labels one)
             # (round 5: the frozen nets are bit-reproducible, so the labels are equal in practice and what is left is the STUDENT's train-mode
             # atomics - BatchNorm sums, depthwise weight gradients - whose order differs between the eager and the captured schedule; the
-            # bf16 operand rounding of the 32-block D4 student amplifies it: measured reg 0.33532 vs 0.33741 = 6.2e-3 with equal labels)
-            rt = 1.5e-2 if same else 0.25
+            # bf16 operand rounding of the 32-block D4 student amplifies it: measured with equal labels reg 0.33532 vs 0.33741 = 6.2e-3 (bf16) and
+            # 0.34093 vs 0.32519 = 4.8e-2 (bf16_hbm), cls 2e-2.  The yardstick is the mode's own distance from fp32, `shift` = the loss
+            # shift of the oracle's emulation of the mode (0.11 at B = 2): two runs of the mode may differ by half of that)
+            rt = (0.5 * shift + 1e-2) if same else 0.25
             print("D4/768 %s replay vs eager at B = %d: labels %s, reg %.6f / %.6f cls %.6f / %.6f" % (
                 precision, B, "equal" if same else "differ (integer truncation)", orp["reg"].item(), le[0], orp["cls"].item(), le[1]))
             # (classification loss with other labels: these random-weight D4 students saturate, every anchor whose assignment changes moves the
