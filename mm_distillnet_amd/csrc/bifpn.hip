@@ -500,8 +500,19 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   __syncthreads();
   NODE_T(2);
   // ---- phase 1
-  for (int it = tid; it < 64 * FN_Q; it += FN_NT) {
-    const int p = it / FN_Q, q = it - p * FN_Q;
+  // Thread -> (pixel, quad): with FN_Q = 28 quads per pixel a 16-lane LDS pass that starts at quad 16 / 20 / 24 runs on into the next
+  // pixel's quads 0 .. 3 / 7 / 11, and those lanes read the SAME tap row of sWd at addresses that share banks with quads 16+ (4 q mod 64
+  // banks wrap at q = 16): two-way conflicts on 3 of 7 passes of every tap read - the 31 - 44 % SQ_LDS_BANK_CONFLICT of every variant of
+  // this kernel (profiles/r04_sq_counters_by_kernel.txt).  No tap-row layout avoids it (a 16-window-injective bank assignment over 28
+  // cyclic quads would need period gcd(16, 28) = 4), so the lanes are dealt 32 per pixel instead (quads 28 .. 31 idle): every pass
+  // stays inside one pixel.  Same trip count (64 x 32 / 512 = 4 = ceil(64 x 28 / 512)); widths where padding would add a trip keep the
+  // dense mapping.
+  constexpr int FN_QP = (FN_Q + 15) / 16 * 16;
+  constexpr bool QPAD = (FN_QP != FN_Q) && ((64 * FN_QP + FN_NT - 1) / FN_NT == (64 * FN_Q + FN_NT - 1) / FN_NT);
+  constexpr int FN_QM = QPAD ? FN_QP : FN_Q;
+  for (int it = tid; it < 64 * FN_QM; it += FN_NT) {
+    const int p = it / FN_QM, q = it - p * FN_QM;
+    if (QPAD && q >= FN_Q) continue;
     const int orow = p >> 3, ocol = p & 7;
     float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll

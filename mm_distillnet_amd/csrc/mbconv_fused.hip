@@ -55,7 +55,8 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
   constexpr int PT = (P + 15) / 16, TPW = (PT + NW - 1) / NW;
   constexpr int NT = NW * 64, NG = NT / 4, CC = MBX_CC, LD = MBX_LD;
   constexpr int SEG = (R - 1) * S + K, NSTRIP = TH * (TW / R);
-  extern __shared__ float smem[];      // ONE array: expanded tile [16 PT][LD] | depthwise weights [K*K][CC] | pool sums [NW][CC] | sc0 sh0 sc1 sh1 [4][CC] | W0 chunk [CC][Cin]
+  constexpr int W0S = 4 * NK + 4;      // LDS row stride of the expand-weight chunk
+  extern __shared__ float smem[];      // ONE array: expanded tile [16 PT][LD] | depthwise weights [K*K][CC] | pool sums [NW][CC] | sc0 sh0 sc1 sh1 [4][CC] | W0 chunk [CC][Cin + 4]
   float* const sE = smem;
   float* const sW = smem + PT * 16 * LD;
   float* const sPool = sW + K * K * CC;
@@ -108,8 +109,12 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
     const int tap = i / 12, q = (i % 12) * 4;
     *reinterpret_cast<float4*>(&sW[tap * CC + q]) = mmd_ld4(a.wd + (size_t)tap * a.C + c0 + q);
   }
-  for (int i = tid; i < CC * NK; i += NT)                       // [CC][Cin] is contiguous in the [Cmid][Cin] weight
-    *reinterpret_cast<float4*>(&sW0[i * 4]) = mmd_ld4(a.w0 + (size_t)c0 * Cin + i * 4);
+  // (LDS row stride Cin + 4: the phase-1 fragment reads below address row r at r * stride - at stride Cin = 16 / 32 / 48 rows r and
+  // r + 4 (r + 2) share their banks, SQ_LDS_BANK_CONFLICT 62 % in mbx_kernel<12, 5, 1>; with the pad the 16 rows fall on distinct banks)
+  for (int i = tid; i < CC * NK; i += NT) {                     // [CC][Cin] is contiguous in the [Cmid][Cin] weight
+    const int n = i / NK, k4 = i - n * NK;
+    *reinterpret_cast<float4*>(&sW0[n * W0S + k4 * 4]) = mmd_ld4(a.w0 + (size_t)c0 * Cin + i * 4);
+  }
   if (tid < CC) {
     sAff[tid] = a.sc0[c0 + tid]; sAff[CC + tid] = a.sh0[c0 + tid]; sAff[2 * CC + tid] = a.sc1[c0 + tid]; sAff[3 * CC + tid] = a.sh1[c0 + tid];
   }
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(MBX_NW * 64) void mbx_kernel(MbxArgs a) {
     // ---- phase 1: 16 expanded channels of the whole input tile -> LDS
     {
       float aw[NK];
-      const float* wp = sW0 + (ct * 16 + r) * (4 * NK) + g * NK;
+      const float* wp = sW0 + (ct * 16 + r) * W0S + g * NK;
 #pragma unroll
       for (int j = 0; j < NK; j += 2) {
         const float2 v = *reinterpret_cast<const float2*>(wp + j);
@@ -215,7 +220,7 @@ static int mbx_launch(MbxArgs& a, hipStream_t st) {
   const long long nb = (long long)a.B * a.tiles_h * a.tiles_w * a.cchunks;
   if (nb > 0x7fffffffLL) return MMD_EINVAL;
   constexpr int IH = (Cf::TH - 1) * S + K, IW = (Cf::TW - 1) * S + K;
-  constexpr size_t lds = (size_t)((IH * IW + 15) / 16 * 16 * MBX_LD + K * K * MBX_CC + (4 + MBX_NW) * MBX_CC + MBX_CC * 4 * NK) * sizeof(float);
+  constexpr size_t lds = (size_t)((IH * IW + 15) / 16 * 16 * MBX_LD + K * K * MBX_CC + (4 + MBX_NW) * MBX_CC + MBX_CC * (4 * NK + 4)) * sizeof(float);
   static_assert(lds <= 64 * 1024, "tile does not fit the default dynamic LDS limit");
   hipLaunchKernelGGL((mbx_kernel<NK, K, S>), dim3((unsigned)nb), dim3(MBX_NW * 64), lds, st, a);
   return mmd_check_launch();

@@ -2,6 +2,7 @@
 same op (autograd supplies the backward references).  Tolerances are fp32: rtol 1e-4..1e-3 as stated per test."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import pytest
@@ -245,8 +246,15 @@ def test_wgrad_grouped_matches_torch_and_is_deterministic():
     dll = _lib.LIB.load()
     cv = lambda o: ctypes.cast(ctypes.pointer(o), ctypes.c_void_p)
     assert dll.mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), len(shapes), 256, cv(ni), cv(nt), cv(wsf)) == 0
-    T = arr[0].pad_        # the planner's output-tile edge (64 or 128)
-    assert T in (64, 128) and nt.value == sum(-(-N // T) * -(-K // T) for _, K, N, _ in shapes) and ni.value >= nt.value
+    # the planner's output tiles: per layer pad_ (N) x 64 (K) in the rectangular form (round 5: pad_ = 128 for N > 64, else 64), or one
+    # square edge for every layer (MMD_WG_TILE = 64 / 128)
+    square = bool(os.environ.get("MMD_WG_TILE"))
+    want = 0
+    for i, (_, K, N, _) in enumerate(shapes):
+        TN = arr[i].pad_
+        assert TN in (64, 128) and (square or TN == (128 if N > 64 else 64)), (i, TN)
+        want += -(-N // TN) * -(-K // (TN if square else 64))
+    assert nt.value == want and ni.value >= nt.value
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
     ws = torch.full((wsf.value,), float("nan"), device=DEV)
     outs = []
