@@ -1034,14 +1034,26 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   // grouped frozen nets (common.h MmdGroup): plain forward launches only, on the LDS-tiled kernels; every group's rows must be whole tiles
   const MmdGroup& gr = mmd_group();
   const bool grouped = gr.n > 1;
+  // which LDS-tiled kernel this launch takes (decided here: the grouped mode needs its row-tile height): 0 = skinny 32 x 64 (K split over
+  // the waves), 1 = 128 x 32, 2 = 64 x 64, 3 = 128 x 64
+  const bool take_skinny = (big_tiles < skinny_tiles || K <= k_small) && N > 16 && !(sq_tiles > 0 && big_tiles >= sq_min && big_tiles < sq_tiles && N > 32);
+  static const int bn32_gain_env = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 0;
+  const int bn32_gain = bn32_gain_env ? bn32_gain_env : (a.bf16 ? 20 : 10);
+  const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
+  const int variant = take_skinny ? 0
+                    : ((!a.bb.z && (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles)))) || (a.bb.z && N <= 32)) ? 1
+                    : ((sq_tiles > 0 && big_tiles < sq_tiles) || a.bb.z) ? 2 : 3;
   if (grouped) {
     if (w16 || a.bb.z || a.st.Cin || a.stats || a.in_bn.stats || a.in_scale) return MMD_EINVAL;
     const int imgs = gr.n * gr.images;
+    // a row tile must not straddle two groups: every group's rows are whole tiles of the kernel taken (round 5: of THAT kernel - 32 rows on
+    // the skinny one, 64 on the 64 x 64 one - so that the 6 x 6 level of D4 / 768^2, 288 rows per group at B = 8, packs too)
+    const int bm = variant == 0 ? SK_BM : variant == 2 ? 64 : PW_BM;
     if (a.pyr.n) {
       if (a.pyr.B != imgs) return MMD_EINVAL;
-      for (int l = 0; l < a.pyr.n; ++l) if (((long long)gr.images * a.pyr.H[l] * a.pyr.W[l]) % PW_BM) return MMD_EINVAL;
+      for (int l = 0; l < a.pyr.n; ++l) if (((long long)gr.images * a.pyr.H[l] * a.pyr.W[l]) % bm) return MMD_EINVAL;
     } else {
-      if (a.rows_per_image <= 0 || (long long)imgs * a.rows_per_image != M || ((long long)gr.images * a.rows_per_image) % PW_BM) return MMD_EINVAL;
+      if (a.rows_per_image <= 0 || (long long)imgs * a.rows_per_image != M || ((long long)gr.images * a.rows_per_image) % bm) return MMD_EINVAL;
     }
     a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
   }
@@ -1053,7 +1065,7 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     if (N <= 32) pw_stream_launch<4, 1>(a, stream);
     else if (N <= 64) pw_stream_launch<2, 1>(a, stream);
     else pw_stream_launch<2, 2>(a, stream);
-  } else if ((big_tiles < skinny_tiles || K <= k_small) && N > 16 && !(sq_tiles > 0 && big_tiles >= sq_min && big_tiles < sq_tiles && N > 32)) {
+  } else if (variant == 0) {
     a.ntn = cdiv(N, SK_BN); a.nblk = cdiv(M, SK_BM) * a.ntn;
     static const int sk_lean = getenv("MMD_NO_LEAN") ? 0 : 1;
     const bool noxf = sk_lean && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
@@ -1080,18 +1092,14 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     // 32-wide column tiles when they waste clearly fewer padded columns than 64-wide ones (N = 88, 144, 208, ...)
     // (bf16 operands: the A tile's conversion and L2 re-reads per column tile outweigh the padded MFMA work sooner - D4's N = 224 nodes on four
     // 64-wide tiles instead of seven 32-wide ones: config 5 49.9 -> 49.5 ms/step)
-    static const int bn32_gain_env = getenv("MMD_BN32_GAIN") ? atoi(getenv("MMD_BN32_GAIN")) : 0;
-    const int bn32_gain = bn32_gain_env ? bn32_gain_env : (a.bf16 ? 20 : 10);
-    const int pad64 = cdiv(N, 64) * 64, pad32 = cdiv(N, 32) * 32;
     void (*kern)(PwArgs);
-    if ((!a.bb.z && (N <= 32 || ((pad64 - pad32) * 100 > bn32_gain * N && !(sq_tiles > 0 && big_tiles < sq_tiles)))) ||
-        (a.bb.z && N <= 32)) {
+    if (variant == 1) {
       // (BatchNorm-backward operand launches take the 128x32 variant only for the thin layers, N <= 32, where 64-wide tiles
       // would multiply 2-4x padding; it holds two VGPRs in scratch there)
       a.ntn = cdiv(N, 32);
       kern = a.bb.z ? pw_pick<128, 32, 1>(nkl, a.bf16) : plain ? pw_pick_lean<128, 32, 3, 6>(nkl, a.bf16)
            : gated ? pw_pick_lean<128, 32, 4, 4>(nkl, a.bf16) : pw_pick<128, 32, 0>(nkl, a.bf16);
-    } else if ((sq_tiles > 0 && big_tiles < sq_tiles) || a.bb.z) {      // 64x64 tiles: small-M layers (and every BatchNorm-
+    } else if (variant == 2) {      // 64x64 tiles: small-M layers (and every BatchNorm-
       // backward operand launch: its two-tensor prologue does not fit the 128-row variants' 128-VGPR budget)
       a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
       if (plain) kern = pw_pick_lean<64, 64, 3, 6>(nkl, a.bf16);

@@ -819,6 +819,37 @@ class Net:
             for i in range(nl):
                 assert ps.bn_off[f"{hname}.bn_list.{lvl}.{i}"] == off0 + lvl * lev_stride + i * C
         desc = pyr["desc"]
+        # Pack forward (grouped frozen nets): the pyramid GEMM's 128-row tiles must not straddle two nets' rows, i.e. every level needs
+        # images_per_group * H * W % 128 == 0.  D4 / 768^2 at B = 8 misses that on the 6 x 6 level only (288 rows per net): the launches
+        # then cover the leading levels and each trailing level runs as a plain launch of its own - few rows, so the GEMM lands on the
+        # 32-row skinny kernel, whose tiles divide 288 (csrc/pw_gemm.hip pw_dispatch checks the tile height of the kernel it takes).
+        nsplit = 5
+        if self._grp is not None:
+            good = [(self._grp[1] * h * w) % 128 == 0 for h, w in pyr["sizes"]]
+            nsplit = good.index(False) if False in good else 5
+            if any(good[nsplit:]) or nsplit == 0:
+                raise RuntimeError("pack forward: pyramid levels %r at %d images per net do not split into whole-tile and small trailing levels" % (pyr["sizes"], self._grp[1]))
+            if nsplit < 5:
+                key = ("desc", nsplit)
+                if key not in pyr:
+                    flat = [nsplit, pyr["B"]]
+                    for h, w in pyr["sizes"][:nsplit]:
+                        flat += [h, w]
+                    pyr[key] = (ctypes.c_int * len(flat))(*flat)
+                desc = pyr[key]
+        tail = list(range(nsplit, 5))
+
+        def lv(t, l):                      # level l's rows of a pyramid row buffer
+            return t[pyr["row0"][l]:pyr["row0"][l] + pyr["rows"][l]]
+
+        def dw_tail(x, wkey, y, xf):       # the trailing levels of a depthwise pyramid launch, one plain launch each
+            sc, sh, act = xf[0], xf[1], xf[2]
+            for l in tail:
+                h, w = pyr["sizes"][l]
+                lo = l * lev_stride
+                self._c("mmd_dwconv_fwd", lv(x, l), ps.w(wkey), lv(y, l), pyr["B"], h, w, C, 3, 1, sc[lo:] if sc is not None else None,
+                        sh[lo:] if sh is not None else None, act, None, None, None, 0, None, None, NONE, None, None, None, 0)
+
         cur, cur_xf = self._fcat, (None, None, NONE, None, None, None)     # (scale, shift, act, stats, gamma, beta)
         layers = []
         for i in range(nl):
@@ -827,10 +858,16 @@ class Net:
             zd = self._alloc_pyr(pyr, C, train)
             self._c("mmd_dwconv3_pyr", cur, ps.w(f"{cname}.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
                  None, None, None, NONE, None, None, None, None)
+            dw_tail(cur, f"{cname}.depthwise_conv.conv.weight", zd, cur_xf)
             z = self._alloc_pyr(pyr, C, train)
             st = self.stats_flat[2 * o:] if train else None
             self._c("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{cname}.pointwise_conv.conv.weight"), z, desc, C, C,
                  ps.w(f"{cname}.pointwise_conv.conv.bias"), NONE, st, lev_stride, 0, None)
+            for l in tail:
+                h, w = pyr["sizes"][l]
+                self._c("mmd_pwconv_fwd" + self._sfx, lv(zd, l), ps.w(f"{cname}.pointwise_conv.conv.weight"), lv(z, l), pyr["rows"][l], C, C,
+                        None, None, NONE, None, None, None, 0, None, h * w, ps.w(f"{cname}.pointwise_conv.conv.bias"), None, None, NONE,
+                        None, None, 0, 0, None, 0)
             if train:
                 for lvl in range(5):
                     ol = o + lvl * lev_stride
@@ -843,6 +880,7 @@ class Net:
         zd = self._alloc_pyr(pyr, C, train)
         self._c("mmd_dwconv3_pyr", cur, ps.w(f"{hname}.header.depthwise_conv.conv.weight"), zd, desc, C, 0, *cur_xf, lev_stride,
              None, None, None, NONE, None, None, None, None)
+        dw_tail(cur, f"{hname}.header.depthwise_conv.conv.weight", zd, cur_xf)
         aoff, yoff = 0, []
         for (h, w) in pyr["sizes"]:
             yoff.append(aoff * per_anchor)
@@ -850,6 +888,11 @@ class Net:
         yoff_c = (ctypes.c_longlong * 5)(*yoff)
         self._c("mmd_pwconv_fwd_pyr" + self._sfx, zd, ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, desc, C, nout,
              ps.w(f"{hname}.header.pointwise_conv.conv.bias"), out_act, None, 0, A * per_anchor, yoff_c)
+        for l in tail:
+            h, w = pyr["sizes"][l]
+            self._c("mmd_pwconv_fwd" + self._sfx, lv(zd, l), ps.w(f"{hname}.header.pointwise_conv.conv.weight"), out, pyr["rows"][l], C, nout,
+                    None, None, NONE, None, None, None, 0, None, h * w, ps.w(f"{hname}.header.pointwise_conv.conv.bias"), None, None, out_act,
+                    None, None, A * per_anchor, yoff[l], None, 0)
         if train:
             tape[hname] = {"layers": layers, "hx": cur, "hx_off": off0 + (nl - 1) * C, "hzd": zd, "yoff": yoff,
                            "lev_stride": lev_stride}

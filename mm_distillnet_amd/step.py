@@ -334,7 +334,9 @@ class DistillEngine:
         # stream.  Needs whole 128-row tiles per group on every pyramid level (the smallest, S/128 squared, decides) and no per-teacher
         # feature surgery (the augmented variant averages images 0 / 1 of each teacher's maps)
         G = len(self.teachers)
-        use_pack = bool(self.pack and G > 1 and not aug and (B * (S // 128) ** 2) % 128 == 0 and S % 128 == 0)
+        # (round 5: the smallest level needs whole 32-row tiles per net only - the heads run a level that misses the 128-row tiles as plain
+        # launches on the skinny kernel, engine.Net._head - so D4 / 768^2 at B = 8, 288 rows per net on its 6 x 6 level, packs too)
+        use_pack = bool(self.pack and G > 1 and not aug and (B * (S // 128) ** 2) % 32 == 0 and S % 128 == 0)
         npk = min(G, max(2, int(os.environ.get("MMD_PACK_SPLIT", G))))      # (dev: pack the first npk teachers, the others on their own streams)
         if use_pack:
             nets = list(self.teachers.values())[:npk]

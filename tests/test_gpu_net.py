@@ -571,12 +571,14 @@ def _pack_case(coef, B, S, fuse_node=True):
     return nets, xs, outs
 
 
-@pytest.mark.parametrize("coef,fuse_node", [(1, True), (2, False)])
+@pytest.mark.parametrize("coef,fuse_node", [(1, True), (2, False), (4, True)])
 def test_teacher_pack_unfused_nodes(coef, fuse_node):
     """a pack forward whose BiFPN nodes take the two-launch path - an fpn width without a whole-node kernel (D1: 88) or
     MMD_NO_NODE_FUSE - must read every net's own fusion weights and depthwise taps (mmd_bifpn_node_dw_fwd honours the group descriptor
     now), not net 0's: each net's slice of the packed result equals that net evaluated alone."""
-    B, S = 8, 512
+    # (4: BASELINE configs[4]'s geometry, D4 at 768^2 - the 6 x 6 level holds 288 rows per net, not whole 128-row tiles: the heads run that
+    # level as plain launches on the 32-row skinny kernel, round 5; its large BiFPN levels take the two-launch node path)
+    B, S = 8, (768 if coef == 4 else 512)
     nets, xs, outs = _pack_case(coef, B, S, fuse_node)
     assert fuse_node is False or not nets[0]._node_fusable(Feat_like(nets[0].spec.fpn_w))
     nets[0].begin_step()
