@@ -541,10 +541,19 @@ def test_teacher_pack_matches_separate_nets():
     nets[2].begin_step()
     c2, r2, _ = nets[2].forward(xs[2], train=False)
     assert relerr(c2, outs[2][0]) < 1e-4 and relerr(r2, outs[2][1]) < 1e-4      # (run to run: the squeeze-excite pools are fp32 atomics)
-    # a geometry whose pyramid levels are not whole tiles per group is refused by the library (the engine then keeps one net per stream)
+    # B = 2: the 4 x 4 level holds 32 rows per net - not whole 128-row tiles, but whole 32-row tiles: since round 5 the heads run such a
+    # trailing level as plain launches on the skinny kernel, and the pack equals the nets one by one here too
+    nets[0].begin_step()
+    c, r, f = nets[0].forward([x[:2] for x in xs], train=False, pack=nets)
+    c, r = c.clone(), r.clone()
+    for gi in range(3):
+        nets[gi].begin_step()
+        c1, r1, _ = nets[gi].forward(xs[gi][:2], train=False)
+        assert relerr(c[2 * gi:2 * gi + 2], c1) < 1e-4 and relerr(r[2 * gi:2 * gi + 2], r1) < 1e-4, gi
+    # a geometry whose smallest level is not whole 32-row tiles per net (B = 1: 16 rows) is refused (the engine then keeps one net per stream)
     nets[0].begin_step()
     with pytest.raises(RuntimeError):
-        nets[0].forward([x[:2] for x in xs], train=False, pack=nets)
+        nets[0].forward([x[:1] for x in xs], train=False, pack=nets)
 
 
 
