@@ -30,6 +30,23 @@ __device__ __forceinline__ float mmd_act(float x, int act) {
 }
 __device__ __forceinline__ float4 mmd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void mmd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// The same accesses through a pointer that was LOADED from memory (a device-side table of operand pointers: the grouped weight-gradient
+// launch, the batched squeeze-excite / MTA kernels).  hipcc cannot prove such a pointer global and emits FLAT loads / stores, which count on
+// vmcnt AND lgkmcnt: every `s_waitcnt lgkmcnt(0)` in front of an LDS fragment read then also waits for the prefetch loads in flight, i.e.
+// the register-staged prefetch of the next slab does not overlap the MFMAs at all (found in round 5 by counting flat_ against global_
+// instructions in the ISA: 140 flat accesses in pw_wgrad_grouped.hip, 0 in pw_gemm.hip).  An explicit address-space cast restores
+// global_load / global_store.
+typedef float mmd_f4v __attribute__((ext_vector_type(4)));
+#define MMD_GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ float4 mmd_ldg4(const float* p) {
+  const mmd_f4v v = *reinterpret_cast<const MMD_GLOBAL_AS mmd_f4v*>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void mmd_stg4(float* p, float4 v) {
+  *reinterpret_cast<MMD_GLOBAL_AS mmd_f4v*>(reinterpret_cast<uintptr_t>(p)) = mmd_f4v{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ float mmd_ldg(const float* p) { return *reinterpret_cast<const MMD_GLOBAL_AS float*>(reinterpret_cast<uintptr_t>(p)); }
+__device__ __forceinline__ void mmd_stg(float* p, float v) { *reinterpret_cast<MMD_GLOBAL_AS float*>(reinterpret_cast<uintptr_t>(p)) = v; }
 
 // ---- bf16 storage of the wide (6x expanded) MBConv tensors in HBM ("w16", BASELINE config 5) ------------------------------------------
 // A tensor argument flagged w16 is a bf16 array behind the same `float*`-typed parameter; arithmetic stays fp32: loads widen exactly

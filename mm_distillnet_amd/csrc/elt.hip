@@ -551,14 +551,15 @@ __global__ void se_fc_wgrad_batched_kernel(const SeWgDesc* __restrict__ desc, in
   const int j = i / C, c = i % C;
   float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
   for (int b = 0; b < B; ++b) {
-    const float pe = d.dpe[(size_t)b * C + c], pr = d.dpr[(size_t)b * S + j];
-    a1 += pe * mmd_swish(d.hpre[(size_t)b * S + j]); b1 += pe;
-    a2 += pr * d.pooled[(size_t)b * C + c]; b2 += pr;
+    // (operand pointers out of a device table: global loads / stores made explicit, common.h mmd_ldg)
+    const float pe = mmd_ldg(d.dpe + (size_t)b * C + c), pr = mmd_ldg(d.dpr + (size_t)b * S + j);
+    a1 += pe * mmd_swish(mmd_ldg(d.hpre + (size_t)b * S + j)); b1 += pe;
+    a2 += pr * mmd_ldg(d.pooled + (size_t)b * C + c); b2 += pr;
   }
-  d.dwe[i] += a1;
-  if (j == 0) d.dbe[c] += b1;
-  d.dwr[i] += a2;
-  if (c == 0) d.dbr[j] += b2;
+  mmd_stg(d.dwe + i, mmd_ldg(d.dwe + i) + a1);
+  if (j == 0) mmd_stg(d.dbe + c, mmd_ldg(d.dbe + c) + b1);
+  mmd_stg(d.dwr + i, mmd_ldg(d.dwr + i) + a2);
+  if (c == 0) mmd_stg(d.dbr + j, mmd_ldg(d.dbr + j) + b2);
 }
 extern "C" int mmd_se_fc_wgrad_batched(const void* desc, int n, int max_cs, int B, hipStream_t stream) {
   if (!desc || n <= 0 || max_cs <= 0 || B <= 0) return MMD_EINVAL;

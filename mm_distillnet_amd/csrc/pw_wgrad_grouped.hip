@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int n0 = tn * T, k0 = tk * T;
     const bool nok = (n0 + c4) < a.N, kok = (k0 + c4) < a.K;
     float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
-    if (a.in_scale && kok) { xsc = mmd_ld4(a.in_scale + k0 + c4); xsh = mmd_ld4(a.in_shift + k0 + c4); }
+    if (a.in_scale && kok) { xsc = mmd_ldg4(a.in_scale + k0 + c4); xsh = mmd_ldg4(a.in_shift + k0 + c4); }
     f32x16 acc[S][S];
 #pragma unroll
     for (int u = 0; u < S; ++u)
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         const int row = mb + lrow + i * RPP;
         rok[i] = row < mend;
         const int rc = rok[i] ? row : mbeg;                     // clamped: loads are unconditional, masked in lstore
-        rd[i] = mmd_ld4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
-        rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
-        if (a.gate) rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
+        rd[i] = mmd_ldg4(a.dy + (size_t)rc * a.N + (nok ? n0 + c4 : 0));
+        rx[i] = mmd_ldg4(a.x + (size_t)rc * a.K + (kok ? k0 + c4 : 0));
+        if (a.gate) rg[i] = mmd_ldg4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4 : 0));
       }
     };
     auto lstore = [&]() {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int c4d = wide ? (tid & 31) * 4 : (tid & 15) * 4, lrowd = wide ? tid >> 5 : tid >> 4, rppd = wide ? 8 : 16;
     const bool nok = (n0 + c4d) < a.N, kok = (k0 + c4x) < a.K;
     float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
-    if (a.in_scale && kok) { xsc = mmd_ld4(a.in_scale + k0 + c4x); xsh = mmd_ld4(a.in_shift + k0 + c4x); }
+    if (a.in_scale && kok) { xsc = mmd_ldg4(a.in_scale + k0 + c4x); xsh = mmd_ldg4(a.in_shift + k0 + c4x); }
     f32x16 acc[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         if (i < 2 || wide) {
           const int row = mb + lrowd + i * rppd;
           rokd[i] = row < mend;
-          rd[i] = mmd_ld4(a.dy + (size_t)(rokd[i] ? row : mbeg) * a.N + (nok ? n0 + c4d : 0));
+          rd[i] = mmd_ldg4(a.dy + (size_t)(rokd[i] ? row : mbeg) * a.N + (nok ? n0 + c4d : 0));
         }
       }
 #pragma unroll
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         const int row = mb + lrowx + i * 16;
         rokx[i] = row < mend;
         const int rc = rokx[i] ? row : mbeg;
-        rx[i] = mmd_ld4(a.x + (size_t)rc * a.K + (kok ? k0 + c4x : 0));
-        if (a.gate) rg[i] = mmd_ld4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4x : 0));
+        rx[i] = mmd_ldg4(a.x + (size_t)rc * a.K + (kok ? k0 + c4x : 0));
+        if (a.gate) rg[i] = mmd_ldg4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4x : 0));
       }
     };
     auto lstore = [&]() {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_rect_kernel(const MmdWgradLaye
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = half * 4096 + u * 1024 + tid * 4, n = tn * TN + e / 64, k = tk * 64 + e % 64;
-      if (n < a.N && k < a.K) mmd_st4(a.dw + (size_t)n * a.K + k, s[u]);
+      if (n < a.N && k < a.K) mmd_stg4(a.dw + (size_t)n * a.K + k, s[u]);
     }
   }
 }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const MmdWgradLayer* __
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int e = u * 1024 + tid * 4, n = tn * T + e / T, k = tk * T + e % T;
-    if (n < a.N && k < a.K) mmd_st4(a.dw + (size_t)n * a.K + k, s[u]);       // K % 4 == 0: a float4 is all-valid or all-out
+    if (n < a.N && k < a.K) mmd_stg4(a.dw + (size_t)n * a.K + k, s[u]);       // K % 4 == 0: a float4 is all-valid or all-out
   }
 }
 
