@@ -241,6 +241,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
     float4 rd[4], rx[2], rg[2]; bool rokd[4], rokx[2];
+    int gimg[2] = {0, 0}, grem[2] = {0, 0}, gimg0 = 0;          // gate rows: image index / row inside the image of the X tile's two row slots
+    if (a.gate) {
+      gimg0 = mbeg / a.rows_per_image;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int r0_ = mbeg + lrowx + i * 16; gimg[i] = r0_ / a.rows_per_image; grem[i] = r0_ - gimg[i] * a.rows_per_image; }
+    }
     auto gload = [&](int mb) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -256,7 +262,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         rokx[i] = row < mend;
         const int rc = rokx[i] ? row : mbeg;
         rx[i] = mmd_ldg4(a.x + (size_t)rc * a.K + (kok ? k0 + c4x : 0));
-        if (a.gate) rg[i] = mmd_ldg4(a.gate + (size_t)(rc / a.rows_per_image) * a.K + (kok ? k0 + c4x : 0));
+        if (a.gate) {
+          // image of the row, carried from step to step (rows advance by GW_BR: an integer division per load was ~20 VALU instructions)
+          while (grem[i] >= a.rows_per_image) { grem[i] -= a.rows_per_image; ++gimg[i]; }
+          rg[i] = mmd_ldg4(a.gate + (size_t)(rokx[i] ? gimg[i] : gimg0) * a.K + (kok ? k0 + c4x : 0));
+          grem[i] += GW_BR;
+        }
       }
     };
     auto lstore = [&]() {
@@ -305,17 +316,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], xv, acc[u], 0, 0, 0);
       }
     };
-    gload(mbeg);
-    for (int mb = mbeg; mb < mend; mb += GW_BR) {
-      lstore();
-      __syncthreads();
-      if (mb + GW_BR < mend) gload(mb + GW_BR);
-      if (nv) {
-        if (nu == 2) mma(std::integral_constant<int, 2>{});
-        else if (nu == 1) mma(std::integral_constant<int, 1>{});
+    // The row loop is instantiated per number of live sub-tiles (item-uniform), not branched inside: with `if (nu == 2) ... else ...` in
+    // the loop body hipcc kept the accumulators of the two variants in different registers and copied all 32 of them at every merge -
+    // 40 v_mov per 32-row step beside 32 MFMAs (ISA of the first version), on a kernel whose VALU and fp32-MFMA work share one pipe.
+    auto rows = [&](auto nu_c) {
+      constexpr int NU = decltype(nu_c)::value;
+      gload(mbeg);
+      for (int mb = mbeg; mb < mend; mb += GW_BR) {
+        lstore();
+        __syncthreads();
+        if (mb + GW_BR < mend) gload(mb + GW_BR);
+        if constexpr (NU > 0) mma(nu_c);
+        __syncthreads();
       }
-      __syncthreads();
-    }
+    };
+    if (!nv || nu == 0) rows(std::integral_constant<int, 0>{});      // (a wave without live sub-tiles still stages its share of the slabs)
+    else if (nu == 2) rows(std::integral_constant<int, 2>{});
+    else rows(std::integral_constant<int, 1>{});
     // partial tile [TN n][64 k] -> this item's workspace slot
     float* out = ws + a.ws_off + (size_t)(item - a.item0) * (TN * 64);
 #pragma unroll

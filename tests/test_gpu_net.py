@@ -557,7 +557,7 @@ def test_teacher_pack_matches_separate_nets():
 
 
 
-def _pack_case(coef, B, S, fuse_node=True):
+def _pack_case(coef, B, S, fuse_node=True, raw_logits=False):
     from mm_distillnet_amd.engine import pack_nets
     mods = {"rgb": (3, 11), "depth": (3, 14), "thermal": (1, 12)}
     slot = 32 * 28 if coef == 2 else None
