@@ -270,6 +270,11 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     lstore();
     __syncthreads();
     gload((kt + 1) * PW_BK);
+#ifdef MMD_PIN_PREFETCH
+    // (dev: keep the next K tile's loads IN FRONT of this tile's MFMAs - left alone, hipcc sinks them behind the MFMAs in the register-lean
+    // variants, where the staging registers double as fragment registers, so a block's K step pays the full load latency)
+    if constexpr ((PRO == 3 || PRO == 4) && !(PRO == 4 && BM_T == 128 && BN_T == 64)) __builtin_amdgcn_sched_barrier(0);
+#endif
     if constexpr (BF) {
 #pragma unroll
       for (int g = 0; g < PW_BK / 16; ++g) mma16(g);

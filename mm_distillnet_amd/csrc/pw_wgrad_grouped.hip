@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // 32 x 32 sub-tiles along N (32 accumulator registers; the 128 x 128 form needed 232 VGPRs and measured slower), 32 MFMAs per wave
 // between the two barriers of a 32-row step instead of 16.  Thin layers (N <= 64: the 256^2 / 128^2 project convs) keep 64 x 64 items in
 // the same launch - all four waves stay busy there.  Same table, planner, workspace scheme and split-ordered fold: bit-reproducible.
+#ifndef WG_RECT_WAVES
+#define WG_RECT_WAVES 4      /* waves per SIMD the register allocation aims at: 4 = at most 128 VGPRs (137 without the bound: three waves) */
+#endif
 template <bool BF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void wgrad_grouped_rect_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAVES, 8))) void wgrad_grouped_rect_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
   constexpr int LDD = 128 + 4, LDX = 64 + 4;
   __shared__ float sD[GW_BR * LDD];
   __shared__ float sX[GW_BR * LDX];
@@ -270,18 +273,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         }
       }
     };
+    // Only ROWS past the item's end are zeroed.  Columns past N / K need no mask: their loads come from clamped (valid, finite) addresses
+    // and only feed output elements n >= N / k >= K of the partial tile, which the fold never stores - 24 selects per step instead of 48
+    // on a kernel whose VALU instructions are MFMA time.
     auto lstore = [&]() {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (i < 2 || wide)
-          *reinterpret_cast<float4*>(&sD[(lrowd + i * rppd) * LDD + c4d]) = (rokd[i] && nok) ? rd[i] : make_float4(0, 0, 0, 0);
+          *reinterpret_cast<float4*>(&sD[(lrowd + i * rppd) * LDD + c4d]) = rokd[i] ? rd[i] : make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float4 v = rx[i];
         if (a.in_scale) { v.x = v.x * xsc.x + xsh.x; v.y = v.y * xsc.y + xsh.y; v.z = v.z * xsc.z + xsh.z; v.w = v.w * xsc.w + xsh.w; }
         if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
         if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
-        if (!(rokx[i] && kok)) v = make_float4(0, 0, 0, 0);
+        if (!rokx[i]) v = make_float4(0, 0, 0, 0);
         *reinterpret_cast<float4*>(&sX[(lrowx + i * 16) * LDX + c4x]) = v;
       }
     };
