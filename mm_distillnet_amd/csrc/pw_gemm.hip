@@ -270,7 +270,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     lstore();
     __syncthreads();
     gload((kt + 1) * PW_BK);
-#ifdef MMD_PIN_PREFETCH
+#ifdef MMD_PIN_PREFETCH      // (measured round 5: 14.74 vs 14.67 ms/step without - the other blocks on the CU hide the latency better than the pinned loads do: left off)
     // (dev: keep the next K tile's loads IN FRONT of this tile's MFMAs - left alone, hipcc sinks them behind the MFMAs in the register-lean
     // variants, where the staging registers double as fragment registers, so a block's K step pays the full load latency)
     if constexpr ((PRO == 3 || PRO == 4) && !(PRO == 4 && BM_T == 128 && BN_T == 64)) __builtin_amdgcn_sched_barrier(0);
