@@ -411,7 +411,12 @@ def main():
             tr = None
             pk = pmc_f.get(FAM_KEY[f])
             if pk and std_shape and args.precision == "fp32" and FAM_KEY[f] != "bn_bwd" and by_f > 0:
-                tr = round(pk["hbm_bytes_per_step"] / by_f, 3)
+                if FAM_KEY[f] in ("dw_fwd", "dw_bwd") and "dw_fwd" in pmc_f and "dw_bwd" in pmc_f:
+                    # the depthwise forward and input-gradient launches share kernels (dw_fwd_kernel with flipped taps), so the counter
+                    # passes - keyed by kernel name - cannot tell the two families apart: both report the ratio of their union
+                    tr = round((pmc_f["dw_fwd"]["hbm_bytes_per_step"] + pmc_f["dw_bwd"]["hbm_bytes_per_step"]) / (res[2][3] + res[3][3]), 3)
+                else:
+                    tr = round(pk["hbm_bytes_per_step"] / by_f, 3)
             fams.append({"name": FAMILIES[f][0].split(" (")[0], "bound": b_f, "launches": int(n_f), "ms": round(ms_f, 3),
                          "achieved": round(ach, 3), "unit": "TFLOP/s" if b_f == "mfma" else "GB/s", "frac": round(ach / PEAK[b_f], 4),
                          "traffic_ratio": tr})
