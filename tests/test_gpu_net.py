@@ -727,7 +727,9 @@ def test_net_d4_train_fwd_bwd_golden(golden_dir):
             assert abs(tot ** 0.5 - float(gold[k])) <= 1e-2 * float(gold[k]), (top, tot ** 0.5, float(gold[k]))
         if k.startswith("grad.") and k.endswith(".head"):
             name = k[5:-5]
-            # (D4: 32 MBConv blocks + 7 BiFPN cells deep, BatchNorm over 8 samples on the 2 x 2 level: the stem's gradient - the far end of
-            # the chain - sits 2e-3 of its largest element from the CPU run's in fp32, measured; D2 at 128^2 holds 1e-3)
-            check_summary(gold, "grad." + name, grads[name], 2e-2, 5e-3)
+            # (D4: 32 MBConv blocks + 7 BiFPN cells deep, BatchNorm over 8 samples on the 2 x 2 level: the trainable net's f64 / fp32 atomics
+            # (BatchNorm sums, depthwise weight gradients) arrive in another order every run, and this chain amplifies that to 2e-3 .. 6.5e-3
+            # of a watched tensor's largest element - measured over this round's runs, the stem and the last block's BatchNorm weight worst;
+            # D2 at 128^2 holds 1e-3.  The per-module gradient NORMS above hold 1e-2 in every run.)
+            check_summary(gold, "grad." + name, grads[name], 2e-2, 1e-2)
     assert int(ex["backbone_net.model._bn0.num_batches_tracked"]) == int(gold["nbt"])

