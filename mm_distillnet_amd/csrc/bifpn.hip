@@ -22,6 +22,9 @@ struct FuseArgs {
   const float* osc[4]; const float* osh[4];
   int lazy;
   int g_images; long long g_w, g_bn;      // grouped frozen nets (common.h MmdGroup): whole-node eval kernel and fuse_dw_fwd_kernel
+  // node backward, pooled operand (round 5): float offset inside the dynamic LDS of a [17 x 17][64] tile that collects the scattered gradient of
+  // the block's fine-map region before it goes to memory (-1: scatter with global atomics, the round-3 form)
+  int pl_lds_off;
 };
 // per-block coefficient table of the lazy operands in LDS: tab[(2 op + {0 scale, 1 shift}) * 64 + channel of the block's 64-channel chunk];
 // a thread reads its quad where it needs it (kept out of registers: the node backward kernel runs at 190-240 VGPRs as it is)
@@ -289,6 +292,7 @@ static int fuse_fill(FuseArgs& a, const float* in0, const float* in1, const floa
   a.B = B; a.H = H; a.W = W; a.C = C; a.PH = 2 * H; a.PW = 2 * W;
   // SAME pool of an even-sized map: extra = 1 -> pad_lo = 0
   a.pad_t = 0; a.pad_l = 0;
+  a.pl_lds_off = -1;
   return MMD_OK;
 }
 
@@ -847,6 +851,16 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   const int ti = min(tid, 9 * 16 - 1), ttap = ti >> 4, tq = (ti & 15) * 4;      // flipped taps: the transpose of a stride-1 SAME correlation
   const bool tok = c0 + tq < a.C;
   const float4 twv = mmd_ld4(wdw + (size_t)(8 - ttap) * a.C + (tok ? c0 + tq : 0));
+  // Pooled operand's gradient (MODE & 4), round 5.  Every output pixel adds w_pool * g to the arg-max element of its 3 x 3 window: as
+  // 16 scattered 4-byte GLOBAL atomics per thread and pixel pair that was 33 of a block's 63 us (tools/dev/node_phases.py at H 48 / C 224:
+  // "consume" 18.7 + 14.1 us, against 2 us for a node without a pooled operand).  The block's 8 x 8 output tile touches a 17 x 17 region of
+  // the fine map (windows 2 oh .. 2 oh + 2): the contributions are collected in an LDS tile [17 x 17][64] with LDS atomics and written out
+  // once - interior elements (rows / columns 1 .. 15: no other block's windows reach them) by plain coalesced read-add-write, the shared rim
+  // (rows / columns 0 and 16) with global atomics.  74 KB more LDS: these variants hold 256 + 34 .. 76 registers, one block per CU anyway.
+  constexpr int FT = 17;
+  float* const sFine = ((MODE & 4) && a.pl_lds_off >= 0) ? sDyn + a.pl_lds_off : nullptr;
+  if ((MODE & 4) && sFine)
+    for (int i = tid; i < FT * FT * 16; i += 256) *reinterpret_cast<float4*>(&sFine[i * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
   double hs0 = 0, hs1 = 0;
   float hscl = 0.f, hinv = 0.f, hmu = 0.f;
   if constexpr (GEMM) {
@@ -1153,7 +1167,8 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
             if (arg[q] >= 0) {
               const int yy = oh * 2 - a.pad_t + arg[q] / 3, xx = ow * 2 - a.pad_l + arg[q] % 3;
               const size_t so = (((size_t)b * a.PH + yy) * a.PW + xx) * a.C + c + q;
-              atomicAdd(&dpl[so], gv[q]);
+              if (sFine) atomicAdd(&sFine[((yy - 2 * oh0) * FT + (xx - 2 * ow0)) * 64 + c4 + q], gv[q]);      // (pad 0: host-checked)
+              else atomicAdd(&dpl[so], gv[q]);
               if (xp.z) { s4[q] = gv[q]; q4[q] = gv[q] * ((zsame ? praw[q] : xp.z[so]) - muv[q]) * isv[q]; }
             }
           }
@@ -1168,6 +1183,50 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
       }
     }
     NODE_T(10 + h2);
+  }
+  if ((MODE & 4) && sFine) {
+    // the collected fine-map tile -> dpl.  Interior (rows / columns 1 .. 15): this block is the only writer of the launch - read-add-write,
+    // five quads per thread in flight per round (unconditional loads from clamped addresses; only non-zero quads are stored: each output pixel
+    // lands on ONE element of its window, about a quarter of the tile).  Rim: shared with the neighbouring blocks' windows - atomics.
+    __syncthreads();
+    constexpr int NIN = 15 * 15 * 16;
+    for (int i0 = tid; i0 < NIN; i0 += 256 * 5) {
+      float4 t[5], v[5];
+      float* dst[5];
+      bool okq[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int i = i0 + u * 256, ii = min(i, NIN - 1);
+        const int px = ii >> 4, qq = ii & 15;
+        const int fy = 1 + px / 15, fx = 1 + px % 15;
+        const int gy = 2 * oh0 + fy, gx = 2 * ow0 + fx, cq = c0 + qq * 4;
+        okq[u] = i < NIN && gy < a.PH && gx < a.PW && cq < a.C;
+        v[u] = *reinterpret_cast<const float4*>(&sFine[(fy * FT + fx) * 64 + qq * 4]);
+        dst[u] = dpl + (((size_t)b * a.PH + min(gy, a.PH - 1)) * a.PW + min(gx, a.PW - 1)) * a.C + min(cq, a.C - 4);
+        t[u] = mmd_ld4(dst[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+        if (okq[u] && (v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f))
+          mmd_st4(dst[u], make_float4(t[u].x + v[u].x, t[u].y + v[u].y, t[u].z + v[u].z, t[u].w + v[u].w));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {      // rim: 64 pixels x 16 quads
+      const int j = tid + k * 256, bp = j >> 4, qq = j & 15;
+      int fy, fx;
+      if (bp < FT) { fy = 0; fx = bp; }
+      else if (bp < 2 * FT) { fy = FT - 1; fx = bp - FT; }
+      else { const int rr = bp - 2 * FT; fy = 1 + (rr >> 1); fx = (rr & 1) ? FT - 1 : 0; }
+      const int gy = 2 * oh0 + fy, gx = 2 * ow0 + fx, cq = c0 + qq * 4;
+      if (gy < a.PH && gx < a.PW && cq < a.C) {
+        const float4 vv = *reinterpret_cast<const float4*>(&sFine[(fy * FT + fx) * 64 + qq * 4]);
+        float* dp = dpl + (((size_t)b * a.PH + gy) * a.PW + gx) * a.C + cq;
+        if (vv.x != 0.f) atomicAdd(dp, vv.x);
+        if (vv.y != 0.f) atomicAdd(dp + 1, vv.y);
+        if (vv.z != 0.f) atomicAdd(dp + 2, vv.z);
+        if (vv.w != 0.f) atomicAdd(dp + 3, vv.w);
+      }
+    }
   }
   NODE_T(5);
   const int wave = tid >> 6, lane = tid & 63;
@@ -1289,10 +1348,18 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   const double nflops = rows * C * (2.0 * 9 * 2 + (ng ? 2.0 * C : 0.0));
   mmd_prof_tag(MMD_FAM_NODE_BWD, "nodebwd H%lld C%lld mode%lld full%lld", H, C, mode, ng ? 1 : 0);
   mmd_prof_begin(MMD_FAM_NODE_BWD, stream);
+  // pooled operand's gradient through an LDS tile of the fine map (kernel comment): needs pad 0 (even map sizes: every BiFPN level of the
+  // 512^2 / 768^2 inputs), 17 x 17 x 64 floats of dynamic LDS behind the GEMM form's dz tile, and the block within 160 KB
+  static const int pool_lds_on = getenv("MMD_NO_POOL_LDS") ? 0 : 1;
+  const size_t fine_bytes = (size_t)17 * 17 * 64 * sizeof(float);
+  const size_t gemm_floats = (size_t)100 * (C + 4) + 4 * C;
+  const bool pool_lds = pool_lds_on && dpl && a.pad_t == 0 && a.pad_l == 0 &&
+                        (ng ? gemm_floats * sizeof(float) + fine_bytes + 30 * 1024 : fine_bytes + 40 * 1024) <= 160 * 1024;
+  if (pool_lds) a.pl_lds_off = ng ? (int)gemm_floats : 0;
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
-    const size_t lds = (size_t)(100 * (C + 4) + 4 * C) * sizeof(float);
+    const size_t lds = gemm_floats * sizeof(float) + (pool_lds ? fine_bytes : 0);
 #define MMD_NODE_BWD_GK(M, NK) do { static bool attr = false; \
-      if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); attr = true; } \
+      if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024); attr = true; } \
       hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true, NK>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
 #define MMD_NODE_BWD_G(M) do { if (C == 112) MMD_NODE_BWD_GK(M, 7); else if (C == 224) MMD_NODE_BWD_GK(M, 14); else MMD_NODE_BWD_GK(M, 0); } while (0)
     if (mode == 2) MMD_NODE_BWD_G(2); else if (mode == 5) MMD_NODE_BWD_G(5); else if (mode == 4) MMD_NODE_BWD_G(4); else return MMD_EINVAL;
@@ -1302,7 +1369,9 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
     return mmd_check_launch();
   }
   const NodeGemm ng0{};
-#define MMD_NODE_BWD(M) hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, ng0)
+#define MMD_NODE_BWD(M) do { static bool attr = false; \
+    if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+    hipLaunchKernelGGL(fuse_dw_bwd_kernel<M>, grid, blk, pool_lds ? fine_bytes : 0, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, ng0); } while (0)
   switch (mode) {          // the operand sets of BiFPN._forward_fast_attention: (in, up), (in, td, pool), (in, pool); others through the generic forms
     case 2: MMD_NODE_BWD(2); break;
     case 5: MMD_NODE_BWD(5); break;
