@@ -857,10 +857,34 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   // the fine map (windows 2 oh .. 2 oh + 2): the contributions are collected in an LDS tile [17 x 17][64] with LDS atomics and written out
   // once - interior elements (rows / columns 1 .. 15: no other block's windows reach them) by plain coalesced read-add-write, the shared rim
   // (rows / columns 0 and 16) with global atomics.  74 KB more LDS: these variants hold 256 + 34 .. 76 registers, one block per CU anyway.
+  // The tile's INTERIOR starts from dpl's current values, fetched here by LDS-DMA (global_load_lds_dwordx4: no registers, in flight behind
+  // everything up to the operand pass), so that the write-out is a plain store - as a read-add-write it was three dependent round trips at
+  // the end of the block (6.8 of the 22.7 us operand pass at H 32 / C 112); the rim and out-of-range slots start from zero.
+  // (GEMM form only: in the two-launch form - config 5's large levels - the DMA loop's index arithmetic pushed the pooled variant, 256 + 70
+  // registers, into 17 spills and cost what it saved: that form zero-fills the tile and writes out by read-add-write, FINE_DMA = false)
   constexpr int FT = 17;
+  constexpr bool FINE_DMA = GEMM;
   float* const sFine = ((MODE & 4) && a.pl_lds_off >= 0) ? sDyn + a.pl_lds_off : nullptr;
-  if ((MODE & 4) && sFine)
+  if ((MODE & 4) && sFine && !FINE_DMA)
     for (int i = tid; i < FT * FT * 16; i += 256) *reinterpret_cast<float4*>(&sFine[i * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((MODE & 4) && sFine && FINE_DMA) {
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6), ln0 = tid & 63;
+    for (int it = wv0; it * 64 < FT * FT * 16; it += 4) {      // one wave instruction = 64 consecutive quads of the tile image
+      const int i = it * 64 + ln0;
+      const int px = i >> 4, qq = i & 15;
+      const int fy = px / FT, fx = px - fy * FT;
+      const int gy = 2 * oh0 + fy, gx = 2 * ow0 + fx, cq = c0 + qq * 4;
+      const bool inr = i < FT * FT * 16 && gy < a.PH && gx < a.PW && cq < a.C;
+      const bool inner = fy >= 1 && fy <= FT - 2 && fx >= 1 && fx <= FT - 2;
+      if (inr && inner)
+        __builtin_amdgcn_global_load_lds((glb_vp)(uintptr_t)(dpl + (((size_t)b * a.PH + gy) * a.PW + gx) * a.C + cq),
+                                         (lds_vp)(uintptr_t)(sFine + it * 256), 16, 0, 0);
+      else if (i < FT * FT * 16)
+        *reinterpret_cast<float4*>(&sFine[i * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   double hs0 = 0, hs1 = 0;
   float hscl = 0.f, hinv = 0.f, hmu = 0.f;
   if constexpr (GEMM) {
@@ -995,7 +1019,8 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     if (p < IH * IW) *reinterpret_cast<float4*>(&sIn[p * 64 + c4]) = make_float4(ok ? sv[i].x : 0.f, ok ? sv[i].y : 0.f, ok ? sv[i].z : 0.f, ok ? sv[i].w : 0.f);
   }
   }
-  __syncthreads();
+  if ((MODE & 4) && sFine && FINE_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the fine tile's LDS-DMA pieces have landed (they count on vmcnt) ...
+  __syncthreads();                                                                  // ... in every wave, before the first LDS add below
   NODE_T(3);
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
@@ -1185,30 +1210,41 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     NODE_T(10 + h2);
   }
   if ((MODE & 4) && sFine) {
-    // the collected fine-map tile -> dpl.  Interior (rows / columns 1 .. 15): this block is the only writer of the launch - read-add-write,
-    // five quads per thread in flight per round (unconditional loads from clamped addresses; only non-zero quads are stored: each output pixel
-    // lands on ONE element of its window, about a quarter of the tile).  Rim: shared with the neighbouring blocks' windows - atomics.
+    // the collected fine-map tile -> dpl.  Interior (rows / columns 1 .. 15): this block is the only writer of the launch and the tile
+    // started from dpl's values - a plain coalesced store.  Rim: shared with the neighbouring blocks' windows - atomics.
     __syncthreads();
     constexpr int NIN = 15 * 15 * 16;
-    for (int i0 = tid; i0 < NIN; i0 += 256 * 5) {
-      float4 t[5], v[5];
-      float* dst[5];
-      bool okq[5];
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        const int i = i0 + u * 256, ii = min(i, NIN - 1);
-        const int px = ii >> 4, qq = ii & 15;
+    if constexpr (FINE_DMA) {
+      for (int i = tid; i < NIN; i += 256) {
+        const int px = i >> 4, qq = i & 15;
         const int fy = 1 + px / 15, fx = 1 + px % 15;
         const int gy = 2 * oh0 + fy, gx = 2 * ow0 + fx, cq = c0 + qq * 4;
-        okq[u] = i < NIN && gy < a.PH && gx < a.PW && cq < a.C;
-        v[u] = *reinterpret_cast<const float4*>(&sFine[(fy * FT + fx) * 64 + qq * 4]);
-        dst[u] = dpl + (((size_t)b * a.PH + min(gy, a.PH - 1)) * a.PW + min(gx, a.PW - 1)) * a.C + min(cq, a.C - 4);
-        t[u] = mmd_ld4(dst[u]);
+        if (gy < a.PH && gx < a.PW && cq < a.C)
+          mmd_st4(dpl + (((size_t)b * a.PH + gy) * a.PW + gx) * a.C + cq, *reinterpret_cast<const float4*>(&sFine[(fy * FT + fx) * 64 + qq * 4]));
       }
+    } else {
+      // (zero-filled tile: read-add-write, five quads per thread in flight per round - unconditional loads from clamped addresses; only
+      // non-zero quads are stored: each output pixel lands on ONE element of its window, about a quarter of the tile)
+      for (int i0 = tid; i0 < NIN; i0 += 256 * 5) {
+        float4 t[5], v[5];
+        float* dst[5];
+        bool okq[5];
 #pragma unroll
-      for (int u = 0; u < 5; ++u)
-        if (okq[u] && (v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f))
-          mmd_st4(dst[u], make_float4(t[u].x + v[u].x, t[u].y + v[u].y, t[u].z + v[u].z, t[u].w + v[u].w));
+        for (int u = 0; u < 5; ++u) {
+          const int i = i0 + u * 256, ii = min(i, NIN - 1);
+          const int px = ii >> 4, qq = ii & 15;
+          const int fy = 1 + px / 15, fx = 1 + px % 15;
+          const int gy = 2 * oh0 + fy, gx = 2 * ow0 + fx, cq = c0 + qq * 4;
+          okq[u] = i < NIN && gy < a.PH && gx < a.PW && cq < a.C;
+          v[u] = *reinterpret_cast<const float4*>(&sFine[(fy * FT + fx) * 64 + qq * 4]);
+          dst[u] = dpl + (((size_t)b * a.PH + min(gy, a.PH - 1)) * a.PW + min(gx, a.PW - 1)) * a.C + min(cq, a.C - 4);
+          t[u] = mmd_ld4(dst[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+          if (okq[u] && (v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f))
+            mmd_st4(dst[u], make_float4(t[u].x + v[u].x, t[u].y + v[u].y, t[u].z + v[u].z, t[u].w + v[u].w));
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {      // rim: 64 pixels x 16 quads
