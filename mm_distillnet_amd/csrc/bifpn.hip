@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
           t[2] = v; sv.x += w[wi] * v.x; sv.y += w[wi] * v.y; sv.z += w[wi] * v.z; sv.w += w[wi] * v.w; ++wi;
         }
         int arg[4] = {-1, -1, -1, -1};
-        float praw[4] = {0.f, 0.f, 0.f, 0.f};
+        float praw[4] = {0.f, 0.f, 0.f, 0.f}, zarg[4] = {0.f, 0.f, 0.f, 0.f};
         if (MODE & 4) {
           // value = max over the window with the zero padding taking part; arg = tap of the FIRST maximum in row-major order, -1 when a
           // padding element wins (pool_window / pool_window_arg above, from one set of loads)
@@ -1151,6 +1151,18 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
           }
           const float4 v = make_float4(best[0], best[1], best[2], best[3]);
           t[3] = v; sv.x += w[wi] * v.x; sv.y += w[wi] * v.y; sv.z += w[wi] * v.z; sv.w += w[wi] * v.w; ++wi;
+          // the BatchNorm input at the arg-max element (the sums of this scatter's share), when it is not the pooled tensor itself (a
+          // materialised - non-lazy - operand: D4): the four gathers are issued HERE, together and unconditionally (clamped tap), and used at
+          // the end of the pixel - inside the scatter loop below each was a dependent round trip of its own (16 per pixel pair: the 6 x 6
+          // node of config 5 took 65 us, the 4 x 4 node of D2 - lazy operands - 33)
+          if (dpl && xp.z && xp.z != a.pl) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int tp = max(arg[q], 0);
+              const int yy = oh * 2 - a.pad_t + tp / 3, xx = ow * 2 - a.pad_l + tp % 3;
+              zarg[q] = xp.z[(((size_t)b * a.PH + min(max(yy, 0), a.PH - 1)) * a.PW + min(max(xx, 0), a.PW - 1)) * a.C + c + q];
+            }
+          }
         }
         if (dwg) fq[o] = make_float4(mmd_swish(sv.x), mmd_swish(sv.y), mmd_swish(sv.z), mmd_swish(sv.w));      // the node's fused activation
         float4 g = acc[o];
@@ -1194,7 +1206,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
               const size_t so = (((size_t)b * a.PH + yy) * a.PW + xx) * a.C + c + q;
               if (sFine) atomicAdd(&sFine[((yy - 2 * oh0) * FT + (xx - 2 * ow0)) * 64 + c4 + q], gv[q]);      // (pad 0: host-checked)
               else atomicAdd(&dpl[so], gv[q]);
-              if (xp.z) { s4[q] = gv[q]; q4[q] = gv[q] * ((zsame ? praw[q] : xp.z[so]) - muv[q]) * isv[q]; }
+              if (xp.z) { s4[q] = gv[q]; q4[q] = gv[q] * ((zsame ? praw[q] : zarg[q]) - muv[q]) * isv[q]; }
             }
           }
           bsp.x += s4[0]; bsp.y += s4[1]; bsp.z += s4[2]; bsp.w += s4[3];
