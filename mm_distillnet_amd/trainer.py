@@ -188,8 +188,10 @@ def save_checkpoint(state: Dict, is_best: bool, cfg) -> None:
 
 
 def checkpoint_state(eng, sched: LrSchedule, epoch: int, best_loss: float, best_epoch: int) -> Dict:
+    # ("drop_draws": the device-side draw counter of the drop-connect masks - an extra key upstream ignores - so a resumed run goes on
+    # with fresh masks instead of replaying the first epoch's)
     return {"epoch": epoch + 1, "state_dict": eng.student.ps.export_state(), "best_loss": best_loss, "best_epoch": best_epoch,
-            "optimizer": optimizer_state_dict(eng), "scheduler": sched.state_dict()}
+            "optimizer": optimizer_state_dict(eng), "scheduler": sched.state_dict(), "drop_draws": int(eng.drop_state[0].item())}
 
 
 def resume_from_checkpoint(cfg, eng, sched: LrSchedule):
@@ -203,6 +205,8 @@ def resume_from_checkpoint(cfg, eng, sched: LrSchedule):
         load_optimizer_state_dict(eng, c["optimizer"])
         sched.load_state_dict(c["scheduler"])
         sched.sync_lr(eng.lr)
+        if "drop_draws" in c:
+            eng.drop_state[0] = int(c["drop_draws"])
         logger.info(f"Starting from epoch={start_epoch}")
         logger.info(f"Load {path}")
     return start_epoch, best_loss, best_epoch
