@@ -914,6 +914,98 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
   mmd_st4(o, acc);
 }
 
+// The same gather with the BatchNorm(+swish)-backward sums of the tensor the gradient belongs to taken on the way (round 5): dx is the gradient
+// w.r.t. a0 = swish(z * scale + shift), so sum g' and sum g' * xhat (g' = dx * swish'(u)) of that BatchNorm ride here, as they do in the stride-1
+// launches, instead of a reduce pass that re-reads dx and z (the four stride-2 MBConv blocks: mmd_bn_bwd_reduce launches of 100 / 40 / 15 / 10 us
+// on the backward chain).  Sums want few, fat blocks - one block per (image, row block, 64-channel chunk), a thread keeps ONE channel quad and
+// walks the block's pixels, two float4 accumulators; the direct form above has one block per 256 (pixel, quad) items, 49 152 blocks on the
+// 256^2 map, i.e. as many rounds of same-address f64 atomics.
+template <int K>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int B, int H, int W, int C, int OH, int OW,
+                                                                 int pad_t, int pad_l, const float* __restrict__ bz,
+                                                                 const float* __restrict__ bscale, const float* __restrict__ bshift,
+                                                                 const float* __restrict__ bmean, const float* __restrict__ binvstd,
+                                                                 double* stats, double* stats_ws, int ws_slots, int rows_per_block,
+                                                                 int rowblocks, int cchunks) {
+  __shared__ float sRed[2 * 4 * 64];
+  __shared__ float sW[K * K * 64];
+  const int tid = threadIdx.x, c4 = (tid & 15) * 4, pl_ = tid >> 4;      // 16 pixel lanes x 16 channel quads
+  int bid = blockIdx.x;
+  const int cc = bid % cchunks; bid /= cchunks;
+  const int rb = bid % rowblocks; bid /= rowblocks;
+  const int b = bid, c = cc * 64 + c4;
+  const bool cok = c < C;
+  const int cs = cok ? c : 0;
+  for (int i = tid; i < K * K * 16; i += 256) {
+    const int t = i >> 4, q = (i & 15) * 4;
+    *reinterpret_cast<float4*>(&sW[t * 64 + q]) = (cc * 64 + q < C) ? mmd_ld4(w + (size_t)t * C + cc * 64 + q) : make_float4(0, 0, 0, 0);
+  }
+  const float4 sc = mmd_ld4(bscale + cs), sh = mmd_ld4(bshift + cs), mu = mmd_ld4(bmean + cs), is = mmd_ld4(binvstd + cs);
+  float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
+  const int ih0 = rb * rows_per_block, ih1 = min(ih0 + rows_per_block, H);
+  const int npix = (ih1 - ih0) * W;
+  __syncthreads();
+  constexpr int NT = (K + 1) / 2;      // taps per dimension that can reach an input pixel: those with the parity of (ih + pad_t)
+  for (int p = pl_; p < npix; p += 16) {
+    const int ih = ih0 + p / W, iw = p % W;
+    const size_t off = (((size_t)b * H + ih) * W + iw) * C + cs;
+    const float4 zz = mmd_ld4(bz + off);
+    // every load of the pixel unconditional from a clamped address, masked afterwards (a guarded load is a dependent round trip)
+    const int i0 = (ih + pad_t) & 1, j0 = (iw + pad_l) & 1;
+    float4 gv[NT * NT];
+    unsigned vm = 0u;
+#pragma unroll
+    for (int ii = 0; ii < NT; ++ii) {
+      const int i = i0 + 2 * ii, oh = (ih + pad_t - i) >> 1;
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj) {
+        const int j = j0 + 2 * jj, ow = (iw + pad_l - j) >> 1;
+        if (i < K && j < K && ih + pad_t - i >= 0 && oh < OH && iw + pad_l - j >= 0 && ow < OW) vm |= 1u << (ii * NT + jj);
+        gv[ii * NT + jj] = mmd_ld4(dy + (((size_t)b * OH + min(max(oh, 0), OH - 1)) * OW + min(max(ow, 0), OW - 1)) * C + cs);
+      }
+    }
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int ii = 0; ii < NT; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj) {
+        const int i = min(i0 + 2 * ii, K - 1), j = min(j0 + 2 * jj, K - 1);
+        const float4 k_ = *reinterpret_cast<const float4*>(&sW[(i * K + j) * 64 + c4]);
+        const float m = ((vm >> (ii * NT + jj)) & 1u) ? 1.f : 0.f;
+        const float4 g = gv[ii * NT + jj];
+        acc.x += m * g.x * k_.x; acc.y += m * g.y * k_.y; acc.z += m * g.z * k_.z; acc.w += m * g.w * k_.w;
+      }
+    if (cok) {
+      mmd_st4(dx + off, acc);
+      const float4 gp = make_float4(acc.x * mmd_swish_grad(zz.x * sc.x + sh.x), acc.y * mmd_swish_grad(zz.y * sc.y + sh.y),
+                                    acc.z * mmd_swish_grad(zz.z * sc.z + sh.z), acc.w * mmd_swish_grad(zz.w * sc.w + sh.w));
+      s4.x += gp.x; s4.y += gp.y; s4.z += gp.z; s4.w += gp.w;
+      q4.x += gp.x * (zz.x - mu.x) * is.x; q4.y += gp.y * (zz.y - mu.y) * is.y;
+      q4.z += gp.z * (zz.z - mu.z) * is.z; q4.w += gp.w * (zz.w - mu.w) * is.w;
+    }
+  }
+  // lanes l, l ^ 16, l ^ 32, l ^ 48 of a wave share the channel quad; then the four waves through LDS
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    s4.x += __shfl_xor(s4.x, o, 64); s4.y += __shfl_xor(s4.y, o, 64); s4.z += __shfl_xor(s4.z, o, 64); s4.w += __shfl_xor(s4.w, o, 64);
+    q4.x += __shfl_xor(q4.x, o, 64); q4.y += __shfl_xor(q4.y, o, 64); q4.z += __shfl_xor(q4.z, o, 64); q4.w += __shfl_xor(q4.w, o, 64);
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 16) {
+    *reinterpret_cast<float4*>(&sRed[wave * 64 + c4]) = s4;
+    *reinterpret_cast<float4*>(&sRed[4 * 64 + wave * 64 + c4]) = q4;
+  }
+  __syncthreads();
+  if (tid < 64 && cc * 64 + tid < C) {
+    const float vs = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
+    const float vq = sRed[256 + tid] + sRed[320 + tid] + sRed[384 + tid] + sRed[448 + tid];
+    double* st = stats_ws ? stats_ws + (size_t)((blockIdx.x / cchunks) % ws_slots) * 2 * C : stats;
+    atomicAdd(&st[cc * 64 + tid], (double)vs);
+    atomicAdd(&st[C + cc * 64 + tid], (double)vq);
+  }
+}
+
 // dx[B,H,W,C] (=) dwconv^T(dy[B,OH,OW,C], w)
 extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int k,
                                    int stride, const float* bn_z, const float* bn_scale, const float* bn_shift,
@@ -921,8 +1013,8 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
                                    int ws_slots, float* dw_grad, hipStream_t stream) {
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
-  if (bn_sums && (stride != 1 || !bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
-  if (dw_grad && !bn_sums) return MMD_EINVAL;        // the weight gradient rides on the BatchNorm-sum form (it needs a0 = swish(u))
+  if (bn_sums && (!bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
+  if (dw_grad && (!bn_sums || stride != 1)) return MMD_EINVAL;        // the weight gradient rides on the stride-1 BatchNorm-sum form (it needs a0 = swish(u))
   int OH, OW;
   int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd H%lld C%lld k%lld s%lld", H, C, k, stride);
@@ -939,6 +1031,18 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
     a.dwg = dw_grad;
     rc = (k == 3 && !dw_grad) ? dw3_rows_launch(a, stream) : 1;      // (the row-streaming kernel has no weight-gradient form)
     if (rc == 1) rc = (k == 3) ? dw_fwd_launch_31(a, stream) : dw_fwd_launch_51(a, stream);
+  } else if (bn_sums) {
+    // ~2048 blocks: rows per block from the map's size; slotted sums when more than MMD_STATS_DEPTH blocks would meet on one address
+    const int cch = cdiv(C, 64);
+    int rpb = (int)cdiv((long long)B * H * cch, 2048); if (rpb < 1) rpb = 1; if (rpb > H) rpb = H;
+    const int rbl = cdiv(H, rpb);
+    const long long per_addr = (long long)B * rbl;
+    double* ws = (stats_ws && ws_slots > 1 && per_addr > MMD_STATS_DEPTH) ? stats_ws : nullptr;
+    const dim3 grid((unsigned)((long long)B * rbl * cch));
+    if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_sums_kernel<3>, grid, dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_sums, ws, ws ? ws_slots : 1, rpb, rbl, cch);
+    else hipLaunchKernelGGL(dw_bwd_data_s2_sums_kernel<5>, grid, dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_sums, ws, ws ? ws_slots : 1, rpb, rbl, cch);
+    if (ws) mmd_stats_fold(bn_sums, ws, ws_slots, 2 * C, stream);
+    rc = mmd_check_launch();
   } else {
     size_t total = (size_t)B * H * W * (C >> 2);
     if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_kernel<3>, dim3(cdiv(total, 256)), dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, 0);

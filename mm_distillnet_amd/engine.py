@@ -133,6 +133,7 @@ BN1_IN_DW = not os.environ.get("MMD_NO_BN1_IN_DW")    # MBConv: BatchNorm-1 back
 POOL_SCATTER = not os.environ.get("MMD_NO_POOL_SCATTER")
 P5_IN_GEMM = not os.environ.get("MMD_NO_P5_IN_GEMM")  # MBConv: the pooled squeeze-excite / BN-1 backward pass in the project GEMM's epilogue (no chan_pool_bwd launch)
 SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
+DW_S2_SUMS = not os.environ.get("MMD_NO_DW_S2_SUMS")     # stride-2 depthwise input gradient takes the BatchNorm-0 backward sums (csrc/dwconv.hip dw_bwd_data_s2_sums_kernel)
 # both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
 # (S*C MACs, serial per wave) - measured 17.0 -> 17.7 ms/step against the two wide launches; off unless MMD_SE_FUSED=1
 SE_FUSED = bool(os.environ.get("MMD_SE_FUSED"))
@@ -1182,7 +1183,7 @@ class Net:
         if not want_dx:
             return None
         dx = self._alloc(x.M, x.C)
-        if bn_aff is not None and s == 1:
+        if bn_aff is not None and (s == 1 or DW_S2_SUMS):      # (stride 2, round 5: the sums ride in the gather launch too - no reduce pass)
             sums = self._zalloc((2 * x.C,), torch.float64)
             call("mmd_dwconv_bwd_data", dzd, ps.w(wkey), dx, x.B, x.H, x.W, x.C, k, s, x.z, bn_aff[0], bn_aff[1], bn_aff[2],
                  bn_aff[3], sums, *self._stats_ws(sums, x.M, x.C), ps.g(wkey) if wg_inside else None)

@@ -344,6 +344,19 @@ def test_dwconv(k, s, H, W, C):
     dxo = torch.empty(B * H * W, C, device=DEV)
     call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dxo, B, H, W, C, k, s, None, None, None, None, None, None, None, 0, None)
     close(dxo.view(B, H, W, C), nhwc(a.grad), 2e-4, 1e-5, "dw bwd data")
+    if s == 2:      # round 5: the stride-2 gather takes the same sums (few fat blocks, one channel quad per thread)
+        mu, istd = torch.randn(C) * 0.2, torch.rand(C) + 0.5
+        ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        call("mmd_bn_bwd_reduce", dxo, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), 1, None, None, None, 0, None, ref, B * H * W, C,
+             None, 0)
+        for slots in (0, 8):
+            got = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+            ws = torch.zeros(slots * 2 * C, dtype=torch.float64, device=DEV) if slots else None
+            dx2 = torch.empty_like(dxo)
+            call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx2, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got, ws, slots, None)
+            close(dx2, dxo, 1e-6, 1e-7, "dx of the stride-2 BatchNorm-sum variant")
+            close(got, ref, 1e-5, 1e-5, "BN sums fused into the stride-2 dw bwd-data")
+            assert ws is None or bool((ws == 0).all())
     if s == 1:      # fused sums of the BatchNorm(+swish) backward that consumes dx == the stand-alone reduce pass
         mu, istd = torch.randn(C) * 0.2, torch.rand(C) + 0.5
         ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
