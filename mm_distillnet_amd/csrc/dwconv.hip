@@ -920,16 +920,22 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
 // on the backward chain).  Sums want few, fat blocks - one block per (image, row block, 64-channel chunk), a thread keeps ONE channel quad and
 // walks the block's pixels, two float4 accumulators; the direct form above has one block per 256 (pixel, quad) items, 49 152 blocks on the
 // 256^2 map, i.e. as many rounds of same-address f64 atomics.
-template <int K>
+// WG: the conv's weight gradient rides along too - dW[i][j] = sum dy[oh, ow] * a0[2 oh + i - pad, 2 ow + j - pad] is, seen from the input pixel, the
+// product of the gathered dy values with a0 = swish(u) at that pixel, and the sigmoid is at hand from swish'.  A thread walks pixels of ONE
+// parity class (pixel lanes 0 .. 3 of a 2 x 2 cell), so its <= ceil(K / 2)^2 reachable taps are the same all along: that many float4 accumulators,
+// LDS atomics into a [K * K][64] tile at the end, K * K * 64 global atomics per block (the stride-1 launches do the same; the separate
+// dw_wgrad_kernel<K, 2> launches were 4 x ~45 us of chip-filling work on the side stream).
+template <int K, bool WG>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                  float* __restrict__ dx, int B, int H, int W, int C, int OH, int OW,
                                                                  int pad_t, int pad_l, const float* __restrict__ bz,
                                                                  const float* __restrict__ bscale, const float* __restrict__ bshift,
                                                                  const float* __restrict__ bmean, const float* __restrict__ binvstd,
                                                                  double* stats, double* stats_ws, int ws_slots, int rows_per_block,
-                                                                 int rowblocks, int cchunks) {
+                                                                 int rowblocks, int cchunks, float* __restrict__ dwg) {
   __shared__ float sRed[2 * 4 * 64];
   __shared__ float sW[K * K * 64];
+  __shared__ float sWg[WG ? K * K * 64 : 1];
   const int tid = threadIdx.x, c4 = (tid & 15) * 4, pl_ = tid >> 4;      // 16 pixel lanes x 16 channel quads
   int bid = blockIdx.x;
   const int cc = bid % cchunks; bid /= cchunks;
@@ -940,19 +946,29 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* _
   for (int i = tid; i < K * K * 16; i += 256) {
     const int t = i >> 4, q = (i & 15) * 4;
     *reinterpret_cast<float4*>(&sW[t * 64 + q]) = (cc * 64 + q < C) ? mmd_ld4(w + (size_t)t * C + cc * 64 + q) : make_float4(0, 0, 0, 0);
+    if (WG) *reinterpret_cast<float4*>(&sWg[t * 64 + q]) = make_float4(0, 0, 0, 0);
   }
   const float4 sc = mmd_ld4(bscale + cs), sh = mmd_ld4(bshift + cs), mu = mmd_ld4(bmean + cs), is = mmd_ld4(binvstd + cs);
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
-  const int ih0 = rb * rows_per_block, ih1 = min(ih0 + rows_per_block, H);
-  const int npix = (ih1 - ih0) * W;
+  const int ih0 = rb * rows_per_block, ih1 = min(ih0 + rows_per_block, H);      // rows_per_block is even (host)
   __syncthreads();
   constexpr int NT = (K + 1) / 2;      // taps per dimension that can reach an input pixel: those with the parity of (ih + pad_t)
-  for (int p = pl_; p < npix; p += 16) {
-    const int ih = ih0 + p / W, iw = p % W;
-    const size_t off = (((size_t)b * H + ih) * W + iw) * C + cs;
+  // pixels by 2 x 2 cells: pixel lane = (cell lane, row parity, column parity); the thread's reachable taps are i0 + 2 ii, j0 + 2 jj
+  const int py = (pl_ >> 1) & 1, px = pl_ & 1, cl = pl_ >> 2;
+  const int i0 = (ih0 + py + pad_t) & 1, j0 = (px + pad_l) & 1;
+  const int cw = (W + 1) >> 1, ncell = ((ih1 - ih0 + 1) >> 1) * cw;
+  float4 wacc[WG ? NT * NT : 1];
+  if (WG) {
+#pragma unroll
+    for (int t = 0; t < NT * NT; ++t) wacc[t] = make_float4(0, 0, 0, 0);
+  }
+  for (int q = cl; q < ncell; q += 4) {
+    const int ih = ih0 + 2 * (q / cw) + py, iw = 2 * (q % cw) + px;
+    const bool pok = cok && ih < ih1 && iw < W;
+    const int ihc = min(ih, H - 1), iwc = min(iw, W - 1);
+    const size_t off = (((size_t)b * H + ihc) * W + iwc) * C + cs;
     const float4 zz = mmd_ld4(bz + off);
     // every load of the pixel unconditional from a clamped address, masked afterwards (a guarded load is a dependent round trip)
-    const int i0 = (ih + pad_t) & 1, j0 = (iw + pad_l) & 1;
     float4 gv[NT * NT];
     unsigned vm = 0u;
 #pragma unroll
@@ -961,7 +977,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* _
 #pragma unroll
       for (int jj = 0; jj < NT; ++jj) {
         const int j = j0 + 2 * jj, ow = (iw + pad_l - j) >> 1;
-        if (i < K && j < K && ih + pad_t - i >= 0 && oh < OH && iw + pad_l - j >= 0 && ow < OW) vm |= 1u << (ii * NT + jj);
+        if (pok && i < K && j < K && ih + pad_t - i >= 0 && oh < OH && iw + pad_l - j >= 0 && ow < OW) vm |= 1u << (ii * NT + jj);
         gv[ii * NT + jj] = mmd_ld4(dy + (((size_t)b * OH + min(max(oh, 0), OH - 1)) * OW + min(max(ow, 0), OW - 1)) * C + cs);
       }
     }
@@ -973,16 +989,26 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* _
         const int i = min(i0 + 2 * ii, K - 1), j = min(j0 + 2 * jj, K - 1);
         const float4 k_ = *reinterpret_cast<const float4*>(&sW[(i * K + j) * 64 + c4]);
         const float m = ((vm >> (ii * NT + jj)) & 1u) ? 1.f : 0.f;
-        const float4 g = gv[ii * NT + jj];
-        acc.x += m * g.x * k_.x; acc.y += m * g.y * k_.y; acc.z += m * g.z * k_.z; acc.w += m * g.w * k_.w;
+        float4& g = gv[ii * NT + jj];
+        g.x *= m; g.y *= m; g.z *= m; g.w *= m;
+        acc.x += g.x * k_.x; acc.y += g.y * k_.y; acc.z += g.z * k_.z; acc.w += g.w * k_.w;
       }
-    if (cok) {
+    if (pok) {
       mmd_st4(dx + off, acc);
-      const float4 gp = make_float4(acc.x * mmd_swish_grad(zz.x * sc.x + sh.x), acc.y * mmd_swish_grad(zz.y * sc.y + sh.y),
-                                    acc.z * mmd_swish_grad(zz.z * sc.z + sh.z), acc.w * mmd_swish_grad(zz.w * sc.w + sh.w));
+      const float ux = zz.x * sc.x + sh.x, uy = zz.y * sc.y + sh.y, uz = zz.z * sc.z + sh.z, uw = zz.w * sc.w + sh.w;
+      const float sx = mmd_sigmoid(ux), sy = mmd_sigmoid(uy), sz = mmd_sigmoid(uz), sw = mmd_sigmoid(uw);
+      const float4 gp = make_float4(acc.x * sx * (1.f + ux * (1.f - sx)), acc.y * sy * (1.f + uy * (1.f - sy)),
+                                    acc.z * sz * (1.f + uz * (1.f - sz)), acc.w * sw * (1.f + uw * (1.f - sw)));
       s4.x += gp.x; s4.y += gp.y; s4.z += gp.z; s4.w += gp.w;
       q4.x += gp.x * (zz.x - mu.x) * is.x; q4.y += gp.y * (zz.y - mu.y) * is.y;
       q4.z += gp.z * (zz.z - mu.z) * is.z; q4.w += gp.w * (zz.w - mu.w) * is.w;
+      if (WG) {
+        const float4 a0 = make_float4(ux * sx, uy * sy, uz * sz, uw * sw);
+#pragma unroll
+        for (int t = 0; t < NT * NT; ++t) {      // (masked taps hold zeros)
+          wacc[t].x += gv[t].x * a0.x; wacc[t].y += gv[t].y * a0.y; wacc[t].z += gv[t].z * a0.z; wacc[t].w += gv[t].w * a0.w;
+        }
+      }
     }
   }
   // lanes l, l ^ 16, l ^ 32, l ^ 48 of a wave share the channel quad; then the four waves through LDS
@@ -996,6 +1022,19 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* _
     *reinterpret_cast<float4*>(&sRed[wave * 64 + c4]) = s4;
     *reinterpret_cast<float4*>(&sRed[4 * 64 + wave * 64 + c4]) = q4;
   }
+  if (WG) {
+#pragma unroll
+    for (int ii = 0; ii < NT; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj) {
+        const int i = i0 + 2 * ii, j = j0 + 2 * jj;
+        if (i < K && j < K) {
+          float* d = &sWg[(i * K + j) * 64 + c4];
+          const float4 v = wacc[ii * NT + jj];
+          atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+        }
+      }
+  }
   __syncthreads();
   if (tid < 64 && cc * 64 + tid < C) {
     const float vs = sRed[tid] + sRed[64 + tid] + sRed[128 + tid] + sRed[192 + tid];
@@ -1004,6 +1043,11 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* _
     atomicAdd(&st[cc * 64 + tid], (double)vs);
     atomicAdd(&st[C + cc * 64 + tid], (double)vq);
   }
+  if (WG)
+    for (int i = tid; i < K * K * 64; i += 256) {
+      const int t = i >> 6, q = i & 63;
+      if (cc * 64 + q < C) atomicAdd(&dwg[(size_t)t * C + cc * 64 + q], sWg[i]);
+    }
 }
 
 // dx[B,H,W,C] (=) dwconv^T(dy[B,OH,OW,C], w)
@@ -1014,7 +1058,7 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if (bn_sums && (!bn_z || !bn_scale || !bn_shift || !bn_mean || !bn_invstd)) return MMD_EINVAL;
-  if (dw_grad && (!bn_sums || stride != 1)) return MMD_EINVAL;        // the weight gradient rides on the stride-1 BatchNorm-sum form (it needs a0 = swish(u))
+  if (dw_grad && !bn_sums) return MMD_EINVAL;        // the weight gradient rides on the BatchNorm-sum forms (it needs a0 = swish(u))
   int OH, OW;
   int pt = same_pad_lo(H, k, stride, &OH), pl = same_pad_lo(W, k, stride, &OW);
   mmd_prof_tag(MMD_FAM_DW_BWD, "dwbd H%lld C%lld k%lld s%lld", H, C, k, stride);
@@ -1034,13 +1078,16 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
   } else if (bn_sums) {
     // ~2048 blocks: rows per block from the map's size; slotted sums when more than MMD_STATS_DEPTH blocks would meet on one address
     const int cch = cdiv(C, 64);
-    int rpb = (int)cdiv((long long)B * H * cch, 2048); if (rpb < 1) rpb = 1; if (rpb > H) rpb = H;
+    int rpb = (int)cdiv((long long)B * H * cch, 2048); if (rpb < 2) rpb = 2; rpb += rpb & 1; if (rpb > H) rpb = H + (H & 1);      // even: a thread keeps one row parity
     const int rbl = cdiv(H, rpb);
     const long long per_addr = (long long)B * rbl;
     double* ws = (stats_ws && ws_slots > 1 && per_addr > MMD_STATS_DEPTH) ? stats_ws : nullptr;
     const dim3 grid((unsigned)((long long)B * rbl * cch));
-    if (k == 3) hipLaunchKernelGGL(dw_bwd_data_s2_sums_kernel<3>, grid, dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_sums, ws, ws ? ws_slots : 1, rpb, rbl, cch);
-    else hipLaunchKernelGGL(dw_bwd_data_s2_sums_kernel<5>, grid, dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_sums, ws, ws ? ws_slots : 1, rpb, rbl, cch);
+#define MMD_S2_GO(KK, WG_) hipLaunchKernelGGL((dw_bwd_data_s2_sums_kernel<KK, WG_>), grid, dim3(256), 0, stream, dy, w, dx, B, H, W, C, OH, OW, pt, pl, bn_z, bn_scale, \
+                                              bn_shift, bn_mean, bn_invstd, bn_sums, ws, ws ? ws_slots : 1, rpb, rbl, cch, dw_grad)
+    if (k == 3) { if (dw_grad) MMD_S2_GO(3, true); else MMD_S2_GO(3, false); }
+    else { if (dw_grad) MMD_S2_GO(5, true); else MMD_S2_GO(5, false); }
+#undef MMD_S2_GO
     if (ws) mmd_stats_fold(bn_sums, ws, ws_slots, 2 * C, stream);
     rc = mmd_check_launch();
   } else {

@@ -133,6 +133,7 @@ BN1_IN_DW = not os.environ.get("MMD_NO_BN1_IN_DW")    # MBConv: BatchNorm-1 back
 POOL_SCATTER = not os.environ.get("MMD_NO_POOL_SCATTER")
 P5_IN_GEMM = not os.environ.get("MMD_NO_P5_IN_GEMM")  # MBConv: the pooled squeeze-excite / BN-1 backward pass in the project GEMM's epilogue (no chan_pool_bwd launch)
 SE_WG_BATCH = not os.environ.get("MMD_NO_SE_WG_BATCH")
+DW_S2_WG = not os.environ.get("MMD_NO_DW_S2_WG")         # ... and the conv's weight gradient (no dw_wgrad_kernel<k, 2> leaf)
 DW_S2_SUMS = not os.environ.get("MMD_NO_DW_S2_SUMS")     # stride-2 depthwise input gradient takes the BatchNorm-0 backward sums (csrc/dwconv.hip dw_bwd_data_s2_sums_kernel)
 # both squeeze-excite FC data gradients in one launch (mmd_se_fc_bwd_fused): correct, but every block recomputes its image's hidden gradient
 # (S*C MACs, serial per wave) - measured 17.0 -> 17.7 ms/step against the two wide launches; off unless MMD_SE_FUSED=1
@@ -1176,7 +1177,7 @@ class Net:
         gradient (tile kernel; for the 3x3 layers that gives up the faster row-streaming input-gradient kernel and still wins: a
         weight-gradient leaf costs its full kernel time on the saturated chip - 18.44 -> 18.27 ms/step)."""
         ps = self.ps
-        wg_inside = self.DW_WG and want_dx and bn_aff is not None and s == 1 and x.C >= 64      # (block 0, 32 channels at 256^2: 221 us inside vs 47 + 67)
+        wg_inside = self.DW_WG and want_dx and bn_aff is not None and ((s == 1 and x.C >= 64) or (s == 2 and DW_S2_SUMS and DW_S2_WG))      # (block 0, 32 channels at 256^2: 221 us inside vs 47 + 67)
         if not wg_inside:
             self._leaf(lambda x=x, dzd=dzd, gw=ps.g(wkey): call("mmd_dwconv_bwd_weight", x.z, dzd, gw, x.B, x.H, x.W, x.C, k, s, x.scale, x.shift,
                                                                  x.act))

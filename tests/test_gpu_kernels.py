@@ -357,6 +357,14 @@ def test_dwconv(k, s, H, W, C):
             close(dx2, dxo, 1e-6, 1e-7, "dx of the stride-2 BatchNorm-sum variant")
             close(got, ref, 1e-5, 1e-5, "BN sums fused into the stride-2 dw bwd-data")
             assert ws is None or bool((ws == 0).all())
+        # ... and with the conv's weight gradient riding along: dW of a conv whose input is a0 = swish(x * isc + ish) (what the prologue of the
+        # forward launch above applied), against autograd's
+        got3 = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+        dx3 = torch.empty_like(dxo); dwg = torch.zeros(k * k, C, device=DEV)
+        call("mmd_dwconv_bwd_data", g(nhwc(dy)), wn, dx3, B, H, W, C, k, s, g(nhwc(x)), g(isc), g(ish), g(mu), g(istd), got3, None, 0, dwg)
+        close(dx3, dxo, 1e-6, 1e-7, "stride-2 dx with the weight gradient riding along")
+        close(got3, ref, 1e-5, 1e-5, "stride-2 BN sums with the weight gradient riding along")
+        close(dwg, w.grad.view(C, k * k).t(), 3e-4, 1e-5, "stride-2 weight gradient out of the input-gradient launch")
     if s == 1:      # fused sums of the BatchNorm(+swish) backward that consumes dx == the stand-alone reduce pass
         mu, istd = torch.randn(C) * 0.2, torch.rand(C) + 0.5
         ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
