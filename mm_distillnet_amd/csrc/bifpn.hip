@@ -1401,7 +1401,10 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   static const int pool_lds_on = getenv("MMD_NO_POOL_LDS") ? 0 : 1;
   const size_t fine_bytes = (size_t)17 * 17 * 64 * sizeof(float);
   const size_t gemm_floats = (size_t)100 * (C + 4) + 4 * C;
-  const bool pool_lds = pool_lds_on && dpl && a.pad_t == 0 && a.pad_l == 0 &&
+  // (only where the launch fills the chip: on the small maps - 16 / 64 blocks, one round of single blocks - the tile's set-up and
+  // write-out are on the block's critical path and cost 3 - 5 us more than the scattered atomics they replace; 256 blocks: 60 -> 44 us)
+  static const int pool_lds_min = getenv("MMD_POOL_LDS_MIN") ? atoi(getenv("MMD_POOL_LDS_MIN")) : 128;
+  const bool pool_lds = pool_lds_on && dpl && a.pad_t == 0 && a.pad_l == 0 && (int)grid.x >= pool_lds_min &&
                         (ng ? gemm_floats * sizeof(float) + fine_bytes + 30 * 1024 : fine_bytes + 40 * 1024) <= 160 * 1024;
   if (pool_lds) a.pl_lds_off = ng ? (int)gemm_floats : 0;
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
