@@ -30,6 +30,15 @@ __device__ __forceinline__ float mmd_act(float x, int act) {
 }
 __device__ __forceinline__ float4 mmd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void mmd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// 16-byte LDS read that stays ONE ds_read_b128.  Where the consumer is pairwise arithmetic (v_pk_fma_f32) hipcc splits a float4 LDS load
+// into two ds_read_b64 - banked per 32-lane half over 256 B, so 16-B-strided lanes q and q + 16 collide (2-way) where the b128 form, banked
+// per 16-lane group, is conflict-free (MI355X_MICROARCH.md, LDS table; found in round 5: the frozen BiFPN node kernels' 43 % SQ_LDS_BANK_CONFLICT).
+// A volatile access is never split or merged; it still orders only against other volatile accesses.
+__device__ __forceinline__ float4 mmd_lds_ld4(const float* p) {
+  typedef float mmd_f4 __attribute__((ext_vector_type(4)));
+  const mmd_f4 v = *reinterpret_cast<const volatile __attribute__((address_space(3))) mmd_f4*>((const __attribute__((address_space(3))) float*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 // The same accesses through a pointer that was LOADED from memory (a device-side table of operand pointers: the grouped weight-gradient
 // launch, the batched squeeze-excite / MTA kernels).  hipcc cannot prove such a pointer global and emits FLAT loads / stores, which count on
 // vmcnt AND lgkmcnt: every `s_waitcnt lgkmcnt(0)` in front of an LDS fragment read then also waits for the prefetch loads in flight, i.e.
