@@ -43,3 +43,9 @@ print("tail (us before the backward's end): start  end  queue  kernel")
 for r in sorted(seg, key=lambda r: int(r["End_Timestamp"]))[-28:]:
     print("  %8.1f %8.1f  q%-3s %s" % ((int(r["Start_Timestamp"]) - t1) / 1e3, (int(r["End_Timestamp"]) - t1) / 1e3,
                                       r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][:60]))
+if len(sys.argv) > 3:      # every launch of the last segment, in start order (times in us since the segment's start)
+    with open(sys.argv[3], "w") as f:
+        for r in seg:
+            f.write("%9.1f %9.1f %7.1f  q%-3s %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
+                                                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"),
+                                                     r["Kernel_Name"].split("(")[0][:70]))
