@@ -811,7 +811,13 @@ struct NodeGemm {
 // NKK (GEMM form): the width in 16-channel groups as a compile-time constant (7 = D2's 112, 14 = D4's 224; 0 = read from the arguments) - the MFMA
 // loop is then straight-line code: with the run-time bound every k group sat behind its own branch, and the LDS reads of the next group
 // could not be hoisted over it
-template <int MODE, bool GEMM = false, int NKK = 0>
+// CW (round 5): channels per block.  64 = the form described above.  16 (GEMM form only) = the SMALL-MAP form: on the 4^2 .. 16^2 levels the
+// 64-channel blocks are 16 .. 64 per launch, a quarter of the chip at best, and a launch lasts as long as one block's dependent chain
+// (19 - 31 us, tools/dev/node_phases.py).  With 16-channel blocks there are 3.5x as many; a block stages the same dz tile, but its four
+// waves share the ONE 16-channel column group of the 1x1 product (wave w takes pixel tiles w and w + 4: 56 MFMAs instead of 196 on the
+// block's critical path) and a thread owns one pixel x one channel quad of the operand pass instead of four (one round of loads, a quarter
+// of the scattered atomics of a pooled operand).
+template <int MODE, bool GEMM = false, int NKK = 0, int CW = 64>
 __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const float* __restrict__ wdw,
                                                          const float* __restrict__ dzd, float* __restrict__ dx, float* wdot,
                                                          float* __restrict__ d0, int acc0, float* __restrict__ d1, int acc1,
@@ -823,9 +829,12 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   // launch over the 4x larger source map (mmd_maxpool_same_bwd_acc: 22 launches of ~22 us per D2 step).  A scattered gradient has no last
   // writer, so the BatchNorm-backward sums of such a tensor are kept LINEARLY: every contribution adds the sums of its own share -
   // own bit 0 / 1 / 2: the sums of d0 / d1 / dup are taken over this launch's share, not over the accumulated total; xp: this scatter's share.
-  constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = 4, SEG = 6;
-  __shared__ float sIn[IH * IW * 64];
-  __shared__ float sW[9 * 64];
+  static_assert(CW == 64 || (CW == 16 && GEMM), "channel chunk");
+  constexpr int TH = 8, TW = 8, IH = 10, IW = 10, R = CW == 64 ? 4 : 1, SEG = R + 2;
+  constexpr int QL = CW / 4;                        // lanes (channel quads) per pixel
+  constexpr int PR = R >= 2 ? 2 : 1;                // pixels of a thread whose loads are in flight together
+  __shared__ float sIn[IH * IW * CW];
+  __shared__ float sW[9 * CW];
   __shared__ float sred[4 * 3];
   // BatchNorm-backward sums of the operand gradients this launch completes: [operand][s|q][wave][channel].  GEMM form: they live in the dz
   // tile's place (dead behind the MFMA phase) - with the 100-row tile that brings the block to 78 KB, two blocks per CU on the large maps
@@ -841,7 +850,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid;
-  const int c0 = cc * 64, c4 = (tid & 15) * 4, c = c0 + c4;
+  const int c0 = cc * CW, c4 = (tid & (QL - 1)) * 4, c = c0 + c4;
   const bool cok = c < a.C;
   const int oh0 = th * TH, ow0 = tw * TW;
   // ---- head: everything the block needs before its first barrier (lazy operands' coefficients, flipped taps, the BatchNorm backward's
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   const int hlc = min(c0 + hcl, a.C - 1);
   // unconditional loads (stand-in address when the operand carries no finalized coefficients): a value loaded inside a branch is waited for at the join
   float hsc = ((hlz && !hlive) ? a.osc[hop] : wdw)[(hlz && !hlive) ? hlc : 0], hsh = ((hlz && !hlive) ? a.osh[hop] : wdw)[(hlz && !hlive) ? hlc : 0];
-  const int ti = min(tid, 9 * 16 - 1), ttap = ti >> 4, tq = (ti & 15) * 4;      // flipped taps: the transpose of a stride-1 SAME correlation
+  const int ti = min(tid, 9 * QL - 1), ttap = ti / QL, tq = (ti % QL) * 4;      // flipped taps: the transpose of a stride-1 SAME correlation
   const bool tok = c0 + tq < a.C;
   const float4 twv = mmd_ld4(wdw + (size_t)(8 - ttap) * a.C + (tok ? c0 + tq : 0));
   // Pooled operand's gradient (MODE & 4), round 5.  Every output pixel adds w_pool * g to the arg-max element of its 3 x 3 window: as
@@ -868,7 +877,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   // registers, into 17 spills and cost what it saved: that form zero-fills the tile and writes out by read-add-write, FINE_DMA = false)
   constexpr int FT = 17;
   constexpr bool FINE_DMA = GEMM;
-  float* const sFine = ((MODE & 4) && a.pl_lds_off >= 0) ? sDyn + a.pl_lds_off : nullptr;
+  float* const sFine = ((MODE & 4) && CW == 64 && a.pl_lds_off >= 0) ? sDyn + a.pl_lds_off : nullptr;      // (64-channel form only)
   if ((MODE & 4) && sFine && !FINE_DMA)
     for (int i = tid; i < FT * FT * 16; i += 256) *reinterpret_cast<float4*>(&sFine[i * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((MODE & 4) && sFine && FINE_DMA) {
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     hs0 = ng.sums[n]; hs1 = ng.sums[a.C + n]; hscl = ng.scale[n]; hinv = ng.invstd[n]; hmu = ng.mean[n];
   }
   auto head_store = [&]() {
-    if (tid < 9 * 16) *reinterpret_cast<float4*>(&sW[ttap * 64 + tq]) = tok ? twv : make_float4(0, 0, 0, 0);
+    if (tid < 9 * QL) *reinterpret_cast<float4*>(&sW[ttap * CW + tq]) = tok ? twv : make_float4(0, 0, 0, 0);
     if (a.lazy) {
       if (hlive) {
         BnLive bn; bn.stats = a.ost[hop]; bn.gamma = a.oga[hop]; bn.beta = a.obe[hop]; bn.inv_count = a.oic[hop]; bn.C = a.C; bn.eps = 1e-3f;
@@ -912,7 +921,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     float* const sCf = sDyn + IH * IW * LDZ;        // [4][C]: a1, a2, a3, mu of the BatchNorm backward
     // the wave's B operand: w[n = 16 kk + 4 g + j][c = c0 + 16 wave + r], kk = 0 .. C / 16 - 1 (at most 14 k groups: C <= 224)
     const int lane = tid & 63, r = lane & 15, gq = lane >> 4, wv_ = tid >> 6;
-    const int cb = c0 + wv_ * 16 + r;
+    const int cb = c0 + (CW == 64 ? wv_ * 16 : 0) + r;
     const bool cvalid = cb < C;
     constexpr int KKN = NKK ? NKK : 14;
     float bw[KKN][4];
@@ -977,30 +986,33 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     for (int it0 = tid + 256 * U; it0 < TOT; it0 += 256 * U) { issue(it0); finish(it0); }
     __syncthreads();
     NODE_T(2);
-    // dzd tile: 7 pixel tiles x this wave's 16 channels
-    f32x4 acc7[7];
+    // dzd tile: 7 pixel tiles x this wave's 16 channels (CW = 16: the block's 16 channels, pixel tiles wave and wave + 4)
+    constexpr int NMT = CW == 64 ? 7 : 2;
+    f32x4 acc7[NMT];
 #pragma unroll
-    for (int mt = 0; mt < 7; ++mt) acc7[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < NMT; ++mi) acc7[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nkk = C >> 4;
 #pragma unroll
     for (int kk = 0; kk < KKN; ++kk) {
       if (NKK || kk < nkk) {
 #pragma unroll
-        for (int mt = 0; mt < 7; ++mt) {
+        for (int mi = 0; mi < NMT; ++mi) {
+          const int mt = CW == 64 ? mi : wv_ + 4 * mi;      // (tile 7 of the last wave: computed on clamped rows, never stored)
           const float4 av = *reinterpret_cast<const float4*>(&sDz[min(mt * 16 + r, IH * IW - 1) * LDZ + kk * 16 + 4 * gq]);
-          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bw[kk][0], acc7[mt], 0, 0, 0);
-          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bw[kk][1], acc7[mt], 0, 0, 0);
-          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bw[kk][2], acc7[mt], 0, 0, 0);
-          acc7[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bw[kk][3], acc7[mt], 0, 0, 0);
+          acc7[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bw[kk][0], acc7[mi], 0, 0, 0);
+          acc7[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bw[kk][1], acc7[mi], 0, 0, 0);
+          acc7[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bw[kk][2], acc7[mi], 0, 0, 0);
+          acc7[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bw[kk][3], acc7[mi], 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int mt = 0; mt < 7; ++mt)
+    for (int mi = 0; mi < NMT; ++mi)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const int mt = CW == 64 ? mi : wv_ + 4 * mi;
         const int pp = mt * 16 + 4 * gq + i;
-        if (pp < IH * IW) sIn[pp * 64 + wv_ * 16 + r] = cvalid ? acc7[mt][i] : 0.f;
+        if (pp < IH * IW) sIn[pp * CW + (CW == 64 ? wv_ * 16 : 0) + r] = cvalid ? acc7[mi][i] : 0.f;
       }
   } else {
   // the dzd tile: all seven loads of a thread in flight together (unconditional, clamped addresses, masked) - guarded they were seven
@@ -1028,7 +1040,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   NODE_T(3);
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
-  const int p = tid >> 4;
+  const int p = tid / QL;
   const int orow = p / (TW / R);
   const int ocol0 = (p % (TW / R)) * R;
   float4 acc[R];
@@ -1037,12 +1049,12 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     float4 in[SEG];
-    const float* prow = &sIn[((orow + i) * IW + ocol0) * 64 + c4];
+    const float* prow = &sIn[((orow + i) * IW + ocol0) * CW + c4];
 #pragma unroll
-    for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+    for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * CW);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * 3 + j) * 64 + c4]);
+      float4 wv = *reinterpret_cast<const float4*>(&sW[(i * 3 + j) * CW + c4]);
 #pragma unroll
       for (int o = 0; o < R; ++o) {
         acc[o].x += in[o + j].x * wv.x; acc[o].y += in[o + j].y * wv.y;
@@ -1072,13 +1084,14 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   // (18 of the 35 us of a pooled-operand node on the small maps, tools/dev/node_phases.py)
   constexpr int NWIN = (MODE & 4) ? 9 : 1;
 #pragma unroll
-  for (int h2 = 0; h2 < R; h2 += 2) {
-    float4 r0[2], r1[2], ru[2], qd0[2], qd1[2], zb0[2], zb1[2], win[2][NWIN];
-    unsigned inb[2] = {0u, 0u};
-    bool okp[2];
-    size_t offp[2];
+  for (int h2 = 0; h2 < R; h2 += PR) {
+    float4 r0[PR], r1[PR], ru[PR], qd0[PR], qd1[PR], zb0[PR], zb1[PR], win[PR][NWIN];
+    unsigned inb[PR];
+    bool okp[PR];
+    size_t offp[PR];
 #pragma unroll
-    for (int oo = 0; oo < 2; ++oo) {
+    for (int oo = 0; oo < PR; ++oo) {
+      inb[oo] = 0u;
       const int ow = ow0 + ocol0 + h2 + oo;
       okp[oo] = cok && oh < a.H && ow < a.W;
       offp[oo] = (((size_t)b * a.H + oh) * a.W + ow) * a.C + c;
@@ -1110,7 +1123,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     }
     NODE_T(9 + h2);
 #pragma unroll
-    for (int oo = 0; oo < 2; ++oo) {
+    for (int oo = 0; oo < PR; ++oo) {
       const int o = h2 + oo;
       const int ow = ow0 + ocol0 + o;
       gq[o] = z4; fq[o] = z4;
@@ -1287,13 +1300,20 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     // horizontal pairs); the row below belongs to lane ^ 32 of the same wave (pixel groups 4w..4w+3 = rows 2w, 2w, 2w+1, 2w+1),
     // tiles start on even rows / columns, so every 2x2 block is complete inside one wave: no atomics
     const float wu = w[1 + ((MODE & 1) ? 1 : 0)];
+    // (CW = 16: one pixel per thread, pixel p = tid / 4 - the pixel to the right is lane + 4, the one below lane + 32; the even-row /
+    // even-column lane of each 2x2 block writes)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float4 sv = make_float4(gq[2 * q].x + gq[2 * q + 1].x, gq[2 * q].y + gq[2 * q + 1].y, gq[2 * q].z + gq[2 * q + 1].z,
-                              gq[2 * q].w + gq[2 * q + 1].w);
+    for (int q = 0; q < (R == 4 ? 2 : 1); ++q) {
+      float4 sv;
+      if constexpr (R == 4) {
+        sv = make_float4(gq[2 * q].x + gq[2 * q + 1].x, gq[2 * q].y + gq[2 * q + 1].y, gq[2 * q].z + gq[2 * q + 1].z, gq[2 * q].w + gq[2 * q + 1].w);
+      } else {
+        sv = gq[0];
+        sv.x += __shfl_xor(sv.x, 4, 64); sv.y += __shfl_xor(sv.y, 4, 64); sv.z += __shfl_xor(sv.z, 4, 64); sv.w += __shfl_xor(sv.w, 4, 64);
+      }
       sv.x += __shfl_xor(sv.x, 32, 64); sv.y += __shfl_xor(sv.y, 32, 64); sv.z += __shfl_xor(sv.z, 32, 64); sv.w += __shfl_xor(sv.w, 32, 64);
       const int uy = oh >> 1, ux = ((ow0 + ocol0) >> 1) + q;
-      if (lane < 32 && cok && uy < (a.H >> 1) && ux < (a.W >> 1)) {
+      if (lane < 32 && (R == 4 || (lane & 4) == 0) && cok && uy < (a.H >> 1) && ux < (a.W >> 1)) {
         float* o = dup + (((size_t)b * (a.H >> 1) + uy) * (a.W >> 1) + ux) * a.C + c;
         sv.x *= wu; sv.y *= wu; sv.z *= wu; sv.w *= wu;
         const float4 mine = sv;
@@ -1306,9 +1326,11 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   {
     // per-channel block sums: lanes l, l^16, l^32, l^48 of a wave share the channel quad, then the 4 waves through LDS
     auto put = [&](float4 v, int slot) {
-      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
-      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
-      if (lane < 16) *reinterpret_cast<float4*>(&sBn[(slot * 4 + wave) * 64 + c4]) = v;
+#pragma unroll
+      for (int o = QL; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+      }
+      if (lane < QL) *reinterpret_cast<float4*>(&sBn[(slot * 4 + wave) * 64 + c4]) = v;
     };
     if (x0.z) { put(bs0, 0); put(bq0, 1); }
     if ((MODE & 1) && x1.z) { put(bs1, 2); put(bq1, 3); }
@@ -1327,9 +1349,9 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float4 in[SEG];
-      const float* prow = &sIn[((orow + i) * IW + ocol0) * 64 + c4];
+      const float* prow = &sIn[((orow + i) * IW + ocol0) * CW + c4];
 #pragma unroll
-      for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * 64);
+      for (int q = 0; q < SEG; ++q) in[q] = *reinterpret_cast<const float4*>(prow + q * CW);
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -1343,7 +1365,7 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   __syncthreads();                                  // sred / sBn complete; every read of the dzd tile done
   NODE_T(7);
   if (tid < a.ntheta) atomicAdd(&wdot[tid], sred[tid] + sred[3 + tid] + sred[6 + tid] + sred[9 + tid]);
-  if (tid < 128 && c0 + (tid & 63) < a.C) {         // threads 0..63: sum g, 64..127: sum g*xhat
+  if (tid < 128 && (tid & 63) < CW && c0 + (tid & 63) < a.C) {         // threads 0..63: sum g, 64..127: sum g*xhat
     const int q = tid & 63, hq = tid >> 6;
     auto flush = [&](const BnSumDst& x, int op) {
       const float* r = &sBn[((op * 2 + hq) * 4) * 64 + q];
@@ -1355,23 +1377,28 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     if ((MODE & 4) && xp.z) flush(xp, 3);
   }
   if (dwg) {
-    float* sRedW = sIn;                             // [4 waves][9][64]
+    float* sRedW = sIn;                             // [4 waves][9][CW]
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       float4 v = dwa[t];
-      v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64); v.z += __shfl_xor(v.z, 16, 64); v.w += __shfl_xor(v.w, 16, 64);
-      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
-      if (lane < 16) *reinterpret_cast<float4*>(&sRedW[(wave * 9 + t) * 64 + c4]) = v;
+#pragma unroll
+      for (int o = QL; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+      }
+      if (lane < QL) *reinterpret_cast<float4*>(&sRedW[(wave * 9 + t) * CW + c4]) = v;
     }
     __syncthreads();
-    for (int i = tid; i < 9 * 64; i += 256) {
-      const int t = i >> 6, q = i & 63;
+    for (int i = tid; i < 9 * CW; i += 256) {
+      const int t = i / CW, q = i - t * CW;
       if (c0 + q < a.C)
-        atomicAdd(&dwg[(size_t)(8 - t) * a.C + c0 + q], sRedW[(0 * 9 + t) * 64 + q] + sRedW[(1 * 9 + t) * 64 + q] + sRedW[(2 * 9 + t) * 64 + q] + sRedW[(3 * 9 + t) * 64 + q]);
+        atomicAdd(&dwg[(size_t)(8 - t) * a.C + c0 + q], sRedW[(0 * 9 + t) * CW + q] + sRedW[(1 * 9 + t) * CW + q] + sRedW[(2 * 9 + t) * CW + q] + sRedW[(3 * 9 + t) * CW + q]);
     }
   }
   NODE_T(8);
 }
+// launches of the whole-node backward with fewer than this many 64-channel blocks take the 16-channel (small-map) form; 0 = never
+static int g_node_cw16_below = getenv("MMD_NODE_CW16_BELOW") ? atoi(getenv("MMD_NODE_CW16_BELOW")) : 128;
+extern "C" int mmd_bifpn_node_bwd_small_below(int blocks) { if (blocks < 0) return MMD_EINVAL; g_node_cw16_below = blocks; return MMD_OK; }
 static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up, const float* pool,
                             const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
                             int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
@@ -1391,6 +1418,9 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
     return MMD_EINVAL;
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
+  // small maps (whole-node form): 16-channel blocks, 3.5x as many, each with a shorter dependent chain (kernel comment, CW)
+  const bool cw16 = ng && (C == 112 || C == 224) && (mode == 2 || mode == 5 || mode == 4) && B * th * tw * cc < g_node_cw16_below;
+  if (cw16) cc = cdiv(C, 16);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
   // algorithmic bytes: the operand maps read (the up / pooled operand at a quarter / four times the node's size), the upstream gradient
   // (two tensors g, z when the 1x1 input gradient rides in this launch) and one gradient map written per operand
@@ -1408,7 +1438,7 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   // (only where the launch fills the chip: on the small maps - 16 / 64 blocks, one round of single blocks - the tile's set-up and
   // write-out are on the block's critical path and cost 3 - 5 us more than the scattered atomics they replace; 256 blocks: 60 -> 44 us)
   static const int pool_lds_min = getenv("MMD_POOL_LDS_MIN") ? atoi(getenv("MMD_POOL_LDS_MIN")) : 128;
-  const bool pool_lds = pool_lds_on && dpl && a.pad_t == 0 && a.pad_l == 0 && (int)grid.x >= pool_lds_min &&
+  const bool pool_lds = pool_lds_on && !cw16 && dpl && a.pad_t == 0 && a.pad_l == 0 && (int)grid.x >= pool_lds_min &&
                         (ng ? gemm_floats * sizeof(float) + fine_bytes + 30 * 1024 : fine_bytes + 40 * 1024) <= 160 * 1024;
   if (pool_lds) a.pl_lds_off = ng ? (int)gemm_floats : 0;
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
@@ -1416,9 +1446,14 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
 #define MMD_NODE_BWD_GK(M, NK) do { static bool attr = false; \
       if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024); attr = true; } \
       hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true, NK>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
-#define MMD_NODE_BWD_G(M) do { if (C == 112) MMD_NODE_BWD_GK(M, 7); else if (C == 224) MMD_NODE_BWD_GK(M, 14); else MMD_NODE_BWD_GK(M, 0); } while (0)
+#define MMD_NODE_BWD_GS(M, NK) do { static bool attr = false; \
+      if (!attr) { hipFuncSetAttribute((const void*)fuse_dw_bwd_kernel<M, true, NK, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024); attr = true; } \
+      hipLaunchKernelGGL((fuse_dw_bwd_kernel<M, true, NK, 16>), grid, blk, lds, stream, a, w_dw, dzd, dx, wdot, d0, acc0, d1, acc1, dup, acc_up, dw_grad, th, tw, cc, x0, x1, xu, dpl, xp, own, *ng); } while (0)
+#define MMD_NODE_BWD_G(M) do { if (cw16) { if (C == 112) MMD_NODE_BWD_GS(M, 7); else MMD_NODE_BWD_GS(M, 14); } \
+                               else if (C == 112) MMD_NODE_BWD_GK(M, 7); else if (C == 224) MMD_NODE_BWD_GK(M, 14); else MMD_NODE_BWD_GK(M, 0); } while (0)
     if (mode == 2) MMD_NODE_BWD_G(2); else if (mode == 5) MMD_NODE_BWD_G(5); else if (mode == 4) MMD_NODE_BWD_G(4); else return MMD_EINVAL;
 #undef MMD_NODE_BWD_G
+#undef MMD_NODE_BWD_GS
 #undef MMD_NODE_BWD_GK
     mmd_prof_end(MMD_FAM_NODE_BWD, stream, nflops, nbytes);
     return mmd_check_launch();

@@ -1997,6 +1997,63 @@ def test_bifpn_node_bwd_full(mode, H, W, C):
             close(a_, b_, 3e-4 if what == "wdot" else 5e-5, 1e-4 if what == "wdot" else 2e-6, what)
 
 
+@pytest.mark.parametrize("mode,H,W,C", [("td", 8, 8, 112), ("bu", 16, 16, 112), ("p7", 4, 4, 112), ("bu", 8, 8, 112), ("td", 12, 12, 224), ("bu", 6, 6, 224)])
+def test_bifpn_node_bwd_full_small_map_form(mode, H, W, C):
+    """Round 5: the whole-node backward's 16-channel blocks (maps of a few tiles: 4^2 .. 16^2 at B = 8) against its 64-channel blocks on the
+    same inputs - every output of the launch, including the BatchNorm-backward sums it takes for the operands it completes (same-size
+    operands, the up-sampled one, the pooled one's scattered share) and the accumulate-into forms."""
+    torch.manual_seed(3 * H + C)
+    B = 8
+    M = B * H * W
+    has1, hasu, hasp = mode == "bu", mode == "td", mode in ("bu", "p7")
+    in0 = g(torch.randn(M, C)); in1 = g(torch.randn(M, C)) if has1 else None
+    up = g(torch.randn(M // 4, C)) if hasu else None
+    pl = g(torch.randn(4 * M, C) - 1.0) if hasp else None
+    theta = g(torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3]))
+    wd = g(torch.randn(9, C) / 3)
+    wp = g(torch.randn(C, C) / math.sqrt(C))
+    gg, zz = g(torch.randn(M, C)), g(torch.randn(M, C) * 1.2 + 0.1)
+    sc, sh, mu, istd = (g(t) for t in (torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.2, torch.rand(C) + 0.5))
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", gg, zz, sc, sh, mu, istd, 0, None, None, None, H * W, None, sums, M, C, None, 0)
+    # BatchNorm inputs / statistics of the operands whose gradient this launch completes; running gradients it accumulates into
+    zs = {k: g(torch.randn(n, C)) for k, n in (("0", M), ("1", M), ("u", M // 4), ("p", 4 * M))}
+    mus = {k: g(torch.randn(C) * 0.2) for k in zs}
+    iss = {k: g(torch.rand(C) + 0.5) for k in zs}
+    prev = {k: g(torch.randn(n, C) * 0.3) for k, n in (("0", M), ("1", M), ("u", M // 4), ("p", 4 * M))}
+    lib = _lib.LIB.load()
+
+    def run(below):
+        assert lib.mmd_bifpn_node_bwd_small_below(below) == 0
+        wdot, dwg = torch.zeros(4, device=DEV), torch.zeros(9, C, device=DEV)
+        d0, d1 = prev["0"].clone(), prev["1"].clone() if has1 else None
+        du = prev["u"].clone() if hasu else None
+        dp = prev["p"].clone() if hasp else None
+        sm = {k: torch.zeros(2 * C, dtype=torch.float64, device=DEV) for k in zs}
+        x = lambda k, on: (zs[k], mus[k], iss[k], sm[k]) if on else (None, None, None, None)
+        dzm = torch.full((M, C), float("nan"), device=DEV); dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
+        call("mmd_bifpn_node_bwd_full", in0, in1, up, pl, theta, wd, wdot, B, H, W, C, d0, 1, d1, 1, du, 1, dwg,
+             *x("0", True), *x("1", has1), *x("u", hasu), dp, *x("p", hasp), 0, None, None,
+             gg, zz, sc, mu, istd, sums, M, wp, dzm, dga, dbe)
+        return dict(wdot=wdot, dwg=dwg, d0=d0, d1=d1, du=du, dp=dp, dz=dzm, dgamma=dga, dbeta=dbe,
+                    s0=sm["0"], s1=sm["1"] if has1 else None, su=sm["u"] if hasu else None, sp=sm["p"] if hasp else None)
+    try:
+        small, big = run(1 << 30), run(0)
+    finally:
+        lib.mmd_bifpn_node_bwd_small_below(128)
+    assert torch.equal(small["dz"], big["dz"]) and torch.equal(small["dgamma"], big["dgamma"]) and torch.equal(small["dbeta"], big["dbeta"])
+    for k in ("d0", "d1", "du"):
+        if big[k] is not None:
+            close(small[k], big[k], 2e-5, 1e-6, k)
+    if hasp:
+        close(small["dp"], big["dp"], 5e-5, 2e-6, "d pool (scatter)")
+    close(small["wdot"], big["wdot"], 3e-4, 1e-4, "wdot")
+    close(small["dwg"], big["dwg"], 5e-5, 2e-5, "depthwise weight gradient")
+    for k in ("s0", "s1", "su", "sp"):
+        if big[k] is not None:
+            close(small[k].float(), big[k].float(), 1e-4, 1e-3, "BatchNorm-backward sums " + k)
+
+
 def test_drop_scale_philox_kernel():
     """drop_connect's per-sample masks drawn by ONE HIP launch (mmd_drop_scale, src/YetAnotherEfficientNet.py:173-182): values are 0 or
     1 / keep, the keep rate matches, draws advance with the device-side counter, equal (seed, counter) give equal draws, and an injected
