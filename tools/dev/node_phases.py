@@ -56,4 +56,4 @@ for mode in ("td", "bu", "p7"):
     print(f"mode {mode}  H {H}  C {C}  blocks {B * ((H + 7) // 8) ** 2 * ((C + 63) // 64)}   event time {tot / n:.1f} us   block 0: {sum(acc) / n:.1f} us")
     for i in range(8):
         print(f"    {names[i]:<40} {acc[i] / n:6.2f} us")
-    print("    operand pass: pair 0 loads %.2f, consume %.2f, pair 1 loads %.2f, consume %.2f us" % tuple(x / n for x in sub))
+    print("    operand pass: pair 0 loads %.2f, consume %.2f, pair 1 loads %.2f, consume %.2f us (16-channel form: one round, the second pair is stale)" % tuple(x / n for x in sub))
