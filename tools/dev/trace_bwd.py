@@ -46,6 +46,8 @@ for r in sorted(seg, key=lambda r: int(r["End_Timestamp"]))[-28:]:
 if len(sys.argv) > 3:      # every launch of the last segment, in start order (times in us since the segment's start)
     with open(sys.argv[3], "w") as f:
         for r in seg:
-            f.write("%9.1f %9.1f %7.1f  q%-3s %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
-                                                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"),
+            gx = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * max(int(r.get("Grid_Size_Y", 1) or 1), 1) * max(int(r.get("Grid_Size_Z", 1) or 1), 1)
+            wx = max(int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1), 1) * max(int(r.get("Workgroup_Size_Y", 1) or 1), 1) * max(int(r.get("Workgroup_Size_Z", 1) or 1), 1)
+            f.write("%9.1f %9.1f %7.1f  q%-3s blocks %6d  %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
+                                                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), gx // wx,
                                                      r["Kernel_Name"].split("(")[0][:70]))
