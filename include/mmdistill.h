@@ -148,7 +148,7 @@ int mmd_bn_finalize(const double* stats, long long count, const float* gamma, co
 
 // All train-mode BN layers of a net finalized in one launch (running stats + saved mean/invstd for the backward);
 // forward consumers derive (scale, shift) on the fly from the raw sums (in_stats/in_gamma/in_beta/in_count arguments).
-int mmd_bn_finalize_all(const double* stats_flat, const float* count, const int* layer_off, const int* layer_C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int total, hipStream_t stream);
+int mmd_bn_finalize_all(const double* stats_flat, const float* count, const int* layer_off, const int* layer_C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean_out, float* invstd_out, int total, long long* num_batches_tracked, int n_layers, hipStream_t stream);
 
 // Eval-mode BatchNorm2d folded to per-channel (scale, shift).
 int mmd_bn_fold(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift, int C, hipStream_t stream);

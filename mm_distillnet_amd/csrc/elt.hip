@@ -73,8 +73,9 @@ __global__ void bn_finalize_all_kernel(const double* __restrict__ stats, const f
                                        const int* __restrict__ layer_off, const int* __restrict__ layer_C,
                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* rmean,
                                        float* rvar, float momentum, float eps, float* scale, float* shift, float* mean_out,
-                                       float* invstd_out, int total) {
+                                       float* invstd_out, int total, long long* nbt, int n_layers) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nbt && c < n_layers) nbt[c] += 1;      // num_batches_tracked of every BatchNorm (n_layers <= total: a layer has at least one channel)
   if (c >= total) return;
   double n = (double)count[c];
   if (n <= 0.0) return;                     // padding channel or a layer that did not run this step
@@ -94,12 +95,13 @@ __global__ void bn_finalize_all_kernel(const double* __restrict__ stats, const f
 extern "C" int mmd_bn_finalize_all(const double* stats_flat, const float* count, const int* layer_off, const int* layer_C,
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float momentum, float eps, float* scale, float* shift, float* mean_out,
-                                   float* invstd_out, int total, hipStream_t stream) {
+                                   float* invstd_out, int total, long long* num_batches_tracked, int n_layers, hipStream_t stream) {
   if (!stats_flat || !count || !layer_off || !layer_C || !gamma || !beta || !running_mean || !running_var || !scale ||
-      !shift || !mean_out || !invstd_out || total <= 0)
+      !shift || !mean_out || !invstd_out || total <= 0 || (num_batches_tracked && (n_layers <= 0 || n_layers > total)))
     return MMD_EINVAL;
   hipLaunchKernelGGL(bn_finalize_all_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, stats_flat, count, layer_off,
-                     layer_C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, total);
+                     layer_C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, total,
+                     num_batches_tracked, n_layers);
   return mmd_check_launch();
 }
 

@@ -591,9 +591,7 @@ class Net:
             call("mmd_bn_finalize_all", self.stats_flat, self.bn_count, self.bn_layer_off, self.bn_layer_c,
                  ps.flat[ps.gamma_off:ps.gamma_off + ps.bn_total], ps.flat[ps.beta_off:ps.beta_off + ps.bn_total],
                  ps.rmean, ps.rvar, float(self.bn_momentum), BN_EPS, self.t_scale, self.t_shift, self.t_mean,
-                 self.t_invstd, ps.bn_total)
-            # num_batches_tracked += 1 for every BN (one tiny torch op on the contiguous counter vector)
-            ps.nbt.add_(1)
+                 self.t_invstd, ps.bn_total, ps.nbt, ps.nbt.numel())      # (+ num_batches_tracked += 1 for every BN, in the same launch)
         return cls, reg, feats
 
     def _sep_bn(self, name: str, x: Feat, train: bool, rec: dict, bn_name: Optional[str] = None, y=None, zd=None) -> Feat:

@@ -876,7 +876,8 @@ def test_live_bn_matches_finalized():
     o = [torch.zeros(tot, device=DEV) for _ in range(4)]
     rm2, rv2 = torch.zeros(tot, device=DEV), torch.ones(tot, device=DEV)
     call("mmd_bn_finalize_all", sflat, cnt, lo, lc, g(torch.cat([gamma, gamma])), g(torch.cat([beta, beta])), rm2, rv2, 0.01, 1e-3,
-         o[0], o[1], o[2], o[3], tot)
+         o[0], o[1], o[2], o[3], tot, nbt := torch.tensor([3, 7], dtype=torch.int64, device=DEV), 2)
+    assert nbt.tolist() == [4, 8]          # num_batches_tracked += 1 per layer, in the same launch
     assert torch.equal(o[0][:C], sc) and torch.equal(o[1][:C], sh) and torch.equal(o[2][:C], mu) and torch.equal(o[3][:C], istd)
     assert torch.equal(rm2[:C], rm) and torch.equal(rv2[:C], rv) and o[0][C:].abs().max().item() == 0
     live = (stats, g(gamma), g(beta), M)

@@ -51,3 +51,14 @@ if len(sys.argv) > 3:      # every launch of the last segment, in start order (t
             f.write("%9.1f %9.1f %7.1f  q%-3s blocks %6d  %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
                                                      (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), gx // wx,
                                                      r["Kernel_Name"].split("(")[0][:70]))
+if len(sys.argv) > 4:      # the whole last step (from the optimizer launch of the step before), same columns
+    a1 = ad[-2]; a0 = ad[-3]
+    st = rows[a0 + 1:a1 + 1]
+    t0 = int(st[0]["Start_Timestamp"])
+    with open(sys.argv[4], "w") as f:
+        for r in st:
+            gx = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * max(int(r.get("Grid_Size_Y", 1) or 1), 1) * max(int(r.get("Grid_Size_Z", 1) or 1), 1)
+            wx = max(int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1), 1) * max(int(r.get("Workgroup_Size_Y", 1) or 1), 1) * max(int(r.get("Workgroup_Size_Z", 1) or 1), 1)
+            f.write("%9.1f %9.1f %7.1f  q%-3s blocks %6d  %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3,
+                                                     (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), gx // wx,
+                                                     r["Kernel_Name"].split("(")[0][:70]))
