@@ -77,9 +77,9 @@ int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, const float* u
 // Whole-node BiFPN backward (round 4): mmd_bifpn_node_dw_bwd3_lz with the node's 1x1 conv's input gradient inside the launch (replaces
 // mmd_pwconv_bwd_data_bn in front of it): dzd = BnBwd(g, z) . w_pw is computed per tile - g the gradient w.r.t. the node's BatchNorm output,
 // z its raw 1x1 output [B*H*W, C], (bn_scale, bn_mean, bn_invstd) of that BatchNorm, bn_sums = [sum g, sum g xhat] over `count` rows,
-// w_pw [C, C]; dz_out receives the evaluated BatchNorm backward (the weight-gradient GEMM's operand), dgamma / dbeta (+)= the sums.
+// w_pw_t [C in, C out] = the conv's weight TRANSPOSED (the operand mmd_pwconv_bwd_data takes); dz_out receives the evaluated BatchNorm backward (the weight-gradient GEMM's operand), dgamma / dbeta (+)= the sums.
 // C % 16 == 0, C <= 224; operand sets (in, up), (in, td, pool), (in, pool).  SeparableConvBlock backward, src/YetAnotherEfficientDet.py:150-185.
-int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, const void* op_scale4, const void* op_shift4, const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd, const double* bn_sums, long long count, const float* w_pw, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
+int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, const void* op_scale4, const void* op_shift4, const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd, const double* bn_sums, long long count, const float* w_pw_t, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
 // mmd_bifpn_node_bwd_full picks its block shape from the launch size: with fewer than `blocks` 64-channel blocks (default 128: the 4x4 .. 16x16
 // levels at B = 8) it runs 16-channel blocks - same results up to the order of the per-channel sums.  0 = never, a large value = always (tests, timing).
 int mmd_bifpn_node_bwd_small_below(int blocks);

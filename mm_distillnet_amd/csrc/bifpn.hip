@@ -800,12 +800,12 @@ extern "C" int mmd_bifpn_fuse_bwd(const float* in0, const float* in1, const floa
 // own in front of this one (mmd_pwconv_bwd_data_bn on the skinny GEMM kernel: 40 launches of 8-25 us on the backward's serial chain).  The
 // block evaluates the node's BatchNorm backward dz = a1 g + a2 (z - mu) + a3 on its 10x10-pixel halo tile for ALL channels into LDS
 // ([112][C + 8], dynamic), multiplies it by W[:, chunk] on v_mfma_f32_16x16x4_f32 (wave w owns 16 channels of the block's 64-channel chunk,
-// all 7 pixel tiles; its 28 B values per lane come straight from L2 and stay in registers) and writes the dzd tile into sIn - where the
+// all 7 pixel tiles; its 28 B values per lane come straight from L2 - the transposed weight, 7 float4 loads - and stay in registers) and writes the dzd tile into sIn - where the
 // plain form stages it from HBM.  The halo is recomputed by the neighbouring blocks (1.56x of a 2.5 MFLOP product); dzd never exists in
 // HBM.  The chunk-0 blocks store dz (interior pixels) for the conv's weight-gradient GEMM; block 0 adds dgamma / dbeta.
 struct NodeGemm {
   const float* g; const float* z; const float* scale; const float* mean; const float* invstd; const double* sums; double inv_count;
-  const float* w;          // the 1x1 conv's weight [C out][C in] (native layout): dzd[p, c] = sum_n dz[p, n] w[n, c]
+  const float* w;          // the 1x1 conv's weight TRANSPOSED, w_t[C in][C out] (what mmd_pwconv_bwd_data takes): dzd[p, c] = sum_n dz[p, n] w_t[c, n]
   float* dz_out; float* dgamma; float* dbeta;
 };
 // NKK (GEMM form): the width in 16-channel groups as a compile-time constant (7 = D2's 112, 14 = D4's 224; 0 = read from the arguments) - the MFMA
@@ -924,11 +924,15 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
     const int cb = c0 + (CW == 64 ? wv_ * 16 : 0) + r;
     const bool cvalid = cb < C;
     constexpr int KKN = NKK ? NKK : 14;
+    // (round 5: from the TRANSPOSED weight w_t[c][n], as the input-gradient GEMMs take it - one 16-byte load per k group and lane instead of
+    // four strided dwords: 7 instead of 28 load instructions per lane in front of the block's first barrier)
     float bw[KKN][4];
 #pragma unroll
-    for (int kk = 0; kk < KKN; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bw[kk][j] = (kk * 16 < C && cvalid) ? ng.w[(size_t)(kk * 16 + 4 * gq + j) * C + cb] : 0.f;
+    for (int kk = 0; kk < KKN; ++kk) {
+      const bool on = kk * 16 < C && cvalid;
+      const float4 t = mmd_ld4(ng.w + (size_t)(cvalid ? cb : 0) * C + (kk * 16 < C ? kk * 16 : 0) + 4 * gq);
+      bw[kk][0] = on ? t.x : 0.f; bw[kk][1] = on ? t.y : 0.f; bw[kk][2] = on ? t.z : 0.f; bw[kk][3] = on ? t.w : 0.f;
+    }
     // dz tile: U items (pixel, channel quad) per trip, all of a trip's loads in flight together; the FIRST trip is issued before the
     // coefficient barrier, so its round trip overlaps the one of the batch sums / weights above (C = 112: two trips in all, one exposed)
     constexpr int U = 6;
@@ -1532,7 +1536,7 @@ extern "C" int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, con
 
 // Whole-node backward (round 4): mmd_bifpn_node_dw_bwd3_lz with the node's 1x1 conv's input gradient inside the launch - dzd is not an
 // argument but computed per tile as BnBwd(g, z) . w_pw, with g the gradient w.r.t. the node's BatchNorm output, z its raw 1x1 output,
-// (scale, mean, invstd) of that BatchNorm, sums = [sum g, sum g xhat] over `count` rows, w_pw [C, C] the conv's weight.  dz_out [B*H*W, C]
+// (scale, mean, invstd) of that BatchNorm, sums = [sum g, sum g xhat] over `count` rows, w_pw_t [C in, C out] the conv's weight transposed.  dz_out [B*H*W, C]
 // receives the evaluated BatchNorm backward (the conv's weight-gradient GEMM reads it), dgamma / dbeta (+)= the sums.  Replaces
 // mmd_pwconv_bwd_data_bn + mmd_bifpn_node_dw_bwd3(_lz): one launch per node on the backward's chain instead of two.  C % 16 == 0, C <= 224.
 extern "C" int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const float* up, const float* pool,

@@ -1388,7 +1388,7 @@ class Net:
                     call("mmd_bifpn_node_bwd_full", in0.z, in1.z if in1 else None, up.z if up else None, pl.z if pl else None, th,
                          ps.w(f"{name}.depthwise_conv.conv.weight"), wdot, in0.B, in0.H, in0.W, W, *same, *upargs,
                          ps.g(f"{name}.depthwise_conv.conv.weight"), *xsargs, *dplargs, own, scs if any(lzb) else None, shs if any(lzb) else None,
-                         L.g, L.z, L.aff[0], L.aff[2], L.aff[3], L.sums, L.count, ps.w(wkey), dzm, bq["dgamma"], bq["dbeta"])
+                         L.g, L.z, L.aff[0], L.aff[2], L.aff[3], L.sums, L.count, ps.w_t(wkey), dzm, bq["dgamma"], bq["dbeta"])
                     zdf = rec["zd"]
                     self._pw_wgrad(dzm, zdf.z, ps.g(wkey), out.M, W, W, None, None, NONE, None, zdf.H * zdf.W)
                     continue

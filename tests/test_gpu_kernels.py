@@ -1990,7 +1990,7 @@ def test_bifpn_node_bwd_full(mode, H, W, C):
     wdot2, dwg2, e0, e1, eu, ep = outs()
     dzm = torch.full((M, C), float("nan"), device=DEV); dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
     call("mmd_bifpn_node_bwd_full", in0, in1, up, pl, theta, wd, wdot2, B, H, W, C, e0, 0, e1, 0, eu, 0, dwg2, *none12, ep, None, None, None, None, 0,
-         None, None, gg, zz, sc, mu, istd, sums, M, g(wp), dzm, dga, dbe)
+         None, None, gg, zz, sc, mu, istd, sums, M, g(wp.t()), dzm, dga, dbe)
     close(dzm, dzm_r, 1e-6, 1e-7, "stored dz")
     assert torch.equal(dga, dga_r) and torch.equal(dbe, dbe_r)
     for a_, b_, what in zip((wdot2, dwg2, e0, e1, eu, ep), (wdot, dwg, d0, d1, du, dp), ("wdot", "depthwise weight gradient", "d in0", "d in1", "d up", "d pool")):
@@ -2035,7 +2035,7 @@ def test_bifpn_node_bwd_full_small_map_form(mode, H, W, C):
         dzm = torch.full((M, C), float("nan"), device=DEV); dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
         call("mmd_bifpn_node_bwd_full", in0, in1, up, pl, theta, wd, wdot, B, H, W, C, d0, 1, d1, 1, du, 1, dwg,
              *x("0", True), *x("1", has1), *x("u", hasu), dp, *x("p", hasp), 0, None, None,
-             gg, zz, sc, mu, istd, sums, M, wp, dzm, dga, dbe)
+             gg, zz, sc, mu, istd, sums, M, wp, dzm, dga, dbe)      # (wp: any [C, C] matrix - both forms read it the same way)
         return dict(wdot=wdot, dwg=dwg, d0=d0, d1=d1, du=du, dp=dp, dz=dzm, dgamma=dga, dbeta=dbe,
                     s0=sm["0"], s1=sm["1"] if has1 else None, su=sm["u"] if hasu else None, sp=sm["p"] if hasp else None)
     try:

@@ -19,7 +19,7 @@ for mode in ("td", "bu", "p7"):
     up = g(torch.randn(M // 4, C)) if hasu else None
     pl = g(torch.randn(4 * M, C) - 1.0) if hasp else None
     theta = g(torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3]))
-    wd = g(torch.randn(9, C) / 3); wp = g(torch.randn(C, C) / math.sqrt(C))
+    wd = g(torch.randn(9, C) / 3); wp = g(torch.randn(C, C) / math.sqrt(C))      # (the transposed weight: any [C, C] matrix times alike)
     gg, zz = g(torch.randn(M, C)), g(torch.randn(M, C) * 1.2 + 0.1)
     sc, sh, mu, istd = (g(t) for t in (torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(C) * 0.2, torch.rand(C) + 0.5))
     sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
