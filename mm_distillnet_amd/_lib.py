@@ -91,8 +91,13 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_DEV_SKIP = frozenset(v for v in os.environ.get("MMD_DEV_SKIP_CALLS", "").split(",") if v)      # timing experiments only: entry points NOT launched (results are wrong)
+
+
 def call(name: str, *args):
     """Invoke `name` with tensors -> device pointers, appending the current torch HIP stream."""
+    if _DEV_SKIP and name in _DEV_SKIP:
+        return 0
     dll = (LIB16 if name.endswith("_w16") else LIB).load()
     fn = getattr(dll, name)
     conv = [_ptr(a) for a in args]
