@@ -32,9 +32,8 @@ sys.path.insert(0, ROOT)
 
 from mm_distillnet_amd import _lib  # noqa: E402
 from mm_distillnet_amd.arch import make_spec  # noqa: E402
-from mm_distillnet_amd.engine import Net  # noqa: E402
 from mm_distillnet_amd.step import DistillEngine, StepConfig  # noqa: E402
-from mm_distillnet_amd.synth import synth_state, synth_inputs, calibrate_bn_  # noqa: E402
+from mm_distillnet_amd.synth import synth_state, synth_inputs, calibrated_state, tune_teacher_bias  # noqa: E402
 
 FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
             1: ("pw_wgrad_kernel (1x1 conv weight-grad MFMA GEMM)", "mfma"),
@@ -46,53 +45,6 @@ FAMILIES = {0: ("pw_gemm_kernel (1x1 conv fwd / input-grad MFMA GEMM)", "mfma"),
             7: ("fuse_dw_bwd_kernel (BiFPN node backward: depthwise + fusion [+ 1x1 input gradient])", "hbm")}
 FAM_KEY = {0: "pw_gemm", 1: "pw_wgrad", 2: "dw_fwd", 3: "dw_bwd", 4: "bn_bwd", 5: "mbx", 6: "se", 7: "node_bwd"}
 PEAK = {"mfma": 157.3, "hbm": 8000.0}      # TFLOP/s fp32 MFMA, GB/s HBM3E (MI355X_MICROARCH.md)
-
-
-def calibrated_state(spec, seed, x, device, cls_bias=-4.0):
-    """hash weights + BN running stats calibrated with one train-mode pass of the HIP engine."""
-    st = synth_state(spec, seed=seed, cls_bias=cls_bias)
-    net = Net(spec, device, trainable=True)
-
-    def tf(state, xin, mom):
-        net.load_state(state)
-        net.bn_momentum = mom
-        net.begin_step()
-        net.forward(xin.to(device), train=True, drop_scale=None)
-        torch.cuda.synchronize()
-        ex = net.ps.export_state()
-        for k in state:
-            if "running_" in k:
-                state[k].copy_(ex[k])
-
-    calibrate_bn_(st, tf, x, seed=seed)
-    del net
-    torch.cuda.empty_cache()
-    return st
-
-
-def tune_teacher_bias(spec, state, x, device, target_per_image=40):
-    """Shift the classifier header bias uniformly so that ~target candidates per image pass (score > 0.3, class car):
-    random-weight teachers otherwise emit either nothing or thousands of boxes, which is not the workload."""
-    import math
-    net = Net(spec, device, trainable=False)
-    xd = x.to(device)
-    for it in range(8):         # sigmoid saturates: iterate until the count is in range
-        net.load_state(state)
-        net.begin_step()
-        logit, _, _ = net.forward(xd, train=False, raw_logits=True)      # pre-sigmoid: probabilities saturate in fp32
-        logit = logit.double()
-        best, arg = logit.max(2)
-        car = best[arg == 6]
-        n_now = int((car > math.log(0.3 / 0.7)).sum().item())
-        tgt = target_per_image * logit.shape[0]
-        if os.environ.get("MMD_BENCH_DEBUG"):
-            log("tune it %d: over-threshold car candidates %d (target %d), car anchors %d" % (it, n_now, tgt, car.numel()))
-        if 0.5 * tgt <= n_now <= 1.5 * tgt or car.numel() <= tgt:
-            break
-        v = torch.sort(car, descending=True)[0][tgt].item()
-        state["classifier.header.pointwise_conv.conv.bias"] += float(math.log(0.3 / 0.7) - v)
-    del net
-    torch.cuda.empty_cache()
 
 
 def cpu_baseline(sstate, tstates, S, sample_b, coef=2):
@@ -194,7 +146,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU baseline's batch (0 = the per-GPU batch)")
+    ap.add_argument("--dev-timing", action="store_true",
+                    help="run although work-skipping dev switches are set (MMD_DEV=1 + MMD_DEV_SKIP_CALLS / _SKIP_WG / _NO_BWD / MMD_ROWS_ABL): the record "
+                         "then carries \"invalid\": true and NO value")
     args = ap.parse_args()
+    # self-certifying record: a run with launches skipped is not a measurement - refuse it before anything else happens
+    skipping = _lib.work_skipping_switches()
+    if skipping and not args.dev_timing:
+        print("bench.py: work-skipping dev switches are set (%s): the timed region would not do the work - refusing.  Unset them, or pass "
+              "--dev-timing for a timing experiment (the record then says \"invalid\": true and has no value)" % ", ".join(skipping),
+              file=sys.stderr, flush=True)
+        sys.stdout.write(json.dumps({"invalid": True, "reason": "work-skipping dev switches set", "switches": skipping}) + "\n")
+        sys.exit(3)
     rc = launch_ranks(args)
     if rc is not None:
         sys.exit(rc)
@@ -388,6 +351,11 @@ def main():
             traffic = None          # the committed PMC passes are of the fp32 kernels
         roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                 "frac": round(achieved / peak, 4), "traffic": traffic,
+                # provenance: `traffic` is NOT measured in this run (PMC counters need rocprofv3 around the process); it is the committed
+                # builder-run counter pass of this same command, divided by THIS run's launch count
+                "traffic_source": (None if traffic is None else
+                                   "profiles/pmc_traffic.json (builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                   "%s launches in the family there, %d here)" % (pm.get("launches", "?"), int(n))),
                 "algorithmic_bytes_per_launch": round(by / max(n, 1), 1), "launches_per_step": int(n),
                 "avg_launch_us": round(tms * 1e3 / max(n, 1), 2), "family_ms_per_step": round(tms, 3),
                 "algorithmic_bytes_per_step": by, "algorithmic_flops_per_step": fl,
@@ -443,8 +411,15 @@ def main():
                                        + ": full 3-teacher (RGB+thermal+depth) -> audio student distillation step, EfficientDet-D%d, "
                                          "%dx%d, per-GPU batch %d, fwd+losses+bwd+all-reduce+Adam" % (args.coef, S, S, B),
                            "global_batch": world * B, "image_size": S, "parallelism": "dp%d" % world,
-                           "graph": use_graph, "pseudo_label_boxes_per_image": nbox, "collective": collective},
+                           "graph": use_graph, "pseudo_label_boxes_per_image": nbox, "collective": collective,
+                           # every MMD_* variable this process saw (A/B knobs select kernels / schedules; the work-skipping ones are refused above)
+                           "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMD_")}},
                 "per_step": per_step, "roofline": roof, "cpu_baseline": cpu}
+        if skipping:        # --dev-timing: launches were skipped - not a measurement
+            line["invalid"] = True
+            line["invalid_reason"] = "work-skipping dev switches set: " + ", ".join(skipping)
+            line["dev_ms_per_step"] = line.pop("ms_per_step")
+            line["value"] = None
         sys.stdout.flush()
         os.write(real_out, (json.dumps(line) + "\n").encode())
     if world > 1:

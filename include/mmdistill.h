@@ -80,9 +80,14 @@ int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, const float* u
 // w_pw_t [C in, C out] = the conv's weight TRANSPOSED (the operand mmd_pwconv_bwd_data takes); dz_out receives the evaluated BatchNorm backward (the weight-gradient GEMM's operand), dgamma / dbeta (+)= the sums.
 // C % 16 == 0, C <= 224; operand sets (in, up), (in, td, pool), (in, pool).  SeparableConvBlock backward, src/YetAnotherEfficientDet.py:150-185.
 int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, const void* op_scale4, const void* op_shift4, const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd, const double* bn_sums, long long count, const float* w_pw_t, float* dz_out, float* dgamma, float* dbeta, hipStream_t stream);
-// mmd_bifpn_node_bwd_full picks its block shape from the launch size: with fewer than `blocks` 64-channel blocks (default 128: the 4x4 .. 16x16
-// levels at B = 8) it runs 16-channel blocks - same results up to the order of the per-channel sums.  0 = never, a large value = always (tests, timing).
-int mmd_bifpn_node_bwd_small_below(int blocks);
+// mmd_bifpn_node_bwd_full picks its block shape from the launch size: with fewer than 128 64-channel blocks (the 4x4 .. 16x16 levels at B = 8)
+// it runs 16-channel blocks - same results up to the order of the per-channel sums - and on launches of >= 128 blocks a pooled operand's
+// scattered gradient is collected in an LDS tile of the fine map.  EXCLUSIVITY (mmd_bifpn_node_bwd_full, mmd_bifpn_node_dw_bwd3[_lz]): with the
+// LDS tile the interior of `dpool` is read at block start and plainly stored at block end, so no other launch may write `dpool` while this
+// one runs (every contributor to a scattered gradient on ONE stream; the engine asserts it).
+// _form: the same launch with both choices made by the caller (tests, timing; per call - no process-wide state): small_below = launches with
+// fewer 64-channel blocks than this take the 16-channel form (0 never, 1 << 30 always, < 0 default); pool_lds = 1 / 0 the LDS tile on / off, < 0 default.
+int mmd_bifpn_node_bwd_full_form(const float* in0, const float* in1, const float* up, const float* pool, const float* theta, const float* w_dw, float* wdot, int B, int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up, float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0, const float* z1, const float* mean1, const float* invstd1, double* sums1, const float* zu, const float* meanu, const float* invstdu, double* sumsu, float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own, const void* op_scale4, const void* op_shift4, const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd, const double* bn_sums, long long count, const float* w_pw_t, float* dz_out, float* dgamma, float* dbeta, int small_below, int pool_lds, hipStream_t stream);
 
 int mmd_bifpn_theta_bwd(const float* theta, const float* wdot, float* dtheta, int n, hipStream_t stream);
 
@@ -362,11 +367,14 @@ int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int 
 // reduced-precision path ("no AMP anywhere"); this is what torch.autocast(bf16) would make of its nn.Conv2d(k=1).
 int mmd_pwconv_fwd_bf16(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, hipStream_t stream);
 
-// Kernel selection of mmd_pwconv_fwd / _bwd_data for K <= 128 (csrc/pw_rows.hip, the thin-K row-slab kernel): 0 = the measured shape
-// filter decides (default), 1 = every supported launch takes it, 2 = none does.  Process-wide; for tests and A/B timing.
-int mmd_pwconv_rows_mode(int mode);
-// Same switch for the long-K small-M kernel with the LDS-DMA pipelined K loop (csrc/pw_longk.hip: K >= 384, about one block per CU).
-int mmd_pwconv_longk_mode(int mode);
+// mmd_pwconv_fwd with the kernel family chosen PER CALL (round 6; replaces the process-wide mmd_pwconv_rows_mode / mmd_pwconv_longk_mode
+// setters - the library keeps no global state besides the communicator): form 0 = the measured shape filters decide (what
+// mmd_pwconv_fwd does), 1 = thin-K row-slab kernel (csrc/pw_rows.hip), 2 = LDS-tiled kernels only, 3 = long-K LDS-DMA kernel (csrc/pw_longk.hip),
+// 4 = all-N K-sliced slab kernel (csrc/pw_slab.hip).  A family that does not support the launch falls through to the LDS-tiled kernels.
+// ws / ws_floats (nullable): caller-owned workspace for the slab kernel's K slices (mmd_pwconv_slab_ws_floats floats; contents undefined
+// before and after, no zeroing needed); without one a launch that would need slices keeps the LDS-tiled kernels (form 0) or is refused (form 4).
+// The engine calls this with form 0; forms 1 - 4: tests and A/B timing.  Conv2dStaticSamePadding(k=1), src/YetAnotherEfficientNet.py:27-65.
+int mmd_pwconv_fwd_form(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, float* ws, long long ws_floats, int form, hipStream_t stream);
 
 int mmd_pwconv_fwd_pyr_bf16(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);
 
@@ -393,6 +401,14 @@ int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, floa
 // p5_scale .. p5_invstd of BatchNorm-1, g1) computes - the pooled pass of the squeeze-excite / BatchNorm-1 backward - taken from the
 // output tiles instead of by a launch re-reading g1 and z1.
 int mmd_pwconv_bwd_data_bn2(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
+// All-N, K-sliced slab GEMM (csrc/pw_slab.hip, round 6) for the small-M 1x1 convs whose A operand carries an arithmetic prologue (the
+// student's expand-conv input gradients behind BatchNorm + swish, its project convs behind live BatchNorm + swish + gate; autograd of
+// src/YetAnotherEfficientNet.py:427-447): a block owns a 32-row slab x ALL N x a slice of K, so the prologue is evaluated once per element
+// instead of once per 64-wide column tile; launches with few row slabs are cut along K and the slices' partial slabs are added in slice
+// order by a second launch that owns the epilogue (deterministic, no atomics).  mmd_pwconv_slab_ws_floats: workspace floats such a launch
+// needs (0 = it runs unsliced, or the family does not take the shape); mmd_pwconv_bwd_data_bn2_form = mmd_pwconv_bwd_data_bn2 + workspace + form.
+int mmd_pwconv_slab_ws_floats(int M, int K, int N, int bn_operand);
+int mmd_pwconv_bwd_data_bn2_form(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, float* ws, long long ws_floats, int form, hipStream_t stream);
 
 int mmd_pwconv_bwd_data_bn2_bf16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, hipStream_t stream);
 

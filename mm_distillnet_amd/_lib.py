@@ -91,7 +91,35 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-_DEV_SKIP = frozenset(v for v in os.environ.get("MMD_DEV_SKIP_CALLS", "").split(",") if v)      # timing experiments only: entry points NOT launched (results are wrong)
+# Work-skipping switches (timing experiments: results are WRONG with any of them).  They take effect only with the second, explicit opt-in
+# MMD_DEV=1; a switch set without it is an error at import (a leaked variable must not silently change a training or bench job), with it the
+# import prints a loud warning.  bench.py and train.py refuse to run while any of them is set (`work_skipping_switches()`).
+WORK_SKIPPING = ("MMD_DEV_SKIP_CALLS",      # _lib.call: the named entry points are not launched
+                 "MMD_DEV_SKIP_WG",         # engine.py: no weight-gradient launches
+                 "MMD_DEV_NO_BWD",          # step.py: forward + losses only
+                 "MMD_ROWS_ABL")            # csrc/pw_rows.hip: ablated row-slab kernel (no stores / no fetch / one k group)
+
+
+def work_skipping_switches(env=None) -> list:
+    """Names of the work-skipping dev switches present (non-empty) in the environment."""
+    env = os.environ if env is None else env
+    return [k for k in WORK_SKIPPING if env.get(k)]
+
+
+def dev_switch(name: str) -> str:
+    """Value of a work-skipping switch, honoured only under MMD_DEV=1 (checked at import: set without it raises)."""
+    return os.environ.get(name, "") if os.environ.get("MMD_DEV") == "1" else ""
+
+
+_set = work_skipping_switches()
+if _set:
+    import sys as _sys
+    if os.environ.get("MMD_DEV") != "1":
+        raise RuntimeError("work-skipping dev switches %s are set without MMD_DEV=1: unset them (results would be wrong), or opt in "
+                           "explicitly with MMD_DEV=1 for a timing experiment" % _set)
+    print("\n" + "!" * 100 + "\nmm_distillnet_amd: MMD_DEV=1 with work-skipping switches %s - launches are being SKIPPED, every result of "
+          "this process is WRONG (timing experiments only)\n" % _set + "!" * 100 + "\n", file=_sys.stderr, flush=True)
+_DEV_SKIP = frozenset(v for v in dev_switch("MMD_DEV_SKIP_CALLS").split(",") if v)
 
 
 def call(name: str, *args):

@@ -1400,15 +1400,15 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   }
   NODE_T(8);
 }
-// launches of the whole-node backward with fewer than this many 64-channel blocks take the 16-channel (small-map) form; 0 = never
-static int g_node_cw16_below = getenv("MMD_NODE_CW16_BELOW") ? atoi(getenv("MMD_NODE_CW16_BELOW")) : 128;
-extern "C" int mmd_bifpn_node_bwd_small_below(int blocks) { if (blocks < 0) return MMD_EINVAL; g_node_cw16_below = blocks; return MMD_OK; }
+// launches of the whole-node backward with fewer than this many 64-channel blocks take the 16-channel (small-map) form; 0 = never.
+// A per-call argument (NodeForm) since round 6: the library keeps no process-global state besides the communicator.
+struct NodeForm { int small_below; int pool_lds; };      // < 0: the library's default (128 blocks; LDS-tile scatter on launches of >= 128 blocks)
 static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up, const float* pool,
                             const float* theta, const float* w_dw, const float* dzd, float* dx, float* wdot, int B,
                             int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
                             float* dw_grad, BnSumDst x0, BnSumDst x1, BnSumDst xu, hipStream_t stream,
                             float* dpl = nullptr, BnSumDst xp = BnSumDst{}, int own = 0, const void* op_scale4 = nullptr,
-                            const void* op_shift4 = nullptr, const NodeGemm* ng = nullptr) {
+                            const void* op_shift4 = nullptr, const NodeGemm* ng = nullptr, NodeForm form = NodeForm{-1, -1}) {
   FuseArgs a{};
   int rc = fuse_fill(a, in0, in1, up, pool, theta, B, H, W, C);
   if (!rc) rc = fuse_fill_lazy_bwd(a, op_scale4, op_shift4);
@@ -1423,7 +1423,9 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   int th = cdiv(H, 8), tw = cdiv(W, 8), cc = cdiv(C, 64);
   const int mode = (in1 ? 1 : 0) | (up ? 2 : 0) | (pool ? 4 : 0);
   // small maps (whole-node form): 16-channel blocks, 3.5x as many, each with a shorter dependent chain (kernel comment, CW)
-  const bool cw16 = ng && (C == 112 || C == 224) && (mode == 2 || mode == 5 || mode == 4) && B * th * tw * cc < g_node_cw16_below;
+  static const int cw16_env = getenv("MMD_NODE_CW16_BELOW") ? atoi(getenv("MMD_NODE_CW16_BELOW")) : 128;
+  const int node_cw16_below = form.small_below >= 0 ? form.small_below : cw16_env;
+  const bool cw16 = ng && (C == 112 || C == 224) && (mode == 2 || mode == 5 || mode == 4) && B * th * tw * cc < node_cw16_below;
   if (cw16) cc = cdiv(C, 16);
   const dim3 grid((unsigned)(B * th * tw * cc)), blk(256);
   // algorithmic bytes: the operand maps read (the up / pooled operand at a quarter / four times the node's size), the upstream gradient
@@ -1436,13 +1438,14 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   mmd_prof_begin(MMD_FAM_NODE_BWD, stream);
   // pooled operand's gradient through an LDS tile of the fine map (kernel comment): needs pad 0 (even map sizes: every BiFPN level of the
   // 512^2 / 768^2 inputs), 17 x 17 x 64 floats of dynamic LDS behind the GEMM form's dz tile, and the block within 160 KB
-  static const int pool_lds_on = getenv("MMD_NO_POOL_LDS") ? 0 : 1;
+  static const int pool_lds_env = getenv("MMD_NO_POOL_LDS") ? 0 : 1;
+  const int pool_lds_on = form.pool_lds >= 0 ? form.pool_lds : pool_lds_env;
   const size_t fine_bytes = (size_t)17 * 17 * 64 * sizeof(float);
   const size_t gemm_floats = (size_t)100 * (C + 8) + 4 * C;
   // (only where the launch fills the chip: on the small maps - 16 / 64 blocks, one round of single blocks - the tile's set-up and
   // write-out are on the block's critical path and cost 3 - 5 us more than the scattered atomics they replace; 256 blocks: 60 -> 44 us)
   static const int pool_lds_min = getenv("MMD_POOL_LDS_MIN") ? atoi(getenv("MMD_POOL_LDS_MIN")) : 128;
-  const bool pool_lds = pool_lds_on && !cw16 && dpl && a.pad_t == 0 && a.pad_l == 0 && (int)grid.x >= pool_lds_min &&
+  const bool pool_lds = pool_lds_on && !cw16 && dpl && a.pad_t == 0 && a.pad_l == 0 && ((int)grid.x >= pool_lds_min || form.pool_lds == 1) &&
                         (ng ? gemm_floats * sizeof(float) + fine_bytes + 30 * 1024 : fine_bytes + 40 * 1024) <= 160 * 1024;
   if (pool_lds) a.pl_lds_off = ng ? (int)gemm_floats : 0;
   if (ng) {       // whole-node backward: the 1x1 conv's input gradient inside this launch
@@ -1539,6 +1542,23 @@ extern "C" int mmd_bifpn_node_dw_bwd3_lz(const float* in0, const float* in1, con
 // (scale, mean, invstd) of that BatchNorm, sums = [sum g, sum g xhat] over `count` rows, w_pw_t [C in, C out] the conv's weight transposed.  dz_out [B*H*W, C]
 // receives the evaluated BatchNorm backward (the conv's weight-gradient GEMM reads it), dgamma / dbeta (+)= the sums.  Replaces
 // mmd_pwconv_bwd_data_bn + mmd_bifpn_node_dw_bwd3(_lz): one launch per node on the backward's chain instead of two.  C % 16 == 0, C <= 224.
+static int node_bwd_full_impl(const float* in0, const float* in1, const float* up, const float* pool,
+                                       const float* theta, const float* w_dw, float* wdot, int B,
+                                       int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                       float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0,
+                                       const float* z1, const float* mean1, const float* invstd1, double* sums1,
+                                       const float* zu, const float* meanu, const float* invstdu, double* sumsu,
+                                       float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own,
+                                       const void* op_scale4, const void* op_shift4,
+                                       const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd,
+                                       const double* bn_sums, long long count, const float* w_pw, float* dz_out, float* dgamma, float* dbeta,
+                                       NodeForm form, hipStream_t stream) {
+  if (count <= 0) return MMD_EINVAL;
+  NodeGemm ng{g, z, bn_scale, bn_mean, bn_invstd, bn_sums, 1.0 / (double)count, w_pw, dz_out, dgamma, dbeta};
+  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, nullptr, nullptr, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
+                          BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
+                          dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own, op_scale4, op_shift4, &ng, form);
+}
 extern "C" int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const float* up, const float* pool,
                                        const float* theta, const float* w_dw, float* wdot, int B,
                                        int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
@@ -1550,11 +1570,27 @@ extern "C" int mmd_bifpn_node_bwd_full(const float* in0, const float* in1, const
                                        const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd,
                                        const double* bn_sums, long long count, const float* w_pw, float* dz_out, float* dgamma, float* dbeta,
                                        hipStream_t stream) {
-  if (count <= 0) return MMD_EINVAL;
-  NodeGemm ng{g, z, bn_scale, bn_mean, bn_invstd, bn_sums, 1.0 / (double)count, w_pw, dz_out, dgamma, dbeta};
-  return node_dw_bwd_impl(in0, in1, up, pool, theta, w_dw, nullptr, nullptr, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad,
-                          BnSumDst{z0, mean0, invstd0, sums0}, BnSumDst{z1, mean1, invstd1, sums1}, BnSumDst{zu, meanu, invstdu, sumsu}, stream,
-                          dpool, BnSumDst{zp, meanp, invstdp, sumsp}, own, op_scale4, op_shift4, &ng);
+  return node_bwd_full_impl(in0, in1, up, pool, theta, w_dw, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad, z0, mean0, invstd0, sums0,
+                            z1, mean1, invstd1, sums1, zu, meanu, invstdu, sumsu, dpool, zp, meanp, invstdp, sumsp, own, op_scale4, op_shift4,
+                            g, z, bn_scale, bn_mean, bn_invstd, bn_sums, count, w_pw, dz_out, dgamma, dbeta, NodeForm{-1, -1}, stream);
+}
+// the same launch with its block shape chosen by the caller instead of by the launch size (tests, timing): small_below = launches with fewer
+// 64-channel blocks than this take the 16-channel form (0: never, 1 << 30: always, < 0: default); pool_lds = the pooled operand's gradient
+// through the LDS tile of the fine map (1) or by global atomics (0), < 0: default
+extern "C" int mmd_bifpn_node_bwd_full_form(const float* in0, const float* in1, const float* up, const float* pool,
+                                       const float* theta, const float* w_dw, float* wdot, int B,
+                                       int H, int W, int C, float* d0, int acc0, float* d1, int acc1, float* dup, int acc_up,
+                                       float* dw_grad, const float* z0, const float* mean0, const float* invstd0, double* sums0,
+                                       const float* z1, const float* mean1, const float* invstd1, double* sums1,
+                                       const float* zu, const float* meanu, const float* invstdu, double* sumsu,
+                                       float* dpool, const float* zp, const float* meanp, const float* invstdp, double* sumsp, int own,
+                                       const void* op_scale4, const void* op_shift4,
+                                       const float* g, const float* z, const float* bn_scale, const float* bn_mean, const float* bn_invstd,
+                                       const double* bn_sums, long long count, const float* w_pw, float* dz_out, float* dgamma, float* dbeta,
+                                       int small_below, int pool_lds, hipStream_t stream) {
+  return node_bwd_full_impl(in0, in1, up, pool, theta, w_dw, wdot, B, H, W, C, d0, acc0, d1, acc1, dup, acc_up, dw_grad, z0, mean0, invstd0, sums0,
+                            z1, mean1, invstd1, sums1, zu, meanu, invstdu, sumsu, dpool, zp, meanp, invstdp, sumsp, own, op_scale4, op_shift4,
+                            g, z, bn_scale, bn_mean, bn_invstd, bn_sums, count, w_pw, dz_out, dgamma, dbeta, NodeForm{small_below, pool_lds}, stream);
 }
 
 // d theta_k += [theta_k > 0] * sum_i wdot_i * (delta_ik * S - r_i) / S^2,  S = sum r + eps   

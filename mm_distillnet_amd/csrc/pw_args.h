@@ -66,12 +66,26 @@ struct StemOp { int Cin, H, W, OH, OW, pad_t, pad_l; };
 // xhat = (z - mean)*invstd - rides here instead of a launch that re-reads y and z (the writer of the last contribution to a gradient
 // computes the sums of the total).  `stats` (or its slotted workspace) receives [sum g', sum g'*xhat].
 struct BnSumOp { const float* z; const float* mean; const float* invstd; const float* mul_b; int rows_per_image; };
+// epilogue helper of the BnSumOp mode: v = the final output value at `off` (row `row`) -> the two BatchNorm-backward sums
+__device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t off, int row, const float4& mu, const float4& is,
+                                          float4& s4, float4& q4) {
+  const float4 zz = mmd_ld4(xs.z + off);
+  if (xs.mul_b) { const float rs = xs.mul_b[row / xs.rows_per_image]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+  s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+  q4.x += v.x * (zz.x - mu.x) * is.x; q4.y += v.y * (zz.y - mu.y) * is.y;
+  q4.z += v.z * (zz.z - mu.z) * is.z; q4.w += v.w * (zz.w - mu.w) * is.w;
+}
 
 // Epilogue of an MBConv project conv's input-gradient GEMM: its output g1 [M, N] is the gradient w.r.t. the squeeze-excite-gated activation;
 // the five per-(image, channel) sums the squeeze-excite backward and the BatchNorm-1 backward need (mmd_chan_pool_bwd's out5 [5][B][N]:
 // sum g1*a, g1*s', g1*s'*xhat, s', s'*xhat with u = z*scale+shift, a = swish(u), s' = swish'(u), xhat = (z-mean)*invstd) are taken from
 // the tile while it is written, instead of by a pass that re-reads g1 and z1.  A row tile must lie inside one image.
 struct Pool5Op { const float* z; const float* scale; const float* shift; const float* mean; const float* invstd; float* out; int B; int rows_per_image; };
+
+// Kernel family of a 1x1-conv launch, chosen per call (round 6: replaces the process-wide mmd_pwconv_rows_mode / _longk_mode setters - the
+// library keeps no global state besides the communicator).  AUTO = the measured shape filters of pw_dispatch decide; the others force one
+// family for every launch it supports (a launch it does not support falls through to the LDS-tiled kernels) - tests and A/B timing.
+enum { MMD_PW_FORM_AUTO = 0, MMD_PW_FORM_ROWS = 1, MMD_PW_FORM_TILED = 2, MMD_PW_FORM_LONGK = 3, MMD_PW_FORM_SLAB = 4 };
 
 struct PwArgs {
   const float* x; const float* w; float* y;
@@ -95,6 +109,8 @@ struct PwArgs {
   // grouped frozen nets (common.h MmdGroup): g_images != 0 -> the row tile's group g = image / g_images reads w / bias g * g_w floats and
   // out_scale / out_shift g * g_bn floats behind the given pointers (LDS-tiled kernels only)
   int g_images; long long g_w, g_bn;
+  float* slab_ws; long long slab_ws_floats;      // host-side: caller's workspace for the K slices' partial slabs of the slab kernel (pw_slab.hip)
+  int form;        // host-side, per call (mmd_pwconv_fwd_form / _bwd_data_bn_form): which kernel family takes the launch, MMD_PW_FORM_*
   int bq_lds;      // BatchNorm-backward operand launches: the per-channel coefficients come from a per-block LDS table (5 x K floats of dynamic LDS)
 };
 
@@ -102,5 +118,8 @@ struct PwArgs {
 // pw_rows.hip: thin-K (K <= 128) launches on the row-slab kernel; returns 1 when it took the launch, 0 when the shape / operand mode is
 // not covered (the caller then uses the LDS-tiled kernels), < 0 on error.
 int pw_rows_try(PwArgs& a, hipStream_t stream);
+// pw_slab.hip: small-M launches with an arithmetic A prologue on the all-N, K-sliced slab kernel; same return convention (auto_ok: the shape
+// filter of pw_dispatch - launches that would run the skinny kernel with PRO 0 / 1 - said yes; ignored when a.form forces the family)
+int pw_slab_try(PwArgs& a, float* ws, long long ws_floats, bool auto_ok, hipStream_t stream);
 // pw_longk.hip: long-K small-M launches (plain / gate-only A operand) on the LDS-DMA pipelined kernel; same return convention.
 int pw_longk_try(PwArgs& a, hipStream_t stream);

@@ -34,15 +34,7 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
-// epilogue helper of the BnSumOp mode: v = the final output value at `off` (row `row`) -> the two BatchNorm-backward sums
-__device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t off, int row, const float4& mu, const float4& is,
-                                          float4& s4, float4& q4) {
-  const float4 zz = mmd_ld4(xs.z + off);
-  if (xs.mul_b) { const float rs = xs.mul_b[row / xs.rows_per_image]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-  s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-  q4.x += v.x * (zz.x - mu.x) * is.x; q4.y += v.y * (zz.y - mu.y) * is.y;
-  q4.z += v.z * (zz.z - mu.z) * is.z; q4.w += v.w * (zz.w - mu.w) * is.w;
-}
+// (pw_xs_acc, the epilogue helper of the BnSumOp mode: pw_args.h)
 
 // Pool5Op epilogue: one output quad v (= g1) at `off` -> the five running sums (chan_pool_bwd_kernel's arithmetic)
 struct P5Coef { float4 sc, sh, mu, is; };
@@ -961,8 +953,10 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
                               const float* bias, const float* out_scale, const float* out_shift, int out_act,
                               const float* residual, double* stats,
                               long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots,
-                              hipStream_t stream, int bf16, int w16 = 0) {
+                              hipStream_t stream, int bf16, int w16 = 0, int form = MMD_PW_FORM_AUTO, float* ws = nullptr,
+                              long long ws_floats = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !x || !w || !y) return MMD_EINVAL;
+  if (form < MMD_PW_FORM_AUTO || form > MMD_PW_FORM_SLAB) return MMD_EINVAL;
   if ((w16 & 2) && (residual || y_batch_stride)) return MMD_EINVAL;      // a bf16 output has no residual / strided form
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
@@ -974,6 +968,7 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
            {0, 0, 0, 0, 0}, 0, bf16};
   if (stats && stats_ws && ws_slots > 1 && cdiv(M, PW_BM) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
   a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1;
+  a.form = form; a.slab_ws = ws; a.slab_ws_floats = ws ? ws_floats : 0;
   return pw_dispatch(a, stream);
 }
 
@@ -987,6 +982,20 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
 #define PW_FWD_ARGS x, w, y, M, K, N, in_scale, in_shift, in_act, in_stats, in_gamma, in_beta, in_count, gate, rows_per_image, \
                     bias, out_scale, out_shift, out_act, residual, stats, y_batch_stride, y_offset, stats_ws, ws_slots, stream
 extern "C" int mmd_pwconv_fwd(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 0); }
+// mmd_pwconv_fwd with the kernel family chosen by the caller (pw_args.h MMD_PW_FORM_*: 0 auto, 1 thin-K row-slab kernel, 2 LDS-tiled kernels only,
+// 3 long-K LDS-DMA kernel, 4 all-N K-sliced slab kernel); a family that does not support the launch falls through to the LDS-tiled kernels.
+// ws / ws_floats (nullable): workspace for the slab kernel's K slices (mmd_pwconv_slab_ws_floats); without one a launch that would need
+// slices keeps the LDS-tiled kernels (form 0) or is refused (form 4)
+extern "C" int mmd_pwconv_fwd_form(const float* x, const float* w, float* y, int M, int K, int N,
+                                   const float* in_scale, const float* in_shift, int in_act,
+                                   const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
+                                   const float* gate, int rows_per_image,
+                                   const float* bias, const float* out_scale, const float* out_shift, int out_act,
+                                   const float* residual, double* stats,
+                                   long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots,
+                                   float* ws, long long ws_floats, int form, hipStream_t stream) {
+  return pw_fwd_impl(PW_FWD_ARGS, 0, 0, form, ws, ws_floats);
+}
 // same contract, operands rounded to bf16 at the MFMA input (fp32 accumulate, fp32 in/out tensors)
 extern "C" int mmd_pwconv_fwd_bf16(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 1); }
 // same contract with bf16 STORAGE of the wide operand ("w16", common.h): w16 bit 0 = x is a bf16 array, bit 1 = y is (no residual / strided
@@ -1062,7 +1071,18 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     }
     a.g_images = gr.images; a.g_w = gr.w_stride; a.g_bn = gr.bn_stride;
   }
-  if (!w16 && !grouped && pw_rows_try(a, stream) == 1) {
+  int slab_rc = 0;
+  if (!w16 && !grouped) {
+    // all-N K-sliced slab kernel (pw_slab.hip, round 6): the launches the skinny kernel would run with an arithmetic prologue (BatchNorm
+    // backward operand, or affine / swish / gate) and more than one column tile - there the prologue is re-evaluated per 64-wide tile
+    const bool slab_auto = take_skinny && !a.p5.z && N > 64 && K >= 256 &&
+                           (a.bb.z || a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE);
+    slab_rc = pw_slab_try(a, a.slab_ws, a.slab_ws_floats, slab_auto, stream);
+    if (slab_rc < 0) return slab_rc;
+  }
+  if (slab_rc == 1) {
+    // taken
+  } else if (!w16 && !grouped && pw_rows_try(a, stream) == 1) {
     // thin-K row-slab kernel (pw_rows.hip) took the launch
   } else if (!w16 && !grouped && pw_longk_try(a, stream) == 1) {
     // long-K small-M kernel with the LDS-DMA pipelined K loop (pw_longk.hip)
@@ -1415,7 +1435,8 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
                                 const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image,
                                 double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale,
                                 const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B,
-                                hipStream_t stream, int bf16, int w16 = 0) {
+                                hipStream_t stream, int bf16, int w16 = 0, int form = MMD_PW_FORM_AUTO, float* ws = nullptr,
+                                long long ws_floats = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !g || !z || !wt || !dx) return MMD_EINVAL;
   if (!scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
   if (mul_b && rows_per_image <= 0) return MMD_EINVAL;
@@ -1429,6 +1450,8 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
   a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1,
                  dz_out, dgamma, dbeta};
   a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1; a.z16 = (w16 >> 2) & 1; a.dz16 = (w16 >> 3) & 1; a.p5z16 = (w16 >> 4) & 1;
+  if (form < MMD_PW_FORM_AUTO || form > MMD_PW_FORM_SLAB) return MMD_EINVAL;
+  a.form = form; a.slab_ws = ws; a.slab_ws_floats = ws ? ws_floats : 0;
   if (a.y16 && (residual || xs_z)) return MMD_EINVAL;
   if (xs_z) {
     a.xs = BnSumOp{xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image > 0 ? xs_rows_per_image : 1};
@@ -1460,6 +1483,17 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
                     p5_invstd, p5_out, p5_B, stream
 extern "C" int mmd_pwconv_bwd_data_bn2(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0); }
 extern "C" int mmd_pwconv_bwd_data_bn2_bf16(PW_BD2_PARAMS) { return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 1); }
+// mmd_pwconv_bwd_data_bn2 with a workspace for the slab kernel's K slices (ws / ws_floats, nullable: mmd_pwconv_slab_ws_floats) and the
+// kernel family chosen per call (form as mmd_pwconv_fwd_form; 0 = the shape filters decide)
+extern "C" int mmd_pwconv_bwd_data_bn2_form(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b,
+                      int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z,
+                      const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums,
+                      double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift,
+                      const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, float* ws, long long ws_floats, int form,
+                      hipStream_t stream) {
+  return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0, 0, form, ws, ws_floats);
+}
 // bf16 storage of the wide tensors: w16 bit 0 = g, bit 1 = dx, bit 2 = z, bit 3 = dz_out, bit 4 = p5_z are bf16 arrays
 extern "C" int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift,
                       const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b,

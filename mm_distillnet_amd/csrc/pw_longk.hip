@@ -211,13 +211,11 @@ __global__ __launch_bounds__(256) void pw_longk_kernel(PwArgs a) {
   }
 }
 
-static int g_longk_mode = 0;      // 0: shape filter, 1: every supported launch, 2: off
-extern "C" int mmd_pwconv_longk_mode(int mode) { if (mode < 0 || mode > 2) return MMD_EINVAL; g_longk_mode = mode; return MMD_OK; }
 
 // -> 1 when the launch was taken.  Supported: fp32, plain or gate-only A operand, no pyramid / strided output, K >= 256, K % 4 == 0.
 int pw_longk_try(PwArgs& a, hipStream_t stream) {
   static const int off = getenv("MMD_NO_LONGK") ? 1 : 0;
-  if (off || g_longk_mode == 2 || a.bf16 || a.bb.z || a.xs.z || a.st.Cin || a.pyr.n || a.y_batch_stride) return 0;
+  if (off || a.form == MMD_PW_FORM_TILED || a.form == MMD_PW_FORM_ROWS || a.form == MMD_PW_FORM_SLAB || a.bf16 || a.bb.z || a.xs.z || a.st.Cin || a.pyr.n || a.y_batch_stride) return 0;
   if (a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE) return 0;
   if (a.stats_ws) return 0;
   const int M = a.M, K = a.K, N = a.N;
@@ -227,7 +225,7 @@ int pw_longk_try(PwArgs& a, hipStream_t stream) {
   // the regime this kernel is for: at most one block per CU - the 144 KB ring allows one resident block, so a 257th block waits for a
   // whole block time.  Measured (tools/dev/one_rows.py, profiles/r02_notes.md): M2048 K1248 N208 24.5 -> 20.5 us, M2048 K720 N208 16.4 ->
   // 13.9, but M8192 K528 N88 (512 blocks) 20.8 -> 22.4 and M2048 K2112 N352 (384 blocks) 57.2 -> 58.9.
-  if (g_longk_mode != 1 && (K < 512 || blocks > 256)) return 0;
+  if (a.form != MMD_PW_FORM_LONGK && (K < 512 || blocks > 256)) return 0;
   a.ntn = cdiv(N, LK_BN); a.nblk = (int)blocks;
   const size_t lds = ((size_t)3 * LK_STAGE + (a.gate ? (size_t)cdiv(K, LK_BK) * LK_BK : 0)) * sizeof(float);
   if (lds > 160 * 1024) return 0;

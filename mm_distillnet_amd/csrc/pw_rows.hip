@@ -296,9 +296,8 @@ static RowsKern rows_pick(int nkk, int c) {
   return c == 7 ? rows_pick_k<7>(nkk) : c == 4 ? rows_pick_k<4>(nkk) : c == 3 ? rows_pick_k<3>(nkk) : c == 1 ? rows_pick_k<1>(nkk) : nullptr;
 }
 
-static int g_rows_mode = 0;
-// 0: the measured shape filter decides; 1: every supported launch takes the row-slab kernel; 2: none does (tests, A/B timing)
-extern "C" int mmd_pwconv_rows_mode(int mode) { if (mode < 0 || mode > 2) return MMD_EINVAL; g_rows_mode = mode; return MMD_OK; }
+// a.form (pw_args.h, per call): MMD_PW_FORM_AUTO = the measured shape filter decides; _ROWS = every supported launch takes the row-slab
+// kernel; _TILED = none does (tests, A/B timing)
 
 int pw_rows_try(PwArgs& a, hipStream_t stream) {
   static const int off = getenv("MMD_NO_ROWS") ? 1 : 0;
@@ -311,8 +310,8 @@ int pw_rows_try(PwArgs& a, hipStream_t stream) {
   // 23.6 -> 22.0, M32768 K48 N288 19.5 -> 18.1, M524288 K16 N96 42.2 -> 40.5) and loses on the short ones (M <= 8192: the panel
   // staging + one slab per wave do not amortise).  MMD_ROWS_ALL=1 lifts the filter (tests run both ways).
   static const int all = getenv("MMD_ROWS_ALL") ? 1 : 0;
-  if (g_rows_mode == 2) return 0;
-  if (!all && g_rows_mode != 1 && (M < 32768 || a.stats || N < 48)) return 0;
+  if (a.form == MMD_PW_FORM_TILED || a.form == MMD_PW_FORM_LONGK || a.form == MMD_PW_FORM_SLAB) return 0;
+  if (!all && a.form != MMD_PW_FORM_ROWS && (M < 32768 || a.stats || N < 48)) return 0;
   if (a.in_act != MMD_ACT_NONE && a.in_act != MMD_ACT_SWISH) return 0;
   if (a.gate && (a.pyr.n || (a.rows_per_image & 15))) return 0;        // a 16-row slab must lie inside one image
   const int nkk = K / 8;
@@ -339,7 +338,7 @@ int pw_rows_try(PwArgs& a, hipStream_t stream) {
   while (cpp > 1 && (long long)nslabs * cdiv(nchunks, cpp) < 1024) --cpp;      // small M: more panels = more waves
   ra.cpp = cpp; ra.pcols = cpp * C * 16; ra.npanels = cdiv(nchunks, cpp);
   ra.mode = ((a.in_scale || a.in_bn.stats) ? RW_AFF : 0) | (a.in_act == MMD_ACT_SWISH ? RW_SWISH : 0) | (a.gate ? RW_GATE : 0);
-  static const int abl = getenv("MMD_ROWS_ABL") ? atoi(getenv("MMD_ROWS_ABL")) : 0;
+  static const int abl = (getenv("MMD_DEV") && getenv("MMD_ROWS_ABL")) ? atoi(getenv("MMD_ROWS_ABL")) : 0;      // honoured under MMD_DEV=1 only (_lib.py WORK_SKIPPING)
   ra.mode |= abl;
   ra.nlev = a.stats ? (a.pyr.n ? a.pyr.n : 1) : 0;
   const size_t lds = ((size_t)ra.pcols * ra.LDB + 2 * K + 3 * ra.pcols + (size_t)ra.nlev * 2 * ra.pcols) * sizeof(float);

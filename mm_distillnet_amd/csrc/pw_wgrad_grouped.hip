@@ -336,6 +336,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAV
         __syncthreads();
       }
     };
+    // BARRIER CONTRACT: the four waves of a block may run DIFFERENT instantiations of `rows` (nu / nv are wave-uniform, not
+    // block-uniform), so they meet at __syncthreads() calls at different program counters.  That is sound on gfx950 because s_barrier counts
+    // arrivals per workgroup, whatever the PC - and ONLY because every instantiation executes exactly the same number of barriers: two per
+    // 32-row step (one behind lstore, one behind the MFMAs), (mend - mbeg) / GW_BR steps, with item-uniform mbeg / mend.  Anything added to one
+    // instantiation's loop that contains a barrier must be added to all three.
     if (!nv || nu == 0) rows(std::integral_constant<int, 0>{});      // (a wave without live sub-tiles still stages its share of the slabs)
     else if (nu == 2) rows(std::integral_constant<int, 2>{});
     else rows(std::integral_constant<int, 1>{});

@@ -189,3 +189,65 @@ class DeviceInputPipeline:
         for t in self._batch.values():
             t.record_stream(torch.cuda.current_stream(self.device))
         return self._batch
+
+
+class TensorInputPipeline:
+    """Ready-made tensors (the reference loader's contract, MultimodalDetection.__getitem__: rgb / thermal / depth / audio fp32 [B,C,S,S],
+    15.7 MB per sample at 512^2) to the device on a COPY stream with the same submit() / wait() interface as DeviceInputPipeline, so
+    train.py keeps one batch of look-ahead on either path: the 126 MB of H2D copies of batch n+1 overlap the step of batch n instead of
+    sitting in front of it on the compute stream (2.5 ms of a 14 ms step at PCIe Gen5 rates)."""
+    KEYS = ("rgb", "thermal", "depth", "audio")
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._event, self._batch, self._held = None, None, []
+
+    def submit(self, item):
+        if self._event is not None:
+            self._event.synchronize()          # the previous submit's (pinned) sources have been read
+        self._held = [item[0], item[1], item[2], item[3]]
+        with torch.cuda.stream(self.stream):
+            # allocated on the copy stream; wait()'s record_stream defers their reuse until the compute stream has consumed them
+            out = {k: t.to(self.device, non_blocking=True) for k, t in zip(self.KEYS, self._held)}
+            self._event = self.stream.record_event()
+        self._batch = out
+        return self
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_event(self._event)
+        for t in self._batch.values():
+            t.record_stream(torch.cuda.current_stream(self.device))
+        return self._batch
+
+
+def _pin(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj if obj.is_pinned() else obj.pin_memory()
+    if isinstance(obj, dict):
+        return {k: _pin(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_pin(v) for v in obj)
+    return obj
+
+
+class CachedBatches:
+    """cfg `synthetic_cache = N` (extension key, absent upstream -> off): the first N batches of `loader` are generated ONCE, kept in pinned
+    host memory and cycled for the loader's length, so that what train.py's loop measures is the loop (H2D, input transforms, graph replay,
+    logging), not the synthetic generator (7 x 512^2 normal draws + a bicubic resize per sample on the tensor path).  The batches still
+    cross PCIe every step.  len() = the wrapped loader's, so epoch / iteration accounting is unchanged."""
+
+    def __init__(self, loader, n: int):
+        self.n_iter = len(loader)
+        self.batches = []
+        for i, b in enumerate(loader):
+            self.batches.append(_pin(b))
+            if i + 1 >= n:
+                break
+
+    def __len__(self):
+        return self.n_iter
+
+    def __iter__(self):
+        for i in range(self.n_iter):
+            yield self.batches[i % len(self.batches)]

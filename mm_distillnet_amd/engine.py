@@ -105,6 +105,7 @@ class GradSlot:
         self.sums: Optional[torch.Tensor] = None
         self.have_sums = False
         self.linear_ok = True          # linear-sum mode (a tensor that is max-pooled somewhere): every contribution so far added its share
+        self.stream: Optional[int] = None   # linear mode: the stream every contribution must be issued on (see Net._contrib)
 
 
 @dataclass
@@ -229,6 +230,7 @@ class Net:
             self.wt_desc = torch.tensor(descs, dtype=torch.int64, device=device)
             self.wt_tiles = tiles
         self.tape: Dict[str, object] = {}
+        self._slab_floats: Dict[tuple, int] = {}
         self._wg_read_done = None
         self._anchors: Dict[int, torch.Tensor] = {}
         self._side = None
@@ -383,9 +385,24 @@ class Net:
                 residual, stats, ybs, yoff, *self._stats_ws(stats, M, N))
         if x.w16 or y16:
             call("mmd_pwconv_fwd_w16", *args, 1, (1 if x.w16 else 0) | (2 if y16 else 0))
+        elif self._grp is None and not self._sfx and not plain_in and ybs == 0:
+            # (fp32, outside a pack forward, with a producer transform: the launch may take the all-N K-sliced slab kernel, csrc/pw_slab.hip,
+            # which needs a workspace for its K slices' partial slabs when the launch has few row slabs)
+            call("mmd_pwconv_fwd_form", *args, *self._slab_ws(M, K, N, 0), 0)
         else:
             self._c("mmd_pwconv_fwd" + self._sfx, *args)
         return y
+
+    def _slab_ws(self, M: int, K: int, N: int, bn_operand: int):
+        """(workspace, floats) for the K slices of a slab-kernel launch of this shape (mmd_pwconv_slab_ws_floats; (None, 0): the launch runs
+        unsliced or on another kernel family).  Plain arena memory: the partial slabs need no zeroing."""
+        if not self.ps.flat.is_cuda:
+            return None, 0
+        key = (M, K, N, bn_operand)
+        n = self._slab_floats.get(key)
+        if n is None:
+            n = self._slab_floats[key] = int(_lib.LIB.load().mmd_pwconv_slab_ws_floats(M, K, N, bn_operand))
+        return (self._alloc(n), n) if n > 0 else (None, 0)
 
     def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None, y16=False):
         OH, OW = -(-x.H // s), -(-x.W // s)
@@ -915,6 +932,15 @@ class Net:
         if FOLD_SUMS and POOL_SCATTER and info is not None and self.ps.flat.is_cuda and f.z.data_ptr() in self._linear:
             # linear mode (the tensor is max-pooled by some node, whose backward scatters into its gradient): every contribution adds the
             # sums of its OWN share (7th element = 1); they are complete when the last one has, provided none was unable to
+            # Exclusivity: the node backward's LDS-tile scatter reads the interior of this gradient at block start and stores it
+            # plainly at block end, so a contribution running BESIDE it on another stream would be lost without a trace (global atomics used
+            # to make that safe).  Every contribution to a scattered gradient therefore has to be issued on ONE stream.
+            cur = torch.cuda.current_stream().cuda_stream
+            if s.stream is None:
+                s.stream = cur
+            elif s.stream != cur:
+                raise RuntimeError("contributions to a scattered (max-pooled) gradient issued on two streams: mmd_bifpn_node_bwd_full's "
+                                   "LDS-tile scatter needs exclusive access to it (include/mmdistill.h, EXCLUSIVITY)")
             if not can_sum:
                 s.linear_ok = False
                 return s, None
@@ -954,7 +980,7 @@ class Net:
             self._wg = torch.cuda.Stream()
         self._wg.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(self._wg):
-            if os.environ.get("MMD_DEV_SKIP_WG"):      # timing experiment only (gradients are WRONG): what do the weight-gradient
+            if _lib.dev_switch("MMD_DEV_SKIP_WG"):      # timing experiment only (gradients are WRONG): what do the weight-gradient
                 global call                            # kernels cost the step through contention with the main chain?
                 saved, call = call, (lambda *a, **k: 0)
                 try:
@@ -1139,8 +1165,13 @@ class Net:
                 xsargs = (None, None, None, None, 0, None, None, 0)
                 if xs is not None:
                     xsargs = (xs[0], xs[1], xs[2], xs[4], xs[5], xs[3], *self._stats_ws(xs[3], M, K))
-                call("mmd_pwconv_bwd_data_bn2" + self._sfx, L.g, L.z, ps.w_t(wkey), slot.t, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
-                     residual, *xsargs, None, None, None, None, None, None, 0)
+                if self._sfx:
+                    call("mmd_pwconv_bwd_data_bn2" + self._sfx, L.g, L.z, ps.w_t(wkey), slot.t, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
+                         residual, *xsargs, None, None, None, None, None, None, 0)
+                else:
+                    # (the GEMM reduces over N = the conv's output channels: the slab kernel's "K")
+                    call("mmd_pwconv_bwd_data_bn2_form", L.g, L.z, ps.w_t(wkey), slot.t, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
+                         residual, *xsargs, None, None, None, None, None, None, 0, *self._slab_ws(M, N, K, 1), 0)
                 self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs)
                 return None
             dx = self._alloc(M, K)

@@ -336,7 +336,17 @@ class DistillEngine:
         G = len(self.teachers)
         # (round 5: the smallest level needs whole 32-row tiles per net only - the heads run a level that misses the 128-row tiles as plain
         # launches on the skinny kernel, engine.Net._head - so D4 / 768^2 at B = 8, 288 rows per net on its 6 x 6 level, packs too)
-        use_pack = bool(self.pack and G > 1 and not aug and (B * (S // 128) ** 2) % 32 == 0 and S % 128 == 0)
+        # (the 32-row relaxation holds only where EVERY per-net launch on that level is covered - the heads split it off themselves,
+        # the BiFPN nodes only on the whole-node kernel, which has no row-tile constraint; a width without one (88 / 288 / 384: D1, D5 - D7), the
+        # wide form past its row cap or MMD_NO_NODE_FUSE send that level's nodes through mmd_pwconv_fwd, whose 64- / 128-row kernels refuse
+        # a tile that straddles two nets: those geometries keep the whole-128-row-tile rule, i.e. run one net per stream as before)
+        rows_small = B * (S // 128) ** 2
+        net_f = next(iter(self.teachers.values()))
+        node_whole = bool(net_f.FUSE_NODE and net_f.ps.flat.is_cuda and
+                          _lib.LIB.load().mmd_bifpn_node_fused_supported(net_f.spec.fpn_w) == 1 and
+                          (net_f.spec.fpn_w <= 160 or G * rows_small <= net_f.NODE_FUSE_WIDE_MAXROWS))
+        use_pack = bool(self.pack and G > 1 and not aug and S % 128 == 0 and
+                        (rows_small % 128 == 0 or (rows_small % 32 == 0 and node_whole)))
         npk = min(G, max(2, int(os.environ.get("MMD_PACK_SPLIT", G))))      # (dev: pack the first npk teachers, the others on their own streams)
         if use_pack:
             nets = list(self.teachers.values())[:npk]
@@ -406,7 +416,7 @@ class DistillEngine:
         call("mmd_focal_loss", cls_s, reg_s, st.anchors(S), boxes, nbox, G, B, A, nc, assign, npos, acc, main, dcls, dreg,
              float(cfg.w_main), 1, self.head_active if train else self.ws.alloc((1,), torch.int32))
         # backward + optimizer
-        if train and not os.environ.get("MMD_DEV_NO_BWD"):      # (MMD_DEV_NO_BWD=1: timing experiment - forward + losses only)
+        if train and not _lib.dev_switch("MMD_DEV_NO_BWD"):      # (MMD_DEV_NO_BWD=1: timing experiment - forward + losses only)
             call("mmd_memset_async", st.ps.grad, 0, st.ps.grad.numel() * 4)
             st.backward(dcls, dreg, dfe, stop_before=self.ar_split, dfeat_pyr=d_all)
         self.out = {"reg": main[0:1], "cls": main[1:2], "kd": kd, "boxes": boxes, "nbox": nbox,
@@ -518,6 +528,10 @@ class DistillEngine:
         """Eager step (no graph): forward, losses, backward, all-reduce, Adam."""
         B = batch["audio"].shape[0]
         if drop_scale is None:
+            if self._drop_injected:
+                # an earlier replay(..., drop_scale=mask) / set_drop_scale(mask) left the device flag up: mmd_drop_scale would then leave the
+                # fresh buffer below unfilled (ADVICE r5: garbage drop-connect scales, no error) - release the injection before drawing
+                self.set_drop_scale(None)
             drop_scale = torch.empty(self.n_skip, B, device=self.device)
             self.draw_drop_scale(drop_scale)
         out = self.step_body(batch, drop_scale)

@@ -8,6 +8,8 @@ the classifier header bias is about -4 so that a realistic handful of anchors pa
 """
 from __future__ import annotations
 
+import os
+import sys
 import zlib
 from typing import Dict
 
@@ -99,3 +101,53 @@ def synth_inputs(batch: int, image_size: int, seed: int = 24, audio_raw: int = 1
     raw = torch.randn(batch, 8, audio_raw, audio_raw, generator=g) * 15.0 - 40.0
     audio = torch.nn.functional.interpolate(raw, size=(image_size, image_size), mode="bicubic", align_corners=False)
     return {"rgb": rgb, "thermal": thermal, "depth": depth, "audio": audio.contiguous()}
+
+
+# ---- synthetic stand-ins with a realistic workload (bench.py; train.py with cfg synthetic_teacher_candidates) ----
+def calibrated_state(spec, seed, x, device, cls_bias=-4.0):
+    """hash weights + BN running stats calibrated with one train-mode pass of the HIP engine."""
+    st = synth_state(spec, seed=seed, cls_bias=cls_bias)
+    from .engine import Net
+    net = Net(spec, device, trainable=True)
+
+    def tf(state, xin, mom):
+        net.load_state(state)
+        net.bn_momentum = mom
+        net.begin_step()
+        net.forward(xin.to(device), train=True, drop_scale=None)
+        torch.cuda.synchronize()
+        ex = net.ps.export_state()
+        for k in state:
+            if "running_" in k:
+                state[k].copy_(ex[k])
+
+    calibrate_bn_(st, tf, x, seed=seed)
+    del net
+    torch.cuda.empty_cache()
+    return st
+
+
+def tune_teacher_bias(spec, state, x, device, target_per_image=40):
+    """Shift the classifier header bias uniformly so that ~target candidates per image pass (score > 0.3, class car):
+    random-weight teachers otherwise emit either nothing or thousands of boxes, which is not the workload."""
+    import math
+    from .engine import Net
+    net = Net(spec, device, trainable=False)
+    xd = x.to(device)
+    for it in range(8):         # sigmoid saturates: iterate until the count is in range
+        net.load_state(state)
+        net.begin_step()
+        logit, _, _ = net.forward(xd, train=False, raw_logits=True)      # pre-sigmoid: probabilities saturate in fp32
+        logit = logit.double()
+        best, arg = logit.max(2)
+        car = best[arg == 6]
+        n_now = int((car > math.log(0.3 / 0.7)).sum().item())
+        tgt = target_per_image * logit.shape[0]
+        if os.environ.get("MMD_BENCH_DEBUG"):
+            print("tune it %d: over-threshold car candidates %d (target %d), car anchors %d" % (it, n_now, tgt, car.numel()), file=sys.stderr)
+        if 0.5 * tgt <= n_now <= 1.5 * tgt or car.numel() <= tgt:
+            break
+        v = torch.sort(car, descending=True)[0][tgt].item()
+        state["classifier.header.pointwise_conv.conv.bias"] += float(math.log(0.3 / 0.7) - v)
+    del net
+    torch.cuda.empty_cache()

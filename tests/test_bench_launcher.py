@@ -67,3 +67,47 @@ def test_mismatch_exits_nonzero_before_any_gpu_call():
     assert p.returncode == 2, p.stderr[-2000:]
     assert p.stdout.strip() == ""
     assert "WORLD_SIZE=2" in p.stderr
+
+
+def test_failed_rank_ends_the_launcher_nonzero(tmp_path, monkeypatch):
+    """A rank that dies must end the launch with a non-zero status instead of leaving the launcher (and the surviving ranks, blocked in a
+    collective) hanging: the real `torch.distributed.run` child, started through launch_ranks' own command line with the script swapped
+    for one whose rank 1 exits with status 5 while rank 0 would sleep for ten minutes."""
+    import time
+    bench = _bench()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(5)\n"
+                      "time.sleep(600)\n")
+
+    def runner(cmd, env):
+        i = cmd.index(os.path.join(ROOT, "bench.py"))
+        return subprocess.run(cmd[:i] + [str(script)], env=env, capture_output=True, timeout=240)
+
+    t0 = time.time()
+    rc = bench.launch_ranks(argparse.Namespace(gpus=2), argv=["--gpus", "2"], runner=runner)
+    assert rc not in (0, None)
+    assert time.time() - t0 < 200                    # (the agent tears the other rank down; it does not wait for the sleep)
+
+
+def test_work_skipping_switches_are_refused():
+    """with a work-skipping dev switch in the environment bench.py prints no `value` and exits non-zero - before any GPU
+    call (this container has none) - and the package itself refuses to import unless MMD_DEV=1 opts in explicitly."""
+    import json
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MMD_")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], env=dict(env, MMD_DEV="1", MMD_DEV_SKIP_CALLS="mmd_se_fc_bwd"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["invalid"] is True and "value" not in rec and rec["switches"] == ["MMD_DEV_SKIP_CALLS"]
+    assert "SKIPPED" in p.stderr                     # the import-time warning
+    # without the explicit opt-in the switch is an error, not a silent no-op and not a silent skip
+    p = subprocess.run([sys.executable, "-c", "import mm_distillnet_amd._lib"], env=dict(env, MMD_DEV_SKIP_WG="1", PYTHONPATH=ROOT),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "MMD_DEV=1" in p.stderr
+    # train.py refuses too (checked on the function: starting train.py needs a GPU)
+    from mm_distillnet_amd import _lib
+    assert _lib.work_skipping_switches({"MMD_DEV_NO_BWD": "1", "MMD_NO_PACK": "1"}) == ["MMD_DEV_NO_BWD"]
+    assert _lib.work_skipping_switches({"MMD_NO_PACK": "1"}) == []

@@ -122,13 +122,10 @@ def test_pwconv_rows_kernel(M, K, N, B, flags):
     y = torch.full((M, N), float("nan"), device=DEV)
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV) if "stats" in f else None
     ws = torch.zeros(64 * 2 * N, dtype=torch.float64, device=DEV) if "ws" in f else None
-    _lib.LIB.load().mmd_pwconv_rows_mode(1)          # every supported launch on the row-slab kernel (default: a measured shape filter)
-    try:
-        call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, *args_in, g(gate) if gate is not None else None, rpi,
-             g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
-             g(res) if res is not None else None, stats, 0, 0, ws, 64 if ws is not None else 0)
-    finally:
-        _lib.LIB.load().mmd_pwconv_rows_mode(0)
+    # form 1: every supported launch on the row-slab kernel (default: a measured shape filter); chosen per call, no process-wide switch
+    call("mmd_pwconv_fwd_form", g(x), g(w), y, M, K, N, *args_in, g(gate) if gate is not None else None, rpi,
+         g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
+         g(res) if res is not None else None, stats, 0, 0, ws, 64 if ws is not None else 0, 1)
     close(y, ref, 2e-4, 1e-5, "rows fwd")
     if stats is not None:
         close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
@@ -166,35 +163,26 @@ def test_pwconv_longk_kernel(M, K, N, B, flags):
     if res is not None:
         ref = ref + res
     stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV) if "stats" in f else None
-    dll = _lib.LIB.load()
-    dll.mmd_pwconv_longk_mode(1)
     outs = []
-    try:
-        for rep in range(3):
-            y = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
-            if stats is not None:
-                stats.zero_()
-            call("mmd_pwconv_fwd", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
-                 g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
-                 y if "acc" in f else (g(res) if res is not None else None), stats, 0, 0, None, 0)
-            torch.cuda.synchronize()
-            outs.append(y.clone())
-    finally:
-        dll.mmd_pwconv_longk_mode(0)
+    for rep in range(3):
+        y = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
+        if stats is not None:
+            stats.zero_()
+        call("mmd_pwconv_fwd_form", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
+             g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
+             y if "acc" in f else (g(res) if res is not None else None), stats, 0, 0, None, 0, 3)      # form 3: the long-K kernel
+        torch.cuda.synchronize()
+        outs.append(y.clone())
     close(outs[0], ref, 2e-4, 1e-5, "longk fwd")
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     if stats is not None:
         close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
         close(stats[N:], (raw.double() ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
     # and the LDS-tiled kernels on the same launch agree
-    dll.mmd_pwconv_longk_mode(2)
-    try:
-        y2 = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
-        call("mmd_pwconv_fwd", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
-             g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
-             y2 if "acc" in f else (g(res) if res is not None else None), None, 0, 0, None, 0)
-    finally:
-        dll.mmd_pwconv_longk_mode(0)
+    y2 = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
+    call("mmd_pwconv_fwd_form", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
+         g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
+         y2 if "acc" in f else (g(res) if res is not None else None), None, 0, 0, None, 0, 2)         # form 2: LDS-tiled kernels only
     close(y2, ref, 2e-4, 1e-5, "tiled fwd")
 
 
@@ -1459,6 +1447,148 @@ def test_pwconv_bwd_data_bn2_residual_and_upstream_sums(M, K, N, act, rowscale, 
         assert not ws.any(), "slotted workspace must be left zero"
 
 
+@pytest.mark.parametrize("M,K,N,act,rowscale,resid,form", [
+    (2048, 208, 1248, 1, False, True, 0),      # headline shapes, as the engine issues them (form 0 = the library's own choice: the slab kernel):
+    (8192, 120, 720, 1, True, True, 0),        #   blocks 17-20 / 13-15 / 9-11 / 22 of the D2 student at B = 8: expand-conv input gradients
+    (8192, 88, 528, 1, False, True, 0),
+    (2048, 352, 2112, 1, False, False, 0),     # two column chunks x two K slices
+    (1000, 88, 528, 1, True, True, 4),         # forced (form 4): ragged M (last slab 8 rows), K tail of 16 inside a granule
+    (96, 36, 260, 0, True, False, 4),          # no activation, ragged N (36 of 64 columns), two K slices of 5 + 4 granules
+    (4096, 48, 288, 1, False, True, 4)])       # two 32-wide tiles, 128 slabs x 2 slices
+def test_pwconv_slab_bn_operand(M, K, N, act, rowscale, resid, form):
+    """Round 6: the all-N, K-sliced slab kernel (csrc/pw_slab.hip) on the BatchNorm-backward operand launches - input
+    gradient of a 1x1 conv behind train-mode BatchNorm (+ swish, + drop-connect row scale) with the residual add and the upstream
+    BatchNorm's backward sums in its epilogue - against torch autograd in float64: dx (+ residual), the stored dz (through dW = dz^T x),
+    dgamma / dbeta, the upstream sums; bit-identical results over repeated launches (the slices are added in a fixed order); and the
+    LDS-tiled kernels on the same launch agree.  fp32 vs float64: 2e-4 of each tensor's largest value."""
+    torch.manual_seed(M + N)
+    B = 8 if M % 256 == 0 else 2
+    rpi = M // B
+    x = torch.randn(M, K, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn(N, K, dtype=torch.float64) / math.sqrt(K)).requires_grad_(True)
+    gamma = (torch.rand(N, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(N, dtype=torch.float64) * 0.2).requires_grad_(True)
+    gy = torch.randn(M, N, dtype=torch.float64)
+    rs = (torch.rand(B, dtype=torch.float64) + 0.5) if rowscale else None
+    if rowscale:
+        rs[1] = 0.0                                   # a dropped sample (drop-connect)
+    z = x @ w.t()
+    mean = z.mean(0); var = z.var(0, unbiased=False)
+    invstd = (var + 1e-3).rsqrt()
+    y = (z - mean) * invstd * gamma + beta
+    a = swish(y) if act else y
+    if rowscale:
+        a = a * rs.repeat_interleave(rpi).view(-1, 1)
+    (a * gy).sum().backward()
+    f32 = lambda t: t.detach().float()
+    scale, shift = f32(gamma * invstd), f32(beta - mean * gamma * invstd)
+    gd, zd = g(f32(gy)), g(f32(z))
+    dsc, dsh, dmu, dis = g(scale), g(shift), g(f32(mean)), g(f32(invstd))
+    rsd = g(f32(rs)) if rowscale else None
+    sums = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", gd, zd, dsc, dsh, dmu, dis, act, None, rsd, None, rpi, None, sums, M, N, None, 0)
+    wt = g(f32(w).t())                                # [K, N]: the transposed copy the input-gradient GEMM reads
+    base = torch.randn(M, K)
+    z_up = torch.randn(M, K) * 0.8 + 0.1
+    mu_up, is_up, rs_up = torch.randn(K) * 0.2, torch.rand(K) + 0.5, torch.rand(B) + 0.5
+    lib = _lib.LIB.load()
+    nws = int(lib.mmd_pwconv_slab_ws_floats(M, N, K, 1))       # (the GEMM reduces over the conv's output channels)
+    if form == 0 and M <= 2048:
+        assert nws > 0, "the M = 2048 launches are cut along K"
+    ws = torch.full((max(nws, 1),), float("nan"), device=DEV)
+
+    def run(f):
+        dx = g(base.clone()) if resid else torch.full((M, K), float("nan"), device=DEV)
+        dzm = torch.full((M, N), float("nan"), device=DEV)
+        xs_sums = torch.zeros(2 * K, dtype=torch.float64, device=DEV)
+        dga, dbe = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+        call("mmd_pwconv_bwd_data_bn2_form", gd, zd, wt, dx, M, K, N, dsc, dsh, dmu, dis, sums, M, act, rsd, rpi, dzm, dga, dbe,
+             dx if resid else None, g(z_up), g(mu_up), g(is_up), g(rs_up), rpi, xs_sums, None, 0, None, None, None, None, None, None, 0,
+             ws if nws else None, nws, f)
+        torch.cuda.synchronize()
+        return dx, dzm, xs_sums, dga, dbe
+    dx, dzm, xs_sums, dga, dbe = run(form)
+    total = x.grad + (base.double() if resid else 0)
+    close(dx, total, 2e-4, 2e-5, "dx (+ residual)")
+    assert torch.isfinite(dzm).all()
+    close(dzm.cpu().double().t() @ x.detach(), w.grad, 2e-4, 2e-5, "dW through the stored dz")
+    close(dga, gamma.grad, 3e-4, 3e-5, "dgamma"); close(dbe, beta.grad, 3e-4, 3e-5, "dbeta")
+    _sums_close(xs_sums, _bn_sums_ref(total.float(), z_up, mu_up, is_up, rs_up, rpi), "upstream BatchNorm sums")
+    dx2, dzm2, xs2, _, _ = run(form)
+    assert torch.equal(dx, dx2) and torch.equal(dzm, dzm2), "repeated launches differ: the slices must be added in a fixed order"
+    dxt, dzmt, xst, _, _ = run(2)                     # form 2: the LDS-tiled kernels
+    close(dx, dxt, 2e-5, 2e-6, "slab vs tiled dx"); close(dzm, dzmt, 1e-6, 1e-7, "slab vs tiled dz")
+    _sums_close(xs_sums, xst.cpu(), "slab vs tiled upstream sums")
+
+
+@pytest.mark.parametrize("M,K,N,flags,form", [
+    (2048, 1248, 208, "live swish gate stats", 0),      # the student's project convs (live BatchNorm-1 + swish + squeeze-excite gate, BatchNorm-2
+    (8192, 720, 120, "live swish gate stats", 0),       #   sums of the output) at the headline shapes, form 0 = the library's own choice
+    (8192, 528, 88, "live swish gate stats", 0),
+    (2048, 2112, 352, "live swish gate stats", 0),
+    (1000, 528, 88, "aff swish gate bias osc res", 4),  # forced: given coefficients, bias, folded BN + residual epilogue, ragged M
+    (160, 260, 40, "swish stats bias", 4),              # activation only, ragged N
+    (4096, 288, 96, "live gate act stats", 4)])
+def test_pwconv_slab_fwd(M, K, N, flags, form):
+    """The slab kernel's forward form: Y = (swish(x * scale + shift) * gate[image]) W^T with live-BatchNorm or given coefficients, every
+    epilogue job (bias, BatchNorm sums, folded BN + activation, residual), against float64 torch; repeated launches bit-identical; the
+    LDS-tiled kernels agree."""
+    torch.manual_seed(M + 3 * K + N)
+    f = set(flags.split())
+    B = 8 if M % 256 == 0 else 2
+    rpi = M // B
+    x = torch.randn(M, K) * 1.5 + 0.3; w = torch.randn(N, K) / math.sqrt(K)
+    a = x.double()
+    args_in = [None, None, 0, None, None, None, 0]
+    if "aff" in f:
+        isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+        a = a * isc.double() + ish.double(); args_in[0], args_in[1] = g(isc), g(ish)
+    if "live" in f:
+        gamma, beta = torch.rand(K) + 0.5, torch.randn(K) * 0.2
+        st_in = torch.cat([x.double().sum(0), (x.double() ** 2).sum(0)])
+        mean = st_in[:K] / M; var = st_in[K:] / M - mean * mean
+        sc = gamma.double() / torch.sqrt(var + 1e-3)
+        a = a * sc + (beta.double() - mean * sc)
+        args_in = [None, None, 0, g(st_in), g(gamma), g(beta), M]
+    if "swish" in f:
+        a = swish(a); args_in[2] = 1
+    gate = torch.rand(B, K) if "gate" in f else None
+    if gate is not None:
+        a = a * gate.double().repeat_interleave(rpi, 0)
+    bias = torch.randn(N) * 0.1 if "bias" in f else None
+    raw = a @ w.double().t() + (bias.double() if bias is not None else 0)
+    osc, osh = (torch.rand(N) + 0.5, torch.randn(N) * 0.1) if "osc" in f else (None, None)
+    ref = raw * osc.double() + osh.double() if osc is not None else raw
+    act = 1 if "act" in f else 0
+    if act:
+        ref = swish(ref)
+    res = torch.randn(M, N) if "res" in f else None
+    if res is not None:
+        ref = ref + res.double()
+    lib = _lib.LIB.load()
+    nws = int(lib.mmd_pwconv_slab_ws_floats(M, K, N, 0))
+    ws = torch.full((max(nws, 1),), float("nan"), device=DEV)
+    gp = lambda t: g(t) if t is not None else None
+
+    def run(fm):
+        y = torch.full((M, N), float("nan"), device=DEV)
+        stats = torch.zeros(2 * N, dtype=torch.float64, device=DEV) if "stats" in f else None
+        call("mmd_pwconv_fwd_form", g(x), g(w), y, M, K, N, *args_in, gp(gate), rpi, gp(bias), gp(osc), gp(osh), act, gp(res), stats, 0, 0,
+             None, 0, ws if nws else None, nws, fm)
+        torch.cuda.synchronize()
+        return y, stats
+    y, stats = run(form)
+    close(y, ref, 2e-4, 2e-5, "slab fwd")
+    if stats is not None:
+        close(stats[:N], raw.sum(0), 1e-4, 1e-4, "stats sum"); close(stats[N:], (raw ** 2).sum(0), 1e-4, 1e-5, "stats sumsq")
+    y2, _ = run(form)
+    assert torch.equal(y, y2)
+    yt, st_t = run(2)
+    close(y, yt, 2e-5, 2e-6, "slab vs tiled")
+    if stats is not None:
+        close(stats, st_t, 1e-5, 1e-6, "slab vs tiled stats")
+
+
 @pytest.mark.parametrize("M,Cin,C,resid,xs", [(40960, 16, 96, True, True), (20480, 24, 144, True, True), (8192, 32, 192, False, False),
                                               (1000, 24, 144, True, False), (131072, 24, 144, True, True), (70, 16, 96, False, True)])
 def test_mbconv_expand_bwd_fused(M, Cin, C, resid, xs):
@@ -2022,10 +2152,7 @@ def test_bifpn_node_bwd_full_small_map_form(mode, H, W, C):
     mus = {k: g(torch.randn(C) * 0.2) for k in zs}
     iss = {k: g(torch.rand(C) + 0.5) for k in zs}
     prev = {k: g(torch.randn(n, C) * 0.3) for k, n in (("0", M), ("1", M), ("u", M // 4), ("p", 4 * M))}
-    lib = _lib.LIB.load()
-
     def run(below):
-        assert lib.mmd_bifpn_node_bwd_small_below(below) == 0
         wdot, dwg = torch.zeros(4, device=DEV), torch.zeros(9, C, device=DEV)
         d0, d1 = prev["0"].clone(), prev["1"].clone() if has1 else None
         du = prev["u"].clone() if hasu else None
@@ -2033,15 +2160,12 @@ def test_bifpn_node_bwd_full_small_map_form(mode, H, W, C):
         sm = {k: torch.zeros(2 * C, dtype=torch.float64, device=DEV) for k in zs}
         x = lambda k, on: (zs[k], mus[k], iss[k], sm[k]) if on else (None, None, None, None)
         dzm = torch.full((M, C), float("nan"), device=DEV); dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
-        call("mmd_bifpn_node_bwd_full", in0, in1, up, pl, theta, wd, wdot, B, H, W, C, d0, 1, d1, 1, du, 1, dwg,
+        call("mmd_bifpn_node_bwd_full_form", in0, in1, up, pl, theta, wd, wdot, B, H, W, C, d0, 1, d1, 1, du, 1, dwg,
              *x("0", True), *x("1", has1), *x("u", hasu), dp, *x("p", hasp), 0, None, None,
-             gg, zz, sc, mu, istd, sums, M, wp, dzm, dga, dbe)      # (wp: any [C, C] matrix - both forms read it the same way)
+             gg, zz, sc, mu, istd, sums, M, wp, dzm, dga, dbe, below, -1)      # (wp: any [C, C] matrix - both forms read it the same way)
         return dict(wdot=wdot, dwg=dwg, d0=d0, d1=d1, du=du, dp=dp, dz=dzm, dgamma=dga, dbeta=dbe,
                     s0=sm["0"], s1=sm["1"] if has1 else None, su=sm["u"] if hasu else None, sp=sm["p"] if hasp else None)
-    try:
-        small, big = run(1 << 30), run(0)
-    finally:
-        lib.mmd_bifpn_node_bwd_small_below(128)
+    small, big = run(1 << 30), run(0)      # the block shape is an argument of the call (mmd_bifpn_node_bwd_full_form): no process-wide switch
     assert torch.equal(small["dz"], big["dz"]) and torch.equal(small["dgamma"], big["dgamma"]) and torch.equal(small["dbeta"], big["dbeta"])
     for k in ("d0", "d1", "du"):
         if big[k] is not None:
@@ -2053,6 +2177,127 @@ def test_bifpn_node_bwd_full_small_map_form(mode, H, W, C):
     for k in ("s0", "s1", "su", "sp"):
         if big[k] is not None:
             close(small[k].float(), big[k].float(), 1e-4, 1e-3, "BatchNorm-backward sums " + k)
+
+
+def _bifpn_node_autograd(mode, B, H, W, C, seed):
+    """A whole BiFPN node of the trainable net in torch (float64, CPU) and everything its backward produces - the direct reference for
+    mmd_bifpn_node_bwd_full: fast-attention fusion weights relu(theta) / (sum + 1e-4), nearest x2 up-sampling,
+    zero-padded SAME max-pool 3x3 / 2, swish, depthwise 3x3 (SAME, no bias), 1x1 conv + bias, train-mode BatchNorm (eps 1e-3)
+    (BiFPN._forward_fast_attention + SeparableConvBlock, src/YetAnotherEfficientDet.py:154-192,320-392).  -> dict of inputs (NHWC rows, fp32)
+    and of autograd's gradients."""
+    gen = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float32)
+    has1, hasu, hasp = mode == "bu", mode == "td", mode in ("bu", "p7")
+    nchw = lambda rows, h, w: rows.double().view(B, h, w, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    rows = {"in0": rn(B * H * W, C), "in1": rn(B * H * W, C) if has1 else None, "up": rn(B * H * W // 4, C) if hasu else None,
+            # mostly negative: bottom / right border windows then take the zero padding, whose gradient is dropped
+            "pl": rn(4 * B * H * W, C) - 1.0 if hasp else None}
+    t = {"in0": nchw(rows["in0"], H, W), "in1": nchw(rows["in1"], H, W) if has1 else None,
+         "up": nchw(rows["up"], H // 2, W // 2) if hasu else None, "pl": nchw(rows["pl"], 2 * H, 2 * W) if hasp else None}
+    theta = torch.tensor([0.7, 1.3, 0.4][:2 if mode != "bu" else 3], dtype=torch.float32)
+    wd = rn(9, C) / 3
+    wp = rn(C, C) / math.sqrt(C)                     # [C out, C in]
+    bias, gamma, beta = rn(C) * 0.1, torch.rand(C, generator=gen) + 0.5, rn(C) * 0.1
+    th64 = theta.double().requires_grad_(True)
+    wd64 = wd.double().t().reshape(C, 1, 3, 3).contiguous().requires_grad_(True)      # tap-major [9, C] -> [C, 1, ky, kx]
+    wp64, b64 = wp.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ga64, be64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    r = F.relu(th64); wts = r / (r.sum() + 1e-4)
+    ops = [t["in0"]] + ([t["in1"]] if has1 else []) + ([F.interpolate(t["up"], scale_factor=2, mode="nearest")] if hasu else []) + \
+          ([_maxpool_ref(t["pl"])] if hasp else [])
+    a = swish(sum(wi * o for wi, o in zip(wts, ops)))
+    zd = F.conv2d(same_pad(a, 3, 1), wd64, groups=C)
+    z = F.conv2d(zd, wp64.view(C, C, 1, 1), b64)
+    z.retain_grad()
+    mean = z.mean((0, 2, 3)); var = z.var((0, 2, 3), unbiased=False)
+    istd = 1.0 / torch.sqrt(var + 1e-3)
+    y = (z - mean.view(1, C, 1, 1)) * (istd * ga64).view(1, C, 1, 1) + be64.view(1, C, 1, 1)
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    y.backward(gy)
+    to_rows = lambda x: x.detach().permute(0, 2, 3, 1).reshape(-1, C)
+    return dict(rows=rows, theta=theta, wd=wd, wp=wp, gy=to_rows(gy).float(), z=to_rows(z).float(), mean=mean.detach().float(),
+                istd=istd.detach().float(), scale=(istd * ga64).detach().float(),
+                shift=(be64 - mean * istd * ga64).detach().float(),
+                grads=dict(d0=to_rows(t["in0"].grad), d1=to_rows(t["in1"].grad) if has1 else None, du=to_rows(t["up"].grad) if hasu else None,
+                           dp=to_rows(t["pl"].grad) if hasp else None, dtheta=th64.grad, dwd=wd64.grad.reshape(C, 9).t().contiguous(),
+                           dz=to_rows(z.grad), dgamma=ga64.grad, dbeta=be64.grad))
+
+
+@pytest.mark.parametrize("mode,H,W,C", [("bu", 64, 64, 112), ("bu", 32, 32, 112), ("td", 64, 64, 112), ("p7", 4, 4, 112), ("bu", 6, 6, 224),
+                                        ("td", 16, 16, 112), ("bu", 8, 8, 112)])
+def test_bifpn_node_bwd_full_vs_autograd(mode, H, W, C):
+    """mmd_bifpn_node_bwd_full against torch autograd of the whole node DIRECTLY (until now the fused backward forms were
+    compared with other HIP launches, four links away from torch): every gradient the launch produces - operand gradients (same-size,
+    up-sampled, the pooled one's scattered gradient) accumulated into running gradients, the fusion-weight gradient (through
+    mmd_bifpn_theta_bwd), the depthwise weight gradient, the stored BatchNorm backward dz, dgamma / dbeta, and the BatchNorm-backward sums it
+    takes for the operands it completes - in all of its forms: 64-channel blocks with the pooled gradient through the LDS tile and by global
+    atomics, 16-channel blocks.  B = 8 at the headline shapes (64^2 / 32^2 levels = the chip-filling launches).  fp32 kernel vs float64
+    reference: 2e-4 of each tensor's largest value."""
+    B = 8
+    M = B * H * W
+    ref = _bifpn_node_autograd(mode, B, H, W, C, seed=5 * H + C)
+    has1, hasu, hasp = mode == "bu", mode == "td", mode in ("bu", "p7")
+    R, G = ref["rows"], ref["grads"]
+    gp = lambda t: g(t) if t is not None else None
+    in0, in1, up, pl = gp(R["in0"]), gp(R["in1"]), gp(R["up"]), gp(R["pl"])
+    theta, wd, wpt = g(ref["theta"]), g(ref["wd"]), g(ref["wp"].t())      # (w_pw_t [C in, C out]: the operand mmd_pwconv_bwd_data takes)
+    gg, zz = g(ref["gy"]), g(ref["z"])
+    sc, sh, mu, istd = g(ref["scale"]), g(ref["shift"]), g(ref["mean"]), g(ref["istd"])
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    call("mmd_bn_bwd_reduce", gg, zz, sc, sh, mu, istd, 0, None, None, None, H * W, None, sums, M, C, None, 0)
+    xhat = (ref["z"].double() - ref["mean"].double()) * ref["istd"].double()
+    close(sums[:C], ref["gy"].double().sum(0), 1e-5, 1e-6, "sum g"); close(sums[C:], (ref["gy"].double() * xhat).sum(0), 1e-5, 1e-5, "sum g xhat")
+    # BatchNorm inputs / statistics of the operands whose gradient this launch completes (any tensors: the sums are linear in the
+    # gradient), and the running gradients it accumulates into
+    torch.manual_seed(H + C)
+    n_of = {"0": M, "1": M, "u": M // 4, "p": 4 * M}
+    zs = {k: torch.randn(n, C) for k, n in n_of.items()}
+    mus = {k: torch.randn(C) * 0.2 for k in zs}
+    iss = {k: torch.rand(C) + 0.5 for k in zs}
+    prev = {k: torch.randn(n, C) * 0.3 for k, n in n_of.items()}
+    dzs, dmu, dis, dprev = ({k: g(v) for k, v in d.items()} for d in (zs, mus, iss, prev))
+
+    def run(below, pool_lds):
+        wdot, dwg = torch.zeros(4, device=DEV), torch.zeros(9, C, device=DEV)
+        d0, d1 = dprev["0"].clone(), dprev["1"].clone() if has1 else None
+        du = dprev["u"].clone() if hasu else None
+        dp = dprev["p"].clone() if hasp else None
+        sm = {k: torch.zeros(2 * C, dtype=torch.float64, device=DEV) for k in zs}
+        x = lambda k, on: (dzs[k], dmu[k], dis[k], sm[k]) if on else (None, None, None, None)
+        dzm = torch.full((M, C), float("nan"), device=DEV); dga = torch.zeros(C, device=DEV); dbe = torch.zeros(C, device=DEV)
+        call("mmd_bifpn_node_bwd_full_form", in0, in1, up, pl, theta, wd, wdot, B, H, W, C, d0, 1, d1, 1, du, 1, dwg,
+             *x("0", True), *x("1", has1), *x("u", hasu), dp, *x("p", hasp), 0, None, None,
+             gg, zz, sc, mu, istd, sums, M, wpt, dzm, dga, dbe, below, pool_lds)
+        dth = torch.zeros(theta.numel(), device=DEV)
+        call("mmd_bifpn_theta_bwd", theta, wdot, dth, theta.numel())
+        return dict(d0=d0, d1=d1, du=du, dp=dp, dth=dth, dwg=dwg, dz=dzm, dga=dga, dbe=dbe, sm=sm)
+
+    def sums_of(grad_total, k):      # [sum g', sum g' xhat] of a gradient w.r.t. the BatchNorm output whose input / statistics are (zs, mus, iss)[k]
+        xh = (zs[k].double() - mus[k].double()) * iss[k].double()
+        return torch.cat([grad_total.sum(0), (grad_total * xh).sum(0)])
+
+    forms = [("64-channel blocks, pooled gradient by global atomics", 0, 0), ("16-channel blocks", 1 << 30, 0)]
+    if hasp:
+        forms.insert(1, ("64-channel blocks, pooled gradient through the LDS tile", 0, 1))
+    for what, below, plds in forms:
+        o = run(below, plds)
+        tol = dict(rtol=2e-4, atol=2e-5)
+        close(o["dz"], G["dz"], msg=what + ": stored dz", **tol)
+        close(o["dga"], G["dgamma"], msg=what + ": dgamma", **tol); close(o["dbe"], G["dbeta"], msg=what + ": dbeta", **tol)
+        close(o["d0"], prev["0"].double() + G["d0"], msg=what + ": d in0 (accumulated)", **tol)
+        close(o["sm"]["0"], sums_of(prev["0"].double() + G["d0"], "0"), msg=what + ": BatchNorm-backward sums of in0's gradient", **tol)
+        if has1:
+            close(o["d1"], prev["1"].double() + G["d1"], msg=what + ": d in1", **tol)
+            close(o["sm"]["1"], sums_of(prev["1"].double() + G["d1"], "1"), msg=what + ": sums in1", **tol)
+        if hasu:
+            close(o["du"], prev["u"].double() + G["du"], msg=what + ": d up (2x2 block sums)", **tol)
+            close(o["sm"]["u"], sums_of(prev["u"].double() + G["du"], "u"), msg=what + ": sums up", **tol)
+        if hasp:
+            close(o["dp"], prev["p"].double() + G["dp"], msg=what + ": d pool (scattered to the window arg-max)", **tol)
+            # a scattered gradient has no last writer: its sums are linear, this launch adds the sums of ITS share
+            close(o["sm"]["p"], sums_of(G["dp"], "p"), msg=what + ": sums pool (this launch's share)", **tol)
+        close(o["dth"], G["dtheta"], 5e-4, 5e-5, what + ": d theta")
+        close(o["dwg"], G["dwd"], 3e-4, 3e-5, what + ": depthwise weight gradient")
 
 
 def test_drop_scale_philox_kernel():

@@ -179,8 +179,9 @@ _D4_EMU = {}       # precision -> (gradient cos of the oracle's emulation to fp3
 def test_d4_768_step_vs_oracle(B):
     """BASELINE configs[4]'s architecture and input size through the WHOLE step: three frozen EfficientDet-D4 teachers + the
     8-channel D4 student at 768 x 768, pseudo-labels,
-    MTA + focal losses, backward - in fp32 against oracle/step_ref (the reference's load_model hard-codes D2, so there is no
-    reference golden for D4; the oracle's D2 step is pinned by the reference goldens above), then the bf16 mixed-precision modes of the
+    MTA + focal losses, backward - in fp32 against oracle/step_ref (itself pinned at D4 by the reference-made goldens of round 5,
+    tests/golden/step_d4_256_pairwise.npz and net_d4_*: test_step_d4_golden below, tests/test_oracle_golden.py::test_step_d4 - the
+    reference's load_model hard-codes D2, its YetAnotherEfficientDet class does not), then the bf16 mixed-precision modes of the
     same step: at B = 2 bounded against the oracle's own emulation of each mode, at B = 8 (configs[4]'s per-GPU batch) against the
     fp32 HIP step with the B = 2 yardsticks, eagerly and through capture() + replay()."""
     from oracle import step_ref as ST

@@ -4,7 +4,7 @@
 sets=$1; rounds=${2:-2}
 for r in $(seq $rounds); do
   for s in $sets; do
-    ( if [ "$s" != none ]; then export MMD_DEV_SKIP_CALLS=$s; fi
-      python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 >/dev/null | grep -a "timed" | sed "s/^/$s  /" )
+    ( if [ "$s" != none ]; then export MMD_DEV=1 MMD_DEV_SKIP_CALLS=$s; fi
+      python bench.py --steps 30 --warmup 5 --no-cpu-baseline --dev-timing 2>&1 >/dev/null | grep -a "timed" | sed "s/^/$s  /" )
   done
 done

@@ -35,8 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from mm_distillnet_amd.arch import make_spec  # noqa: E402
-from mm_distillnet_amd.data import (SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, collate, collate_raw,  # noqa: E402
-                                    valid_classes_dict)
+from mm_distillnet_amd.data import (SyntheticMultimodalDetection, RawSyntheticMultimodalDetection, DeviceInputPipeline, TensorInputPipeline,  # noqa: E402
+                                    CachedBatches, collate, collate_raw, valid_classes_dict)
+from mm_distillnet_amd import _lib  # noqa: E402
 from mm_distillnet_amd import trainer as TR  # noqa: E402
 from mm_distillnet_amd.model import filter_state_dict  # noqa: E402
 from mm_distillnet_amd.step import DistillEngine, StepConfig  # noqa: E402
@@ -119,8 +120,39 @@ def load_states(cfg, coef=2):
     return sspec, sstate, tspecs, tstates
 
 
+class AsyncScalars:
+    """The loop's loss read-back without a host sync: [reg, cls, kd sum, lr, overflow flag] go to pinned memory behind the step that produced
+    them (a non-blocking D2H copy + an event on the compute stream) and are logged when the NEXT read-back is posted, ten steps later (or at
+    the end of the epoch) - by then the copy has long finished, so the host never waits for the GPU to drain.  (The reference reads
+    `loss.item()` every iteration, src/optimization/traditional.py:171-190; three .item() calls + check_overflow were four syncs per log.)"""
+
+    def __init__(self):
+        self.buf = torch.empty(6, dtype=torch.float32).pin_memory()
+        self.ev, self.meta = None, None
+
+    def post(self, eng, out, meta):
+        vec = torch.stack([out["reg"].reshape(-1)[0], out["cls"].reshape(-1)[0], out["kd"].sum(), eng.hyper[0].float(),
+                           eng.overflow.reshape(-1)[0].float(), out["nbox"].float().mean()])
+        self.buf.copy_(vec, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+        self.meta = meta
+
+    def take(self):
+        """-> ((reg, cls, kd, lr, overflow), meta) of the pending post, or None."""
+        if self.ev is None:
+            return None
+        self.ev.synchronize()
+        vals, meta = self.buf.tolist(), self.meta
+        self.ev, self.meta = None, None
+        return vals, meta
+
+
 def main(argv=None):
     cfg, args = parse_config(argv)
+    if _lib.work_skipping_switches():
+        raise Exception("work-skipping dev switches are set (%s): train.py refuses to start - every gradient would be wrong"
+                        % ", ".join(_lib.work_skipping_switches()))
     rank, local = args.rank, args.local_rank
     ngpu = cfg.getint("ngpu", 1)
     world = int(os.environ.get("WORLD_SIZE", ngpu * args.nodes if cfg.get("engine") == "DistributedDataParallel" else 1))
@@ -140,6 +172,18 @@ def main(argv=None):
     torch.manual_seed(cfg.getint("seed", 24))
     scfg = step_config(cfg)                      # raises on an unsupported train_method / optimizer, like upstream
     sspec, sstate, tspecs, tstates = load_states(cfg, int(cfg.get("compound_coef", 2)))
+    if cfg.getint("synthetic_teacher_candidates", 0) > 0:
+        # extension key (synthetic stand-in teachers only): shift each teacher's classifier bias so that about this many candidates per
+        # image pass the confidence threshold on the first training samples - bench.py's workload (random-weight teachers otherwise emit
+        # nothing or thousands of boxes per image, and the pseudo-label / loss phase of the step is then not the headline workload's)
+        from mm_distillnet_amd.synth import tune_teacher_bias
+        probe = SyntheticMultimodalDetection(cfg, "train")
+        nb = min(cfg.getint("batch_size"), len(probe))
+        first = collate([probe[i] for i in range(nb)])
+        xin = {"rgb": first[0], "thermal": first[1], "depth": first[2]}
+        for m in tspecs:
+            if not os.path.exists(_MOD_PATH[m]):
+                tune_teacher_bias(tspecs[m], tstates[m], xin[m], dev, cfg.getint("synthetic_teacher_candidates"))
     eng = DistillEngine(sspec, tspecs, dev, scfg, world_size=world)
     eng.load(sstate, tstates)
     sched = TR.LrSchedule(eng, cfg)              # raises on an unsupported scheduler, like upstream
@@ -154,13 +198,16 @@ def main(argv=None):
     raw = cfg.get("input_pipeline", "tensor") == "raw"
     Set = RawSyntheticMultimodalDetection if raw else SyntheticMultimodalDetection
     train_set, val_set = Set(cfg, "train"), Set(cfg, "val")
-    pipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
+    pipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else TensorInputPipeline(dev)
     vpipe = DeviceInputPipeline(cfg.getint("image_size"), dev) if raw else None
     collate_fn = collate_raw if raw else collate
     sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank) if world > 1 else None
     loader = torch.utils.data.DataLoader(train_set, batch_size=cfg.getint("batch_size"), shuffle=sampler is None,
                                          drop_last=True, collate_fn=collate_fn,
                                          num_workers=cfg.getint("num_workers", 0), sampler=sampler, pin_memory=True)
+    if cfg.getint("synthetic_cache", 0) > 0:
+        # extension key: the first N batches generated once, kept pinned and cycled - the loop is what is measured, not the generator
+        loader = CachedBatches(loader, cfg.getint("synthetic_cache"))
 
     def to_batch(item):
         if raw:
@@ -184,19 +231,36 @@ def main(argv=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         t0, n_img, out = time.time(), 0, None
+        t_50, n_50 = None, 0
         # MMD_TRAIN_TIMING=1: host seconds per segment of the loop (loader / input wait / capture+replay / submit / logging), printed per epoch
         seg = {"loader": 0.0, "input": 0.0, "step": 0.0, "submit": 0.0, "log": 0.0} if os.environ.get("MMD_TRAIN_TIMING") else None
         tick = time.perf_counter
         it = iter(loader)
-        # one batch of look-ahead: the raw pipeline transforms batch n+1 on its copy stream while the step of batch n runs
+        # one batch of look-ahead on either input path: batch n+1 is copied (and, raw path, transformed) on the pipeline's copy stream while
+        # the step of batch n runs
         nxt = next(it, None)
-        staged = pipe.submit(nxt) if (raw and nxt is not None) else None
+        staged = pipe.submit(nxt) if nxt is not None else None
         num_iter = len(loader)
         i_iter = 0
+        scal = AsyncScalars()
+        inflight = [None, None]          # backpressure: the host stays at most two steps ahead of the GPU
+
+        def emit(taken):
+            nonlocal loss
+            (reg, cls, kd, lr, ovf, nbox), (ep, it_no, gstep) = taken
+            if ovf:
+                eng.check_overflow()         # raises with the configured capacities
+            loss = w_main * (reg + cls) + w_kd * kd
+            logger.info("Epoch: %d/%d Iteration: %d/%d Lr: %g Loss:%.5f Regression:%.5f Cls:%.5f KLDiv:0 KD:%.5f PseudoLabels/img:%.1f", ep + 1,
+                        n_epochs, it_no + 1, num_iter, lr, loss, reg, cls, kd, nbox)
+            writer.add_scalar("Train/Total_loss", loss, gstep); writer.add_scalar("Train_/Regression_loss", reg, gstep)
+            writer.add_scalar("Train/Class_loss", cls, gstep); writer.add_scalar("Train/KLDiv", 0.0, gstep)
+            writer.add_scalar("Train/KD", kd, gstep)
+
         while nxt is not None:
             item = nxt
             ts = tick()
-            batch = staged.wait() if raw else to_batch(item)
+            batch = staged.wait()
             if seg is not None:
                 seg["input"] += tick() - ts
             if kdlist_aug and TR.kdlist_augment_now(epoch):
@@ -212,31 +276,35 @@ def main(argv=None):
             ts = tick()
             nxt = next(it, None)
             t1 = tick()
+            if inflight[steps & 1] is not None:
+                inflight[steps & 1].synchronize()        # step n-2 has finished (normally long ago: no wait)
             if not captured:
                 eng.capture(batch); captured = True
             out = eng.replay(batch)
+            ev = torch.cuda.Event(); ev.record(); inflight[steps & 1] = ev
             t2 = tick()
-            if raw and nxt is not None:
+            if nxt is not None:
                 staged = pipe.submit(nxt)        # after replay(): the static inputs were copied out of `batch` on the compute stream
             t3 = tick()
             n_img += batch["audio"].shape[0]; steps += 1
             if steps % 10 == 0 or steps == 1:
-                reg, cls, kd = out["reg"].item(), out["cls"].item(), out["kd"].sum().item()
-                eng.check_overflow()             # sticky device flag; checked where the host syncs anyway
-                loss = w_main * (reg + cls) + w_kd * kd
-                logger.info("Epoch: %d/%d Iteration: %d/%d Lr: %g Loss:%.5f Regression:%.5f Cls:%.5f KLDiv:0 KD:%.5f", epoch + 1,
-                            n_epochs, i_iter + 1, num_iter, eng.hyper[0].item(), loss, reg, cls, kd)
-                gstep = epoch * num_iter + i_iter
-                writer.add_scalar("Train/Total_loss", loss, gstep); writer.add_scalar("Train_/Regression_loss", reg, gstep)
-                writer.add_scalar("Train/Class_loss", cls, gstep); writer.add_scalar("Train/KLDiv", 0.0, gstep)
-                writer.add_scalar("Train/KD", kd, gstep)
+                prev = scal.take()               # posted ten steps ago: its copy has finished, no wait
+                if prev is not None:
+                    emit(prev)
+                scal.post(eng, out, (epoch, i_iter, epoch * num_iter + i_iter))
             if seg is not None:
                 seg["loader"] += t1 - ts; seg["step"] += t2 - t1; seg["submit"] += t3 - t2; seg["log"] += tick() - t3
+            if i_iter + 1 == 50:
+                torch.cuda.synchronize(); t_50, n_50 = time.time(), n_img      # steady-state rate: the first 50 steps (capture, worker start-up) excluded
             i_iter += 1
             if 0 < args.max_steps <= steps:
                 stop = True
                 break
+        last = scal.take()
+        if last is not None:
+            emit(last)
         torch.cuda.synchronize()
+        t_end = time.time()
         eng.check_overflow()
         if out is None:
             logger.warning("epoch %d: the loader yielded no batch (dataset smaller than batch_size with drop_last)", epoch + 1)
@@ -248,6 +316,9 @@ def main(argv=None):
         logger.info("epoch %d: %.1f images/sec on this rank, last loss %.5f", epoch + 1, n_img / (time.time() - t0), loss)
         if seg is not None:
             logger.info("epoch %d host seconds: %s (wall %.2f, %d steps)", epoch + 1, {k: round(v, 3) for k, v in seg.items()}, time.time() - t0, i_iter)
+        if t_50 is not None and n_img > n_50:
+            logger.info("epoch %d steady state (iterations 51..%d, device synchronised at both ends): %.1f images/sec = %.2f ms/step", epoch + 1,
+                        i_iter, (n_img - n_50) / (t_end - t_50), (t_end - t_50) / ((n_img - n_50) / batch["audio"].shape[0]) * 1e3)
         sched.step(loss)
         if no_validation:
             if stop:
