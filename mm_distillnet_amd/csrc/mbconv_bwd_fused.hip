@@ -50,7 +50,7 @@ struct MbwCfg {
 };
 
 template <int C, int CIN, int MBW_TM>
-__global__ __launch_bounds__(256, 2) void mbconv_expand_bwd_kernel(MbwArgs a) {
+__global__ __launch_bounds__(256, (C >= 288 ? 1 : 2)) void mbconv_expand_bwd_kernel(MbwArgs a) {      // (C = 288: 112 KB of LDS, one block per CU - no register cap)
   using Cf = MbwCfg<C, CIN, MBW_TM>;
   constexpr int LD = Cf::LD, LDW = Cf::LDW, LDX = Cf::LDX, LDO = Cf::LDO, NT = Cf::NT, MT = Cf::MT, TPW = Cf::TPW;
   constexpr int NQ = Cf::NQ, RG = Cf::RG, NQX = Cf::NQX, RGX = Cf::RGX;
@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_expand_bwd_kernel(MbwArgs a) {
 
 // 1 when mmd_mbconv_expand_bwd_fused has a kernel for (Cin, Cmid) and the layer is tall enough for the single pass to pay
 extern "C" int mmd_mbconv_expand_bwd_supported(int Cin, int Cmid) {
-  return ((Cin == 16 && Cmid == 96) || (Cin == 24 && Cmid == 144) || (Cin == 32 && Cmid == 192)) ? 1 : 0;
+  // (48, 288): the 64^2 blocks of D2 (blocks 6 - 8, M = 32768 at B = 8; round 6) on 32-row tiles - W [288][52] alone is 60 KB of LDS
+  static const int no48 = getenv("MMD_NO_MBW48") ? 1 : 0;
+  return ((Cin == 16 && Cmid == 96) || (Cin == 24 && Cmid == 144) || (Cin == 32 && Cmid == 192) || (Cin == 48 && Cmid == 288 && !no48)) ? 1 : 0;
 }
 
 template <int C, int CIN, int TM>
@@ -304,7 +306,8 @@ extern "C" int mmd_mbconv_expand_bwd_fused(const float* g0, const float* z0, con
   static const int tm32 = getenv("MMD_MBW_TM32") ? 1 : 0;
   if (Cin == 16) rc = mbw_launch<96, 16, 64>(a, stream, 768);                    // 43 KB of LDS: three blocks per CU
   else if (Cin == 24) rc = tm32 ? mbw_launch<144, 24, 32>(a, stream, 768) : mbw_launch<144, 24, 64>(a, stream, 512);
-  else rc = tm32 ? mbw_launch<192, 32, 32>(a, stream, 512) : mbw_launch<192, 32, 64>(a, stream, 256);
+  else if (Cin == 32) rc = tm32 ? mbw_launch<192, 32, 32>(a, stream, 512) : mbw_launch<192, 32, 64>(a, stream, 256);
+  else rc = mbw_launch<288, 48, 32>(a, stream, 256);                                  // 112 KB of LDS: one block per CU
   // two GEMMs' worth of products; bytes: g0, z0 read, x read, dx written (+ residual, + the sums' z)
   mmd_prof_end(MMD_FAM_PW, stream, 4.0 * M * (double)Cmid * Cin, 4.0 * M * (2.0 * Cmid + Cin * (2.0 + (residual ? 1 : 0) + (xs_z ? 1 : 0))));
   return rc;

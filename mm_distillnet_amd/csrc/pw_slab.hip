@@ -24,6 +24,17 @@
 
 #define SL_BM 32
 
+// -DMMD_SLSTAMPS (dev build, tools/dev/slab_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock along the kernel
+#ifdef MMD_SLSTAMPS
+__device__ unsigned long long g_slst[128];
+#define SL_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 128) g_slst[i] = wall_clock64(); } while (0)
+#define SL_TW(i) do { __builtin_amdgcn_s_waitcnt(0); SL_T(i); } while (0)
+extern "C" int mmd_slab_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slst), sizeof(g_slst)) == hipSuccess ? 0 : -1; }
+#else
+#define SL_T(i)
+#define SL_TW(i)
+#endif
+
 struct SlabArgs {
   PwArgs p;
   int nchunk;        // column chunks (blocks along N; 1 unless N > 256)
@@ -228,15 +239,25 @@ __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
     }
   };
 
+  SL_T(0);
   gload(kbeg);
   __syncthreads();                                   // the coefficient table is complete
+  SL_T(1);
+  int sti = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    SL_TW(2 + 5 * sti);                              // (dev build only: the step's loads have landed)
     lstore(k0);
+    SL_T(3 + 5 * sti);
     __syncthreads();
+    SL_T(4 + 5 * sti);
     if (k0 + BK < kend) gload(k0 + BK);
     mma(min(NG, (kend - k0 + 31) >> 5));
+    SL_T(5 + 5 * sti);
     __syncthreads();
+    SL_T(6 + 5 * sti);
+    ++sti;
   }
+  SL_T(60);
 
   // ---- cross-wave K reduction in the accumulator layout (two rounds, 2 x 32 x NW floats of scratch), then the finished tile row-major
   float* scr = sB;                                    // [2][NT32][16][64]: lane-contiguous, conflict-free
@@ -271,6 +292,7 @@ __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
       }
   }
   __syncthreads();
+  SL_T(61);
   constexpr int NC4 = NW / 4;
   constexpr int LG = NC4 <= 16 ? 4 : NC4 <= 32 ? 5 : NC4 <= 64 ? 6 : 7;
   if (sa.nslice > 1) {
@@ -281,9 +303,11 @@ __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
       const int rl = i / NC4, c4 = i - rl * NC4;
       mmd_st4(dst + (size_t)rl * NWT + c4 * 4, *reinterpret_cast<const float4*>(&tile[rl * NW + c4 * 4]));
     }
+    SL_TW(62);
     return;
   }
   slab_epilogue(a, m0, n0, NC4, LG, [&](int rl, int c4) { return *reinterpret_cast<const float4*>(&tile[rl * NW + c4 * 4]); }, tile + SL_BM * NW);
+  SL_TW(62);
 }
 
 // Combine launch of a K-sliced slab GEMM: adds the slices' partial slabs in slice order and runs the epilogue.  One block per 32 rows x
@@ -297,12 +321,14 @@ __global__ __launch_bounds__(256) void pw_slab_combine_kernel(SlabArgs sa, int n
   const size_t sstride = (size_t)(gridDim.x / sa.nchunk) * SL_BM * NWT;
   const float* src = sa.part + (size_t)m0 * NWT + n0;
   const int ns = sa.nslice;
+  SL_T(64);
   slab_epilogue(a, m0, n0, nw / 4, lg, [&](int rl, int c4) {
     const float* p = src + (size_t)rl * NWT + c4 * 4;
     float4 v = mmd_ld4(p);
     for (int s = 1; s < ns; ++s) { const float4 u = mmd_ld4(p + s * sstride); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
     return v;
   }, smem);
+  SL_TW(65);
 }
 
 typedef void (*SlabKern)(SlabArgs);

@@ -125,7 +125,7 @@ def test_pwconv_rows_kernel(M, K, N, B, flags):
     # form 1: every supported launch on the row-slab kernel (default: a measured shape filter); chosen per call, no process-wide switch
     call("mmd_pwconv_fwd_form", g(x), g(w), y, M, K, N, *args_in, g(gate) if gate is not None else None, rpi,
          g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
-         g(res) if res is not None else None, stats, 0, 0, ws, 64 if ws is not None else 0, 1)
+         g(res) if res is not None else None, stats, 0, 0, ws, 64 if ws is not None else 0, None, 0, 1)
     close(y, ref, 2e-4, 1e-5, "rows fwd")
     if stats is not None:
         close(stats[:N], raw.double().sum(0), 1e-4, 1e-4, "stats sum")
@@ -170,7 +170,7 @@ def test_pwconv_longk_kernel(M, K, N, B, flags):
             stats.zero_()
         call("mmd_pwconv_fwd_form", g(x), g(w), y, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
              g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
-             y if "acc" in f else (g(res) if res is not None else None), stats, 0, 0, None, 0, 3)      # form 3: the long-K kernel
+             y if "acc" in f else (g(res) if res is not None else None), stats, 0, 0, None, 0, None, 0, 3)      # form 3: the long-K kernel
         torch.cuda.synchronize()
         outs.append(y.clone())
     close(outs[0], ref, 2e-4, 1e-5, "longk fwd")
@@ -182,7 +182,7 @@ def test_pwconv_longk_kernel(M, K, N, B, flags):
     y2 = g(res) if "acc" in f else torch.full((M, N), float("nan"), device=DEV)
     call("mmd_pwconv_fwd_form", g(x), g(w), y2, M, K, N, None, None, 0, None, None, None, 0, g(gate) if gate is not None else None, rpi,
          g(bias) if bias is not None else None, g(osc) if osc is not None else None, g(osh) if osh is not None else None, act,
-         y2 if "acc" in f else (g(res) if res is not None else None), None, 0, 0, None, 0, 2)         # form 2: LDS-tiled kernels only
+         y2 if "acc" in f else (g(res) if res is not None else None), None, 0, 0, None, 0, None, 0, 2)         # form 2: LDS-tiled kernels only
     close(y2, ref, 2e-4, 1e-5, "tiled fwd")
 
 
@@ -1590,7 +1590,8 @@ def test_pwconv_slab_fwd(M, K, N, flags, form):
 
 
 @pytest.mark.parametrize("M,Cin,C,resid,xs", [(40960, 16, 96, True, True), (20480, 24, 144, True, True), (8192, 32, 192, False, False),
-                                              (1000, 24, 144, True, False), (131072, 24, 144, True, True), (70, 16, 96, False, True)])
+                                              (1000, 24, 144, True, False), (131072, 24, 144, True, True), (70, 16, 96, False, True),
+                                              (32768, 48, 288, True, True), (1000, 48, 288, False, True)])      # round 6: the 64^2 blocks (D2 blocks 6 - 8)
 def test_mbconv_expand_bwd_fused(M, Cin, C, resid, xs):
     """Round 4: the expand conv's backward (BatchNorm-0 + swish backward, input gradient (+ residual, + upstream BatchNorm sums), weight
     gradient) in one pass over (g0, z0) - csrc/mbconv_bwd_fused.hip - against the launches it replaces: mmd_pwconv_bwd_data_bn2 (which
