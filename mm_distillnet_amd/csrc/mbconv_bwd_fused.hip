@@ -260,11 +260,18 @@ __global__ __launch_bounds__(256, (C >= 288 ? 1 : 2)) void mbconv_expand_bwd_ker
   }
 }
 
-// 1 when mmd_mbconv_expand_bwd_fused has a kernel for (Cin, Cmid) and the layer is tall enough for the single pass to pay
+// (Cin, Cmid) pairs with a kernel instantiation
+static bool mbw_has_kernel(int Cin, int Cmid) {
+  return (Cin == 16 && Cmid == 96) || (Cin == 24 && Cmid == 144) || (Cin == 32 && Cmid == 192) || (Cin == 48 && Cmid == 288);
+}
+// 1 when mmd_mbconv_expand_bwd_fused has a kernel for (Cin, Cmid) AND the single pass measured faster than the two GEMM launches it
+// replaces.  (48, 288) - the 64^2 blocks of D2, blocks 6 - 8, M = 32768 at B = 8 - has a kernel (round 6, VERDICT r5 item 3: 32-row tiles,
+// W [288][52] alone is 60 KB of LDS, one block per CU) but does NOT pay: 88 us per launch against 40 us for the input-gradient GEMM + ~15 us
+// of the grouped weight-gradient launch, step 14.17 vs 13.98 ms in alternating runs (profiles/r06_notes.md); MMD_MBW48=1 switches it on.
 extern "C" int mmd_mbconv_expand_bwd_supported(int Cin, int Cmid) {
-  // (48, 288): the 64^2 blocks of D2 (blocks 6 - 8, M = 32768 at B = 8; round 6) on 32-row tiles - W [288][52] alone is 60 KB of LDS
-  static const int no48 = getenv("MMD_NO_MBW48") ? 1 : 0;
-  return ((Cin == 16 && Cmid == 96) || (Cin == 24 && Cmid == 144) || (Cin == 32 && Cmid == 192) || (Cin == 48 && Cmid == 288 && !no48)) ? 1 : 0;
+  static const int on48 = getenv("MMD_MBW48") ? 1 : 0;
+  if (Cin == 48 && Cmid == 288) return on48;
+  return mbw_has_kernel(Cin, Cmid) ? 1 : 0;
 }
 
 template <int C, int CIN, int TM>
@@ -290,7 +297,7 @@ extern "C" int mmd_mbconv_expand_bwd_fused(const float* g0, const float* z0, con
                                            const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b,
                                            int xs_rows_per_image, double* xs_sums, hipStream_t stream) {
   if (!g0 || !z0 || !x || !w || !dx || !dw || M <= 0 || !scale || !shift || !mean || !invstd || !sums || count <= 0) return MMD_EINVAL;
-  if (!mmd_mbconv_expand_bwd_supported(Cin, Cmid) || (dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
+  if (!mbw_has_kernel(Cin, Cmid) || (dgamma == nullptr) != (dbeta == nullptr)) return MMD_EINVAL;
   if (xs_z && (!xs_mean || !xs_invstd || !xs_sums || (xs_mul_b && xs_rows_per_image <= 0))) return MMD_EINVAL;
   MbwArgs a{};
   a.g0 = g0; a.z0 = z0; a.x = x; a.w = w; a.dx = dx; a.residual = residual; a.dw = dw;

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "pw_args.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define SL_BM 32
 
@@ -47,10 +48,12 @@ struct SlabArgs {
 
 __device__ __forceinline__ float4 sl_mask(bool ok, const float4& v) { return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// Epilogue of one 32-row x ncols block: bias, BatchNorm sums (of the output, or the BnSumOp form), folded BN / activation, residual, store.
+// Epilogue of one BR-row x ncols block: bias, BatchNorm sums (of the output, or the BnSumOp form), folded BN / activation, residual, store.
 // `ld(rl, c4)` returns the finished dot products of row rl, columns 4 c4 .. 4 c4 + 3 of the block.  NC4 = float4 columns of the block,
-// lg = log2 of NC4 rounded up to a power of two (threads are dealt c4 = tid & (2^lg - 1), row group tid >> lg); sRed: (2 * 256 / 2^lg) * NC4 * 4 floats.
-template <class LD4>
+// lg = log2 of NC4 rounded up to a power of two (threads are dealt c4 = tid & (2^lg - 1), row group tid >> lg; R = BR / (256 >> lg) rows per
+// thread); sRed: (2 * 256 / 2^lg) * NC4 * 4 floats.  Every global load of the thread's rows (the operand through `ld`, residual, the z of the
+// BnSumOp sums) is issued before the first use: the first version walked its rows one dependent round trip at a time (5.8 us per block).
+template <int BR, int R, class LD4>
 __device__ __forceinline__ void slab_epilogue(const PwArgs& a, int m0, int n0, int NC4, int lg, LD4 ld, float* sRed) {
   const int tid = threadIdx.x;
   const int c4 = tid & ((1 << lg) - 1), rg = tid >> lg, RG = 256 >> lg;
@@ -58,28 +61,43 @@ __device__ __forceinline__ void slab_epilogue(const PwArgs& a, int m0, int n0, i
   const bool cok = c4 < NC4 && col < a.N;
   float4 b4 = make_float4(0, 0, 0, 0), osc = make_float4(1, 1, 1, 1), osh = make_float4(0, 0, 0, 0);
   float4 xmu = make_float4(0, 0, 0, 0), xis = make_float4(0, 0, 0, 0);
-  if (cok) {
-    if (a.bias) b4 = mmd_ld4(a.bias + col);
-    if (a.out_scale) { osc = mmd_ld4(a.out_scale + col); osh = mmd_ld4(a.out_shift + col); }
-    if (a.xs.z) { xmu = mmd_ld4(a.xs.mean + col); xis = mmd_ld4(a.xs.invstd + col); }
-  }
+  const int cc = cok ? col : 0;
+  if (a.bias) b4 = mmd_ld4(a.bias + cc);
+  if (a.out_scale) { osc = mmd_ld4(a.out_scale + cc); osh = mmd_ld4(a.out_shift + cc); }
+  if (a.xs.z) { xmu = mmd_ld4(a.xs.mean + cc); xis = mmd_ld4(a.xs.invstd + cc); }
   float4 s4 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
-  if (cok) {
-    for (int rl = rg; rl < SL_BM; rl += RG) {
-      const int row = m0 + rl;
-      if (row >= a.M) break;
-      float4 v = ld(rl, c4);
-      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+  float4 v[R], rr[R], zz[R];
+  float rs[R];
+  // clamped (always valid) addresses, masked afterwards: guarded loads compile to one dependent round trip each
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int rl = rg + i * RG, row = min(m0 + rl, a.M - 1);
+    const size_t off = (size_t)row * a.N + cc;
+    v[i] = ld(rl, cok ? c4 : 0);
+    rr[i] = make_float4(0, 0, 0, 0); zz[i] = rr[i]; rs[i] = 1.f;
+    if (a.residual) rr[i] = mmd_ld4(a.residual + off);
+    if (a.xs.z) { zz[i] = mmd_ld4(a.xs.z + off); if (a.xs.mul_b) rs[i] = a.xs.mul_b[row / a.xs.rows_per_image]; }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int rl = rg + i * RG, row = m0 + rl;
+    if (cok && row < a.M) {
+      float4 u = v[i];
+      u.x += b4.x; u.y += b4.y; u.z += b4.z; u.w += b4.w;
       if (!a.xs.z) {
-        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-        q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+        s4.x += u.x; s4.y += u.y; s4.z += u.z; s4.w += u.w;
+        q4.x += u.x * u.x; q4.y += u.y * u.y; q4.z += u.z * u.z; q4.w += u.w * u.w;
       }
-      if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-      if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
-      const size_t off = (size_t)row * a.N + col;
-      if (a.residual) { const float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-      mmd_st4(a.y + off, v);
-      if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
+      if (a.out_scale) { u.x = u.x * osc.x + osh.x; u.y = u.y * osc.y + osh.y; u.z = u.z * osc.z + osh.z; u.w = u.w * osc.w + osh.w; }
+      if (a.out_act) { u.x = mmd_act(u.x, a.out_act); u.y = mmd_act(u.y, a.out_act); u.z = mmd_act(u.z, a.out_act); u.w = mmd_act(u.w, a.out_act); }
+      if (a.residual) { u.x += rr[i].x; u.y += rr[i].y; u.z += rr[i].z; u.w += rr[i].w; }
+      mmd_st4(a.y + (size_t)row * a.N + col, u);
+      if (a.xs.z) {      // (pw_xs_acc's arithmetic on the prefetched z)
+        const float4 g = make_float4(u.x * rs[i], u.y * rs[i], u.z * rs[i], u.w * rs[i]);
+        s4.x += g.x; s4.y += g.y; s4.z += g.z; s4.w += g.w;
+        q4.x += g.x * (zz[i].x - xmu.x) * xis.x; q4.y += g.y * (zz[i].y - xmu.y) * xis.y;
+        q4.z += g.z * (zz[i].z - xmu.z) * xis.z; q4.w += g.w * (zz[i].w - xmu.w) * xis.w;
+      }
     }
   }
   if (a.stats) {
@@ -102,194 +120,176 @@ __device__ __forceinline__ void slab_epilogue(const PwArgs& a, int m0, int n0, i
   }
 }
 
-template <int NT32, int BK, int PRO>
+// Rows per thread of the epilogue: 32 / (256 >> LG)
+template <int NT32, int PRO>
 __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
-  constexpr int LD = BK + 4;
-  constexpr int F4R = BK / 4;             // float4 per tile row
-  constexpr int RSTEP = 256 / F4R;        // rows covered by one pass of the 256 threads: 8 (BK 128) / 16 (BK 64)
-  constexpr int NA = SL_BM / RSTEP;       // A rows per thread: 4 / 2
-  constexpr int NB = NT32 * 32 / RSTEP;   // B rows per thread
   constexpr int NW = NT32 * 32;           // columns of the block
-  constexpr int NG = BK / 32;             // k granules per step
   constexpr int NCO = (PRO == 1) ? 5 : 2; // table rows
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                       // [32][LD]
-  float* sB = smem + SL_BM * LD;          // [NW][LD]; after the K loop: reduction scratch, finished tile, epilogue sums
-  float* sTab = sB + NW * LD;             // [NCO][ktab]
+  float* sTab = smem;                     // [NCO][ktab]; dead after the K loop
   const PwArgs& a = sa.p;
+  float* scr = smem + NCO * sa.ktab;      // [NT32][3][4][64] float4: the non-owners' accumulators of every tile
+  float* tile = scr + NT32 * 3 * 1024;    // [32][NW] finished dot products, row-major
   const int tid = threadIdx.x;
   const int t = blockIdx.x;
   const int slice = t % sa.nslice, rest = t / sa.nslice, chunk = rest % sa.nchunk, slab = rest / sa.nchunk;
   const int m0 = slab * SL_BM, n0 = chunk * NW;
   const int kbeg = slice * sa.gran * 32;
   const int kend = min(a.K, kbeg + sa.gran * 32);
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int kq = (tid % F4R) * 4, lrow = tid / F4R;
+  const int G = (kend - kbeg + 31) >> 5;  // 32-wide k granules of the slice; wave w takes granules w, w + 4, ...
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  SL_T(0);
+
+  // ---- operand rows of this lane, in the MFMA operand layout: lane (r, h) holds row r, k = 16 h + {0..15} of a granule (one float4 per i,
+  // i = 0..3: 64 contiguous bytes per lane, the two halves of a wave cover one 128-byte line per row and load group - every line is
+  // fetched by exactly ONE wave, no LDS round trip for either operand).  Rows / columns past the end are clamped: computed, never stored.
+  const int arow = min(m0 + r, a.M - 1);
+  const float* xrow = a.x + (size_t)arow * a.K + h * 16;
+  const float* grow = nullptr;
+  float rowsc = 1.f;
+  if constexpr (PRO == 1) {
+    grow = a.bb.z + (size_t)arow * a.K + h * 16;
+    rowsc = a.bb.mul_b ? a.bb.mul_b[arow / a.bb.rows_per_image] : 1.f;
+  } else {
+    if (a.gate) grow = a.gate + (size_t)(arow / a.rows_per_image) * a.K + h * 16;
+  }
+  const float* wrow[NT32];
+#pragma unroll
+  for (int j = 0; j < NT32; ++j) wrow[j] = a.w + (size_t)min(n0 + j * 32 + r, a.N - 1) * a.K + h * 16;
+  const bool dz_here = PRO == 1 && a.bb.dz_out != nullptr && chunk == 0 && m0 + r < a.M;
+  const bool has_gate = PRO == 0 && a.gate != nullptr;
+  const bool swish_in = PRO == 0 && a.in_act == MMD_ACT_SWISH;
+  const bool swish_bb = PRO == 1 && a.bb.act == MMD_ACT_SWISH;
+
+  // k offset (floats, from the row start) of sub-block i of granule g for this lane, clamped inside the slice (a tail granule's surplus
+  // elements are zeroed on the A side)
+  auto koff = [&](int g, int i) { return min(kbeg + g * 32 + 4 * i, kend - 4 - h * 16); };      // (>= 0: a slice ends at k >= 128)
+  float4 ra[4], rz[4], rb[NT32][4];
+  auto load_a = [&](int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = koff(g, i);
+      ra[i] = mmd_ld4(xrow + k);
+      if constexpr (PRO == 1) rz[i] = mmd_ld4(grow + k);
+      else if (has_gate) rz[i] = mmd_ld4(grow + k);
+    }
+  };
+  auto load_b = [&](int g, int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[j][i] = mmd_ld4(wrow[j] + koff(g, i));
+  };
+  // first granule's loads in flight while the coefficient table is filled
+  const int g0 = wave < G ? wave : 0;
+  load_a(g0);
+#pragma unroll
+  for (int j = 0; j < NT32; ++j) load_b(g0, j);
 
   // ---- per-channel coefficients of the slice, once per block
   if constexpr (PRO == 1) {
-    if (a.bb.dgamma && t == 0)
-      for (int c = tid; c < a.K; c += 256) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
-    for (int c = kbeg + tid; c < kend; c += 256) {
+    // dgamma / dbeta (+)= the reduce pass' sums: channel group `it` (256 channels) of a slice by that slice's block of row slab `it` - one
+    // round per block, riding on the sums the table fill loads anyway (block 0 doing all K channels was the launch's slowest block by 5+ us)
+    const bool dg = a.bb.dgamma != nullptr && chunk == 0;
+    int it = 0;
+    for (int c = kbeg + tid; c < kend; c += 256, ++it) {
       float a1, a2, a3, mu, sh;
       bn_bwd_coef(a.bb, c, a1, a2, a3, mu, sh);
       const int j = c - kbeg;
       sTab[j] = a1; sTab[sa.ktab + j] = a2; sTab[2 * sa.ktab + j] = a3; sTab[3 * sa.ktab + j] = mu; sTab[4 * sa.ktab + j] = sh;
+      if (dg && it == slab) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
     }
   } else {
-    if (sa.has_aff)
-      for (int c = kbeg + tid; c < kend; c += 256) {
-        float sc, sh;
-        if (a.in_bn.stats) bn_live_coef(a.in_bn, c, sc, sh);
-        else { sc = a.in_scale[c]; sh = a.in_shift[c]; }
-        sTab[c - kbeg] = sc; sTab[sa.ktab + c - kbeg] = sh;
-      }
-  }
-
-  // ---- operand rows of this thread (clamped: rows / columns past the end are computed and never stored)
-  const float* xrow[NA]; const float* grow[NA]; float rowsc[NA]; bool rok[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int row = m0 + lrow + i * RSTEP;
-    rok[i] = row < a.M;
-    const int rr = rok[i] ? row : a.M - 1;
-    xrow[i] = a.x + (size_t)rr * a.K;
-    if constexpr (PRO == 1) {
-      grow[i] = a.bb.z + (size_t)rr * a.K;
-      rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
-    } else {
-      grow[i] = a.gate ? a.gate + (size_t)(rr / a.rows_per_image) * a.K : nullptr;
-      rowsc[i] = 1.f;
+    for (int c = kbeg + tid; c < kend; c += 256) {
+      float sc = 1.f, sh = 0.f;
+      if (a.in_bn.stats) bn_live_coef(a.in_bn, c, sc, sh);
+      else if (a.in_scale) { sc = a.in_scale[c]; sh = a.in_shift[c]; }
+      sTab[c - kbeg] = sc; sTab[sa.ktab + c - kbeg] = sh;
     }
-  }
-  const float* wrow[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int col = n0 + lrow + i * RSTEP;
-    wrow[i] = a.w + (size_t)(col < a.N ? col : a.N - 1) * a.K;
   }
   f32x16 acc[NT32];
 #pragma unroll
   for (int j = 0; j < NT32; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-  const bool dz_here = PRO == 1 && a.bb.dz_out != nullptr && chunk == 0;
-  const bool has_gate = PRO == 0 && a.gate != nullptr;
-  const bool swish_in = PRO == 0 && a.in_act == MMD_ACT_SWISH;
-  const bool swish_bb = PRO == 1 && a.bb.act == MMD_ACT_SWISH;
-
-  float4 ra[NA], rg4[NA], rb[NB];
-  auto gload = [&](int k0) {
-    // unconditional loads from clamped (always valid) addresses, masked at the LDS store of a tail step only
-    const int k = k0 + kq;
-    const int kc = k < kend ? k : kend - 4;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      ra[i] = mmd_ld4(xrow[i] + kc);
-      if constexpr (PRO == 1) rg4[i] = mmd_ld4(grow[i] + kc);
-      else if (has_gate) rg4[i] = mmd_ld4(grow[i] + kc);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
-  };
-  auto lstore = [&](int k0) {
-    const int k = k0 + kq;
-    const bool kok = k < kend;
-    const int j = (kok ? k : kend - 4) - kbeg;
-    if constexpr (PRO == 1) {
-      BnBwdCoef4 bq;
-      bn_bwd_tab4(sTab, sa.ktab, j, bq);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        float4 v = swish_bb ? bn_bwd_eval4(ra[i], rg4[i], rowsc[i], MMD_ACT_SWISH, bq) : bn_bwd_eval4(ra[i], rg4[i], rowsc[i], MMD_ACT_NONE, bq);
-        if (dz_here && kok && rok[i]) mmd_st4(a.bb.dz_out + (size_t)(m0 + lrow + i * RSTEP) * a.K + k, v);
-        *reinterpret_cast<float4*>(&sA[(lrow + i * RSTEP) * LD + kq]) = sl_mask(kok, v);
-      }
-    } else {
-      float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-      if (sa.has_aff) { sc = *reinterpret_cast<const float4*>(sTab + j); sh = *reinterpret_cast<const float4*>(sTab + sa.ktab + j); }
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        float4 v = ra[i];
-        if (sa.has_aff) { v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w; }
-        if (swish_in) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
-        if (has_gate) { v.x *= rg4[i].x; v.y *= rg4[i].y; v.z *= rg4[i].z; v.w *= rg4[i].w; }
-        *reinterpret_cast<float4*>(&sA[(lrow + i * RSTEP) * LD + kq]) = sl_mask(kok, v);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&sB[(lrow + i * RSTEP) * LD + kq]) = rb[i];
-  };
-  auto mma = [&](int ng) {      // ng = populated granules of the step (block-uniform)
-    const float* pa = &sA[r * LD + wave * 8 + h * 4];
-    const float* pb = &sB[r * LD + wave * 8 + h * 4];
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-      if (gi < ng) {
-        const float4 av = *reinterpret_cast<const float4*>(pa + gi * 32);
-#pragma unroll
-        for (int j = 0; j < NT32; ++j) {
-          const float4 bv = *reinterpret_cast<const float4*>(pb + j * 32 * LD + gi * 32);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  SL_T(0);
-  gload(kbeg);
   __syncthreads();                                   // the coefficient table is complete
   SL_T(1);
-  int sti = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    SL_TW(2 + 5 * sti);                              // (dev build only: the step's loads have landed)
-    lstore(k0);
-    SL_T(3 + 5 * sti);
-    __syncthreads();
-    SL_T(4 + 5 * sti);
-    if (k0 + BK < kend) gload(k0 + BK);
-    mma(min(NG, (kend - k0 + 31) >> 5));
-    SL_T(5 + 5 * sti);
-    __syncthreads();
-    SL_T(6 + 5 * sti);
-    ++sti;
+
+  // One granule: prologue of the lane's 16 A elements (each (row, k) element of the launch is evaluated by exactly one lane), then
+  // 16 MFMAs per column tile; with NEXT the loads of the wave's next granule are issued into the registers just consumed - the A
+  // operand's right behind the prologue, tile j's right behind tile j's MFMAs - so every load has a whole granule of MFMAs
+  // (NT32 x 16 x 64 cycles) to land.  No LDS in the loop, no barrier: the four waves of a block run independent K ranges.
+  auto granule = [&](int g, int gn, auto next) {
+    constexpr bool NEXT = decltype(next)::value;
+    float4 av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = kbeg + g * 32 + h * 16 + 4 * i;           // this lane's k of sub-block i (may lie past the slice's end)
+      const bool kok = kk < kend;
+      const int jt = (kok ? kk : kend - 4) - kbeg;
+      float4 v;
+      if constexpr (PRO == 1) {
+        BnBwdCoef4 bq;
+        bn_bwd_tab4(sTab, sa.ktab, jt, bq);
+        const float4 vs = bn_bwd_eval4(ra[i], rz[i], rowsc, MMD_ACT_SWISH, bq), vn = bn_bwd_eval4(ra[i], rz[i], rowsc, MMD_ACT_NONE, bq);
+        v = swish_bb ? vs : vn;
+        if (dz_here && kok) mmd_st4(a.bb.dz_out + (size_t)(m0 + r) * a.K + kk, v);
+      } else {
+        const float4 sc = *reinterpret_cast<const float4*>(sTab + jt), sh = *reinterpret_cast<const float4*>(sTab + sa.ktab + jt);
+        v = make_float4(ra[i].x * sc.x + sh.x, ra[i].y * sc.y + sh.y, ra[i].z * sc.z + sh.z, ra[i].w * sc.w + sh.w);
+        if (swish_in) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+        if (has_gate) { v.x *= rz[i].x; v.y *= rz[i].y; v.z *= rz[i].z; v.w *= rz[i].w; }
+      }
+      av[i] = sl_mask(kok, v);
+    }
+    if constexpr (NEXT) load_a(gn);
+#pragma unroll
+    for (int j = 0; j < NT32; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, rb[j][i].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, rb[j][i].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, rb[j][i].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, rb[j][i].w, acc[j], 0, 0, 0);
+      }
+      if constexpr (NEXT) load_b(gn, j);
+    }
+  };
+  if (wave < G) {
+    int g = wave;
+    int sti = 0;
+    for (; g + 4 < G; g += 4) { granule(g, g + 4, std::true_type{}); SL_T(2 + sti); ++sti; }
+    granule(g, g, std::false_type{});
   }
   SL_T(60);
 
-  // ---- cross-wave K reduction in the accumulator layout (two rounds, 2 x 32 x NW floats of scratch), then the finished tile row-major
-  float* scr = sB;                                    // [2][NT32][16][64]: lane-contiguous, conflict-free
-  auto put = [&](int slot) {
+  // ---- cross-wave K reduction as a reduce-scatter: tile j is finished by wave j % 4; every other wave hands its accumulators of that tile
+  // over in LDS (lane-contiguous float4: conflict-free ds_write_b128 / ds_read_b128), one barrier, then the owner adds the three and
+  // writes the tile row-major for the vectorised epilogue
 #pragma unroll
-    for (int j = 0; j < NT32; ++j)
+  for (int j = 0; j < NT32; ++j) {
+    const int owner = j & 3;
+    if (wave != owner) {
+      const int idx = (wave - owner - 1) & 3;       // 0..2
 #pragma unroll
-      for (int q = 0; q < 16; ++q) scr[((slot * NT32 + j) * 16 + q) * 64 + lane] = acc[j][q];
-  };
-  auto add = [&](int slot) {
-#pragma unroll
-    for (int j = 0; j < NT32; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[j][q] += scr[((slot * NT32 + j) * 16 + q) * 64 + lane];
-  };
-  if (wave >= 2) put(wave - 2);
+      for (int qq = 0; qq < 4; ++qq)
+        *reinterpret_cast<float4*>(&scr[(((j * 3 + idx) * 4 + qq) * 64 + lane) * 4]) =
+            make_float4(acc[j][4 * qq], acc[j][4 * qq + 1], acc[j][4 * qq + 2], acc[j][4 * qq + 3]);
+    }
+  }
   __syncthreads();
-  if (wave < 2) add(wave);
-  __syncthreads();
-  if (wave == 1) put(0);
-  __syncthreads();
-  float* tile = sB;                                   // [32][NW]
-  if (wave == 0) add(0);
-  __syncthreads();                                    // (every wave is past its scratch reads before wave 0 overwrites the scratch)
-  if (wave == 0) {
 #pragma unroll
-    for (int j = 0; j < NT32; ++j)
+  for (int j = 0; j < NT32; ++j) {
+    if (wave == (j & 3)) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-        tile[row * NW + j * 32 + r] = acc[j][q];
-      }
+      for (int idx = 0; idx < 3; ++idx)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float4 u = *reinterpret_cast<const float4*>(&scr[(((j * 3 + idx) * 4 + qq) * 64 + lane) * 4]);
+          acc[j][4 * qq] += u.x; acc[j][4 * qq + 1] += u.y; acc[j][4 * qq + 2] += u.z; acc[j][4 * qq + 3] += u.w;
+        }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tile[((q & 3) + 8 * (q >> 2) + 4 * h) * NW + j * 32 + r] = acc[j][q];
+    }
   }
   __syncthreads();
   SL_T(61);
@@ -306,48 +306,73 @@ __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
     SL_TW(62);
     return;
   }
-  slab_epilogue(a, m0, n0, NC4, LG, [&](int rl, int c4) { return *reinterpret_cast<const float4*>(&tile[rl * NW + c4 * 4]); }, tile + SL_BM * NW);
+  slab_epilogue<SL_BM, (SL_BM >> (8 - LG))>(a, m0, n0, NC4, LG, [&](int rl, int c4) { return *reinterpret_cast<const float4*>(&tile[rl * NW + c4 * 4]); },
+                                            tile + SL_BM * NW);
   SL_TW(62);
 }
 
-// Combine launch of a K-sliced slab GEMM: adds the slices' partial slabs in slice order and runs the epilogue.  One block per 32 rows x
-// column chunk (the same decomposition, so the BatchNorm-sum atomics per address are what the GEMM launch itself would issue).
-__global__ __launch_bounds__(256) void pw_slab_combine_kernel(SlabArgs sa, int nw, int lg) {
+// Combine launch of a K-sliced slab GEMM: adds the slices' partial slabs in slice order and runs the epilogue.  One block per 16 rows x
+// column chunk (twice the GEMM launch's row slabs: 128 blocks at M = 2048, every thread with all its loads - NS partials, residual, the
+// BatchNorm sums' z for each of its rows - in flight at once; the first version, 64 blocks walking 8 rows one dependent round trip at a
+// time, took 16 us).
+template <int NS, int LG>
+__global__ __launch_bounds__(256) void pw_slab_combine_kernel(SlabArgs sa, int nw) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BR = 16, R = (BR >> (8 - LG)) > 0 ? (BR >> (8 - LG)) : 1;
   const PwArgs& a = sa.p;
-  const int chunk = blockIdx.x % sa.nchunk, slab = blockIdx.x / sa.nchunk;
-  const int m0 = slab * SL_BM, n0 = chunk * nw;
+  const int chunk = blockIdx.x % sa.nchunk, sub = blockIdx.x / sa.nchunk;
+  const int m0 = sub * BR, n0 = chunk * nw;
   const int NWT = sa.nchunk * nw;
-  const size_t sstride = (size_t)(gridDim.x / sa.nchunk) * SL_BM * NWT;
+  const size_t sstride = (size_t)((gridDim.x / sa.nchunk + 1) / 2) * SL_BM * NWT;      // rows of a slice's slab: whole 32-row slabs
   const float* src = sa.part + (size_t)m0 * NWT + n0;
-  const int ns = sa.nslice;
   SL_T(64);
-  slab_epilogue(a, m0, n0, nw / 4, lg, [&](int rl, int c4) {
+  slab_epilogue<BR, R>(a, m0, n0, nw / 4, LG, [&](int rl, int c4) {
     const float* p = src + (size_t)rl * NWT + c4 * 4;
-    float4 v = mmd_ld4(p);
-    for (int s = 1; s < ns; ++s) { const float4 u = mmd_ld4(p + s * sstride); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    float4 u[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) u[s] = mmd_ld4(p + s * sstride);
+    float4 v = u[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) { v.x += u[s].x; v.y += u[s].y; v.z += u[s].z; v.w += u[s].w; }
     return v;
   }, smem);
   SL_TW(65);
 }
 
 typedef void (*SlabKern)(SlabArgs);
-template <int BK, int PRO>
+typedef void (*SlabComb)(SlabArgs, int);
+template <int PRO>
 static SlabKern slab_pick_nt(int nt32) {
   switch (nt32) {
-    case 2: return pw_slab_kernel<2, BK, PRO>;
-    case 3: return pw_slab_kernel<3, BK, PRO>;
-    case 4: return pw_slab_kernel<4, BK, PRO>;
-    case 5: return pw_slab_kernel<5, BK, PRO>;
-    case 6: return pw_slab_kernel<6, BK, PRO>;
-    case 7: return pw_slab_kernel<7, BK, PRO>;
-    case 8: return pw_slab_kernel<8, BK, PRO>;
+    case 2: return pw_slab_kernel<2, PRO>;
+    case 3: return pw_slab_kernel<3, PRO>;
+    case 4: return pw_slab_kernel<4, PRO>;
+    case 5: return pw_slab_kernel<5, PRO>;
+    case 6: return pw_slab_kernel<6, PRO>;
+    case 7: return pw_slab_kernel<7, PRO>;
+    case 8: return pw_slab_kernel<8, PRO>;
+    default: return nullptr;
+  }
+}
+template <int NS>
+static SlabComb slab_pick_comb_lg(int lg) {
+  return lg == 4 ? pw_slab_combine_kernel<NS, 4> : lg == 5 ? pw_slab_combine_kernel<NS, 5> : lg == 6 ? pw_slab_combine_kernel<NS, 6> : nullptr;
+}
+static SlabComb slab_pick_comb(int ns, int lg) {
+  switch (ns) {
+    case 2: return slab_pick_comb_lg<2>(lg);
+    case 3: return slab_pick_comb_lg<3>(lg);
+    case 4: return slab_pick_comb_lg<4>(lg);
+    case 5: return slab_pick_comb_lg<5>(lg);
+    case 6: return slab_pick_comb_lg<6>(lg);
+    case 7: return slab_pick_comb_lg<7>(lg);
+    case 8: return slab_pick_comb_lg<8>(lg);
     default: return nullptr;
   }
 }
 
 // Geometry of a launch: -> false when the slab kernel does not cover it
-struct SlabPlan { int nt32, nchunk, nslab, nslice, gran, bk, ktab; size_t lds; long long part_floats; };
+struct SlabPlan { int nt32, nchunk, nslab, nslice, gran, ktab, lg; size_t lds; long long part_floats; };
 static bool slab_plan(int M, int K, int N, int pro, SlabPlan& p) {
   if (M <= 0 || (K & 3) || (N & 3) || K < 128 || N < 36) return false;
   const int tiles = cdiv(N, 32);
@@ -358,24 +383,20 @@ static bool slab_plan(int M, int K, int N, int pro, SlabPlan& p) {
   const int blocks = p.nslab * p.nchunk;
   const int gtot = cdiv(K, 32);
   static const int target = getenv("MMD_SLAB_BLOCKS") ? atoi(getenv("MMD_SLAB_BLOCKS")) : 256;
-  // K slices: fill the chip (about one block per CU), at least 4 granules (128 k) per slice
+  // K slices: fill the chip (about one block per CU); at least 8 granules per slice (two per wave), at most 8 slices
   int ns = blocks >= target ? 1 : target / blocks;
-  ns = max(1, min(ns, gtot / 4));
+  ns = max(1, min(min(ns, 8), gtot / 8));
   p.gran = cdiv(gtot, ns);
   p.nslice = cdiv(gtot, p.gran);
   const int nco = pro == 1 ? 5 : 2;
-  // BK = 128 where the tiles + the coefficient table fit (one block per CU either way), BK = 64 otherwise
-  static const int bk_env = getenv("MMD_SLAB_BK") ? atoi(getenv("MMD_SLAB_BK")) : 0;
-  for (int bk = (bk_env == 64 ? 64 : 128); bk >= 64; bk -= 64) {
-    p.bk = bk;
-    p.ktab = cdiv(p.gran * 32, bk) * bk;
-    p.lds = ((size_t)(SL_BM + p.nt32 * 32) * (bk + 4) + (size_t)nco * p.ktab) * sizeof(float);
-    // after the K loop the B tile's space holds: reduction scratch 2 x 32 x NW floats, then the finished tile 32 x NW + the epilogue's
-    // sums (2 x RG x NW <= 16 x NW with RG <= 8): 48 x NW floats - both within NW x (BK + 4)
-    if (p.lds <= 158 * 1024) break;
-    if (bk == 64) return false;
-  }
-  p.part_floats = p.nslice > 1 ? (long long)p.nslice * p.nslab * SL_BM * p.nchunk * p.nt32 * 32 : 0;
+  p.ktab = p.gran * 32;
+  const int nw = p.nt32 * 32, nc4 = nw / 4;
+  p.lg = nc4 <= 16 ? 4 : nc4 <= 32 ? 5 : 6;
+  // table | the non-owners' accumulators [NT32][3][4 KB] | finished tile [32][NW] | epilogue sums [2 RG][NW]
+  p.lds = ((size_t)nco * p.ktab + (size_t)p.nt32 * 3 * 1024 + (size_t)SL_BM * nw + (size_t)2 * (256 >> p.lg) * nw) * sizeof(float);
+  if (p.lds > 158 * 1024) return false;
+  if (pro == 1 && cdiv(p.gran * 32, 256) > p.nslab) return false;      // (dgamma / dbeta: one 256-channel group per row slab's block)
+  p.part_floats = p.nslice > 1 ? (long long)p.nslice * p.nslab * SL_BM * p.nchunk * nw : 0;
   return true;
 }
 
@@ -409,25 +430,24 @@ int pw_slab_try(PwArgs& a, float* ws, long long ws_floats, bool auto_ok, hipStre
   SlabArgs sa{};
   sa.p = a; sa.nchunk = p.nchunk; sa.nslice = p.nslice; sa.gran = p.gran; sa.ktab = p.ktab; sa.part = ws;
   sa.has_aff = (!pro && (a.in_scale || a.in_bn.stats)) ? 1 : 0;
-  SlabKern kern = p.bk == 128 ? (pro ? slab_pick_nt<128, 1>(p.nt32) : slab_pick_nt<128, 0>(p.nt32))
-                              : (pro ? slab_pick_nt<64, 1>(p.nt32) : slab_pick_nt<64, 0>(p.nt32));
-  if (!kern) return 0;
-  {       // raise the kernel's dynamic-LDS limit once per instantiation (at most 28 of them)
-    static SlabKern done[32]; static int ndone = 0;
+  SlabKern kern = pro ? slab_pick_nt<1>(p.nt32) : slab_pick_nt<0>(p.nt32);
+  SlabComb comb = p.nslice > 1 ? slab_pick_comb(p.nslice, p.lg) : nullptr;
+  if (!kern || (p.nslice > 1 && !comb)) return 0;
+  {       // raise the kernel's dynamic-LDS limit once per instantiation (14 of them)
+    static SlabKern done[16]; static int ndone = 0;
     bool seen = false;
     for (int i = 0; i < ndone; ++i) seen |= done[i] == kern;
     if (!seen) {
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MMD_ELAUNCH;
-      if (ndone < 32) done[ndone++] = kern;
+      if (ndone < 16) done[ndone++] = kern;
     }
   }
   const int nblk = p.nslab * p.nchunk * p.nslice;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), p.lds, stream, sa);
   if (p.nslice > 1) {
-    const int nw = p.nt32 * 32, nc4 = nw / 4;
-    const int lg = nc4 <= 16 ? 4 : nc4 <= 32 ? 5 : nc4 <= 64 ? 6 : 7;
-    const size_t lds = (size_t)2 * (256 >> lg) * nw * sizeof(float);
-    hipLaunchKernelGGL(pw_slab_combine_kernel, dim3(p.nslab * p.nchunk), dim3(256), lds, stream, sa, nw, lg);
+    const int nw = p.nt32 * 32;
+    const size_t lds = (size_t)2 * (256 >> p.lg) * nw * sizeof(float);
+    hipLaunchKernelGGL(comb, dim3(2 * p.nslab * p.nchunk), dim3(256), lds, stream, sa, nw);
   }
   return 1;
 }

@@ -45,13 +45,12 @@ for form in (4, 2):
     print(f"form {form}: M {M} Kred {KR} Nout {NO}  ws floats {nws}  event {ev / n:.1f} us")
     if rows:
         r = [x / n for x in rows]
-        print(f"   block 0: start -> table + first loads issued {r[1] - r[0]:.2f}")
-        s = 0
-        while r[2 + 5 * s] > 0 and 6 + 5 * s < 60 and r[6 + 5 * s] >= r[2 + 5 * s]:
-            b = 2 + 5 * s
-            prev = r[1] if s == 0 else r[b - 1]
-            print(f"   step {s}: load wait {r[b] - prev:5.2f}  prologue+store {r[b + 1] - r[b]:5.2f}  barrier {r[b + 2] - r[b + 1]:5.2f}  issue+mma {r[b + 3] - r[b + 2]:5.2f}  barrier {r[b + 4] - r[b + 3]:5.2f}")
-            s += 1
+        print(f"   block 0 / wave 0: start -> first loads issued + table filled {r[1] - r[0]:.2f}")
+        prev, i = r[1], 0
+        while 2 + i < 60 and r[2 + i] > prev:
+            print(f"   granule {i}: {r[2 + i] - prev:5.2f}")
+            prev = r[2 + i]; i += 1
+        print(f"   last granule: {r[60] - prev:5.2f}")
         print(f"   reduction + tile {r[61] - r[60]:.2f}   write-out / epilogue {r[62] - r[61]:.2f}   kernel body {r[62] - r[0]:.2f}")
         if r[65] > r[64] > 0:
             print(f"   combine launch: starts {r[64] - r[62]:.2f} after block 0's end, body {r[65] - r[64]:.2f};  first stamp -> last stamp {r[65] - r[0]:.2f}")
