@@ -59,6 +59,7 @@ __device__ __forceinline__ void pw_p5_acc(const Pool5Op& p, const P5Coef& q, con
 #define PW_BM 128
 #define PW_BK 32
 #define PW_LD 36
+#define PW_LDH 20      // bf16 mode: words per tile row (PW_BK / 2 data + 4 pad)
 
 // NKL = 8-wide k groups of the LAST K tile that hold data (1..4): fp32 MFMA runs at the vector rate (64 cycles per
 // 32x32x2), so multiplying the zero padding of K = 112 / 48 / 24 ... is real time.  Compile-time so the hot loop keeps its schedule
@@ -85,6 +86,8 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   __shared__ float sRed5[(PRO == 1) ? 5 * 4 * BN_T : 1];      // Pool5Op sums (BatchNorm-backward operand launches only)
   float* const sA = smem;
   float* const sB = smem + BM_T * PW_LD;
+  unsigned* const sAu = reinterpret_cast<unsigned*>(smem);                   // BF: bf16 tiles, two elements per word, [row][PW_LDH]
+  unsigned* const sBu = reinterpret_cast<unsigned*>(smem) + BM_T * PW_LDH;
 
   const int tid = threadIdx.x;
   const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
@@ -225,11 +228,20 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
       }
       if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
-      *reinterpret_cast<float4*>(&sA[(lrow + i * 32) * PW_LD + kq]) = v;
+      if constexpr (BF) {
+        // bf16 mode (round 6): the tile is stored as bf16 - rounded ONCE here (RNE, v_cvt_pk_bf16_f32) instead of by every lane in front of
+        // every MFMA (12 converts + 6 ds_read_b128 per two MFMAs: the 16x faster pipe bought 24 %) - rows of PW_BK bf16 + 8 pad = 20 words
+        *reinterpret_cast<uint2*>(&sAu[(lrow + i * 32) * PW_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+      } else {
+        *reinterpret_cast<float4*>(&sA[(lrow + i * 32) * PW_LD + kq]) = v;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
+    for (int i = 0; i < NB; ++i) {
+      const float4 w4 = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
+      if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 32) * PW_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
+      else *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = w4;
+    }
   };
 
   const int nk = (a.K + PW_BK - 1) / PW_BK;
@@ -247,14 +259,15 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[j], 0, 0, 0);
     }
   };
-  const float* const pa16 = &sA[(wm * 32 + r) * PW_LD + h * 8];
-  const float* const pb16 = &sB[(wn * NS * 32 + r) * PW_LD + h * 8];
+  // lane (r, h) supplies row r, k = 16 g + 8 h .. + 7: eight bf16 = ONE 16-byte LDS read per operand (row stride 20 words: conflict-free
+  // for the hardware's ds_read_b128 lane groups, tools/dev/lds_bank_model.py)
+  const unsigned* const pa16 = &sAu[(wm * 32 + r) * PW_LDH + h * 4];
+  const unsigned* const pb16 = &sBu[(wn * NS * 32 + r) * PW_LDH + h * 4];
   auto mma16 = [&](int g) {      // one 16-wide k group on the bf16 MFMA
-    const bf16x8 av = pack_bf16x8(*reinterpret_cast<const float4*>(pa16 + g * 16), *reinterpret_cast<const float4*>(pa16 + g * 16 + 4));
+    const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(pa16 + g * 8));
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      const float* q = pb16 + j * 32 * PW_LD + g * 16;
-      const bf16x8 bv = pack_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+      const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(pb16 + j * 32 * PW_LDH + g * 8));
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
     }
   };
@@ -432,6 +445,7 @@ static size_t pw_bq_lds(PwArgs& a, const void* kern, size_t static_bytes) {
 #define SK_BN 64
 #define SK_BK 128
 #define SK_LD 132
+#define SK_LDH 68      // bf16 mode: words per tile row (SK_BK / 2 data + 4 pad)
 
 // -DMMD_KSTAMPS (dev build, tools/dev/skinny_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock along the K loop
 #ifdef MMD_KSTAMPS
@@ -450,6 +464,8 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
   __shared__ float sRed[2 * 4 * SK_BN];
   __shared__ float sRed5[(PRO == 1) ? 5 * 4 * SK_BN : 1];
+  unsigned* const sAu = reinterpret_cast<unsigned*>(sA);      // BF: bf16 tiles [row][SK_LDH words]
+  unsigned* const sBu = reinterpret_cast<unsigned*>(sB);
   const int tid = threadIdx.x;
   const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
   const int tn = t % a.ntn, tm = t / a.ntn;
@@ -554,23 +570,27 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       if (a.gate) { v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w; }
       }
       if (!(s.kok && rok[i])) v = make_float4(0, 0, 0, 0);
-      *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
+      if constexpr (BF) *reinterpret_cast<uint2*>(&sAu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+      else *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = (s.kok && wok[i]) ? s.rb[i] : make_float4(0, 0, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+      const float4 w4 = (s.kok && wok[i]) ? s.rb[i] : make_float4(0, 0, 0, 0);
+      if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
+      else *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = w4;
+    }
   };
   auto mma = [&]() {
     if constexpr (BF) {
-      const float* pa = &sA[r * SK_LD + wave * 32 + h * 8];
-      const float* pb = &sB[r * SK_LD + wave * 32 + h * 8];
+      // bf16 tiles (rounded once at the LDS store): one 16-byte read per operand and MFMA, no per-lane conversion
+      const unsigned* pa = &sAu[r * SK_LDH + wave * 16 + h * 4];
+      const unsigned* pb = &sBu[r * SK_LDH + wave * 16 + h * 4];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const bf16x8 av = pack_bf16x8(*reinterpret_cast<const float4*>(pa + g * 16), *reinterpret_cast<const float4*>(pa + g * 16 + 4));
+        const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(pa + g * 8));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float* q = pb + j * 32 * SK_LD + g * 16;
-          const bf16x8 bv = pack_bf16x8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+          const bf16x8 bv = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(pb + j * 32 * SK_LDH + g * 8));
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
         }
       }
@@ -1075,8 +1095,10 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
   if (!w16 && !grouped) {
     // all-N K-sliced slab kernel (pw_slab.hip, round 6): the launches the skinny kernel would run with an arithmetic prologue (BatchNorm
     // backward operand, or affine / swish / gate) and more than one column tile - there the prologue is re-evaluated per 64-wide tile
+    // (measured per shape, profiles/r06_notes.md: the BatchNorm-backward operand launches gain 10 - 24 %; the forward form - affine / swish /
+    // gate operand - only where N > 224 splits into column chunks, 58 vs 70 us, and is within +-5 % of the skinny kernel elsewhere)
     const bool slab_auto = take_skinny && !a.p5.z && N > 64 && K >= 256 &&
-                           (a.bb.z || a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE);
+                           (a.bb.z || ((a.in_scale || a.in_bn.stats || a.in_act != MMD_ACT_NONE) && N > 224));
     slab_rc = pw_slab_try(a, a.slab_ws, a.slab_ws_floats, slab_auto, stream);
     if (slab_rc < 0) return slab_rc;
   }

@@ -120,15 +120,19 @@ __device__ __forceinline__ void slab_epilogue(const PwArgs& a, int m0, int n0, i
   }
 }
 
-// Rows per thread of the epilogue: 32 / (256 >> LG)
-template <int NT32, int PRO>
+// DZK: the BatchNorm-backward launches' stored dz - 0 = none, 1 = every row slab whole (M % 32 == 0: stored without a per-lane guard), 2 = guarded
+template <int NT32, int PRO, int DZK>
 __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
   constexpr int NW = NT32 * 32;           // columns of the block
   constexpr int NCO = (PRO == 1) ? 5 : 2; // table rows
+  constexpr int GLD = 36;                 // floats per staged row: a granule's 32 k + 4 pad (conflict-free ds_read_b128 of the MFMA fragments)
+  constexpr int WREG = (32 + NW) * GLD;   // floats of one wave's private staging region: A [32][36] | B [NW][36]
+  constexpr int NBI = NW / 8;             // B load instructions per granule (8 rows x 128 bytes each)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sTab = smem;                     // [NCO][ktab]; dead after the K loop
   const PwArgs& a = sa.p;
-  float* scr = smem + NCO * sa.ktab;      // [NT32][3][4][64] float4: the non-owners' accumulators of every tile
+  float* sTab = smem;                     // [NCO][ktab]
+  float* stage = smem + NCO * sa.ktab;    // [4 waves][WREG]; after the K loop: reduction scratch | finished tile | epilogue sums
+  float* scr = stage;                     // [NT32][3][4][64] float4: the non-owners' accumulators of every tile
   float* tile = scr + NT32 * 3 * 1024;    // [32][NW] finished dot products, row-major
   const int tid = threadIdx.x;
   const int t = blockIdx.x;
@@ -139,128 +143,188 @@ __global__ __launch_bounds__(256) void pw_slab_kernel(SlabArgs sa) {
   const int G = (kend - kbeg + 31) >> 5;  // 32-wide k granules of the slice; wave w takes granules w, w + 4, ...
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const wA = stage + (size_t)wave * WREG;      // this wave's staged A granule [32][GLD]
+  float* const wB = wA + 32 * GLD;                    // ... and B granule [NW][GLD]
   SL_T(0);
 
-  // ---- operand rows of this lane, in the MFMA operand layout: lane (r, h) holds row r, k = 16 h + {0..15} of a granule (one float4 per i,
-  // i = 0..3: 64 contiguous bytes per lane, the two halves of a wave cover one 128-byte line per row and load group - every line is
-  // fetched by exactly ONE wave, no LDS round trip for either operand).  Rows / columns past the end are clamped: computed, never stored.
-  const int arow = min(m0 + r, a.M - 1);
-  const float* xrow = a.x + (size_t)arow * a.K + h * 16;
-  const float* grow = nullptr;
-  float rowsc = 1.f;
-  if constexpr (PRO == 1) {
-    grow = a.bb.z + (size_t)arow * a.K + h * 16;
-    rowsc = a.bb.mul_b ? a.bb.mul_b[arow / a.bb.rows_per_image] : 1.f;
-  } else {
-    if (a.gate) grow = a.gate + (size_t)(arow / a.rows_per_image) * a.K + h * 16;
-  }
-  const float* wrow[NT32];
+  // ---- A wave owns whole granules (32 k = one 128-byte line per row) of the slice and stages them through its OWN LDS region: loads are
+  // row-contiguous (lane = 16-byte piece p of row q + 8 it: eight lanes cover a row's line - fully coalesced; loading straight in the MFMA
+  // operand layout, one row per lane, ran at one lane per cycle in the texture addresser and bound the loop), the prologue runs on the
+  // coalesced registers (every (row, k) element of the launch is evaluated by exactly one lane), the MFMA fragments are read back from
+  // LDS.  Nothing is shared between waves, so the K loop has no barrier; rows / columns past the end are clamped: computed, never stored.
+  const int p = lane & 7, q = lane >> 3;
+  const float* xrow[4]; const float* grow[4]; float rowsc[4]; bool rok[4];
 #pragma unroll
-  for (int j = 0; j < NT32; ++j) wrow[j] = a.w + (size_t)min(n0 + j * 32 + r, a.N - 1) * a.K + h * 16;
-  const bool dz_here = PRO == 1 && a.bb.dz_out != nullptr && chunk == 0 && m0 + r < a.M;
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + q + 8 * i;
+    rok[i] = row < a.M;
+    const int rr = rok[i] ? row : a.M - 1;
+    xrow[i] = a.x + (size_t)rr * a.K;
+    grow[i] = nullptr; rowsc[i] = 1.f;
+    if constexpr (PRO == 1) {
+      grow[i] = a.bb.z + (size_t)rr * a.K;
+      rowsc[i] = a.bb.mul_b ? a.bb.mul_b[rr / a.bb.rows_per_image] : 1.f;
+    } else {
+      if (a.gate) grow[i] = a.gate + (size_t)(rr / a.rows_per_image) * a.K;
+    }
+  }
+  int wofs[NBI];                                     // B row q + 8 it (clamped to the last column), as a 32-bit element offset
+#pragma unroll
+  for (int it = 0; it < NBI; ++it) wofs[it] = min(n0 + q + 8 * it, a.N - 1) * a.K;
+  const bool dz_here = PRO == 1 && a.bb.dz_out != nullptr && chunk == 0;
   const bool has_gate = PRO == 0 && a.gate != nullptr;
   const bool swish_in = PRO == 0 && a.in_act == MMD_ACT_SWISH;
   const bool swish_bb = PRO == 1 && a.bb.act == MMD_ACT_SWISH;
 
-  // k offset (floats, from the row start) of sub-block i of granule g for this lane, clamped inside the slice (a tail granule's surplus
-  // elements are zeroed on the A side)
-  auto koff = [&](int g, int i) { return min(kbeg + g * 32 + 4 * i, kend - 4 - h * 16); };      // (>= 0: a slice ends at k >= 128)
-  float4 ra[4], rz[4], rb[NT32][4];
+  // this lane's k (from the row start) in granule g, clamped inside the slice (a tail granule's surplus elements are zeroed on the A side)
+  auto koff = [&](int g) { return min(kbeg + g * 32 + 4 * p, kend - 4); };
+  float4 ra[4], rz[4], rb[NBI];
   auto load_a = [&](int g) {
+    const int k = koff(g);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = koff(g, i);
-      ra[i] = mmd_ld4(xrow + k);
-      if constexpr (PRO == 1) rz[i] = mmd_ld4(grow + k);
-      else if (has_gate) rz[i] = mmd_ld4(grow + k);
+      ra[i] = mmd_ld4(xrow[i] + k);
+      if constexpr (PRO == 1) rz[i] = mmd_ld4(grow[i] + k);
+      else if (has_gate) rz[i] = mmd_ld4(grow[i] + k);
     }
   };
-  auto load_b = [&](int g, int j) {
+  auto load_b = [&](int g) {
+    const int k = koff(g);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[j][i] = mmd_ld4(wrow[j] + koff(g, i));
+    for (int it = 0; it < NBI; ++it) rb[it] = mmd_ld4(a.w + (wofs[it] + k));
   };
   // first granule's loads in flight while the coefficient table is filled
   const int g0 = wave < G ? wave : 0;
   load_a(g0);
-#pragma unroll
-  for (int j = 0; j < NT32; ++j) load_b(g0, j);
+  load_b(g0);
 
-  // ---- per-channel coefficients of the slice, once per block
-  if constexpr (PRO == 1) {
-    // dgamma / dbeta (+)= the reduce pass' sums: channel group `it` (256 channels) of a slice by that slice's block of row slab `it` - one
-    // round per block, riding on the sums the table fill loads anyway (block 0 doing all K channels was the launch's slowest block by 5+ us)
-    const bool dg = a.bb.dgamma != nullptr && chunk == 0;
-    int it = 0;
-    for (int c = kbeg + tid; c < kend; c += 256, ++it) {
-      float a1, a2, a3, mu, sh;
-      bn_bwd_coef(a.bb, c, a1, a2, a3, mu, sh);
-      const int j = c - kbeg;
-      sTab[j] = a1; sTab[sa.ktab + j] = a2; sTab[2 * sa.ktab + j] = a3; sTab[3 * sa.ktab + j] = mu; sTab[4 * sa.ktab + j] = sh;
-      if (dg && it == slab) { a.bb.dgamma[c] += (float)a.bb.sums[a.K + c]; a.bb.dbeta[c] += (float)a.bb.sums[c]; }
-    }
-  } else {
-    for (int c = kbeg + tid; c < kend; c += 256) {
-      float sc = 1.f, sh = 0.f;
-      if (a.in_bn.stats) bn_live_coef(a.in_bn, c, sc, sh);
-      else if (a.in_scale) { sc = a.in_scale[c]; sh = a.in_shift[c]; }
-      sTab[c - kbeg] = sc; sTab[sa.ktab + c - kbeg] = sh;
+  // ---- per-channel coefficients of the slice, once per block.  A thread owns channels kbeg + tid + 256 u; the loads of all its channels
+  // are issued before the first use (clamped addresses): one round trip for the table instead of one per 256 channels.
+  constexpr int TU = 3;                              // channels per thread (slices of up to 768 channels; longer ones loop)
+  for (int cb = kbeg; cb < kend; cb += 256 * TU) {
+    if constexpr (PRO == 1) {
+      // dgamma / dbeta (+)= the reduce pass' sums: channel group `it` (256 channels) of a slice by that slice's block of row slab `it` - one
+      // round per block, riding on the sums the table fill loads anyway (block 0 doing all K channels was the launch's slowest block by 5+ us)
+      const bool dg = a.bb.dgamma != nullptr && chunk == 0;
+      double s0[TU], s1[TU]; float is[TU], scl[TU], mn[TU], shf[TU];
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int c = min(cb + tid + 256 * u, kend - 1);
+        s0[u] = a.bb.sums[c]; s1[u] = a.bb.sums[a.bb.C + c]; is[u] = a.bb.invstd[c]; scl[u] = a.bb.scale[c]; mn[u] = a.bb.mean[c]; shf[u] = a.bb.shift[c];
+      }
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int c = cb + tid + 256 * u;
+        if (c < kend) {
+          const float m1 = (float)(s0[u] * a.bb.inv_count), m2 = (float)(s1[u] * a.bb.inv_count);      // (bn_bwd_coef's arithmetic)
+          const int j = c - kbeg;
+          sTab[j] = scl[u]; sTab[sa.ktab + j] = -scl[u] * is[u] * m2; sTab[2 * sa.ktab + j] = -scl[u] * m1;
+          sTab[3 * sa.ktab + j] = mn[u]; sTab[4 * sa.ktab + j] = shf[u];
+          if (dg && (c - kbeg) / 256 == slab) { a.bb.dgamma[c] += (float)s1[u]; a.bb.dbeta[c] += (float)s0[u]; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int c = cb + tid + 256 * u;
+        if (c < kend) {
+          float sc = 1.f, sh = 0.f;
+          if (a.in_bn.stats) bn_live_coef(a.in_bn, c, sc, sh);
+          else if (a.in_scale) { sc = a.in_scale[c]; sh = a.in_shift[c]; }
+          sTab[c - kbeg] = sc; sTab[sa.ktab + c - kbeg] = sh;
+        }
+      }
     }
   }
   f32x16 acc[NT32];
 #pragma unroll
   for (int j = 0; j < NT32; ++j)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    for (int qq = 0; qq < 16; ++qq) acc[j][qq] = 0.f;
   __syncthreads();                                   // the coefficient table is complete
   SL_T(1);
 
-  // One granule: prologue of the lane's 16 A elements (each (row, k) element of the launch is evaluated by exactly one lane), then
-  // 16 MFMAs per column tile; with NEXT the loads of the wave's next granule are issued into the registers just consumed - the A
-  // operand's right behind the prologue, tile j's right behind tile j's MFMAs - so every load has a whole granule of MFMAs
-  // (NT32 x 16 x 64 cycles) to land.  No LDS in the loop, no barrier: the four waves of a block run independent K ranges.
-  auto granule = [&](int g, int gn, auto next) {
+  // One granule: prologue on the coalesced registers -> this wave's LDS region (+ the stored dz), B rows -> LDS, then (NEXT) the loads of the
+  // wave's next granule into the registers just stored - they have the granule's NT32 x 16 MFMAs (x 64 cycles) to land - and the MFMAs on
+  // fragments read back from LDS.  DS operations of one wave execute in issue order, so the write -> read hand-off inside the wave needs
+  // no barrier (the fence keeps the compiler from reordering them).
+  // DZ: 0 = no dz side output, 1 = stored unconditionally (whole 32-row slab, whole granule: the common case), 2 = per-lane guard.  A guarded
+  // store is a branch, and behind a branch hipcc's wait counting starts over: every later use of a prefetched register waited vmcnt(0),
+  // i.e. for the stores just issued - so the guard is compiled in only where a tail needs it.
+  auto granule = [&](int g, int gn, auto next, auto dzc) __attribute__((always_inline)) {
     constexpr bool NEXT = decltype(next)::value;
-    float4 av[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kk = kbeg + g * 32 + h * 16 + 4 * i;           // this lane's k of sub-block i (may lie past the slice's end)
-      const bool kok = kk < kend;
-      const int jt = (kok ? kk : kend - 4) - kbeg;
-      float4 v;
-      if constexpr (PRO == 1) {
-        BnBwdCoef4 bq;
-        bn_bwd_tab4(sTab, sa.ktab, jt, bq);
-        const float4 vs = bn_bwd_eval4(ra[i], rz[i], rowsc, MMD_ACT_SWISH, bq), vn = bn_bwd_eval4(ra[i], rz[i], rowsc, MMD_ACT_NONE, bq);
-        v = swish_bb ? vs : vn;
-        if (dz_here && kok) mmd_st4(a.bb.dz_out + (size_t)(m0 + r) * a.K + kk, v);
-      } else {
-        const float4 sc = *reinterpret_cast<const float4*>(sTab + jt), sh = *reinterpret_cast<const float4*>(sTab + sa.ktab + jt);
-        v = make_float4(ra[i].x * sc.x + sh.x, ra[i].y * sc.y + sh.y, ra[i].z * sc.z + sh.z, ra[i].w * sc.w + sh.w);
-        if (swish_in) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
-        if (has_gate) { v.x *= rz[i].x; v.y *= rz[i].y; v.z *= rz[i].z; v.w *= rz[i].w; }
-      }
-      av[i] = sl_mask(kok, v);
-    }
-    if constexpr (NEXT) load_a(gn);
-#pragma unroll
-    for (int j = 0; j < NT32; ++j) {
+    constexpr int DZ = decltype(dzc)::value;
+    const int kk = kbeg + g * 32 + 4 * p;                      // this lane's k (may lie past the slice's end in a tail granule)
+    const bool kok = kk < kend;
+    const int jt = (kok ? kk : kend - 4) - kbeg;
+    if constexpr (PRO == 1) {
+      BnBwdCoef4 bq;
+      bn_bwd_tab4(sTab, sa.ktab, jt, bq);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, rb[j][i].x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, rb[j][i].y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, rb[j][i].z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, rb[j][i].w, acc[j], 0, 0, 0);
+        const float4 vs = bn_bwd_eval4(ra[i], rz[i], rowsc[i], MMD_ACT_SWISH, bq), vn = bn_bwd_eval4(ra[i], rz[i], rowsc[i], MMD_ACT_NONE, bq);
+        const float4 v = swish_bb ? vs : vn;
+        // (DZ 1 stores from every column chunk's block: the chunks evaluate identical values - N > 224 only)
+        if constexpr (DZ == 1) mmd_st4(a.bb.dz_out + (size_t)(m0 + q + 8 * i) * a.K + kk, v);
+        else if constexpr (DZ == 2) { if (dz_here && kok && rok[i]) mmd_st4(a.bb.dz_out + (size_t)(m0 + q + 8 * i) * a.K + kk, v); }
+        *reinterpret_cast<float4*>(&wA[(q + 8 * i) * GLD + 4 * p]) = sl_mask(kok, v);
       }
-      if constexpr (NEXT) load_b(gn, j);
+    } else {
+      const float4 sc = *reinterpret_cast<const float4*>(sTab + jt), sh = *reinterpret_cast<const float4*>(sTab + sa.ktab + jt);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 v = make_float4(ra[i].x * sc.x + sh.x, ra[i].y * sc.y + sh.y, ra[i].z * sc.z + sh.z, ra[i].w * sc.w + sh.w);
+        if (swish_in) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+        if (has_gate) { v.x *= rz[i].x; v.y *= rz[i].y; v.z *= rz[i].z; v.w *= rz[i].w; }
+        *reinterpret_cast<float4*>(&wA[(q + 8 * i) * GLD + 4 * p]) = sl_mask(kok, v);
+      }
     }
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) *reinterpret_cast<float4*>(&wB[(q + 8 * it) * GLD + 4 * p]) = rb[it];
+    if constexpr (NEXT) { load_a(gn); load_b(gn); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // fragments: lane (r, h) supplies row r, k = 16 h + 4 i + {0..3}
+    const float* pa = wA + r * GLD + h * 16;
+    const float* pb = wB + r * GLD + h * 16;
+    // (the fragments of sub-block i + 1 - one A and NT32 B float4 - are read before the 4 NT32 MFMAs of sub-block i are issued, pinned by
+    // sched_barrier: written the plain way hipcc puts every read right in front of its four MFMAs with an lgkmcnt(0) - ~100 cycles of LDS
+    // latency exposed per 256 cycles of MFMA issue)
+    float4 av[2], bv[2][NT32];
+    auto frag = [&](int i, int sl) {
+      av[sl] = *reinterpret_cast<const float4*>(pa + 4 * i);
+#pragma unroll
+      for (int j = 0; j < NT32; ++j) bv[sl][j] = *reinterpret_cast<const float4*>(pb + j * 32 * GLD + 4 * i);
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sl = i & 1;
+      if (i + 1 < 4) frag(i + 1, sl ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT32; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl].x, bv[sl][j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl].y, bv[sl][j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl].z, bv[sl][j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl].w, bv[sl][j].w, acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the next granule's LDS stores stay behind these reads)
+    __builtin_amdgcn_wave_barrier();
   };
   if (wave < G) {
     int g = wave;
     int sti = 0;
-    for (; g + 4 < G; g += 4) { granule(g, g + 4, std::true_type{}); SL_T(2 + sti); ++sti; }
-    granule(g, g, std::false_type{});
+    for (; g + 4 < G; g += 4) { granule(g, g + 4, std::true_type{}, std::integral_constant<int, DZK>{}); SL_T(2 + sti); ++sti; }
+    // (only the slice's very last granule can be cut by kend - always some wave's LAST one: it runs the guarded form)
+    if (DZK == 1 && kbeg + g * 32 + 32 > kend) granule(g, g, std::false_type{}, std::integral_constant<int, 2>{});
+    else granule(g, g, std::false_type{}, std::integral_constant<int, DZK>{});
   }
   SL_T(60);
+  __syncthreads();                                   // every wave is done with its staging region: the space becomes the reduction scratch
 
   // ---- cross-wave K reduction as a reduce-scatter: tile j is finished by wave j % 4; every other wave hands its accumulators of that tile
   // over in LDS (lane-contiguous float4: conflict-free ds_write_b128 / ds_read_b128), one barrier, then the owner adds the three and
@@ -341,16 +405,15 @@ __global__ __launch_bounds__(256) void pw_slab_combine_kernel(SlabArgs sa, int n
 
 typedef void (*SlabKern)(SlabArgs);
 typedef void (*SlabComb)(SlabArgs, int);
-template <int PRO>
+template <int PRO, int DZK>
 static SlabKern slab_pick_nt(int nt32) {
   switch (nt32) {
-    case 2: return pw_slab_kernel<2, PRO>;
-    case 3: return pw_slab_kernel<3, PRO>;
-    case 4: return pw_slab_kernel<4, PRO>;
-    case 5: return pw_slab_kernel<5, PRO>;
-    case 6: return pw_slab_kernel<6, PRO>;
-    case 7: return pw_slab_kernel<7, PRO>;
-    case 8: return pw_slab_kernel<8, PRO>;
+    case 2: return pw_slab_kernel<2, PRO, DZK>;
+    case 3: return pw_slab_kernel<3, PRO, DZK>;
+    case 4: return pw_slab_kernel<4, PRO, DZK>;
+    case 5: return pw_slab_kernel<5, PRO, DZK>;
+    case 6: return pw_slab_kernel<6, PRO, DZK>;
+    case 7: return pw_slab_kernel<7, PRO, DZK>;
     default: return nullptr;
   }
 }
@@ -376,7 +439,7 @@ struct SlabPlan { int nt32, nchunk, nslab, nslice, gran, ktab, lg; size_t lds; l
 static bool slab_plan(int M, int K, int N, int pro, SlabPlan& p) {
   if (M <= 0 || (K & 3) || (N & 3) || K < 128 || N < 36) return false;
   const int tiles = cdiv(N, 32);
-  p.nchunk = cdiv(tiles, 8);
+  p.nchunk = cdiv(tiles, 7);      // at most 7 tiles per block: 4 waves x (32 + 224) staged rows x 144 bytes = 147 KB of LDS
   p.nt32 = cdiv(tiles, p.nchunk);
   if (p.nt32 < 2) return false;
   p.nslab = cdiv(M, SL_BM);
@@ -392,8 +455,10 @@ static bool slab_plan(int M, int K, int N, int pro, SlabPlan& p) {
   p.ktab = p.gran * 32;
   const int nw = p.nt32 * 32, nc4 = nw / 4;
   p.lg = nc4 <= 16 ? 4 : nc4 <= 32 ? 5 : 6;
-  // table | the non-owners' accumulators [NT32][3][4 KB] | finished tile [32][NW] | epilogue sums [2 RG][NW]
-  p.lds = ((size_t)nco * p.ktab + (size_t)p.nt32 * 3 * 1024 + (size_t)SL_BM * nw + (size_t)2 * (256 >> p.lg) * nw) * sizeof(float);
+  // table | max(the four waves' staging regions [32 + NW][36], the non-owners' accumulators [NT32][3][4 KB] + finished tile [32][NW] +
+  // epilogue sums [2 RG][NW])
+  const size_t stage_f = (size_t)4 * (32 + nw) * 36, red_f = (size_t)p.nt32 * 3 * 1024 + (size_t)SL_BM * nw + (size_t)2 * (256 >> p.lg) * nw;
+  p.lds = ((size_t)nco * p.ktab + (stage_f > red_f ? stage_f : red_f)) * sizeof(float);
   if (p.lds > 158 * 1024) return false;
   if (pro == 1 && cdiv(p.gran * 32, 256) > p.nslab) return false;      // (dgamma / dbeta: one 256-channel group per row slab's block)
   p.part_floats = p.nslice > 1 ? (long long)p.nslice * p.nslab * SL_BM * p.nchunk * nw : 0;
@@ -430,16 +495,16 @@ int pw_slab_try(PwArgs& a, float* ws, long long ws_floats, bool auto_ok, hipStre
   SlabArgs sa{};
   sa.p = a; sa.nchunk = p.nchunk; sa.nslice = p.nslice; sa.gran = p.gran; sa.ktab = p.ktab; sa.part = ws;
   sa.has_aff = (!pro && (a.in_scale || a.in_bn.stats)) ? 1 : 0;
-  SlabKern kern = pro ? slab_pick_nt<1>(p.nt32) : slab_pick_nt<0>(p.nt32);
+  SlabKern kern = !pro ? slab_pick_nt<0, 0>(p.nt32) : (a.bb.dz_out && a.M % SL_BM == 0) ? slab_pick_nt<1, 1>(p.nt32) : slab_pick_nt<1, 2>(p.nt32);
   SlabComb comb = p.nslice > 1 ? slab_pick_comb(p.nslice, p.lg) : nullptr;
   if (!kern || (p.nslice > 1 && !comb)) return 0;
-  {       // raise the kernel's dynamic-LDS limit once per instantiation (14 of them)
-    static SlabKern done[16]; static int ndone = 0;
+  {       // raise the kernel's dynamic-LDS limit once per instantiation (18 of them)
+    static SlabKern done[24]; static int ndone = 0;
     bool seen = false;
     for (int i = 0; i < ndone; ++i) seen |= done[i] == kern;
     if (!seen) {
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MMD_ELAUNCH;
-      if (ndone < 16) done[ndone++] = kern;
+      if (ndone < 24) done[ndone++] = kern;
     }
   }
   const int nblk = p.nslab * p.nchunk * p.nslice;
