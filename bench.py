@@ -140,9 +140,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--coef", type=int, default=2, help="EfficientDet compound coefficient (2 = the BASELINE configs 1-4; 4 with --size 768 = config 5's architecture, run in fp32)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16_hbm"],
-                    help="bf16 = mixed precision (BASELINE config 5): 1x1-conv GEMMs on the bf16 MFMA, fp32 accumulate; bf16_hbm = that plus "
-                         "bf16 storage of the wide MBConv tensors in HBM; the default workload is fp32 like the reference")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = mixed precision (BASELINE config 5): 1x1-conv GEMMs on the bf16 MFMA, fp32 accumulate; the default workload is fp32 like the "
+                         "reference (the bf16_hbm storage mode was deleted in round 6: no faster for three rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU baseline's batch (0 = the per-GPU batch)")
@@ -294,8 +294,7 @@ def main():
     cpu = None
     if rank == 0:
         dll = _lib.LIB.load()
-        # the *_w16 entry points live in the second build of the library, which has its own profiler state: enable and collect on both
-        dlls = [dll] + ([_lib.LIB16.load()] if args.precision == "bf16_hbm" else [])
+        dlls = [dll]
         if os.environ.get("MMD_PROF_DUMP"):
             for i, d in enumerate(dlls):
                 d.mmd_prof_dump_to((os.environ["MMD_PROF_DUMP"] + (".w16" if i else "")).encode())
@@ -403,8 +402,7 @@ def main():
         line = {"metric": "distillation-step images/sec (3 teachers + audio student, D%d, bs=%d)" % (args.coef, B), "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.precision == "fp32" else ("bf16 MFMA operands in the 1x1 convs, f32 elsewhere" if args.precision == "bf16" else
-                          "bf16 MFMA operands in the 1x1 convs, bf16 storage of the wide MBConv tensors, f32 elsewhere"), "data": "synthetic",
+                "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands in the 1x1 convs, f32 elsewhere", "data": "synthetic",
                 "config": {"workload": ("BASELINE configs[2]" if std else
                                         "BASELINE configs[4] on one GPU (D4 / 768, bf16 mixed precision: " + args.precision + ")" if (args.coef == 4 and S == 768 and args.precision != "fp32") else
                                         "non-default shape / precision (BASELINE config 5 = D4 / 768 in bf16)")

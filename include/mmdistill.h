@@ -471,28 +471,6 @@ int mmd_comm_allreduce_bucket(void* comm, void* buf, long long count, int dtype,
 int mmd_comm_count(void* comm, void* count_out);
 int mmd_comm_destroy(void* comm);
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// bf16 STORAGE of the wide (6x expanded) MBConv tensors in HBM ("w16"; BASELINE configs[4]: "bf16 mixed precision ... HBM-bound").
-// A tensor argument named in a function's w16 bit list is a bf16 array behind the same float*-typed parameter (same shape, half the
-// bytes); arithmetic, BatchNorm sums, accumulators, parameters and every other tensor stay fp32: loads widen exactly, stores round to
-// nearest even.  bf16_mma = 1 additionally selects the bf16 MFMA for the inner product (the *_bf16 entry points' arithmetic).  The
-// reference has no reduced-precision path (src/YetAnotherEfficientNet.py:450-485 runs fp32): the rounding rule is this build's, stated
-// in DESIGN.md section 5 and emulated by oracle/effdet_ref.py (W16).  LDS-tiled kernels only.
-// mmd_pwconv_fwd:            bit 0 = x, bit 1 = y (no residual / strided output with a bf16 y)
-int mmd_pwconv_fwd_w16(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, int bf16_mma, int w16, hipStream_t stream);
-// mmd_dwconv_fwd:            bit 0 = x, bit 1 = y
-int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* out_scale, const float* out_shift, int out_act, double* stats, long long* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream);
-// mmd_chan_pool:             z
-int mmd_chan_pool_w16(const float* z, const float* scale, const float* shift, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g, float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream);
-// mmd_mbconv_expand_dw_fwd:  y
-int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0, const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool, int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream);
-// mmd_pwconv_bwd_data_bn2:   bit 0 = g, bit 1 = dx, bit 2 = z, bit 3 = dz_out, bit 4 = p5_z
-int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b, int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z, const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums, double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift, const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, int bf16_mma, int w16, hipStream_t stream);
-// mmd_dwconv_bwd_data_bn1:   bit 0 = g1, bit 1 = dx, bit 2 = z1, bit 3 = bn_z
-int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k, const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd, const double* q_sums, long long q_count, const float* q_gate, const float* q_add, float* q_dgamma, float* q_dbeta, const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad, int w16, hipStream_t stream);
-// mmd_pwconv_bwd_weight:     bit 0 = dy, bit 1 = x
-int mmd_pwconv_bwd_weight_w16(const float* dy, const float* x, float* dw, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const float* gate, int rows_per_image, int bf16_mma, int w16, hipStream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -15,9 +15,6 @@ import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMD_LIB") or os.path.join(PKG, "libmmdistill_hip.so")      # MMD_LIB: another build of the same library (A/B timing)
-# the same sources built WITH the bf16-storage branches (csrc/common.h "w16"): the *_w16 entry points are bound to this one, so the
-# default library - the fp32 headline path - carries no run-time storage tests
-LIB16_PATH = os.environ.get("MMD_LIB16") or os.path.join(PKG, "libmmdistill_hip_w16.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "mmdistill.h")
 
 _CT = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong,
@@ -72,7 +69,6 @@ class _Lib:
 
 
 LIB = _Lib()
-LIB16 = _Lib(LIB16_PATH)
 
 
 def _ptr(x):
@@ -126,7 +122,7 @@ def call(name: str, *args):
     """Invoke `name` with tensors -> device pointers, appending the current torch HIP stream."""
     if _DEV_SKIP and name in _DEV_SKIP:
         return 0
-    dll = (LIB16 if name.endswith("_w16") else LIB).load()
+    dll = LIB.load()
     fn = getattr(dll, name)
     conv = [_ptr(a) for a in args]
     if len(fn.argtypes) == len(conv) + 1:

@@ -13,10 +13,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-std=c
          "-Wno-unused-result"] + os.environ.get("MMD_EXTRA_HIPCC_FLAGS", "").split()
 
 
-LIB16 = os.path.join(PKG, "libmmdistill_hip_w16.so")
-# Two builds of the same sources: LIB with the bf16-storage ("w16", csrc/common.h) branches compiled out - the fp32 / bf16-operand
-# paths, i.e. the headline workload, pay nothing for them - and LIB16 with them; _lib.py sends the *_w16 entry points to LIB16.
-VARIANTS = ((LIB, "build", ["-DMMD_NO_W16"]), (LIB16, os.path.join("build", "w16"), []))
+# ONE build (round 6: the second one, libmmdistill_hip_w16.so with the bf16-storage branches compiled in, went with the bf16_hbm mode)
+VARIANTS = ((LIB, "build", ["-DMMD_NO_W16"]),)
 
 
 def _want_flags(extra) -> str:

@@ -66,17 +66,12 @@ __device__ __forceinline__ unsigned mmd_pk_bf16(float a, float b) {
   mmd_f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mmd_bf16x2));
 }
-// The library is built twice (mm_distillnet_amd/build.py): libmmdistill_hip.so with -DMMD_NO_W16 - the storage branches compiled out, every
-// tensor fp32: the run-time test per load / store costs the fp32 headline step 0.1 ms (16.50 -> 16.62 ms, alternating runs) - and
-// libmmdistill_hip_w16.so with them; the host binds the *_w16 entry points to the second one.  In the first a *_w16 call with a non-zero
-// mask is refused (MMD_EINVAL).
-#ifdef MMD_NO_W16
+// Round 6: the bf16 STORAGE mode ("bf16_hbm", a second build of the library with these branches compiled in) was deleted - it measured no
+// faster than fp32 storage on D4 / 768^2 for three rounds (53.7 vs 53.6, 50.5 vs 49.2, 48.8 vs 48.4 ms/step: those launches are bound by
+// instruction issue and latency, not bytes).  The w16 arguments of the kernels' load / store helpers remain as
+// compiled-out hooks: MMD_W16(x) is the constant false, every tensor is fp32.
 #define MMD_W16(x) false
 #define MMD_W16_BUILD 0
-#else
-#define MMD_W16(x) (x)
-#define MMD_W16_BUILD 1
-#endif
 __device__ __forceinline__ float4 mmd_ldw4(const float* p, size_t off, int w16) {
   if (MMD_W16(w16)) {
     const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off);

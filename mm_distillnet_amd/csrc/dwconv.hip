@@ -774,12 +774,12 @@ extern "C" int mmd_dwconv_fwd(const float* x, const float* w, float* y, int B, i
 }
 
 // same contract with bf16 storage of the wide tensors: w16 bit 0 = x, bit 1 = y are bf16 arrays (common.h)
-extern "C" int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
+static int mmd_dwconv_fwd_w16(const float* x, const float* w, float* y, int B, int H, int W, int C, int k, int stride,
                                   const float* in_scale, const float* in_shift, int in_act,
                                   const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
                                   const float* out_scale, const float* out_shift, int out_act,
                                   double* stats, long long* pool, double* stats_ws, int ws_slots, int w16, hipStream_t stream) {
-  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
+  if (w16) return MMD_EINVAL;      // (bf16 storage of the wide tensors was deleted in round 6: the branches are compiled out, common.h)
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MMD_EINVAL;
   if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr) || (out_scale == nullptr) != (out_shift == nullptr)) return MMD_EINVAL;
@@ -1100,7 +1100,7 @@ extern "C" int mmd_dwconv_bwd_data(const float* dy, const float* w, float* dx, i
   return rc;
 }
 
-extern "C" int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
+static int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
                                            const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd,
                                            const double* q_sums, long long q_count, const float* q_gate, const float* q_add,
                                            float* q_dgamma, float* q_dbeta,
@@ -1121,14 +1121,14 @@ extern "C" int mmd_dwconv_bwd_data_bn1(const float* g1, const float* z1, const f
                                      q_dbeta, bn_z, bn_scale, bn_shift, bn_mean, bn_invstd, bn_sums, stats_ws, ws_slots, dw_grad, 0, stream);
 }
 // bf16 storage: w16 bit 0 = g1, bit 1 = dx, bit 2 = z1, bit 3 = bn_z are bf16 arrays
-extern "C" int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
+static int mmd_dwconv_bwd_data_bn1_w16(const float* g1, const float* z1, const float* w, float* dx, int B, int H, int W, int C, int k,
                                            const float* q_scale, const float* q_shift, const float* q_mean, const float* q_invstd,
                                            const double* q_sums, long long q_count, const float* q_gate, const float* q_add,
                                            float* q_dgamma, float* q_dbeta,
                                            const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                            const float* bn_invstd, double* bn_sums, double* stats_ws, int ws_slots, float* dw_grad,
                                            int w16, hipStream_t stream) {
-  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
+  if (w16) return MMD_EINVAL;      // (bf16 storage of the wide tensors was deleted in round 6: the branches are compiled out, common.h)
   if (!g1 || !z1 || !w || !dx || B <= 0 || H <= 0 || W <= 0 || C < 64 || (C & 3) || (k != 3 && k != 5)) return MMD_EINVAL;
   if (!q_scale || !q_shift || !q_mean || !q_invstd || !q_sums || q_count <= 0 || !q_gate || !q_add) return MMD_EINVAL;
   if ((q_dgamma == nullptr) != (q_dbeta == nullptr)) return MMD_EINVAL;

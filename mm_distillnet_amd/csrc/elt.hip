@@ -216,7 +216,7 @@ extern "C" int mmd_chan_pool(const float* z, const float* scale, const float* sh
   return chan_pool_impl(z, scale, shift, in_stats, in_gamma, in_beta, in_count, act, g, out, out_scale, B, rows_per_image, C, 0, stream);
 }
 // z is a bf16 array (common.h w16)
-extern "C" int mmd_chan_pool_w16(const float* z, const float* scale, const float* shift, const double* in_stats,
+static int mmd_chan_pool_w16(const float* z, const float* scale, const float* shift, const double* in_stats,
                                  const float* in_gamma, const float* in_beta, long long in_count, int act, const float* g,
                                  float* out, float out_scale, int B, int rows_per_image, int C, hipStream_t stream) {
   if (true && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out

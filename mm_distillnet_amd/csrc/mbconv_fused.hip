@@ -286,7 +286,7 @@ extern "C" int mmd_mbconv_expand_dw_fwd(const float* x, const float* w_expand, c
   return mbx_impl(x, w_expand, scale0, shift0, w_dw, scale1, shift1, y, pool, B, H, W, Cin, Cmid, k, stride, 0, stream);
 }
 // y is stored as a bf16 array (common.h w16): the frozen nets' activated depthwise output, read back by the project conv
-extern "C" int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+static int mmd_mbconv_expand_dw_fwd_w16(const float* x, const float* w_expand, const float* scale0, const float* shift0,
                                             const float* w_dw, const float* scale1, const float* shift1, float* y, long long* pool,
                                             int B, int H, int W, int Cin, int Cmid, int k, int stride, hipStream_t stream) {
   if (true && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out

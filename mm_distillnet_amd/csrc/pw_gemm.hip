@@ -1018,19 +1018,6 @@ extern "C" int mmd_pwconv_fwd_form(const float* x, const float* w, float* y, int
 }
 // same contract, operands rounded to bf16 at the MFMA input (fp32 accumulate, fp32 in/out tensors)
 extern "C" int mmd_pwconv_fwd_bf16(PW_FWD_PARAMS) { return pw_fwd_impl(PW_FWD_ARGS, 1); }
-// same contract with bf16 STORAGE of the wide operand ("w16", common.h): w16 bit 0 = x is a bf16 array, bit 1 = y is (no residual / strided
-// output then); bf16_mma = 1 selects the bf16 MFMA as mmd_pwconv_fwd_bf16.  BatchNorm sums are taken from the fp32 values before rounding.
-extern "C" int mmd_pwconv_fwd_w16(const float* x, const float* w, float* y, int M, int K, int N,
-                                  const float* in_scale, const float* in_shift, int in_act,
-                                  const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count,
-                                  const float* gate, int rows_per_image,
-                                  const float* bias, const float* out_scale, const float* out_shift, int out_act,
-                                  const float* residual, double* stats,
-                                  long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, int bf16_mma, int w16,
-                                  hipStream_t stream) {
-  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
-  return pw_fwd_impl(PW_FWD_ARGS, bf16_mma, w16);
-}
 
 int mmd_pw_stem_gemm(const float* x, const float* w, float* y, int B, int Cin, int H, int W, int OH, int OW, int pad_t, int pad_l,
                      int Kp, int Cout, const float* out_scale, const float* out_shift, int out_act, double* stats,
@@ -1400,13 +1387,6 @@ static int pw_wgrad_bn_impl(const float* g, const float* z, const float* x, floa
                      mul_b, bn_rows_per_image, dgamma, dbeta, stream
 extern "C" int mmd_pwconv_bwd_weight_bn(PW_WGBN_PARAMS) { return pw_wgrad_bn_impl(PW_WGBN_ARGS, 0); }
 extern "C" int mmd_pwconv_bwd_weight_bn_bf16(PW_WGBN_PARAMS) { return pw_wgrad_bn_impl(PW_WGBN_ARGS, 1); }
-// bf16 storage: w16 bit 0 = dy, bit 1 = x are bf16 arrays
-extern "C" int mmd_pwconv_bwd_weight_w16(const float* dy, const float* x, float* dw, int M, int K, int N,
-                                         const float* in_scale, const float* in_shift, int in_act,
-                                         const float* gate, int rows_per_image, int bf16_mma, int w16, hipStream_t stream) {
-  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
-  return pw_wgrad_impl(dy, x, dw, M, K, N, in_scale, in_shift, in_act, gate, rows_per_image, stream, bf16_mma, nullptr, nullptr, nullptr, w16);
-}
 extern "C" int mmd_pwconv_bwd_weight_bf16(const float* dy, const float* x, float* dw, int M, int K, int N,
                                           const float* in_scale, const float* in_shift, int in_act,
                                           const float* gate, int rows_per_image, hipStream_t stream) {
@@ -1515,16 +1495,6 @@ extern "C" int mmd_pwconv_bwd_data_bn2_form(const float* g, const float* z, cons
                       const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, float* ws, long long ws_floats, int form,
                       hipStream_t stream) {
   return pw_bwd_data_bn2_impl(PW_BD2_ARGS, 0, 0, form, ws, ws_floats);
-}
-// bf16 storage of the wide tensors: w16 bit 0 = g, bit 1 = dx, bit 2 = z, bit 3 = dz_out, bit 4 = p5_z are bf16 arrays
-extern "C" int mmd_pwconv_bwd_data_bn2_w16(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N, const float* scale, const float* shift,
-                      const float* mean, const float* invstd, const double* sums, long long count, int act, const float* mul_b,
-                      int rows_per_image, float* dz_out, float* dgamma, float* dbeta, const float* residual, const float* xs_z,
-                      const float* xs_mean, const float* xs_invstd, const float* xs_mul_b, int xs_rows_per_image, double* xs_sums,
-                      double* stats_ws, int ws_slots, const float* p5_z, const float* p5_scale, const float* p5_shift,
-                      const float* p5_mean, const float* p5_invstd, float* p5_out, int p5_B, int bf16_mma, int w16, hipStream_t stream) {
-  if (w16 && !MMD_W16_BUILD) return MMD_EINVAL;      // this build has the bf16-storage branches compiled out
-  return pw_bwd_data_bn2_impl(PW_BD2_ARGS, bf16_mma, w16);
 }
 
 extern "C" int mmd_pwconv_bwd_data_bn(const float* g, const float* z, const float* wt, float* dx, int M, int K, int N,

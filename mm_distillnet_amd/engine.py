@@ -88,7 +88,6 @@ class Feat:
     shift: Optional[torch.Tensor] = None
     act: int = NONE
     bn: Optional[tuple] = None     # train-mode forward: (stats[2C] double, gamma, beta, count) -> coefficients derived on the fly
-    w16: bool = False              # z is a bf16 array (precision "bf16_hbm": the wide MBConv tensors)
 
     @property
     def M(self) -> int:
@@ -121,7 +120,6 @@ class LazyDz:
     rpi: int
     bn_name: str
     count: int
-    w16: bool = False           # g and z are bf16 arrays (and the stored dz is written as one)
 
 
 LAZY_BN = not os.environ.get("MMD_NO_LAZY_BN")
@@ -184,14 +182,13 @@ def pack_nets(nets: List["Net"]) -> bool:
 class Net:
     def __init__(self, spec: NetSpec, device, trainable: bool, arena: Optional[Arena] = None,
                  zarena: Optional[Arena] = None, precision: str = "fp32", stem_slot: int = 0):
-        if precision not in ("fp32", "bf16", "bf16_hbm"):
+        if precision not in ("fp32", "bf16"):
+            # ("bf16_hbm", bf16 STORAGE of the wide MBConv tensors, was deleted in round 6 together with its second library build: measured no
+            # faster than "bf16" for three rounds - D4 / 768^2: 53.7 vs 53.6, 50.5 vs 49.2, 48.8 vs 48.4 ms/step - DESIGN.md section 5)
             raise ValueError(f"Unsupported precision {precision}")
         # "bf16" = mixed precision: the 1x1-conv GEMMs (forward, input- and weight-gradient) feed the bf16 MFMA, fp32
         # accumulate; tensors in HBM, depthwise convs, BatchNorm statistics, losses and Adam stay fp32
-        # "bf16_hbm" (BASELINE configs[4]) = "bf16" + the wide (6x expanded) MBConv tensors stored as bf16 in HBM: expand / depthwise outputs
-        # and, in the backward, the gradients w.r.t. them (csrc/common.h "w16"); BatchNorm sums from the fp32 values, everything narrow fp32
-        self.precision = "bf16" if precision == "bf16_hbm" else precision
-        self.w16 = precision == "bf16_hbm"
+        self.precision = precision
         self._sfx = "_bf16" if self.precision == "bf16" else ""
         self.spec = spec
         self.device = device
@@ -270,8 +267,6 @@ class Net:
         """call() for the frozen-forward entry points that honour the group mode: inside a pack forward the group is set around the launch."""
         if self._grp is None:
             return call(name, *args)
-        if name.endswith("_w16"):
-            raise RuntimeError(f"{name}: the bf16-storage library has no group mode")
         dll = _lib.LIB.load()
         if dll.mmd_set_group(*self._grp) != 0:
             raise RuntimeError("mmd_set_group refused %r" % (self._grp,))
@@ -372,20 +367,15 @@ class Net:
             return None, 0
         return self._zalloc((self.STATS_SLOTS * 2 * C,), torch.float64), self.STATS_SLOTS
 
-    def _alloc16(self, *shape):
-        return self.arena.alloc(shape, torch.bfloat16)
-
     def _pw(self, x: Feat, wkey: str, N: int, bias=None, stats=None, out_aff=None, out_act=NONE, residual=None,
-            gate=None, y=None, ybs=0, yoff=0, plain_in=False, y16=False):
+            gate=None, y=None, ybs=0, yoff=0, plain_in=False):
         M, K = x.M, x.C
         if y is None:
-            y = self._alloc16(M, N) if y16 else self._alloc(M, N)
+            y = self._alloc(M, N)
         xf = (None, None, NONE, None, None, None, 0) if plain_in else self._xf(x)
         args = (x.z, self.ps.w(wkey), y, M, K, N, *xf, gate, x.H * x.W, bias, out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act,
                 residual, stats, ybs, yoff, *self._stats_ws(stats, M, N))
-        if x.w16 or y16:
-            call("mmd_pwconv_fwd_w16", *args, 1, (1 if x.w16 else 0) | (2 if y16 else 0))
-        elif self._grp is None and not self._sfx and not plain_in and ybs == 0:
+        if self._grp is None and not self._sfx and not plain_in and ybs == 0:
             # (fp32, outside a pack forward, with a producer transform: the launch may take the all-N K-sliced slab kernel, csrc/pw_slab.hip,
             # which needs a workspace for its K slices' partial slabs when the launch has few row slabs)
             call("mmd_pwconv_fwd_form", *args, *self._slab_ws(M, K, N, 0), 0)
@@ -404,16 +394,13 @@ class Net:
             n = self._slab_floats[key] = int(_lib.LIB.load().mmd_pwconv_slab_ws_floats(M, K, N, bn_operand))
         return (self._alloc(n), n) if n > 0 else (None, 0)
 
-    def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None, y16=False):
+    def _dw(self, x: Feat, wkey: str, k: int, s: int, stats=None, out_aff=None, out_act=NONE, pool=None):
         OH, OW = -(-x.H // s), -(-x.W // s)
-        y = self._alloc16(x.B * OH * OW, x.C) if y16 else self._alloc(x.B * OH * OW, x.C)
+        y = self._alloc(x.B * OH * OW, x.C)
         args = (x.z, self.ps.w(wkey), y, x.B, x.H, x.W, x.C, k, s, *self._xf(x),
                 out_aff[0] if out_aff else None, out_aff[1] if out_aff else None, out_act, stats, pool,
                 *self._stats_ws(stats, x.B * OH * OW, x.C))
-        if x.w16 or y16:
-            call("mmd_dwconv_fwd_w16", *args, (1 if x.w16 else 0) | (2 if y16 else 0))
-        else:
-            self._c("mmd_dwconv_fwd", *args)
+        self._c("mmd_dwconv_fwd", *args)
         return y, OH, OW
 
     def anchors(self, image_size: int) -> torch.Tensor:
@@ -512,20 +499,17 @@ class Net:
                 self._use(inp)              # ... and the identity skip
             fused_front = (not train and blk.expand != 1 and self.FUSE_FRONT and ps.flat.is_cuda
                            and _lib.LIB.load().mmd_mbconv_expand_dw_supported(inp.C, blk.cmid, blk.kernel, blk.stride) == 1)
-            # bf16 storage of the block's wide tensors: every block with an expand conv in the frozen nets; in the trainable net the
-            # stride-1 ones whose backward runs on the w16-capable launches (BatchNorm-1 backward in the depthwise prologue)
-            wide = self.w16 and blk.expand != 1 and ps.flat.is_cuda and (not train or (blk.stride == 1 and blk.cmid >= 64 and BN1_IN_DW and P5_IN_GEMM and self.DW_WG and (inp.H * inp.W) % 128 == 0))
             if fused_front:
                 f0 = None           # frozen net, thin input: expand + depthwise in one kernel below, the expanded tensor stays in LDS
             elif blk.expand != 1:
                 st0 = self._bn_stats(f"{q}._bn0", train)
                 a0 = self._bn_aff(f"{q}._bn0", train, st0, inp.M)
                 if train:
-                    z0 = self._pw(inp, f"{q}._expand_conv.conv.weight", blk.cmid, stats=st0, y16=wide)
-                    f0 = Feat(z0, B, inp.H, inp.W, blk.cmid, a0[0], a0[1], SWISH, a0[4], w16=wide)
+                    z0 = self._pw(inp, f"{q}._expand_conv.conv.weight", blk.cmid, stats=st0)
+                    f0 = Feat(z0, B, inp.H, inp.W, blk.cmid, a0[0], a0[1], SWISH, a0[4])
                 else:           # frozen net: activate in the producer's epilogue (see the stem)
-                    z0 = self._pw(inp, f"{q}._expand_conv.conv.weight", blk.cmid, out_aff=(a0[0], a0[1]), out_act=SWISH, y16=wide)
-                    f0 = Feat(z0, B, inp.H, inp.W, blk.cmid, w16=wide)
+                    z0 = self._pw(inp, f"{q}._expand_conv.conv.weight", blk.cmid, out_aff=(a0[0], a0[1]), out_act=SWISH)
+                    f0 = Feat(z0, B, inp.H, inp.W, blk.cmid)
                 rec["f0"], rec["bn0"] = f0, a0
             else:
                 f0 = inp
@@ -540,10 +524,10 @@ class Net:
                     ps.w(f"{q}._se_expand.conv.weight"), ps.w(f"{q}._se_expand.conv.bias"))
             if train:
                 st1 = self._bn_stats(f"{q}._bn1", True)
-                z1, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, stats=st1, y16=wide)
+                z1, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride, stats=st1)
                 a1 = self._bn_aff(f"{q}._bn1", True, st1, M1)
-                f1 = Feat(z1, B, H1, W1, blk.cmid, a1[0], a1[1], SWISH, a1[4], w16=wide)
-                call("mmd_chan_pool_w16" if wide else "mmd_chan_pool", z1, *self._xf(f1)[:2], *self._xf(f1)[3:], SWISH, None, pooled, 1.0 / (H1 * W1), B,
+                f1 = Feat(z1, B, H1, W1, blk.cmid, a1[0], a1[1], SWISH, a1[4])
+                call("mmd_chan_pool", z1, *self._xf(f1)[:2], *self._xf(f1)[3:], SWISH, None, pooled, 1.0 / (H1 * W1), B,
                      H1 * W1, blk.cmid)
                 call("mmd_se_fc_fwd", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 st2 = self._bn_stats(f"{q}._bn2", True)
@@ -562,14 +546,14 @@ class Net:
                 b1 = ps.bn(f"{q}._bn1")
                 if fused_front:
                     b0 = ps.bn(f"{q}._bn0")
-                    a1v = self._alloc16(M1, blk.cmid) if wide else self._alloc(M1, blk.cmid)
-                    self._c("mmd_mbconv_expand_dw_fwd_w16" if wide else "mmd_mbconv_expand_dw_fwd", inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
+                    a1v = self._alloc(M1, blk.cmid)
+                    self._c("mmd_mbconv_expand_dw_fwd", inp.z, ps.w(f"{q}._expand_conv.conv.weight"), b0["fscale"], b0["fshift"],
                          ps.w(f"{q}._depthwise_conv.conv.weight"), b1["fscale"], b1["fshift"], a1v, pooled, B, inp.H, inp.W, inp.C,
                          blk.cmid, blk.kernel, blk.stride)
                 else:
                     a1v, _, _ = self._dw(f0, f"{q}._depthwise_conv.conv.weight", blk.kernel, blk.stride,
-                                         out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled, y16=wide)
-                f1 = Feat(a1v, B, H1, W1, blk.cmid, w16=wide)
+                                         out_aff=(b1["fscale"], b1["fshift"]), out_act=SWISH, pool=pooled)
+                f1 = Feat(a1v, B, H1, W1, blk.cmid)
                 self._c("mmd_se_fc_fwd_q", pooled, *se_w, hpre, gate, B, blk.cmid, blk.se)
                 b2 = ps.bn(f"{q}._bn2")
                 y = self._pw(f1, f"{q}._project_conv.conv.weight", blk.cout, gate=gate,
@@ -991,18 +975,14 @@ class Net:
             yield
 
     def _pw_wgrad(self, dy: torch.Tensor, xz: torch.Tensor, dw: torch.Tensor, M: int, K: int, N: int, in_scale=None, in_shift=None,
-                  in_act: int = NONE, gate=None, rpi: int = 1, w16: int = 0):
-        """dW[N,K] (+)= dY^T pro(X).  Grouped mode: recorded, computed by _wg_flush() at the end of the backward segment.
-        w16: bit 0 = dy, bit 1 = x are bf16 arrays (per-layer launch)."""
+                  in_act: int = NONE, gate=None, rpi: int = 1):
+        """dW[N,K] (+)= dY^T pro(X).  Grouped mode: recorded, computed by _wg_flush() at the end of the backward segment."""
         # precision "bf16": grouped as well (round 4, mmd_wgrad_grouped_bf16) where the per-layer launches are skeleton-bound - D2 / 512^2 in
         # bf16 15.50 -> 14.64 ms/step; at D4 / 768^2 the layers are tall enough that the per-layer launches on the side stream measure the
         # same or better (53.0-53.3 vs 53.5-53.8 ms), so tall nets keep them (rows of the stem output decide; MMD_WG_GROUP_BF16=0/1 forces)
-        if not WG_GROUP or w16 or not self.ps.flat.is_cuda or (self.precision != "fp32" and not self._group_bf16()):
+        if not WG_GROUP or not self.ps.flat.is_cuda or (self.precision != "fp32" and not self._group_bf16()):
             with self._wgrad_stream():
-                if w16:
-                    call("mmd_pwconv_bwd_weight_w16", dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi, 1, w16)
-                else:
-                    call("mmd_pwconv_bwd_weight" + self._sfx, dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi)
+                call("mmd_pwconv_bwd_weight" + self._sfx, dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi)
             return
         self._wg_pending.append((dy, xz, dw, M, K, N, in_scale, in_shift, in_act, gate, rpi))
         self._wg_count += 1
@@ -1075,7 +1055,7 @@ class Net:
                  plan["flops"], plan["bytes"])
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
-                mul_bc=None, mul_b=None, add_bc=None, sums=None, lazy: bool = False, w16: bool = False):
+                mul_bc=None, mul_b=None, add_bc=None, sums=None, lazy: bool = False):
         """BN(+act) backward: returns dz (gradient w.r.t. the conv's raw output); dgamma/dbeta accumulated.
         `sums` given = the per-channel sums were produced elsewhere (fused into another pass): pass 2 only.
         lazy: no pass 2 at all - returns a LazyDz that the 1x1 conv's two gradient GEMMs evaluate in their prologues."""
@@ -1085,8 +1065,7 @@ class Net:
             call("mmd_bn_bwd_reduce", g_in, z, aff[0], aff[1], aff[2], aff[3], act, mul_bc, mul_b, add_bc, rpi, None, sums, M, C,
                  *self._stats_ws(sums, M, C))
         if lazy and LAZY_BN and mul_bc is None and add_bc is None:
-            return LazyDz(g_in, z, aff, sums, act, mul_b, rpi, bn_name, M, w16)
-        assert not w16, "bf16-stored operands only run on the lazy (GEMM prologue) BatchNorm backward"
+            return LazyDz(g_in, z, aff, sums, act, mul_b, rpi, bn_name, M)
         dz = self._alloc(M, C)
         call("mmd_bn_bwd_apply", g_in, z, aff[2], aff[3], b["gamma"], sums, M, dz, b["dgamma"], b["dbeta"], M, C,
              aff[0], aff[1], act, mul_bc, mul_b, add_bc, rpi)
@@ -1113,38 +1092,9 @@ class Net:
                          b["dbeta"])
                     self._wg_read_done = torch.cuda.current_stream().record_event() if ps.flat.is_cuda else None
                 return None
-            dzm = self._alloc16(M, N) if L.w16 else self._alloc(M, N)
-            wg16 = (1 if L.w16 else 0) | (2 if x.w16 else 0)        # weight gradient: dy = the stored dz, x = the conv's forward input
-            if L.w16 or x.w16:
-                # bf16-stored wide tensors (precision bf16_hbm): g / z / dz of a wide BatchNorm (expand conv), or the conv's wide input
-                # (project conv: dx = g1 is then written as bf16, the pooled pass reads z1 as bf16)
-                bd16 = (1 | 4 | 8) if L.w16 else 0
-                xsargs = (None, None, None, None, 0, None, None, 0)
-                p5args = (None, None, None, None, None, None, 0)
-                if into is not None:
-                    assert not x.w16
-                    slot, xs = self._contrib(into, True)
-                    assert xs is None or not xs[6], "the GEMM epilogue sums the accumulated total: not a linear-sum (pooled) tensor"
-                    residual = slot.t
-                    if slot.t is None:
-                        slot.t = self._alloc(M, K)
-                    dx = slot.t
-                    if xs is not None:
-                        xsargs = (xs[0], xs[1], xs[2], xs[4], xs[5], xs[3], *self._stats_ws(xs[3], M, K))
-                else:
-                    residual = None
-                    dx = self._alloc16(M, K) if x.w16 else self._alloc(M, K)
-                    if x.w16:
-                        bd16 |= 2
-                    if pool5 is not None:
-                        p5args = pool5
-                        bd16 |= 16 if x.w16 else 0
-                call("mmd_pwconv_bwd_data_bn2_w16", L.g, L.z, ps.w_t(wkey), dx, M, K, N, *bnargs, dzm, b["dgamma"], b["dbeta"],
-                     residual, *xsargs, *p5args, 1, bd16)
-                self._pw_wgrad(dzm, x.z, ps.g(wkey), M, K, N, *xargs, w16=wg16)
-                return None if into is not None else dx
+            dzm = self._alloc(M, N)
             if (into is not None and FOLD_SUMS and MBW_FUSED and M >= MBW_MIN_ROWS and L.act == SWISH and L.mul_b is None and gate is None
-                    and not x.w16 and x.scale is None and x.bn is None and x.act == NONE and ps.flat.is_cuda
+                    and x.scale is None and x.bn is None and x.act == NONE and ps.flat.is_cuda
                     and _lib.LIB.load().mmd_mbconv_expand_bwd_supported(K, N) == 1):
                 # thin-input expand conv of a high-resolution block: one pass over (g0, z0) - input gradient, weight gradient, no dz0 in HBM
                 slot, xs = self._contrib(into, True)
@@ -1578,16 +1528,10 @@ class Net:
                 wkey = f"{q}._depthwise_conv.conv.weight"
                 g0 = self._alloc(f0.M, f0.C)
                 sums0 = self._zalloc((2 * f0.C,), torch.float64)
-                if f1.w16:       # bf16-stored g1, z1, z0 in, g0 out
-                    g0 = self._alloc16(f0.M, f0.C)
-                    call("mmd_dwconv_bwd_data_bn1_w16", g1, f1.z, ps.w(wkey), g0, f0.B, f0.H, f0.W, f0.C, blk.kernel, a1[0], a1[1], a1[2], a1[3],
-                         sums1, M1, rec["gate"], dpooled, b1["dgamma"], b1["dbeta"], f0.z, a0[0], a0[1], a0[2], a0[3], sums0,
-                         *self._stats_ws(sums0, f0.M, f0.C), ps.g(wkey), 15)
-                else:
-                    call("mmd_dwconv_bwd_data_bn1", g1, f1.z, ps.w(wkey), g0, f0.B, f0.H, f0.W, f0.C, blk.kernel, a1[0], a1[1], a1[2], a1[3],
-                         sums1, M1, rec["gate"], dpooled, b1["dgamma"], b1["dbeta"], f0.z, a0[0], a0[1], a0[2], a0[3], sums0,
-                         *self._stats_ws(sums0, f0.M, f0.C), ps.g(wkey))
-                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0, lazy=True, w16=f0.w16)
+                call("mmd_dwconv_bwd_data_bn1", g1, f1.z, ps.w(wkey), g0, f0.B, f0.H, f0.W, f0.C, blk.kernel, a1[0], a1[1], a1[2], a1[3],
+                     sums1, M1, rec["gate"], dpooled, b1["dgamma"], b1["dbeta"], f0.z, a0[0], a0[1], a0[2], a0[3], sums0,
+                     *self._stats_ws(sums0, f0.M, f0.C), ps.g(wkey))
+                dz0 = self._bn_bwd(g0, f0.z, rec["bn0"], f"{q}._bn0", SWISH, f0.M, blk.cmid, sums=sums0, lazy=True)
                 if dy_read is not None:
                     torch.cuda.current_stream().wait_event(dy_read)
                 self._pw_bwd(dz0, inp, f"{q}._expand_conv.conv.weight", blk.cmid, None, True, into=inp)

@@ -55,7 +55,7 @@ class StepConfig:
                                        # has no cap, src/utils/utils.py:179-205), so nothing can overflow
     augment: bool = False              # cfg audio_augmentation_merge (ModelWithNMSLossAugmented.forward augment=True)
     seed: int = 0                      # cfg `seed` (train.py:120 make_reproducible_run): keys the device-side drop-connect draws
-    precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors); "bf16_hbm": + the wide MBConv tensors stored as bf16
+    precision: str = "fp32"            # "bf16": 1x1-conv GEMMs of every net on the bf16 MFMA (fp32 accumulate, fp32 tensors)
 
 
 class DistillEngine:
@@ -75,7 +75,7 @@ class DistillEngine:
         # chain: tools/dev/diag_phases.py proxy - student forward + a frozen net at batch 3B 7.28 ms against 8.41 with three nets on three
         # streams).  MMD_NO_PACK=1: one net per stream, the round-3 schedule
         tl = list(self.teachers.values())
-        self.pack = (len(tl) > 1 and cfg.precision != "bf16_hbm" and not os.environ.get("MMD_NO_PACK") and str(device).startswith("cuda")
+        self.pack = (len(tl) > 1 and not os.environ.get("MMD_NO_PACK") and str(device).startswith("cuda")
                      and pack_nets(tl))
         ps = self.student.ps
         n = ps.n_params

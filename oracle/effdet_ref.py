@@ -88,38 +88,6 @@ def _bf16_ste(t):
     return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
 
 
-# Oracle-only switch for the build's bf16 STORAGE mode (precision "bf16_hbm", BASELINE config 5): the wide (6x expanded) MBConv
-# tensors live in HBM as bf16.  Rounding rule (round-to-nearest-even at the store, exact widening at the load; everything narrow,
-# all arithmetic, BatchNorm statistics and parameters fp32):
-#   frozen net, every block with an expand conv:   a0 = swish(BN0(expand(x))) and a1 = swish(BN1(dw(a0))) are stored rounded
-#                                                  (blocks on the fused expand+depthwise kernel - Cin in {16..56 step 8}, Cmid % 48 == 0 -
-#                                                  never store a0: it stays fp32 in LDS);
-#   trainable net, stride-1 blocks with an expand conv, Cmid >= 64 and H*W % 128 == 0: z0 = expand(x) and z1 = dw(a0) are stored rounded
-#                                                  (their BatchNorms normalise the rounded values), and in the backward the gradients
-#                                                  w.r.t. a0 (g0), w.r.t. the gated activation (g1) and the BatchNorm-0 backward's
-#                                                  output dz0 are stored rounded.
-# (The HIP kernels take the BatchNorm sums / the frozen nets' SE pool from the fp32 values before the store; this emulation takes them
-# from the rounded tensor - a difference of order 2^-9 / sqrt(samples), far below the rounding noise itself.)
-W16 = False
-
-
-def _r16(t):
-    return t.to(torch.bfloat16).to(t.dtype)
-
-
-class _Store16(torch.autograd.Function):
-    """y = the tensor as stored (rounded when fwd), dy -> the gradient as stored (rounded when bwd)."""
-
-    @staticmethod
-    def forward(ctx, x, fwd, bwd):
-        ctx.bwd = bwd
-        return _r16(x) if fwd else x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        return (_r16(g) if ctx.bwd else g), None, None
-
-
 # Oracle-only tap: when a dict, forward() records the output of every unit the HIP engine materialises - "stem" (eval: activated),
 # "blk<i>" (MBConv block outputs), "bifpn.<c>.<down-channel | conv*_up | conv*_down>" (NCHW tensors, detached) - so a test can hand each
 # unit of the HIP net exactly the inputs this restatement saw ("teacher forcing": rounding differences cannot compound across units).
@@ -131,9 +99,6 @@ def _tap(name, x):
         TAP[name] = x.detach().clone()
     return x
 
-
-def _mbx_fused(cin, cmid):
-    return cin in (16, 24, 32, 40, 48, 56) and cmid % 48 == 0
 
 
 def pw_conv(x, weight, bias=None):
@@ -170,30 +135,15 @@ def batchnorm(state, prefix, x, training):
 def mbconv(state, p, x, blk, training, drop_rate, drop_mask):
     k, s, cin, cout, e, se, skip = blk
     inp = x
-    cmid = state[p + "._depthwise_conv.conv.weight"].shape[0]
-    wide_t = W16 and training and e != 1 and s == 1 and cmid >= 64 and (x.shape[2] * x.shape[3]) % 128 == 0      # trainable net
-    wide_f = W16 and (not training) and e != 1                                                                  # frozen net
     if e != 1:
         x = conv_same(x, state[p + "._expand_conv.conv.weight"])
-        if wide_t:
-            x = _Store16.apply(x, True, True)            # z0 stored; dz0 stored
         x = swish(batchnorm(state, p + "._bn0", x, training))
-        if wide_t:
-            x = _Store16.apply(x, False, True)           # g0 stored
-        elif wide_f and not _mbx_fused(cin, cmid):
-            x = _Store16.apply(x, True, False)           # a0 stored
     x = conv_same(x, state[p + "._depthwise_conv.conv.weight"], stride=s, groups=x.shape[1])
-    if wide_t:
-        x = _Store16.apply(x, True, False)               # z1 stored (dz1 is never materialised)
     x = swish(batchnorm(state, p + "._bn1", x, training))
-    if wide_f:
-        x = _Store16.apply(x, True, False)               # a1 stored
     sq = F.adaptive_avg_pool2d(x, 1)
     sq = swish(F.conv2d(sq, state[p + "._se_reduce.conv.weight"], state[p + "._se_reduce.conv.bias"]))
     sq = F.conv2d(sq, state[p + "._se_expand.conv.weight"], state[p + "._se_expand.conv.bias"])
     x = torch.sigmoid(sq) * x
-    if wide_t:
-        x = _Store16.apply(x, False, True)               # g1 (gradient w.r.t. the gated activation) stored
     x = conv_same(x, state[p + "._project_conv.conv.weight"])
     x = batchnorm(state, p + "._bn2", x, training)
     if skip:

@@ -1838,148 +1838,6 @@ def test_bifpn_node_whole_fused_train(mode, H, W, C):
     close(st[:C], st_ref[:C], 1e-4, 1e-4, "sum z"); close(st[C:], st_ref[C:], 1e-4, 1e-5, "sum z^2")
 
 
-# ---------------------------------------------------------------- bf16 storage of the wide MBConv tensors ("w16", BASELINE configs[4])
-def _r16(t):
-    return t.to(torch.bfloat16).float()
-
-
-def _b16(t):
-    return t.to(torch.bfloat16).contiguous().to(DEV)
-
-
-def _close16(got_bf16, ref_f32, what):
-    """a bf16-stored result against the fp32 result of the same launch: equal after rounding, up to one bf16 ulp (a last-bit
-    difference in the fp32 value can flip the rounding)"""
-    a, b = got_bf16.float().cpu(), ref_f32.float().cpu()
-    tol = b.abs() * 2.0 ** -7 + 1e-6 * max(b.abs().max().item(), 1e-30)
-    assert ((a - b).abs() <= tol).all(), f"{what}: max err {(a - b).abs().max().item():.3e}"
-
-
-@pytest.mark.parametrize("M,K,N,gate,act", [(8192, 120, 720, False, 0), (2048, 1248, 208, True, 1), (20480, 24, 144, False, 0), (300, 528, 88, True, 1)])
-def test_w16_pwconv_fwd(M, K, N, gate, act):
-    """mmd_pwconv_fwd_w16: a bf16-stored x reads as its exact widening; a bf16-stored y is the fp32 result rounded to nearest even; the
-    BatchNorm sums come from the fp32 values."""
-    torch.manual_seed(M + N)
-    B = 4 if M % 4 == 0 else 1
-    x = _r16(torch.randn(M, K)); w = torch.randn(N, K) / math.sqrt(K)
-    isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
-    gt = torch.rand(B, K) if gate else None
-    args = lambda xt, y, st: (xt, g(w), y, M, K, N, g(isc) if act else None, g(ish) if act else None, act, None, None, None, 0,
-                              g(gt) if gate else None, M // B, None, None, None, 0, None, st, 0, 0, None, 0)
-    y_ref = torch.empty(M, N, device=DEV); st_ref = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    call("mmd_pwconv_fwd_bf16", *args(g(x), y_ref, st_ref))
-    y1 = torch.empty(M, N, device=DEV); st1 = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    call("mmd_pwconv_fwd_w16", *args(_b16(x), y1, st1), 1, 1)              # x stored as bf16
-    close(y1, y_ref, 1e-5, 1e-6, "bf16-stored x"); close(st1, st_ref, 1e-5, 1e-6)
-    y2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); st2 = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
-    call("mmd_pwconv_fwd_w16", *args(_b16(x), y2, st2), 1, 3)              # and y stored as bf16
-    _close16(y2, y_ref, "bf16-stored y"); close(st2, st_ref, 1e-5, 1e-6, "sums from the fp32 values")
-
-
-@pytest.mark.parametrize("k,s,H,W,C,mode", [(3, 1, 16, 16, 144, "train"), (5, 2, 17, 12, 96, "train"), (5, 1, 16, 12, 528, "eval"), (3, 2, 32, 32, 96, "eval")])
-def test_w16_dwconv_fwd_and_pool(k, s, H, W, C, mode):
-    torch.manual_seed(k + C)
-    B = 2
-    x = _r16(torch.randn(B * H * W, C)); wd = torch.randn(k * k, C) / k
-    sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.1
-    OH, OW = -(-H // s), -(-W // s)
-    if mode == "train":      # producer BN + swish in the prologue, raw output + sums
-        rest = lambda st, pool: (g(sc), g(sh), 1, None, None, None, 0, None, None, 0, st, pool, None, 0)
-    else:                    # plain input, folded BN + swish + SE pool in the epilogue
-        rest = lambda st, pool: (None, None, 0, None, None, None, 0, g(sc), g(sh), 1, st, pool, None, 0)
-    y_ref = torch.empty(B * OH * OW, C, device=DEV)
-    st_ref = torch.zeros(2 * C, dtype=torch.float64, device=DEV) if mode == "train" else None
-    pl_ref = torch.zeros(B, C, dtype=torch.int64, device=DEV) if mode == "eval" else None      # Q36 fixed-point pool sums
-    call("mmd_dwconv_fwd", g(x), g(wd), y_ref, B, H, W, C, k, s, *rest(st_ref, pl_ref))
-    y = torch.empty(B * OH * OW, C, dtype=torch.bfloat16, device=DEV)
-    st = torch.zeros(2 * C, dtype=torch.float64, device=DEV) if mode == "train" else None
-    pl = torch.zeros(B, C, dtype=torch.int64, device=DEV) if mode == "eval" else None
-    call("mmd_dwconv_fwd_w16", _b16(x), g(wd), y, B, H, W, C, k, s, *rest(st, pl), 3)
-    _close16(y, y_ref, "bf16-stored depthwise output")
-    if st is not None:
-        close(st, st_ref, 2e-5, 1e-6, "BatchNorm sums")
-    if pl is not None:
-        close(pl.double() * 2.0 ** -36, pl_ref.double() * 2.0 ** -36, 2e-5, 1e-6, "SE pool")
-    # the SE pool over a bf16-stored tensor == the pool over its widening
-    z = _r16(torch.randn(B * 64, C))
-    p_ref, p16 = torch.zeros(B, C, device=DEV), torch.zeros(B, C, device=DEV)
-    call("mmd_chan_pool", g(z), g(sc), g(sh), None, None, None, 0, 1, None, p_ref, 1.0 / 64, B, 64, C)
-    call("mmd_chan_pool_w16", _b16(z), g(sc), g(sh), None, None, None, 0, 1, None, p16, 1.0 / 64, B, 64, C)
-    assert torch.equal(p_ref, p16)
-
-
-def test_w16_mbconv_backward_launches():
-    """The three backward launches of a wide MBConv block with bf16-stored tensors against the same launches on fp32 copies of the
-    (bf16-exact) inputs: project input gradient (dx = g1 stored bf16, pooled pass over a bf16 z1), depthwise input gradient with the
-    BatchNorm-1 prologue (g1, z1, z0 in / g0 out as bf16), expand input gradient (g0, z0 in, dz stored bf16), and the two weight gradients."""
-    torch.manual_seed(23)
-    B, H, W, cin, cmid, cout, k = 2, 16, 16, 48, 288, 48, 5
-    M = B * H * W
-    rnd = lambda *s: _r16(torch.randn(*s))
-    vec = lambda c: (torch.rand(c) + 0.5, torch.randn(c) * 0.1, torch.randn(c) * 0.2, torch.rand(c) + 0.5)
-    # --- project conv: dz2 = BnBwd(dy, z2) [M, cout] narrow; dx = g1 [M, cmid] wide
-    dy, z2 = torch.randn(M, cout), torch.randn(M, cout)
-    sc2, sh2, mu2, is2 = vec(cout)
-    wt_p = torch.randn(cmid, cout) / math.sqrt(cout)
-    z1 = rnd(M, cmid); sc1, sh1, mu1, is1 = vec(cmid)
-    sums2 = torch.zeros(2 * cout, dtype=torch.float64, device=DEV)
-    call("mmd_bn_bwd_reduce", g(dy), g(z2), g(sc2), g(sh2), g(mu2), g(is2), 0, None, None, None, H * W, None, sums2, M, cout, None, 0)
-    pa = lambda z1t, p5: (None, None, None, None, None, 0, None, None, 0, z1t, g(sc1), g(sh1), g(mu1), g(is1), p5, B)
-    g1_ref = torch.empty(M, cmid, device=DEV); dzm_ref = torch.empty(M, cout, device=DEV); p5_ref = torch.zeros(5, B, cmid, device=DEV)
-    call("mmd_pwconv_bwd_data_bn2_bf16", g(dy), g(z2), g(wt_p), g1_ref, M, cmid, cout, g(sc2), g(sh2), g(mu2), g(is2), sums2, M, 0, None, H * W,
-         dzm_ref, None, None, *pa(g(z1), p5_ref))
-    g1 = torch.empty(M, cmid, dtype=torch.bfloat16, device=DEV); dzm = torch.empty(M, cout, device=DEV); p5 = torch.zeros(5, B, cmid, device=DEV)
-    call("mmd_pwconv_bwd_data_bn2_w16", g(dy), g(z2), g(wt_p), g1, M, cmid, cout, g(sc2), g(sh2), g(mu2), g(is2), sums2, M, 0, None, H * W,
-         dzm, None, None, *pa(_b16(z1), p5), 1, 2 | 16)
-    _close16(g1, g1_ref, "g1 stored as bf16"); assert torch.equal(dzm, dzm_ref)
-    close(p5, p5_ref, 1e-5, 1e-6, "pooled pass over the fp32 accumulators and a bf16 z1")
-    # project weight gradient: x = z1 stored bf16 (BN + swish + gate prologue)
-    gate = torch.rand(B, cmid)
-    dw_ref, dw16 = torch.zeros(cout, cmid, device=DEV), torch.zeros(cout, cmid, device=DEV)
-    call("mmd_pwconv_bwd_weight_bf16", dzm_ref, g(z1), dw_ref, M, cmid, cout, g(sc1), g(sh1), 1, g(gate), H * W)
-    call("mmd_pwconv_bwd_weight_w16", dzm_ref, _b16(z1), dw16, M, cmid, cout, g(sc1), g(sh1), 1, g(gate), H * W, 1, 2)
-    close(dw16, dw_ref, 2e-5, 1e-6, "project weight gradient")
-    # --- depthwise input gradient with the BatchNorm-1 prologue
-    g1f = g1.float().cpu()                     # bf16-exact
-    dpool = torch.randn(B, cmid) * 0.05
-    z0 = rnd(M, cmid); sc0, sh0, mu0, is0 = vec(cmid)
-    wd = torch.randn(k * k, cmid) / k
-    sums1 = torch.zeros(2 * cmid, dtype=torch.float64, device=DEV)
-    call("mmd_bn_bwd_reduce", g(g1f), g(z1), g(sc1), g(sh1), g(mu1), g(is1), 1, g(gate), None, g(dpool), H * W, None, sums1, M, cmid, None, 0)
-    outs = {}
-    for name in ("ref", "w16"):
-        dga, dbe = torch.zeros(cmid, device=DEV), torch.zeros(cmid, device=DEV)
-        s0 = torch.zeros(2 * cmid, dtype=torch.float64, device=DEV); dwg = torch.zeros(k * k, cmid, device=DEV)
-        cv = g if name == "ref" else _b16
-        g0 = torch.empty(M, cmid, dtype=torch.float32 if name == "ref" else torch.bfloat16, device=DEV)
-        fn = "mmd_dwconv_bwd_data_bn1" + ("" if name == "ref" else "_w16")
-        call(fn, cv(g1f), cv(z1), g(wd), g0, B, H, W, cmid, k, g(sc1), g(sh1), g(mu1), g(is1), sums1, M, g(gate), g(dpool), dga, dbe,
-             cv(z0), g(sc0), g(sh0), g(mu0), g(is0), s0, None, 0, dwg, *(() if name == "ref" else (15,)))
-        outs[name] = (g0, s0, dwg, dga, dbe)
-    _close16(outs["w16"][0], outs["ref"][0], "g0 stored as bf16")
-    for a_, b_, what in zip(outs["ref"][1:], outs["w16"][1:], ("BatchNorm-0 sums", "depthwise weight gradient", "dgamma1", "dbeta1")):
-        close(b_, a_, 2e-5, 2e-5, what)
-    # --- expand conv: dz0 = BnBwd(g0, z0) wide, dx narrow (+ residual), dz stored as bf16
-    g0f = outs["w16"][0].float().cpu()
-    wt_e = torch.randn(cin, cmid) / math.sqrt(cmid)
-    sums0 = outs["ref"][1]
-    base = torch.randn(M, cin)
-    dx_ref = g(base.clone()); dz_ref = torch.empty(M, cmid, device=DEV)
-    none15 = (None,) * 4 + (0,) + (None, None, 0) + (None,) * 6 + (0,)      # no upstream sums, no pooled pass
-    call("mmd_pwconv_bwd_data_bn2_bf16", g(g0f), g(z0), g(wt_e), dx_ref, M, cin, cmid, g(sc0), g(sh0), g(mu0), g(is0), sums0, M, 1, None, H * W,
-         dz_ref, None, None, dx_ref, *none15)
-    dx = g(base.clone()); dz16 = torch.empty(M, cmid, dtype=torch.bfloat16, device=DEV)
-    call("mmd_pwconv_bwd_data_bn2_w16", _b16(g0f), _b16(z0), g(wt_e), dx, M, cin, cmid, g(sc0), g(sh0), g(mu0), g(is0), sums0, M, 1, None, H * W,
-         dz16, None, None, dx, *none15, 1, 1 | 4 | 8)
-    close(dx, dx_ref, 1e-5, 1e-6, "expand input gradient from bf16-stored g0 / z0")
-    _close16(dz16, dz_ref, "dz stored as bf16")
-    xin = torch.randn(M, cin)
-    dwe_ref, dwe = torch.zeros(cmid, cin, device=DEV), torch.zeros(cmid, cin, device=DEV)
-    call("mmd_pwconv_bwd_weight_bf16", g(dz16.float().cpu()), g(xin), dwe_ref, M, cin, cmid, None, None, 0, None, 1)
-    call("mmd_pwconv_bwd_weight_w16", dz16, g(xin), dwe, M, cin, cmid, None, None, 0, None, 1, 1, 1)
-    close(dwe, dwe_ref, 2e-5, 1e-6, "expand weight gradient from the bf16-stored dz")
-
-
 @pytest.mark.parametrize("mode,H,W,C", [("bu", 16, 12, 48), ("p7", 4, 4, 112), ("bu", 32, 32, 112), ("bu", 3, 5, 112)])
 def test_bifpn_node_dw_bwd3_pooled_scatter_and_linear_sums(mode, H, W, C):
     """mmd_bifpn_node_dw_bwd3: the pooled operand's gradient scattered by the node backward launch (atomics at each window's arg-max, on

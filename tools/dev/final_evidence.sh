@@ -6,7 +6,7 @@ bash tools/dev/collect_profiles.sh final > $out/collect.log 2>&1 || { tail -5 $o
 bash tools/dev/trace_chain.sh final_chain > $out/chain.log 2>&1 || { tail -5 $out/chain.log; exit 1; }
 bash tools/dev/trace_step.sh > $out/trace_step.log 2>&1 || { tail -5 $out/trace_step.log; exit 1; }
 MMD_DIAG_FWD_ONLY=1 timeout -k 10 300 python tools/dev/diag_phases.py > $out/phases.txt 2> $out/phases.err || { tail -5 $out/phases.err; exit 1; }
-for p in bf16 bf16_hbm fp32; do
+for p in bf16 fp32; do
   python bench.py --coef 4 --size 768 --precision $p --no-cpu-baseline --steps 20 --warmup 3 2> $out/cfg5_$p.err | tail -1 > $out/cfg5_$p.json || exit 1
   grep -a timed $out/cfg5_$p.err
 done
