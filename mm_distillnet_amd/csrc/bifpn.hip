@@ -1431,8 +1431,18 @@ static int node_dw_bwd_impl(const float* in0, const float* in1, const float* up,
   // algorithmic bytes: the operand maps read (the up / pooled operand at a quarter / four times the node's size), the upstream gradient
   // (two tensors g, z when the 1x1 input gradient rides in this launch) and one gradient map written per operand
   const double rows = (double)B * H * W;
-  const double maps = 1.0 + (in1 ? 1.0 : 0.0) + (up ? 0.25 : 0.0) + (pool ? 4.0 : 0.0);
-  const double nbytes = 4.0 * rows * C * (2.0 * maps + (ng ? 2.0 : 1.0));
+  // Round 6: the bytes of the launch's CONTRACT, as for the GEMM family (every tensor it must move once by definition): the operand maps
+  // read; per operand gradient one write, + one read where it accumulates into a running gradient, + the z of the BatchNorm whose backward
+  // sums ride along; the pooled operand's scattered gradient read + written over the fine map; upstream (g, z) read + dz written (whole-node
+  // form) or dzd read.  The earlier formula (2 x maps + upstream) left out the accumulate reads, the sums' z tensors and the stored dz:
+  // it priced the 64^2 (in, up) launch at 66 MB where the contract is 118 MB and the counters read 146 MB (profiles/r06_notes.md).
+  const double s0 = 1.0, s1 = in1 ? 1.0 : 0.0, su = up ? 0.25 : 0.0, sp = pool ? 4.0 : 0.0;
+  double maps = s0 + s1 + su + sp;                                       // operand reads
+  maps += (d0 ? s0 * (1.0 + (acc0 ? 1.0 : 0.0)) : 0.0) + (d1 ? s1 * (1.0 + (acc1 ? 1.0 : 0.0)) : 0.0) + (dup ? su * (1.0 + (acc_up ? 1.0 : 0.0)) : 0.0);
+  maps += (dpl ? 2.0 * sp : 0.0) + (dx ? 1.0 : 0.0);
+  maps += (x0.z ? s0 : 0.0) + (x1.z ? s1 : 0.0) + (xu.z ? su : 0.0) + (xp.z ? sp : 0.0);
+  maps += ng ? (2.0 + (ng->dz_out ? 1.0 : 0.0)) : 1.0;
+  const double nbytes = 4.0 * rows * C * maps;
   const double nflops = rows * C * (2.0 * 9 * 2 + (ng ? 2.0 * C : 0.0));
   mmd_prof_tag(MMD_FAM_NODE_BWD, "nodebwd H%lld C%lld mode%lld full%lld", H, C, mode, ng ? 1 : 0);
   mmd_prof_begin(MMD_FAM_NODE_BWD, stream);

@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   MMD_PROF_DUMP=$out/prof_dump_$c.csv rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $out/pmc_$c.log 2>&1 || { tail -5 $out/pmc_$c.log; exit 1; }
 done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python tools/dev/pmc_summary.py $f $w > $out/pmc_hbm_traffic.csv; cat $out/pmc_hbm_traffic.csv
+python tools/dev/pmc_summary.py $f $w $out/pmc_node_bwd_variants.txt > $out/pmc_hbm_traffic.csv; cat $out/pmc_hbm_traffic.csv
 # the GEMM family's traffic per shape (excess over the algorithmic bytes: where the re-reads are)
 python tools/dev/pmc_by_shape.py $f $w $out/prof_dump_FETCH_SIZE.csv > $out/pmc_gemm_by_shape.txt 2>&1; head -30 $out/pmc_gemm_by_shape.txt
 # per-shape launch times of the eager roofline step of the plain bench run above (NOT of a counter pass: those launches run ~100 us each)

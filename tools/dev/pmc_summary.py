@@ -3,7 +3,7 @@ per kernel family, with the gfx950 FETCH_SIZE correction (x2 for wide coalesced 
 Usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv>"""
 import collections, csv, sys
 
-FAM = {"pw_gemm": ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel"),
+FAM = {"pw_gemm": ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel", "pw_slab_kernel", "pw_slab_combine_kernel"),
        "pw_wgrad": ("pw_wgrad_kernel", "wgrad_grouped_kernel", "wgrad_fold_kernel", "wgrad_grouped_rect_kernel", "wgrad_fold_rect_kernel"),
        "dw_fwd": ("dw_fwd_kernel", "fuse_dw_fwd_kernel", "dw3_rows_kernel"), "dw_bwd": ("dw_wgrad_kernel", "dw_bwd_data_s2_kernel", "dw3_wgrad_rows_kernel"),
        "bn_bwd": ("bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"), "mbx": ("mbx_kernel", "bifpn_node_fused_kernel"),
@@ -30,3 +30,27 @@ print("family,launches,fetch_bytes_corrected(2x),write_bytes,total_hbm_bytes_per
 for fam in FAM:
     fb, wb = 2.0 * f[fam][1], w[fam][1]
     print("%s,%d,%.4g,%.4g,%.4g" % (fam, f[fam][0], fb, wb, fb + wb))
+
+
+# per-variant view of the BiFPN node backward (where does its 2.3x traffic go?): template arguments = <MODE (bit 0 in1,
+# bit 1 up, bit 2 pool), GEMM, NKK, CW>
+def variants(path, key="fuse_dw_bwd_kernel"):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ad = [i for i, r in enumerate(rows) if "adam2_kernel" in r["Kernel_Name"]]
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows[ad[-1] + 1:]:
+        n = r["Kernel_Name"]
+        if key in n:
+            k = n[n.index(key):].split("(")[0] + " grid " + r.get("Grid_Size", "?")
+            out[k][0] += 1; out[k][1] += float(r["Counter_Value"]) * 1024.0
+    return out
+
+
+if len(sys.argv) > 3:
+    fv, wv = variants(sys.argv[1]), variants(sys.argv[2])
+    with open(sys.argv[3], "w") as fh:
+        fh.write("BiFPN node backward, HBM bytes per launch by kernel variant (FETCH_SIZE x 2 + WRITE_SIZE, one eager step)\n")
+        for k in sorted(fv, key=lambda k_: -(2 * fv[k_][1] + wv[k_][1])):
+            n = max(fv[k][0], 1)
+            fh.write("%-72s n=%2d  read %7.2f MB  written %7.2f MB  per launch\n" % (k, fv[k][0], 2 * fv[k][1] / n / 1e6, wv[k][1] / n / 1e6))
