@@ -67,13 +67,16 @@ struct StemOp { int Cin, H, W, OH, OW, pad_t, pad_l; };
 // computes the sums of the total).  `stats` (or its slotted workspace) receives [sum g', sum g'*xhat].
 struct BnSumOp { const float* z; const float* mean; const float* invstd; const float* mul_b; int rows_per_image; };
 // epilogue helper of the BnSumOp mode: v = the final output value at `off` (row `row`) -> the two BatchNorm-backward sums
-__device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t off, int row, const float4& mu, const float4& is,
-                                          float4& s4, float4& q4) {
-  const float4 zz = mmd_ld4(xs.z + off);
-  if (xs.mul_b) { const float rs = xs.mul_b[row / xs.rows_per_image]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+// (_pre: the z quad and the row's scale already in registers - the epilogues issue every row's loads before the first use)
+__device__ __forceinline__ void pw_xs_acc_pre(float4 v, const float4& zz, float rs, const float4& mu, const float4& is, float4& s4, float4& q4) {
+  v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
   s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
   q4.x += v.x * (zz.x - mu.x) * is.x; q4.y += v.y * (zz.y - mu.y) * is.y;
   q4.z += v.z * (zz.z - mu.z) * is.z; q4.w += v.w * (zz.w - mu.w) * is.w;
+}
+__device__ __forceinline__ void pw_xs_acc(const BnSumOp& xs, float4 v, size_t off, int row, const float4& mu, const float4& is,
+                                          float4& s4, float4& q4) {
+  pw_xs_acc_pre(v, mmd_ld4(xs.z + off), xs.mul_b ? xs.mul_b[row / xs.rows_per_image] : 1.f, mu, is, s4, q4);
 }
 
 // Epilogue of an MBConv project conv's input-gradient GEMM: its output g1 [M, N] is the gradient w.r.t. the squeeze-excite-gated activation;

@@ -36,10 +36,13 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
 
 // (pw_xs_acc, the epilogue helper of the BnSumOp mode: pw_args.h)
 
-// Pool5Op epilogue: one output quad v (= g1) at `off` -> the five running sums (chan_pool_bwd_kernel's arithmetic)
+// Pool5Op epilogue: one output quad v (= g1) and the z1 quad at the same position -> the five running sums (chan_pool_bwd_kernel's arithmetic)
 struct P5Coef { float4 sc, sh, mu, is; };
+__device__ __forceinline__ void pw_p5_acc_pre(const P5Coef& q, const float4& v, const float4& zz, float4 (&acc)[5]);
 __device__ __forceinline__ void pw_p5_acc(const Pool5Op& p, const P5Coef& q, const float4& v, size_t off, float4 (&acc)[5], int z16) {
-  const float4 zz = mmd_ldw4(p.z, off, z16);
+  pw_p5_acc_pre(q, v, mmd_ldw4(p.z, off, z16), acc);
+}
+__device__ __forceinline__ void pw_p5_acc_pre(const P5Coef& q, const float4& v, const float4& zz, float4 (&acc)[5]) {
   const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {v.x, v.y, v.z, v.w};
   const float scv[4] = {q.sc.x, q.sc.y, q.sc.z, q.sc.w}, shv[4] = {q.sh.x, q.sh.y, q.sh.z, q.sh.w};
   const float muv[4] = {q.mu.x, q.mu.y, q.mu.z, q.mu.w}, isv[4] = {q.is.x, q.is.y, q.is.z, q.is.w};
@@ -329,29 +332,57 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     for (int k = 0; k < 5; ++k) p5a[k] = make_float4(0, 0, 0, 0);
     if (a.p5.z && cok) { p5q.sc = mmd_ld4(a.p5.scale + col); p5q.sh = mmd_ld4(a.p5.shift + col); p5q.mu = mmd_ld4(a.p5.mean + col); p5q.is = mmd_ld4(a.p5.invstd + col); }
   }
+  // Round 6: every global load of the epilogue (residual, the z of the BnSumOp sums, the z1 of the pooled pass) is issued for ALL of the
+  // thread's rows before the first use, from clamped (always valid) addresses.  Inside the per-row guard each of them was a dependent round
+  // trip - `if (ok) v = ld` compiles to a branch with a full s_waitcnt vmcnt(0) (profiles/r04_notes.md sections 23 - 29) - i.e. 4 - 8 round
+  // trips in sequence per block, longer than the K loop of the K = 88 .. 144 layers.
+  // (in chunks of CH rows: all NI = 4 .. 8 rows at once cost the register-lean variants their occupancy - 16 - 24 spilled registers at the
+  // 80-register bound)
+  constexpr int NI = BM_T / RSTEP;
+  constexpr int CH = 2;
+  const int colc = cok ? col : 0;
 #pragma unroll
-  for (int i = 0; i < BM_T / RSTEP; ++i) {
-    const int rl = rgrp + RSTEP * i, row = m0 + rl;
-    if (cok && row < Mv) {
-      float4 v = *reinterpret_cast<const float4*>(&smem[rl * LDC + cg * 4]);
-      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      if (!a.xs.z) {
-        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-        q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
-      }
-      if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-      if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
-      size_t off;
+  for (int c0 = 0; c0 < NI; c0 += CH) {
+    size_t offs[CH];
+    float4 rr[CH], xz[(PRO == 1) ? CH : 1], pz[(PRO == 1) ? CH : 1];
+    float xrs[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int rowc = min(m0 + rgrp + RSTEP * (c0 + u), Mv - 1);
       if (a.y_batch_stride) {
-        int img = (row - srow0) / rpi;
-        off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
+        const int img = (rowc - srow0) / rpi;
+        offs[u] = (size_t)img * a.y_batch_stride + yoff + (size_t)(rowc - srow0 - img * rpi) * a.N + colc;
       } else {
-        off = (size_t)row * a.N + col;
+        offs[u] = (size_t)rowc * a.N + colc;
       }
-      if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-      mmd_stw4(a.y, off, v, a.y16);
-      if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
-      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a, a.p5z16); }
+      xrs[u] = 1.f;
+      if (a.residual) rr[u] = mmd_ld4(a.residual + offs[u]);
+      if constexpr (PRO == 1) {      // (the BnSumOp sums and the pooled pass only ride on the BatchNorm-backward operand launches)
+        if (a.xs.z) { xz[u] = mmd_ld4(a.xs.z + offs[u]); if (a.xs.mul_b) xrs[u] = a.xs.mul_b[rowc / a.xs.rows_per_image]; }
+        if (a.p5.z) pz[u] = mmd_ldw4(a.p5.z, offs[u], a.p5z16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int rl = rgrp + RSTEP * (c0 + u), row = m0 + rl;
+      if (cok && row < Mv) {
+        float4 v = *reinterpret_cast<const float4*>(&smem[rl * LDC + cg * 4]);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (!a.xs.z) {
+          s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+          q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
+        }
+        if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
+        if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
+        if (a.residual) { v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w; }
+        mmd_stw4(a.y, offs[u], v, a.y16);
+        if constexpr (PRO == 1) {
+          if (a.xs.z) pw_xs_acc_pre(v, xz[u], xrs[u], xmu, xis, s4, q4);
+          if (a.p5.z) pw_p5_acc_pre(p5q, v, pz[u], p5a);
+        } else {
+          if (a.xs.z) pw_xs_acc(a.xs, v, offs[u], row, xmu, xis, s4, q4);
+        }
+      }
     }
   }
   if constexpr (PRO == 1) {
@@ -669,6 +700,26 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     for (int k = 0; k < 5; ++k) p5a[k] = make_float4(0, 0, 0, 0);
     if (a.p5.z && cok) { p5q.sc = mmd_ld4(a.p5.scale + col); p5q.sh = mmd_ld4(a.p5.shift + col); p5q.mu = mmd_ld4(a.p5.mean + col); p5q.is = mmd_ld4(a.p5.invstd + col); }
   }
+  // (round 6: the epilogue's global loads - residual, the sums' z, the pooled pass' z1 - for both of the thread's rows up front, from
+  // clamped addresses: inside the per-row guard each was a dependent round trip)
+  size_t offs[2];
+  float4 rr[2], xz[2], pz[(PRO == 1) ? 2 : 1];
+  float xrs[2];
+  const int colc = cok ? col : 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rowc = min(m0 + rgrp + 16 * i, Mv - 1);
+    if (a.y_batch_stride) {
+      const int img = (rowc - srow0) / rpi;
+      offs[i] = (size_t)img * a.y_batch_stride + yoff + (size_t)(rowc - srow0 - img * rpi) * a.N + colc;
+    } else {
+      offs[i] = (size_t)rowc * a.N + colc;
+    }
+    xrs[i] = 1.f;
+    if (a.residual) rr[i] = mmd_ld4(a.residual + offs[i]);
+    if (a.xs.z) { xz[i] = mmd_ld4(a.xs.z + offs[i]); if (a.xs.mul_b) xrs[i] = a.xs.mul_b[rowc / a.xs.rows_per_image]; }
+    if constexpr (PRO == 1) { if (a.p5.z) pz[i] = mmd_ldw4(a.p5.z, offs[i], a.p5z16); }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int rl = rgrp + 16 * i, row = m0 + rl;
@@ -686,17 +737,10 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       }
       if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
       if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
-      size_t off;
-      if (a.y_batch_stride) {
-        int img = (row - srow0) / rpi;
-        off = (size_t)img * a.y_batch_stride + yoff + (size_t)(row - srow0 - img * rpi) * a.N + col;
-      } else {
-        off = (size_t)row * a.N + col;
-      }
-      if (a.residual) { float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-      mmd_stw4(a.y, off, v, a.y16);
-      if (a.xs.z) pw_xs_acc(a.xs, v, off, row, xmu, xis, s4, q4);
-      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc(a.p5, p5q, v, off, p5a, a.p5z16); }
+      if (a.residual) { v.x += rr[i].x; v.y += rr[i].y; v.z += rr[i].z; v.w += rr[i].w; }
+      mmd_stw4(a.y, offs[i], v, a.y16);
+      if (a.xs.z) pw_xs_acc_pre(v, xz[i], xrs[i], xmu, xis, s4, q4);
+      if constexpr (PRO == 1) { if (a.p5.z) pw_p5_acc_pre(p5q, v, pz[i], p5a); }
     }
   }
   if constexpr (PRO == 1) {
