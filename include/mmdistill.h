@@ -357,6 +357,10 @@ int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, int n_items
 // precision "bf16" (BASELINE configs[4]): the same launch with both operands rounded to bf16 at the MFMA input, fp32 accumulate
 // (mmd_pwconv_bwd_weight_bf16's arithmetic for every layer of the table)
 int mmd_wgrad_grouped_bf16(const void* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks, double flops, double bytes, hipStream_t stream);
+// mmd_wgrad_grouped / _bf16 with one more choice made by the caller: rows32 = 1 promises that every layer's M is a multiple of 32 (any net
+// at B >= 2: the smallest map is 4 x 4) - the kernel then runs without row clamps / masks and with running operand pointers
+// (57 v_cndmask + 43 address instructions per 32-row step less on a kernel whose VALU instructions are MFMA time).  rows32 = 0: as the plain entry points.
+int mmd_wgrad_grouped_form(const void* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks, double flops, double bytes, int bf16, int rows32, hipStream_t stream);
 
 // dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
 int mmd_pwconv_bwd_data(const float* dy, const float* wt, float* dx, int M, int K, int N, int accumulate, hipStream_t stream);

@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #ifndef WG_RECT_WAVES
 #define WG_RECT_WAVES 4      /* waves per SIMD the register allocation aims at: 4 = at most 128 VGPRs (137 without the bound: three waves) */
 #endif
-template <bool BF>
+// R32: every item's row range is whole 32-row steps (every layer's M a multiple of 32 - the caller's promise, mmd_wgrad_rows32): the row
+// clamps / masks and the per-load address multiplies are compiled out.  (Both forms in ONE kernel, chosen per item, spilled 51 registers.)
+template <bool BF, bool R32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAVES, 8))) void wgrad_grouped_rect_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
   constexpr int LDD = 128 + 4, LDX = 64 + 4;
   __shared__ float sD[GW_BR * LDD];
@@ -250,44 +252,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAV
 #pragma unroll
       for (int i = 0; i < 2; ++i) { const int r0_ = mbeg + lrowx + i * 16; gimg[i] = r0_ / a.rows_per_image; grem[i] = r0_ - gimg[i] * a.rows_per_image; }
     }
-    auto gload = [&](int mb) {
+    // Round 6: running operand pointers (a row step is one 64-bit add per load instead of a 64-bit multiply-add: 16 v_mad_i64_i32 + 27
+    // v_lshl_add_u64 per 32-row step in the ISA) and - FULL: the item's row range is whole 32-row steps, i.e. every layer of a B >= 2 net -
+    // no row clamps and no row masks at all (57 v_cndmask per step).  On this kernel VALU instructions are MFMA time.
+    // (ONE running pointer per operand - the thread's first row; its other rows are wave-uniform offsets from it: pointer arrays cost the
+    // 128-register bound 18 - 25 spilled registers)
+    const float* pdy0 = nullptr; const float* pxx0 = nullptr;
+    if constexpr (R32) {
+      pdy0 = a.dy + (size_t)(mbeg + lrowd) * a.N + (nok ? n0 + c4d : 0);
+      pxx0 = a.x + (size_t)(mbeg + lrowx) * a.K + (kok ? k0 + c4x : 0);
+    }
+    const int dro = rppd * a.N, xro = 16 * a.K;          // element offsets between a thread's rows (wave-uniform)
+    const int dstep = GW_BR * a.N, xstep = GW_BR * a.K;
+    auto gload = [&](int mb, auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < 2 || wide) {
-          const int row = mb + lrowd + i * rppd;
-          rokd[i] = row < mend;
-          rd[i] = mmd_ldg4(a.dy + (size_t)(rokd[i] ? row : mbeg) * a.N + (nok ? n0 + c4d : 0));
+          if constexpr (FULL) {
+            rd[i] = mmd_ldg4(pdy0 + i * dro);
+          } else {
+            const int row = mb + lrowd + i * rppd;
+            rokd[i] = row < mend;
+            rd[i] = mmd_ldg4(a.dy + (size_t)(rokd[i] ? row : mbeg) * a.N + (nok ? n0 + c4d : 0));
+          }
         }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = mb + lrowx + i * 16;
-        rokx[i] = row < mend;
-        const int rc = rokx[i] ? row : mbeg;
-        rx[i] = mmd_ldg4(a.x + (size_t)rc * a.K + (kok ? k0 + c4x : 0));
+        if constexpr (FULL) {
+          rx[i] = mmd_ldg4(pxx0 + i * xro);
+        } else {
+          rokx[i] = row < mend;
+          const int rc = rokx[i] ? row : mbeg;
+          rx[i] = mmd_ldg4(a.x + (size_t)rc * a.K + (kok ? k0 + c4x : 0));
+        }
         if (a.gate) {
           // image of the row, carried from step to step (rows advance by GW_BR: an integer division per load was ~20 VALU instructions)
           while (grem[i] >= a.rows_per_image) { grem[i] -= a.rows_per_image; ++gimg[i]; }
-          rg[i] = mmd_ldg4(a.gate + (size_t)(rokx[i] ? gimg[i] : gimg0) * a.K + (kok ? k0 + c4x : 0));
+          rg[i] = mmd_ldg4(a.gate + (size_t)((FULL || rokx[i]) ? gimg[i] : gimg0) * a.K + (kok ? k0 + c4x : 0));
           grem[i] += GW_BR;
         }
       }
+      if constexpr (FULL) { pdy0 += dstep; pxx0 += xstep; }
     };
     // Only ROWS past the item's end are zeroed.  Columns past N / K need no mask: their loads come from clamped (valid, finite) addresses
     // and only feed output elements n >= N / k >= K of the partial tile, which the fold never stores - 24 selects per step instead of 48
     // on a kernel whose VALU instructions are MFMA time.
-    auto lstore = [&]() {
+    auto lstore = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (i < 2 || wide)
-          *reinterpret_cast<float4*>(&sD[(lrowd + i * rppd) * LDD + c4d]) = rokd[i] ? rd[i] : make_float4(0, 0, 0, 0);
+          *reinterpret_cast<float4*>(&sD[(lrowd + i * rppd) * LDD + c4d]) = (FULL || rokd[i]) ? rd[i] : make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float4 v = rx[i];
         if (a.in_scale) { v.x = v.x * xsc.x + xsh.x; v.y = v.y * xsc.y + xsh.y; v.z = v.z * xsc.z + xsh.z; v.w = v.w * xsc.w + xsh.w; }
         if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
         if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
-        if (!rokx[i]) v = make_float4(0, 0, 0, 0);
+        if constexpr (!FULL) { if (!rokx[i]) v = make_float4(0, 0, 0, 0); }
         *reinterpret_cast<float4*>(&sX[(lrowx + i * 16) * LDX + c4x]) = v;
       }
     };
@@ -325,25 +350,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAV
     // The row loop is instantiated per number of live sub-tiles (item-uniform), not branched inside: with `if (nu == 2) ... else ...` in
     // the loop body hipcc kept the accumulators of the two variants in different registers and copied all 32 of them at every merge -
     // 40 v_mov per 32-row step beside 32 MFMAs (ISA of the first version), on a kernel whose VALU and fp32-MFMA work share one pipe.
-    auto rows = [&](auto nu_c) {
+    auto rows = [&](auto nu_c, auto full_c) {
       constexpr int NU = decltype(nu_c)::value;
-      gload(mbeg);
+      gload(mbeg, full_c);
       for (int mb = mbeg; mb < mend; mb += GW_BR) {
-        lstore();
+        lstore(full_c);
         __syncthreads();
-        if (mb + GW_BR < mend) gload(mb + GW_BR);
+        if (mb + GW_BR < mend) gload(mb + GW_BR, full_c);
         if constexpr (NU > 0) mma(nu_c);
         __syncthreads();
       }
     };
     // BARRIER CONTRACT: the four waves of a block may run DIFFERENT instantiations of `rows` (nu / nv are wave-uniform, not
-    // block-uniform), so they meet at __syncthreads() calls at different program counters.  That is sound on gfx950 because s_barrier counts
-    // arrivals per workgroup, whatever the PC - and ONLY because every instantiation executes exactly the same number of barriers: two per
-    // 32-row step (one behind lstore, one behind the MFMAs), (mend - mbeg) / GW_BR steps, with item-uniform mbeg / mend.  Anything added to one
-    // instantiation's loop that contains a barrier must be added to all three.
-    if (!nv || nu == 0) rows(std::integral_constant<int, 0>{});      // (a wave without live sub-tiles still stages its share of the slabs)
-    else if (nu == 2) rows(std::integral_constant<int, 2>{});
-    else rows(std::integral_constant<int, 1>{});
+    // block-uniform; `full` is item-uniform), so they meet at __syncthreads() calls at different program counters.  That is sound on gfx950
+    // because s_barrier counts arrivals per workgroup, whatever the PC - and ONLY because every instantiation executes exactly the same number
+    // of barriers: two per 32-row step (one behind lstore, one behind the MFMAs), (mend - mbeg) / GW_BR steps, with item-uniform mbeg / mend.
+    // Anything added to one instantiation's loop that contains a barrier must be added to all of them.
+    const int nuw = (!nv || nu == 0) ? 0 : nu;      // (a wave without live sub-tiles still stages its share of the slabs)
+    if (nuw == 0) rows(std::integral_constant<int, 0>{}, std::integral_constant<bool, R32>{});
+    else if (nuw == 2) rows(std::integral_constant<int, 2>{}, std::integral_constant<bool, R32>{});
+    else rows(std::integral_constant<int, 1>{}, std::integral_constant<bool, R32>{});
     // partial tile [TN n][64 k] -> this item's workspace slot
     float* out = ws + a.ws_off + (size_t)(item - a.item0) * (TN * 64);
 #pragma unroll
@@ -505,15 +531,20 @@ extern "C" int mmd_wgrad_plan(MmdWgradLayer* layers, int n, int rows_per_item, i
 
 // layers_dev: the planned table in device memory; ws: workspace of ws_floats floats (needs no initialisation).
 static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
-                              double flops, double bytes, int bf16, hipStream_t stream) {
+                              double flops, double bytes, int bf16, hipStream_t stream, int rows32 = 0) {
   if (!layers_dev || n_layers <= 0 || n_layers > GW_MAXL || n_items <= 0 || n_tiles <= 0 || !ws) return MMD_EINVAL;
   if (blocks <= 0) blocks = 1024;
   if (blocks > n_items) blocks = n_items;
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wgrouped L%lld items%lld tiles%lld b%lld", n_layers, n_items, n_tiles, blocks);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
   if (wg_tile() == 0) {
-    if (bf16) hipLaunchKernelGGL(wgrad_grouped_rect_kernel<true>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
-    else hipLaunchKernelGGL(wgrad_grouped_rect_kernel<false>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    if (bf16) {
+      if (rows32) hipLaunchKernelGGL((wgrad_grouped_rect_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+      else hipLaunchKernelGGL((wgrad_grouped_rect_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    } else {
+      if (rows32) hipLaunchKernelGGL((wgrad_grouped_rect_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+      else hipLaunchKernelGGL((wgrad_grouped_rect_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    }
     hipLaunchKernelGGL(wgrad_fold_rect_kernel, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
   } else if (wg_tile() == 128) {
     if (bf16) hipLaunchKernelGGL((wgrad_grouped_kernel<128, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
@@ -530,6 +561,12 @@ static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int
 extern "C" int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
                                  double flops, double bytes, hipStream_t stream) {
   return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, 0, stream);
+}
+// the same launch with two choices made by the caller: bf16 (as mmd_wgrad_grouped_bf16) and rows32 = 1: the caller promises that every
+// layer's M is a multiple of 32 - the kernel then runs without row clamps / masks and with running operand pointers (round 6)
+extern "C" int mmd_wgrad_grouped_form(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
+                                      double flops, double bytes, int bf16, int rows32, hipStream_t stream) {
+  return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, bf16 ? 1 : 0, stream, rows32 ? 1 : 0);
 }
 // precision "bf16": operands rounded to bf16 at the MFMA input (mmd_pwconv_bwd_weight_bf16's arithmetic), same table / workspace / fold
 extern "C" int mmd_wgrad_grouped_bf16(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,

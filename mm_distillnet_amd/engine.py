@@ -1047,12 +1047,14 @@ class Net:
             table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             plan = {"sig": sig, "table": table, "n": n, "items": ni.value, "tiles": nt.value, "ws": wsf.value,
                     "flops": float(sum(2.0 * M * K * N for _, _, _, M, K, N, *_ in pend)),
-                    "bytes": float(sum(4.0 * (M * K + M * N + N * K) for _, _, _, M, K, N, *_ in pend))}
+                    "bytes": float(sum(4.0 * (M * K + M * N + N * K) for _, _, _, M, K, N, *_ in pend)),
+                    # every layer's M a multiple of 32 (any net at B >= 2): the launch runs without row clamps / masks (mmd_wgrad_grouped_form)
+                    "rows32": int(all(M % 32 == 0 for _, _, _, M, *_ in pend) and not os.environ.get("MMD_NO_WG_R32"))}
             self._wg_plans[(seg, sig)] = plan
         ws = self._alloc(plan["ws"])
         with self._wgrad_stream():
-            call("mmd_wgrad_grouped" + self._sfx, plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS if final else WG_BLOCKS_MID,
-                 plan["flops"], plan["bytes"])
+            call("mmd_wgrad_grouped_form", plan["table"], plan["n"], plan["items"], plan["tiles"], ws, WG_BLOCKS if final else WG_BLOCKS_MID,
+                 plan["flops"], plan["bytes"], 1 if self._sfx else 0, plan["rows32"])
 
     def _bn_bwd(self, g_in: torch.Tensor, z: torch.Tensor, aff, bn_name: str, act: int, M: int, C: int, rpi: int = 0,
                 mul_bc=None, mul_b=None, add_bc=None, sums=None, lazy: bool = False):

@@ -1284,7 +1284,10 @@ def test_pwconv_pyr_bf16():
 
 
 @pytest.mark.parametrize("M,K,N,act,rowscale", [(512, 40, 24, 0, True), (4096, 96, 16, 1, False), (1000, 528, 88, 1, False),
-                                                 (8192, 112, 112, 0, False), (20480, 24, 144, 1, False), (130, 208, 1248, 0, True)])
+                                                 (8192, 112, 112, 0, False), (20480, 24, 144, 1, False), (130, 208, 1248, 0, True),
+                                                 # round 6: the shapes the slab kernel (csrc/pw_slab.hip) takes on its own - unsliced at
+                                                 # M = 8192; the M = 2048 ones need a workspace (test_pwconv_slab_bn_operand) and run skinny here
+                                                 (8192, 120, 720, 1, False), (8192, 88, 528, 1, True), (2048, 208, 1248, 1, False), (2048, 352, 2112, 1, False)])
 @pytest.mark.parametrize("sfx", ["", "_bf16"])
 def test_pwconv_bwd_bn_prologue(M, K, N, act, rowscale, sfx):
     """Input- and weight-gradient GEMMs of a 1x1 conv with the BatchNorm(+swish, +drop-connect row scale) backward evaluated in
@@ -1406,7 +1409,8 @@ def _sums_close(got, ref, what):
 
 @pytest.mark.parametrize("M,K,N,act,rowscale,resid", [(512, 40, 24, 0, True, True), (4096, 96, 16, 1, False, False), (1000, 528, 88, 1, False, True),
                                                        (8192, 112, 112, 0, False, True), (20480, 24, 144, 1, True, True), (130, 208, 1248, 0, True, False),
-                                                       (40960, 16, 96, 1, True, True)])
+                                                       (40960, 16, 96, 1, True, True),
+                                                       (8192, 120, 720, 1, False, True), (8192, 88, 528, 1, True, True)])      # (round 6: on the slab kernel)
 def test_pwconv_bwd_data_bn2_residual_and_upstream_sums(M, K, N, act, rowscale, resid):
     """mmd_pwconv_bwd_data_bn2 = mmd_pwconv_bwd_data_bn + residual (in place) + the backward sums of the UPSTREAM BatchNorm taken over the
     completed gradient, against the launches it replaces (bwd_data_bn, scale_acc, bn_bwd_reduce)."""
