@@ -225,6 +225,32 @@ __device__ __forceinline__ void mmd_pool_add(long long* p, float v, float scale)
 __device__ __forceinline__ float mmd_pool_get(long long q) { return (float)((double)q * (1.0 / MMD_POOL_Q)); }
 #endif
 
+
+// ---- fp32 products on the bf16 matrix pipe ("split" form of the GEMM kernels, round 6) ------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the vector rate (64 FLOP / clk / SIMD), 1/16 of v_mfma_f32_32x32x16_bf16.  An fp32 value splits EXACTLY into
+// three bf16 pieces by round-to-nearest, x = h + m + l (x - h and (x - h) - m are exact in fp32; the last residual has at most 8 significant
+// bits), a bf16 x bf16 product is exact in fp32, so
+//     a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + [am*bl + al*bm + al*bl]
+// and the bracket is <= 2^-26 |a * b| - a quarter of the 2^-24 rounding EVERY fp32 accumulate makes anyway.  Six bf16 MFMAs (fp32 accumulate,
+// smallest terms first) per 16-deep k group = 192 cycles against 512 for eight v_mfma_f32_32x32x2_f32; the error against float64 measured
+// BELOW the fp32 MFMA chain's on every shape (fewer accumulator roundings: profiles/r06_notes.md section 10, test_split3_precision).
+// Not for Inf operands (Inf - Inf in the residual gives NaN where fp32 gives Inf) - activations and gradients here are finite.
+// MMD_MFMA_F32=1: every GEMM kernel on v_mfma_f32 (A/B timing, bisecting); per call: the `native` flags of the _form entry points.
+#include <cstdlib>
+static inline int mmd_split_default() {
+  static const int on = getenv("MMD_MFMA_F32") ? 0 : 1;
+  return on;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ void mmd_split3_pk(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = mmd_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = mmd_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = mmd_pk_bf16(s0, s1);
+}
+#endif
+
 static inline int mmd_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMD_OK : MMD_ELAUNCH;

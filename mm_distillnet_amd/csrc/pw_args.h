@@ -89,6 +89,9 @@ struct Pool5Op { const float* z; const float* scale; const float* shift; const f
 // library keeps no global state besides the communicator).  AUTO = the measured shape filters of pw_dispatch decide; the others force one
 // family for every launch it supports (a launch it does not support falls through to the LDS-tiled kernels) - tests and A/B timing.
 enum { MMD_PW_FORM_AUTO = 0, MMD_PW_FORM_ROWS = 1, MMD_PW_FORM_TILED = 2, MMD_PW_FORM_LONGK = 3, MMD_PW_FORM_SLAB = 4 };
+// OR-ed into `form`: fp32 launches on v_mfma_f32_32x32x2_f32 instead of the split form (six bf16 MFMAs on a three-way exact split of both
+// operands, common.h) - the per-call version of MMD_MFMA_F32=1; tests compare the two forms against float64 with it
+enum { MMD_PW_FORM_NATIVE = 16 };
 
 struct PwArgs {
   const float* x; const float* w; float* y;
@@ -113,6 +116,7 @@ struct PwArgs {
   // out_scale / out_shift g * g_bn floats behind the given pointers (LDS-tiled kernels only)
   int g_images; long long g_w, g_bn;
   float* slab_ws; long long slab_ws_floats;      // host-side: caller's workspace for the K slices' partial slabs of the slab kernel (pw_slab.hip)
+  int native;      // host-side, per call: MMD_PW_FORM_NATIVE was set (a.form holds the family only)
   int form;        // host-side, per call (mmd_pwconv_fwd_form / _bwd_data_bn_form): which kernel family takes the launch, MMD_PW_FORM_*
   int bq_lds;      // BatchNorm-backward operand launches: the per-channel coefficients come from a per-block LDS table (5 x K floats of dynamic LDS)
 };

@@ -29,6 +29,16 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   f32x2_t v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// ---- split mode (BF == 2): fp32 products as six bf16 MFMAs on a three-way exact split of both operands (common.h)
+// one quad of a tile row -> its words in the three planes of the row ([h: KW words][m: KW words][l: KW words], KW = tile k / 2)
+template <int KW>
+__device__ __forceinline__ void split3_store(unsigned* p, const float4& v) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  mmd_split3_pk(v.x, v.y, h0, m0, l0); mmd_split3_pk(v.z, v.w, h1, m1, l1);
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(p + KW) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(p + 2 * KW) = make_uint2(l0, l1);
+}
 __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
   u32x4_t u = {pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
   return __builtin_bit_cast(bf16x8, u);
@@ -63,6 +73,7 @@ __device__ __forceinline__ void pw_p5_acc_pre(const P5Coef& q, const float4& v, 
 #define PW_BK 32
 #define PW_LD 36
 #define PW_LDH 20      // bf16 mode: words per tile row (PW_BK / 2 data + 4 pad)
+#define PW_LD3 52      // split mode: three planes of PW_BK / 2 words + 4 pad (52 = 20 mod 32: the bf16 rows' bank pattern)
 
 // NKL = 8-wide k groups of the LAST K tile that hold data (1..4): fp32 MFMA runs at the vector rate (64 cycles per
 // 32x32x2), so multiplying the zero padding of K = 112 / 48 / 24 ... is real time.  Compile-time so the hot loop keeps its schedule
@@ -75,7 +86,7 @@ __device__ __forceinline__ void pw_p5_acc_pre(const P5Coef& q, const float4& v, 
 // The unused gate / coefficient registers and branches are compiled out: 62-80 VGPRs instead of 90-128, i.e. five to six waves
 // per SIMD instead of four (pw_gemm_kernel_lean) - the K loops of these layers are 1-7 tiles long, so what hides the load ->
 // LDS -> MFMA chain of one block is the other blocks on the CU (weighted over a step's shapes: 8.78 -> 8.29 ms).
-template <int BM_T, int BN_T, int NKL, bool BF, int PRO>
+template <int BM_T, int BN_T, int NKL, int BF, int PRO>
 __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   constexpr int WM = BM_T / 32;          // waves along M
   constexpr int WN = 4 / WM;             // waves along N
@@ -83,14 +94,20 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   constexpr int NA = BM_T / 32;          // A float4 loads per thread (BM_T*8/256)
   constexpr int NB = BN_T / 32;          // B float4 loads per thread (BN_T*8/256)
   constexpr int LDC = BN_T + 4;            // C staging row stride (floats)
-  constexpr int SM = (BM_T * LDC > (BM_T + BN_T) * PW_LD) ? BM_T * LDC : (BM_T + BN_T) * PW_LD;
+  constexpr int LDT = BF == 2 ? PW_LD3 : PW_LD;      // words per tile row in the K loop
+  constexpr int SM = (BM_T * LDC > (BM_T + BN_T) * LDT) ? BM_T * LDC : (BM_T + BN_T) * LDT;
   __shared__ float smem[SM];              // A|B tiles in the K loop, then the C tile for the vectorised epilogue
-  __shared__ float sRed[2 * 4 * BN_T];
-  __shared__ float sRed5[(PRO == 1) ? 5 * 4 * BN_T : 1];      // Pool5Op sums (BatchNorm-backward operand launches only)
+  // split mode: the K loop's tiles are larger than the C tile - the reduction scratch lives behind the C tile instead of beside the tiles
+  // (39.9 KB per 128 x 64 block: four blocks per CU, which 42 KB would not allow)
+  constexpr bool RED_IN = BF == 2 && BM_T * LDC + 8 * BN_T + ((PRO == 1) ? 20 * BN_T : 0) <= SM;
+  __shared__ float sRedS[RED_IN ? 1 : 2 * 4 * BN_T];
+  __shared__ float sRed5S[(PRO == 1 && !RED_IN) ? 5 * 4 * BN_T : 1];      // Pool5Op sums (BatchNorm-backward operand launches only)
+  float* const sRed = RED_IN ? smem + BM_T * LDC : sRedS;
+  float* const sRed5 = RED_IN ? smem + BM_T * LDC + 8 * BN_T : sRed5S;
   float* const sA = smem;
   float* const sB = smem + BM_T * PW_LD;
   unsigned* const sAu = reinterpret_cast<unsigned*>(smem);                   // BF: bf16 tiles, two elements per word, [row][PW_LDH]
-  unsigned* const sBu = reinterpret_cast<unsigned*>(smem) + BM_T * PW_LDH;
+  unsigned* const sBu = reinterpret_cast<unsigned*>(smem) + BM_T * (BF == 2 ? PW_LD3 : PW_LDH);
 
   const int tid = threadIdx.x;
   const int t = mmd_xcd_swizzle(blockIdx.x, a.nblk);
@@ -231,7 +248,9 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
       }
       if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
-      if constexpr (BF) {
+      if constexpr (BF == 2) {
+        split3_store<PW_BK / 2>(&sAu[(lrow + i * 32) * PW_LD3 + (kq >> 1)], v);
+      } else if constexpr (BF) {
         // bf16 mode (round 6): the tile is stored as bf16 - rounded ONCE here (RNE, v_cvt_pk_bf16_f32) instead of by every lane in front of
         // every MFMA (12 converts + 6 ds_read_b128 per two MFMAs: the 16x faster pipe bought 24 %) - rows of PW_BK bf16 + 8 pad = 20 words
         *reinterpret_cast<uint2*>(&sAu[(lrow + i * 32) * PW_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
@@ -242,7 +261,8 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const float4 w4 = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
-      if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 32) * PW_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
+      if constexpr (BF == 2) split3_store<PW_BK / 2>(&sBu[(lrow + i * 32) * PW_LD3 + (kq >> 1)], w4);
+      else if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 32) * PW_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
       else *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = w4;
     }
   };
@@ -274,6 +294,24 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
     }
   };
+  // split mode: the three planes of both operands, six MFMAs per column slab - smallest partial products first
+  const unsigned* const pa3 = &sAu[(wm * 32 + r) * PW_LD3 + h * 4];
+  const unsigned* const pb3 = &sBu[(wn * NS * 32 + r) * PW_LD3 + h * 4];
+  auto ldf = [](const unsigned* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(p)); };
+  auto mma3 = [&](int g) {
+    const bf16x8 ah = ldf(pa3 + g * 8), am = ldf(pa3 + PW_BK / 2 + g * 8), al = ldf(pa3 + PW_BK + g * 8);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const unsigned* q = pb3 + j * 32 * PW_LD3 + g * 8;
+      const bf16x8 bh = ldf(q), bm = ldf(q + PW_BK / 2), bl = ldf(q + PW_BK);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+    }
+  };
   for (int kt = 0; kt < nk - 1; ++kt) {
     lstore();
     __syncthreads();
@@ -283,7 +321,10 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     // variants, where the staging registers double as fragment registers, so a block's K step pays the full load latency)
     if constexpr ((PRO == 3 || PRO == 4) && !(PRO == 4 && BM_T == 128 && BN_T == 64)) __builtin_amdgcn_sched_barrier(0);
 #endif
-    if constexpr (BF) {
+    if constexpr (BF == 2) {
+#pragma unroll
+      for (int g = 0; g < PW_BK / 16; ++g) mma3(g);
+    } else if constexpr (BF) {
 #pragma unroll
       for (int g = 0; g < PW_BK / 16; ++g) mma16(g);
     } else {
@@ -294,7 +335,10 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   }
   lstore();                      // last K tile: only its populated 8-wide groups (the tile is zero-filled beyond K)
   __syncthreads();
-  if constexpr (BF) {
+  if constexpr (BF == 2) {
+#pragma unroll
+    for (int g = 0; g < (NKL + 1) / 2; ++g) mma3(g);
+  } else if constexpr (BF) {
 #pragma unroll
     for (int g = 0; g < (NKL + 1) / 2; ++g) mma16(g);
   } else {
@@ -431,17 +475,22 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
   }
 }
 
-template <int BM_T, int BN_T, int NKL, bool BF, int PRO>
+template <int BM_T, int BN_T, int NKL, int BF, int PRO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pw_gemm_kernel(PwArgs a) {
   pw_gemm_body<BM_T, BN_T, NKL, BF, PRO>(a);
 }
 // register-lean operand modes (PRO 3 / 4) at a higher occupancy target (WAVES per SIMD)
-template <int BM_T, int BN_T, int NKL, bool BF, int PRO, int WAVES>
+template <int BM_T, int BN_T, int NKL, int BF, int PRO, int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pw_gemm_kernel_lean(PwArgs a) {
   pw_gemm_body<BM_T, BN_T, NKL, BF, PRO>(a);
 }
 template <int BM_T, int BN_T, int PRO, int WAVES>
 static void (*pw_pick_lean(int nkl, int bf))(PwArgs) {
+  // (split mode: 33 - 40 KB of tiles per 128-row block - four blocks per CU - so the register budget of four waves per SIMD there; the
+  // 64 x 64 blocks' 26.6 KB leave six)
+  constexpr int WS = BM_T == 64 ? WAVES : 4;
+  if (bf == 2) return nkl == 1 ? pw_gemm_kernel_lean<BM_T, BN_T, 1, 2, PRO, WS> : nkl == 2 ? pw_gemm_kernel_lean<BM_T, BN_T, 2, 2, PRO, WS>
+                    : nkl == 3 ? pw_gemm_kernel_lean<BM_T, BN_T, 3, 2, PRO, WS> : pw_gemm_kernel_lean<BM_T, BN_T, 4, 2, PRO, WS>;
   if (bf) return nkl == 1 ? pw_gemm_kernel_lean<BM_T, BN_T, 1, true, PRO, WAVES> : nkl == 2 ? pw_gemm_kernel_lean<BM_T, BN_T, 2, true, PRO, WAVES>
                : nkl == 3 ? pw_gemm_kernel_lean<BM_T, BN_T, 3, true, PRO, WAVES> : pw_gemm_kernel_lean<BM_T, BN_T, 4, true, PRO, WAVES>;
   return nkl == 1 ? pw_gemm_kernel_lean<BM_T, BN_T, 1, false, PRO, WAVES> : nkl == 2 ? pw_gemm_kernel_lean<BM_T, BN_T, 2, false, PRO, WAVES>
@@ -477,6 +526,7 @@ static size_t pw_bq_lds(PwArgs& a, const void* kern, size_t static_bytes) {
 #define SK_BK 128
 #define SK_LD 132
 #define SK_LDH 68      // bf16 mode: words per tile row (SK_BK / 2 data + 4 pad)
+#define SK_LD3 196     // split mode: three planes of SK_BK / 2 words + 4 pad (196 = 4 mod 32, as 36 / 68 / 132)
 
 // -DMMD_KSTAMPS (dev build, tools/dev/skinny_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock along the K loop
 #ifdef MMD_KSTAMPS
@@ -489,10 +539,11 @@ extern "C" int mmd_k_stamps(unsigned long long* out) { return hipMemcpyFromSymbo
 // PF = register prefetch depth.  The skinny launches have at most one or two blocks per CU, so nothing but the block itself hides
 // its load latency: with PF = 2 the loads of K steps t+1 and t+2 are in flight while step t is multiplied (two register stages,
 // ~250 VGPRs - occupancy is irrelevant at these grid sizes).
-template <bool BF, int PRO, int PF>
+template <int BF, int PRO, int PF>
 __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
-  __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
-  __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
+  constexpr int LDT = BF == 2 ? SK_LD3 : SK_LD;
+  __shared__ float sA[SK_BM * LDT];          // 16.5 KB (split mode: 24.5 KB)
+  __shared__ float sB[SK_BN * LDT];          // 33 KB (49 KB) ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
   __shared__ float sRed[2 * 4 * SK_BN];
   __shared__ float sRed5[(PRO == 1) ? 5 * 4 * SK_BN : 1];
   unsigned* const sAu = reinterpret_cast<unsigned*>(sA);      // BF: bf16 tiles [row][SK_LDH words]
@@ -601,18 +652,40 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       if (a.gate) { v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w; }
       }
       if (!(s.kok && rok[i])) v = make_float4(0, 0, 0, 0);
-      if constexpr (BF) *reinterpret_cast<uint2*>(&sAu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+      if constexpr (BF == 2) split3_store<SK_BK / 2>(&sAu[(lrow + i * 8) * SK_LD3 + (kq >> 1)], v);
+      else if constexpr (BF) *reinterpret_cast<uint2*>(&sAu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
       else *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float4 w4 = (s.kok && wok[i]) ? s.rb[i] : make_float4(0, 0, 0, 0);
-      if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
+      if constexpr (BF == 2) split3_store<SK_BK / 2>(&sBu[(lrow + i * 8) * SK_LD3 + (kq >> 1)], w4);
+      else if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
       else *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = w4;
     }
   };
   auto mma = [&]() {
-    if constexpr (BF) {
+    if constexpr (BF == 2) {
+      // split mode: the wave's 32 k of the step = two 16-deep groups, six MFMAs per group and column slab (smallest partial products first)
+      const unsigned* pa = &sAu[r * SK_LD3 + wave * 16 + h * 4];
+      const unsigned* pb = &sBu[r * SK_LD3 + wave * 16 + h * 4];
+      auto ldf = [](const unsigned* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(p)); };
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const bf16x8 ah = ldf(pa + g * 8), am = ldf(pa + SK_BK / 2 + g * 8), al = ldf(pa + SK_BK + g * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned* q = pb + j * 32 * SK_LD3 + g * 8;
+          const bf16x8 bh = ldf(q), bm = ldf(q + SK_BK / 2), bl = ldf(q + SK_BK);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        }
+      }
+    } else if constexpr (BF) {
       // bf16 tiles (rounded once at the LDS store): one 16-byte read per operand and MFMA, no per-lane conversion
       const unsigned* pa = &sAu[r * SK_LDH + wave * 16 + h * 4];
       const unsigned* pb = &sBu[r * SK_LDH + wave * 16 + h * 4];
@@ -1004,6 +1077,8 @@ int mmd_pw_stem_gemm(const float* x, const float* w, float* y, int B, int Cin, i
 
 template <int BM_T, int BN_T, int PRO>
 static void (*pw_pick(int nkl, int bf))(PwArgs) {
+  if (bf == 2) return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, 2, PRO> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, 2, PRO>
+                    : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, 2, PRO> : pw_gemm_kernel<BM_T, BN_T, 4, 2, PRO>;
   if (bf) return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, true, PRO> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, true, PRO>
                : nkl == 3 ? pw_gemm_kernel<BM_T, BN_T, 3, true, PRO> : pw_gemm_kernel<BM_T, BN_T, 4, true, PRO>;
   return nkl == 1 ? pw_gemm_kernel<BM_T, BN_T, 1, false, PRO> : nkl == 2 ? pw_gemm_kernel<BM_T, BN_T, 2, false, PRO>
@@ -1020,7 +1095,7 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
                               hipStream_t stream, int bf16, int w16 = 0, int form = MMD_PW_FORM_AUTO, float* ws = nullptr,
                               long long ws_floats = 0) {
   if (M <= 0 || K <= 0 || N <= 0 || (K & 3) || (N & 3) || !x || !w || !y) return MMD_EINVAL;
-  if (form < MMD_PW_FORM_AUTO || form > MMD_PW_FORM_SLAB) return MMD_EINVAL;
+  if (form < 0 || (form & ~MMD_PW_FORM_NATIVE) > MMD_PW_FORM_SLAB) return MMD_EINVAL;
   if ((w16 & 2) && (residual || y_batch_stride)) return MMD_EINVAL;      // a bf16 output has no residual / strided form
   if ((gate || y_batch_stride) && rows_per_image <= 0) return MMD_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return MMD_EINVAL;
@@ -1032,7 +1107,7 @@ static int pw_fwd_impl(const float* x, const float* w, float* y, int M, int K, i
            {0, 0, 0, 0, 0}, 0, bf16};
   if (stats && stats_ws && ws_slots > 1 && cdiv(M, PW_BM) > MMD_STATS_DEPTH) { a.stats_ws = stats_ws; a.ws_slots = ws_slots; }
   a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1;
-  a.form = form; a.slab_ws = ws; a.slab_ws_floats = ws ? ws_floats : 0;
+  a.form = form & ~MMD_PW_FORM_NATIVE; a.native = (form & MMD_PW_FORM_NATIVE) ? 1 : 0; a.slab_ws = ws; a.slab_ws_floats = ws ? ws_floats : 0;
   return pw_dispatch(a, stream);
 }
 
@@ -1149,7 +1224,9 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     const bool noxf = sk_lean && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
     const int pro = a.bb.z ? 1 : noxf ? (a.gate ? 4 : 3) : 0;
     void (*sk)(PwArgs);
-#define SK_PICK(P, F) (a.bf16 ? pw_gemm_skinny_kernel<true, P, F> : pw_gemm_skinny_kernel<false, P, F>)
+    static const int sk_split = getenv("MMD_SK_SPLIT") ? atoi(getenv("MMD_SK_SPLIT")) : 0;
+    const int skm = a.bf16 ? 1 : (sk_split && mmd_split_default() && !a.native && !w16) ? 2 : 0;
+#define SK_PICK(P, F) (skm == 2 ? pw_gemm_skinny_kernel<2, P, F> : skm == 1 ? pw_gemm_skinny_kernel<1, P, F> : pw_gemm_skinny_kernel<0, P, F>)
     // (PF = 2 instantiates and runs, but hipcc drains both register stages before each LDS store - its waitcnt pass counts down to
     // vmcnt(0) across the per-lane masking branches - so it measured 1 % slower than PF = 1; see profiles/r01_notes.md)
     static const int sk_pf2 = getenv("MMD_SK_PF2") ? atoi(getenv("MMD_SK_PF2")) : 0;      // (dev: bit 0 = BatchNorm-backward operand launches, bit 1 = the others, with two register stages)
@@ -1163,6 +1240,8 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(sk, dim3(a.nblk), dim3(256), bql, stream, a);
   } else {
     const int nkl = ((K - 1) % PW_BK) / 8 + 1;      // populated 8-wide groups of the last K tile
+    const bool split_on = mmd_split_default() && !a.native;
+    const int bfm = a.bf16 ? 1 : (split_on && !w16 && !a.st.Cin && K >= 64 && N > 48) ? 2 : 0;      // MFMA form of the tiles: 0 fp32, 1 bf16 operands, 2 fp32 by three-way bf16 split
     // plain A operand (no producer transform, no gate) or gate only: register-lean variants at a higher occupancy
     static const int lean_on = getenv("MMD_NO_LEAN") ? 0 : 1;
     const bool noxf = lean_on && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
@@ -1175,21 +1254,21 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
       // (BatchNorm-backward operand launches take the 128x32 variant only for the thin layers, N <= 32, where 64-wide tiles
       // would multiply 2-4x padding; it holds two VGPRs in scratch there)
       a.ntn = cdiv(N, 32);
-      kern = a.bb.z ? pw_pick<128, 32, 1>(nkl, a.bf16) : plain ? pw_pick_lean<128, 32, 3, 6>(nkl, a.bf16)
-           : gated ? pw_pick_lean<128, 32, 4, 4>(nkl, a.bf16) : pw_pick<128, 32, 0>(nkl, a.bf16);
+      kern = a.bb.z ? pw_pick<128, 32, 1>(nkl, bfm) : plain ? pw_pick_lean<128, 32, 3, 6>(nkl, bfm)
+           : gated ? pw_pick_lean<128, 32, 4, 4>(nkl, bfm) : pw_pick<128, 32, 0>(nkl, bfm);
     } else if (variant == 2) {      // 64x64 tiles: small-M layers (and every BatchNorm-
       // backward operand launch: its two-tensor prologue does not fit the 128-row variants' 128-VGPR budget)
       a.ntn = cdiv(N, 64); ntm = cdiv(M, 64);
-      if (plain) kern = pw_pick_lean<64, 64, 3, 6>(nkl, a.bf16);
-      else if (gated) kern = pw_pick_lean<64, 64, 4, 6>(nkl, a.bf16);
+      if (plain) kern = pw_pick_lean<64, 64, 3, 6>(nkl, bfm);
+      else if (gated) kern = pw_pick_lean<64, 64, 4, 6>(nkl, bfm);
       else
-      kern = a.bb.z ? pw_pick<64, 64, 1>(nkl, a.bf16) : pw_pick<64, 64, 0>(nkl, a.bf16);
+      kern = a.bb.z ? pw_pick<64, 64, 1>(nkl, bfm) : pw_pick<64, 64, 0>(nkl, bfm);
     } else {
       a.ntn = cdiv(N, 64);
-      kern = plain ? pw_pick_lean<128, 64, 3, 5>(nkl, a.bf16) : gated ? pw_pick_lean<128, 64, 4, 5>(nkl, a.bf16) : pw_pick<128, 64, 0>(nkl, a.bf16);
+      kern = plain ? pw_pick_lean<128, 64, 3, 5>(nkl, bfm) : gated ? pw_pick_lean<128, 64, 4, 5>(nkl, bfm) : pw_pick<128, 64, 0>(nkl, bfm);
     }
     a.nblk = ntm * a.ntn;
-    const size_t bql = pw_bq_lds(a, (const void*)kern, 28 * 1024);     // (sets a.bq_lds: before `a` is copied into the launch)
+    const size_t bql = pw_bq_lds(a, (const void*)kern, (bfm == 2 ? 40 : 28) * 1024);     // (sets a.bq_lds: before `a` is copied into the launch)
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), bql, stream, a);
   }
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * N, stream);
@@ -1496,8 +1575,8 @@ static int pw_bwd_data_bn2_impl(const float* g, const float* z, const float* wt,
   a.bb = BnBwdOp{z, scale, shift, mean, invstd, sums, 1.0 / (double)count, N, act, mul_b, rows_per_image > 0 ? rows_per_image : 1,
                  dz_out, dgamma, dbeta};
   a.x16 = w16 & 1; a.y16 = (w16 >> 1) & 1; a.z16 = (w16 >> 2) & 1; a.dz16 = (w16 >> 3) & 1; a.p5z16 = (w16 >> 4) & 1;
-  if (form < MMD_PW_FORM_AUTO || form > MMD_PW_FORM_SLAB) return MMD_EINVAL;
-  a.form = form; a.slab_ws = ws; a.slab_ws_floats = ws ? ws_floats : 0;
+  if (form < 0 || (form & ~MMD_PW_FORM_NATIVE) > MMD_PW_FORM_SLAB) return MMD_EINVAL;
+  a.form = form & ~MMD_PW_FORM_NATIVE; a.native = (form & MMD_PW_FORM_NATIVE) ? 1 : 0; a.slab_ws = ws; a.slab_ws_floats = ws ? ws_floats : 0;
   if (a.y16 && (residual || xs_z)) return MMD_EINVAL;
   if (xs_z) {
     a.xs = BnSumOp{xs_z, xs_mean, xs_invstd, xs_mul_b, xs_rows_per_image > 0 ? xs_rows_per_image : 1};

@@ -383,6 +383,176 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAV
   }
 }
 
+// ---- round 6: the rectangular form with fp32 products on the bf16 matrix pipe (split form, common.h) --------------------------------------
+// The fp32 kernel above is MFMA-bound (54 % of its SIMD cycles in v_mfma_f32_32x32x2_f32: 32 x 64 cycles per wave and 32-row step).  Here a
+// step's slabs are split into three bf16 planes while they are staged and stored TRANSPOSED, [column][k], so that a lane's eight k of a
+// 16-deep MFMA group are one ds_read_b128 per plane (the bf16 form above gathers them with eight ds_read_b32):
+//   * the reduction index of a weight gradient is the ROW, and the order of k inside an MFMA is free as long as both operands agree:
+//     k slot w (0..15) of a 32-row step holds rows (w, w + 16) as one bf16 pair - exactly the two rows a staging thread of the X tile (and
+//     of a 64-wide dY tile) holds, so one 32-bit store per column and plane; a thread of a 128-wide dY tile holds rows 2l, 2l + 1, 2l + 16,
+//     2l + 17 -> slots 2l, 2l + 1: one 64-bit store;
+//   * sT[column][3 planes x 16 words + 4 pad] with the 4-word groups of a plane XOR-ed by (column >> 5) & 3: fragment reads conflict-free,
+//     the staging stores 2-way (unswizzled: 16-way; tools/dev/lds_bank_model.py);
+//   * 24 bf16 MFMAs x 32 cycles per wave and step instead of 32 x 64.
+// Whole 32-row steps only (the caller's rows32 promise: no row masks); same table, workspace and fold - bit-reproducible.
+#define GW_LD3 52
+#define GW_MAXL3 255      // layers per launch on this kernel: its table copy must leave four 40 KB blocks per CU
+template <int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void wgrad_grouped_split_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
+  __shared__ unsigned sD[128 * GW_LD3];
+  __shared__ unsigned sX[64 * GW_LD3];
+  __shared__ int sItem0[GW_MAXL3 + 1];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nl; i += 256) sItem0[i] = L[i].item0;
+  if (tid == 0) sItem0[nl] = nitems;
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int c4x = (tid & 15) * 4, lx = tid >> 4;      // X tile: rows lx, lx + 16 of a step -> k slot lx
+  int li = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    while (sItem0[li + 1] <= item) ++li;
+    li = __builtin_amdgcn_readfirstlane(li);
+    const MmdWgradLayer a = L[li];
+    const int TN = a.pad_;
+    const bool wide = TN == 128;
+    int b = item - a.item0;
+    const int tk = b % a.ntk; b /= a.ntk;
+    const int tn = b % a.ntn; b /= a.ntn;
+    const int mbeg = b * a.mchunk;
+    const int mend = min(a.M, mbeg + a.mchunk);
+    const int n0 = tn * TN, k0 = tk * 64;
+    // dY tile: 128-wide -> thread (column quad tid & 31, l = tid >> 5) holds rows 2l, 2l + 1, 2l + 16, 2l + 17; 64-wide -> (tid & 15, l = tid >> 4), rows l, l + 16
+    const int c4d = wide ? (tid & 31) * 4 : (tid & 15) * 4, ld_ = wide ? tid >> 5 : tid >> 4;
+    const bool nok = (n0 + c4d) < a.N, kok = (k0 + c4x) < a.K;
+    float4 xsc = make_float4(1, 1, 1, 1), xsh = make_float4(0, 0, 0, 0);
+    if (a.in_scale && kok) { xsc = mmd_ldg4(a.in_scale + k0 + c4x); xsh = mmd_ldg4(a.in_shift + k0 + c4x); }
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+    float4 rd[4], rx[2], rg[2];
+    int gimg[2] = {0, 0}, grem[2] = {0, 0};
+    if (a.gate) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int r0_ = mbeg + lx + i * 16; gimg[i] = r0_ / a.rows_per_image; grem[i] = r0_ - gimg[i] * a.rows_per_image; }
+    }
+    // columns past N / K: loads from clamped (valid, finite) addresses; they only feed output elements the fold never stores
+    const float* pdy0 = a.dy + (size_t)(mbeg + (wide ? 2 * ld_ : ld_)) * a.N + (nok ? n0 + c4d : 0);
+    const float* pxx0 = a.x + (size_t)(mbeg + lx) * a.K + (kok ? k0 + c4x : 0);
+    const int d1 = wide ? a.N : 16 * a.N, d2 = 16 * a.N, d3 = 17 * a.N, xro = 16 * a.K;      // element offsets of a thread's other rows (wave-uniform)
+    const int dstep = GW_BR * a.N, xstep = GW_BR * a.K;
+    auto gload = [&]() {
+      rd[0] = mmd_ldg4(pdy0); rd[1] = mmd_ldg4(pdy0 + d1);
+      if (wide) { rd[2] = mmd_ldg4(pdy0 + d2); rd[3] = mmd_ldg4(pdy0 + d3); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rx[i] = mmd_ldg4(pxx0 + i * xro);
+        if (a.gate) {
+          while (grem[i] >= a.rows_per_image) { grem[i] -= a.rows_per_image; ++gimg[i]; }
+          rg[i] = mmd_ldg4(a.gate + (size_t)gimg[i] * a.K + (kok ? k0 + c4x : 0));
+          grem[i] += GW_BR;
+        }
+      }
+      pdy0 += dstep; pxx0 += xstep;
+    };
+    // word address of k slot w of column c inside a tile: plane p adds 16 p
+    auto slot = [](int c, int w) { return c * GW_LD3 + ((((w >> 2) ^ (c >> 5)) & 3) << 2) + (w & 3); };
+    auto lstore = [&]() {
+      if (wide) {
+        const float e0[4] = {rd[0].x, rd[0].y, rd[0].z, rd[0].w}, e1[4] = {rd[1].x, rd[1].y, rd[1].z, rd[1].w};
+        const float e2[4] = {rd[2].x, rd[2].y, rd[2].z, rd[2].w}, e3[4] = {rd[3].x, rd[3].y, rd[3].z, rd[3].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned h0, m0, l0, h1, m1, l1;
+          mmd_split3_pk(e0[j], e2[j], h0, m0, l0);      // slot 2l:     rows 2l,     2l + 16
+          mmd_split3_pk(e1[j], e3[j], h1, m1, l1);      // slot 2l + 1: rows 2l + 1, 2l + 17
+          unsigned* q = &sD[slot(c4d + j, 2 * ld_)];
+          *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(q + 16) = make_uint2(m0, m1);
+          *reinterpret_cast<uint2*>(q + 32) = make_uint2(l0, l1);
+        }
+      } else {
+        const float e0[4] = {rd[0].x, rd[0].y, rd[0].z, rd[0].w}, e1[4] = {rd[1].x, rd[1].y, rd[1].z, rd[1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned h0, m0, l0;
+          mmd_split3_pk(e0[j], e1[j], h0, m0, l0);      // slot l: rows l, l + 16
+          unsigned* q = &sD[slot(c4d + j, ld_)];
+          q[0] = h0; q[16] = m0; q[32] = l0;
+        }
+      }
+      float4 v[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        v[i] = rx[i];
+        if (a.in_scale) { v[i].x = v[i].x * xsc.x + xsh.x; v[i].y = v[i].y * xsc.y + xsh.y; v[i].z = v[i].z * xsc.z + xsh.z; v[i].w = v[i].w * xsc.w + xsh.w; }
+        if (a.in_act == MMD_ACT_SWISH) { v[i].x = mmd_swish(v[i].x); v[i].y = mmd_swish(v[i].y); v[i].z = mmd_swish(v[i].z); v[i].w = mmd_swish(v[i].w); }
+        if (a.gate) { v[i].x *= rg[i].x; v[i].y *= rg[i].y; v[i].z *= rg[i].z; v[i].w *= rg[i].w; }
+      }
+      const float x0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, x1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned h0, m0, l0;
+        mmd_split3_pk(x0[j], x1[j], h0, m0, l0);
+        unsigned* q = &sX[slot(c4x + j, lx)];
+        q[0] = h0; q[16] = m0; q[32] = l0;
+      }
+    };
+    const int nb = wide ? wn * 64 : wn * 32;
+    int nu = (n0 + nb < a.N ? 1 : 0) + ((wide && n0 + nb + 32 < a.N) ? 1 : 0);
+    int nv = (k0 + wk * 32 < a.K) ? 1 : 0;
+    nu = __builtin_amdgcn_readfirstlane(nu); nv = __builtin_amdgcn_readfirstlane(nv);
+    auto ldf = [](const unsigned* p) { return __builtin_bit_cast(gw_bf16x8, *reinterpret_cast<const gw_u32x4*>(p)); };
+    auto mma = [&](auto nu_c) {
+      constexpr int NU = decltype(nu_c)::value;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int w0 = (g * 2 + h) * 4;      // this lane's four k slots of the group
+        const unsigned* qx = &sX[slot(wk * 32 + r, w0)];
+        const gw_bf16x8 xh = ldf(qx), xm = ldf(qx + 16), xl = ldf(qx + 32);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const unsigned* qd = &sD[slot(nb + u * 32 + r, w0)];
+          const gw_bf16x8 dh = ldf(qd), dm = ldf(qd + 16), dl = ldf(qd + 32);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl, xh, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xl, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dm, xm, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dm, xh, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xm, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh, xh, acc[u], 0, 0, 0);
+        }
+      }
+    };
+    // (instantiated per number of live sub-tiles, two barriers per step in every instantiation: the BARRIER CONTRACT of the kernel above)
+    auto rows = [&](auto nu_c) {
+      constexpr int NU = decltype(nu_c)::value;
+      gload();
+      for (int mb = mbeg; mb < mend; mb += GW_BR) {
+        lstore();
+        __syncthreads();
+        if (mb + GW_BR < mend) gload();
+        if constexpr (NU > 0) mma(nu_c);
+        __syncthreads();
+      }
+    };
+    const int nuw = (!nv || nu == 0) ? 0 : nu;
+    if (nuw == 0) rows(std::integral_constant<int, 0>{});
+    else if (nuw == 2) rows(std::integral_constant<int, 2>{});
+    else rows(std::integral_constant<int, 1>{});
+    float* out = ws + a.ws_off + (size_t)(item - a.item0) * (TN * 64);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (u == 0 || wide)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n = nb + u * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          out[n * 64 + wk * 32 + r] = acc[u][q];
+        }
+  }
+}
+
 // fold of the rectangular form: one block per output tile [TN][64] (TN = the layer's pad_), splits added in split order
 __global__ __launch_bounds__(256) void wgrad_fold_rect_kernel(const MmdWgradLayer* __restrict__ L, int nl, int ntiles, const float* __restrict__ ws) {
   __shared__ int s_li;
@@ -538,7 +708,11 @@ static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int
   mmd_prof_tag(MMD_FAM_PW_WGRAD, "wgrouped L%lld items%lld tiles%lld b%lld", n_layers, n_items, n_tiles, blocks);
   mmd_prof_begin(MMD_FAM_PW_WGRAD, stream);
   if (wg_tile() == 0) {
-    if (bf16) {
+    if (bf16 == 0 && rows32 && mmd_split_default() && n_layers <= GW_MAXL3) {
+      static const int w3 = getenv("MMD_WG_SPLIT_W3") ? 1 : 0;
+      if (w3) hipLaunchKernelGGL(wgrad_grouped_split_kernel<3>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+      else hipLaunchKernelGGL(wgrad_grouped_split_kernel<4>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    } else if (bf16 == 1) {
       if (rows32) hipLaunchKernelGGL((wgrad_grouped_rect_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
       else hipLaunchKernelGGL((wgrad_grouped_rect_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     } else {
@@ -547,11 +721,11 @@ static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int
     }
     hipLaunchKernelGGL(wgrad_fold_rect_kernel, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
   } else if (wg_tile() == 128) {
-    if (bf16) hipLaunchKernelGGL((wgrad_grouped_kernel<128, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    if (bf16 == 1) hipLaunchKernelGGL((wgrad_grouped_kernel<128, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     else hipLaunchKernelGGL((wgrad_grouped_kernel<128, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     hipLaunchKernelGGL(wgrad_fold_kernel<128>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
   } else {
-    if (bf16) hipLaunchKernelGGL((wgrad_grouped_kernel<64, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+    if (bf16 == 1) hipLaunchKernelGGL((wgrad_grouped_kernel<64, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     else hipLaunchKernelGGL((wgrad_grouped_kernel<64, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
     hipLaunchKernelGGL(wgrad_fold_kernel<64>, dim3(n_tiles), dim3(256), 0, stream, layers_dev, n_layers, n_tiles, ws);
   }
@@ -562,11 +736,14 @@ extern "C" int mmd_wgrad_grouped(const MmdWgradLayer* layers_dev, int n_layers, 
                                  double flops, double bytes, hipStream_t stream) {
   return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, 0, stream);
 }
-// the same launch with two choices made by the caller: bf16 (as mmd_wgrad_grouped_bf16) and rows32 = 1: the caller promises that every
-// layer's M is a multiple of 32 - the kernel then runs without row clamps / masks and with running operand pointers (round 6)
+// the same launch with two choices made by the caller.  rows32 = 1: the caller promises that every layer's M is a multiple of 32 - the kernel
+// then runs without row clamps / masks and with running operand pointers (round 6).  bf16: 0 = fp32 products (with rows32: the split form -
+// six bf16 MFMAs on a three-way exact split of both operands, common.h - unless MMD_MFMA_F32=1), 1 = operands rounded to bf16 (as
+// mmd_wgrad_grouped_bf16), 2 = fp32 products on v_mfma_f32_32x32x2_f32 (the per-call form of MMD_MFMA_F32=1)
 extern "C" int mmd_wgrad_grouped_form(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
                                       double flops, double bytes, int bf16, int rows32, hipStream_t stream) {
-  return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, bf16 ? 1 : 0, stream, rows32 ? 1 : 0);
+  if (bf16 < 0 || bf16 > 2) return MMD_EINVAL;
+  return wgrad_grouped_impl(layers_dev, n_layers, n_items, n_tiles, ws, blocks, flops, bytes, bf16, stream, rows32 ? 1 : 0);
 }
 // precision "bf16": operands rounded to bf16 at the MFMA input (mmd_pwconv_bwd_weight_bf16's arithmetic), same table / workspace / fold
 extern "C" int mmd_wgrad_grouped_bf16(const MmdWgradLayer* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks,
