@@ -526,7 +526,6 @@ static size_t pw_bq_lds(PwArgs& a, const void* kern, size_t static_bytes) {
 #define SK_BK 128
 #define SK_LD 132
 #define SK_LDH 68      // bf16 mode: words per tile row (SK_BK / 2 data + 4 pad)
-#define SK_LD3 196     // split mode: three planes of SK_BK / 2 words + 4 pad (196 = 4 mod 32, as 36 / 68 / 132)
 
 // -DMMD_KSTAMPS (dev build, tools/dev/skinny_phases.py): block 0 / thread 0 stamps the 100 MHz wall clock along the K loop
 #ifdef MMD_KSTAMPS
@@ -539,11 +538,12 @@ extern "C" int mmd_k_stamps(unsigned long long* out) { return hipMemcpyFromSymbo
 // PF = register prefetch depth.  The skinny launches have at most one or two blocks per CU, so nothing but the block itself hides
 // its load latency: with PF = 2 the loads of K steps t+1 and t+2 are in flight while step t is multiplied (two register stages,
 // ~250 VGPRs - occupancy is irrelevant at these grid sizes).
-template <int BF, int PRO, int PF>
+// (split form - common.h - tried here in round 6 and not kept: a block re-splits its 64 x 128 weight tile at every K step, 2/3 of the staging
+// VALU work, and the step measured 13.44 vs 13.44 ms with it)
+template <bool BF, int PRO, int PF>
 __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
-  constexpr int LDT = BF == 2 ? SK_LD3 : SK_LD;
-  __shared__ float sA[SK_BM * LDT];          // 16.5 KB (split mode: 24.5 KB)
-  __shared__ float sB[SK_BN * LDT];          // 33 KB (49 KB) ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
+  __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
+  __shared__ float sB[SK_BN * SK_LD];          // 33 KB ; reused as the 4 x [32][64] partial-sum buffer (32 KB)
   __shared__ float sRed[2 * 4 * SK_BN];
   __shared__ float sRed5[(PRO == 1) ? 5 * 4 * SK_BN : 1];
   unsigned* const sAu = reinterpret_cast<unsigned*>(sA);      // BF: bf16 tiles [row][SK_LDH words]
@@ -652,40 +652,18 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       if (a.gate) { v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w; }
       }
       if (!(s.kok && rok[i])) v = make_float4(0, 0, 0, 0);
-      if constexpr (BF == 2) split3_store<SK_BK / 2>(&sAu[(lrow + i * 8) * SK_LD3 + (kq >> 1)], v);
-      else if constexpr (BF) *reinterpret_cast<uint2*>(&sAu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+      if constexpr (BF) *reinterpret_cast<uint2*>(&sAu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
       else *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float4 w4 = (s.kok && wok[i]) ? s.rb[i] : make_float4(0, 0, 0, 0);
-      if constexpr (BF == 2) split3_store<SK_BK / 2>(&sBu[(lrow + i * 8) * SK_LD3 + (kq >> 1)], w4);
-      else if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
+      if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
       else *reinterpret_cast<float4*>(&sB[(lrow + i * 8) * SK_LD + kq]) = w4;
     }
   };
   auto mma = [&]() {
-    if constexpr (BF == 2) {
-      // split mode: the wave's 32 k of the step = two 16-deep groups, six MFMAs per group and column slab (smallest partial products first)
-      const unsigned* pa = &sAu[r * SK_LD3 + wave * 16 + h * 4];
-      const unsigned* pb = &sBu[r * SK_LD3 + wave * 16 + h * 4];
-      auto ldf = [](const unsigned* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(p)); };
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const bf16x8 ah = ldf(pa + g * 8), am = ldf(pa + SK_BK / 2 + g * 8), al = ldf(pa + SK_BK + g * 8);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const unsigned* q = pb + j * 32 * SK_LD3 + g * 8;
-          const bf16x8 bh = ldf(q), bm = ldf(q + SK_BK / 2), bl = ldf(q + SK_BK);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-        }
-      }
-    } else if constexpr (BF) {
+    if constexpr (BF) {
       // bf16 tiles (rounded once at the LDS store): one 16-byte read per operand and MFMA, no per-lane conversion
       const unsigned* pa = &sAu[r * SK_LDH + wave * 16 + h * 4];
       const unsigned* pb = &sBu[r * SK_LDH + wave * 16 + h * 4];
@@ -1224,9 +1202,7 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
     const bool noxf = sk_lean && !a.bb.z && !a.in_scale && !a.in_bn.stats && a.in_act == MMD_ACT_NONE;
     const int pro = a.bb.z ? 1 : noxf ? (a.gate ? 4 : 3) : 0;
     void (*sk)(PwArgs);
-    static const int sk_split = getenv("MMD_SK_SPLIT") ? atoi(getenv("MMD_SK_SPLIT")) : 0;
-    const int skm = a.bf16 ? 1 : (sk_split && mmd_split_default() && !a.native && !w16) ? 2 : 0;
-#define SK_PICK(P, F) (skm == 2 ? pw_gemm_skinny_kernel<2, P, F> : skm == 1 ? pw_gemm_skinny_kernel<1, P, F> : pw_gemm_skinny_kernel<0, P, F>)
+#define SK_PICK(P, F) (a.bf16 ? pw_gemm_skinny_kernel<true, P, F> : pw_gemm_skinny_kernel<false, P, F>)
     // (PF = 2 instantiates and runs, but hipcc drains both register stages before each LDS store - its waitcnt pass counts down to
     // vmcnt(0) across the per-lane masking branches - so it measured 1 % slower than PF = 1; see profiles/r01_notes.md)
     static const int sk_pf2 = getenv("MMD_SK_PF2") ? atoi(getenv("MMD_SK_PF2")) : 0;      // (dev: bit 0 = BatchNorm-backward operand launches, bit 1 = the others, with two register stages)
