@@ -360,6 +360,8 @@ int mmd_wgrad_grouped_bf16(const void* layers_dev, int n_layers, int n_items, in
 // mmd_wgrad_grouped / _bf16 with one more choice made by the caller: rows32 = 1 promises that every layer's M is a multiple of 32 (any net
 // at B >= 2: the smallest map is 4 x 4) - the kernel then runs without row clamps / masks and with running operand pointers
 // (57 v_cndmask + 43 address instructions per 32-row step less on a kernel whose VALU instructions are MFMA time).  rows32 = 0: as the plain entry points.
+// bf16: 0 = fp32 products - with rows32 on the bf16 matrix pipe in the SPLIT form (see mmd_pwconv_fwd_form below; MMD_MFMA_F32=1 in the
+// environment keeps v_mfma_f32), 1 = operands rounded to bf16 (mmd_wgrad_grouped_bf16), 2 = fp32 products on v_mfma_f32_32x32x2_f32.
 int mmd_wgrad_grouped_form(const void* layers_dev, int n_layers, int n_items, int n_tiles, float* ws, int blocks, double flops, double bytes, int bf16, int rows32, hipStream_t stream);
 
 // dX[M,K] (=|+=) dY[M,N] * W[N,K] using the transposed weight copy Wt[K,N] (autograd of the 1x1 conv input).
@@ -378,6 +380,13 @@ int mmd_pwconv_fwd_bf16(const float* x, const float* w, float* y, int M, int K, 
 // ws / ws_floats (nullable): caller-owned workspace for the slab kernel's K slices (mmd_pwconv_slab_ws_floats floats; contents undefined
 // before and after, no zeroing needed); without one a launch that would need slices keeps the LDS-tiled kernels (form 0) or is refused (form 4).
 // The engine calls this with form 0; forms 1 - 4: tests and A/B timing.  Conv2dStaticSamePadding(k=1), src/YetAnotherEfficientNet.py:27-65.
+// form | 16 (MMD_PW_FORM_NATIVE): fp32 products on v_mfma_f32_32x32x2_f32.  Without it the LDS-tiled kernels compute the SAME fp32 GEMM in the
+// split form where K >= 64 and N > 48 (csrc/common.h): each fp32 operand value is split exactly into three bf16 pieces (round to nearest:
+// x = h + m + l, both residuals exact), a * b is taken as the six largest of the nine partial products - each exact in fp32 - on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulate; the three dropped ones are <= 2^-26 |a * b|, below the 2^-24 rounding of every fp32
+// accumulate.  192 matrix-pipe cycles per 16-deep k group instead of 512.  Error against float64: not above the v_mfma_f32 chain's
+// (tests/test_gpu_kernels.py::test_split3_precision; measured lower on every shape).  Operands must be finite (Inf - Inf in a residual is NaN).
+// MMD_MFMA_F32=1 in the environment: the whole library on v_mfma_f32 (A/B timing, bisecting).
 int mmd_pwconv_fwd_form(const float* x, const float* w, float* y, int M, int K, int N, const float* in_scale, const float* in_shift, int in_act, const double* in_stats, const float* in_gamma, const float* in_beta, long long in_count, const float* gate, int rows_per_image, const float* bias, const float* out_scale, const float* out_shift, int out_act, const float* residual, double* stats, long long y_batch_stride, long long y_offset, double* stats_ws, int ws_slots, float* ws, long long ws_floats, int form, hipStream_t stream);
 
 int mmd_pwconv_fwd_pyr_bf16(const float* x, const float* w, float* y, const int* pyr_desc, int K, int N, const float* bias, int out_act, double* stats, long long lev_stride, long long y_batch_stride, const long long* y_off_lev, hipStream_t stream);

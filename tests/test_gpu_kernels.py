@@ -265,6 +265,127 @@ def test_wgrad_grouped_matches_torch_and_is_deterministic():
             close(dw, _bf(dd.cpu()).double().t() @ _bf(dx.cpu()).double(), 2e-4, 2e-3, f"grouped bf16 dW vs rounded operands M{M} K{K} N{N}")
 
 
+# ---- fp32 products on the bf16 matrix pipe (csrc/common.h "split" form): accuracy against float64, beside v_mfma_f32_32x32x2_f32 -------------
+MMD_PW_FORM_TILED, MMD_PW_FORM_NATIVE = 2, 16
+
+
+def _rel_err(y, ref, mag):
+    """largest and rms error in units of sum_k |a_k b_k| - the scale fp32 rounding errors of a dot product are relative to"""
+    e = (y.double() - ref).abs() / mag
+    return float(e.max()), float(e.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("M,K,N,wide", [(16384, 112, 112, False), (16384, 112, 112, True), (24576, 720, 120, True), (8192, 120, 720, True),
+                                         (4096, 88, 528, False), (4096, 2112, 352, True)])
+def test_split3_precision(M, K, N, wide):
+    """The split form (x = h + m + l exactly in three bf16 pieces, six bf16 MFMAs with fp32 accumulate per k group) must be an fp32 GEMM: its
+    error against float64 is bounded by the same bound as the v_mfma_f32 chain's and is not larger than that chain's (measured: smaller, it
+    rounds the accumulator 6 K / 16 times instead of K times) - on unit-scale operands and on operands spread over eight decades."""
+    gen = torch.Generator(device=DEV); gen.manual_seed(M + K)
+    x = torch.randn(M, K, device=DEV, generator=gen); w = torch.randn(N, K, device=DEV, generator=gen) / math.sqrt(K)
+    if wide:
+        x = x * torch.exp2(torch.randint(-13, 14, (M, K), device=DEV, generator=gen).float())
+        w = w * torch.exp2(torch.randint(-13, 14, (N, K), device=DEV, generator=gen).float())
+    ref = x.double() @ w.double().t()
+    mag = x.double().abs() @ w.double().abs().t()
+    out = {}
+    for name, form in (("split", MMD_PW_FORM_TILED), ("native", MMD_PW_FORM_TILED | MMD_PW_FORM_NATIVE)):
+        y = torch.full((M, N), float("nan"), device=DEV)
+        call("mmd_pwconv_fwd_form", x, w, y, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0,
+             None, 0, form)
+        torch.cuda.synchronize()
+        out[name] = (y, *_rel_err(y, ref, mag))
+    (ys, ms, rs), (yn, mn, rn) = out["split"], out["native"]
+    if not os.environ.get("MMD_MFMA_F32"):
+        assert not torch.equal(ys, yn), "the two forms gave the same bits: the split form did not run"
+    u = 2.0 ** -24
+    # a K-term fp32 dot product: |err| <= ~K u sum|ab| worst case; both forms sit at a few u (random-walk growth: 5 u on unit-scale operands,
+    # 12 - 25 u on the eight-decade ones at K = 112 .. 2112)
+    bound = 24 * u * max(1.0, math.sqrt(K / 112))
+    assert ms <= bound and mn <= bound, (ms, mn, bound)
+    assert ms <= 1.25 * mn and rs <= 1.1 * rn, f"split form less accurate than v_mfma_f32: max {ms:.3e} vs {mn:.3e}, rms {rs:.3e} vs {rn:.3e}"
+
+
+def test_split3_exact_on_bf16_representable_operands():
+    """Operands that are sums of three bf16 pieces by construction, products whose six kept partial sums are exact in fp32: the split form
+    reproduces the float64 result to the last bit of fp32 rounding, and values the split must not disturb (zeros, negative zeros, denormal
+    residuals, powers of two) come through."""
+    M, K, N = 2048, 128, 128
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    # integers < 2^11 in both operands: every product < 2^22 and every K = 128 partial sum < 2^29 ... exact in float64, and in fp32 while the
+    # running sum stays below 2^24: scale the weights down so it does
+    x = torch.randint(-2047, 2048, (M, K), device=DEV, generator=gen).float()
+    w = torch.randint(-15, 16, (N, K), device=DEV, generator=gen).float()
+    x[::7] = 0.0; x[3::11] *= -0.0
+    y = torch.empty(M, N, device=DEV)
+    call("mmd_pwconv_fwd_form", x, w, y, M, K, N, None, None, 0, None, None, None, 0, None, 0, None, None, None, 0, None, None, 0, 0, None, 0,
+         None, 0, MMD_PW_FORM_TILED)
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t()
+    assert float(ref.abs().max()) < 2 ** 24
+    assert torch.equal(y.double(), ref)
+
+
+def test_wgrad_grouped_rows32_forms():
+    """mmd_wgrad_grouped_form with the rows32 promise (every M a multiple of 32: no row masks, running pointers) in both fp32 forms - the
+    split kernel (bf16 = 0: transposed three-plane slabs, six bf16 MFMAs per group) and v_mfma_f32 (bf16 = 2) - against float64 autograd,
+    bit-identical run to run and for different grids, and the split form at least as accurate as the v_mfma_f32 one."""
+    import ctypes
+    from mm_distillnet_amd.engine import WgLayer
+    torch.manual_seed(11)
+    shapes = [(4096, 16, 96, "aff"), (3072, 528, 88, "gate"), (8192, 112, 112, ""), (40000 // 32 * 32, 24, 144, "aff gate"), (64, 1248, 208, ""),
+              (1024, 72, 32, ""), (2048, 208, 1248, "gate"), (32, 112, 36, "")]
+    keep, refs, mags, arr = [], [], [], (WgLayer * len(shapes))()
+    for i, (M, K, N, fl) in enumerate(shapes):
+        B = 2
+        rpi = M // B
+        x = torch.randn(M, K); dy = torch.randn(M, N) * torch.exp2(torch.randint(-6, 7, (M, N)).float())
+        isc, ish = torch.rand(K) + 0.5, torch.randn(K) * 0.1
+        gate = torch.rand(B, K)
+        a = x
+        if "aff" in fl:
+            a = swish(a * isc + ish)
+        if "gate" in fl:
+            a = a * gate.repeat_interleave(rpi, 0)
+        refs.append(dy.double().t() @ a.double()); mags.append(dy.double().abs().t() @ a.double().abs())
+        dx, dd, dw = g(x), g(dy), torch.full((N, K), 7.0, device=DEV)
+        dsc, dsh = (g(isc), g(ish)) if "aff" in fl else (None, None)
+        dg = g(gate) if "gate" in fl else None
+        keep.append((dx, dd, dw, dsc, dsh, dg))
+        arr[i].dy, arr[i].x, arr[i].dw = dd.data_ptr(), dx.data_ptr(), dw.data_ptr()
+        arr[i].in_scale = dsc.data_ptr() if dsc is not None else None
+        arr[i].in_shift = dsh.data_ptr() if dsh is not None else None
+        arr[i].gate = dg.data_ptr() if dg is not None else None
+        arr[i].M, arr[i].K, arr[i].N, arr[i].in_act, arr[i].rows_per_image = M, K, N, (1 if "aff" in fl else 0), rpi
+    ni, nt, wsf = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+    dll = _lib.LIB.load()
+    cv = lambda o: ctypes.cast(ctypes.pointer(o), ctypes.c_void_p)
+    assert dll.mmd_wgrad_plan(ctypes.cast(arr, ctypes.c_void_p), len(shapes), 256, cv(ni), cv(nt), cv(wsf)) == 0
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    ws = torch.full((wsf.value,), float("nan"), device=DEV)
+    errs = {}
+    for mode in (0, 2):
+        outs = []
+        for rep in range(2):
+            for k in keep:
+                k[2].fill_(7.0)
+            call("mmd_wgrad_grouped_form", table, len(shapes), ni.value, nt.value, ws, 0 if rep else 300, 0.0, 0.0, mode, 1)
+            torch.cuda.synchronize()
+            outs.append([k[2].clone() for k in keep])
+        for (M, K, N, fl), ref, mag, o0, o1 in zip(shapes, refs, mags, outs[0], outs[1]):
+            close(o0, ref, 3e-4, 1e-5, f"grouped dW (rows32, mode {mode}) M{M} K{K} N{N} {fl}")
+            assert torch.equal(o0, o1), (mode, M, K, N)
+            errs[(mode, M, K, N)] = _rel_err(o0.cpu(), ref, mag)
+    if not os.environ.get("MMD_MFMA_F32") and not os.environ.get("MMD_WG_TILE"):
+        for (M, K, N, fl) in shapes:
+            if "aff" in fl:
+                continue      # (swish on the GPU vs torch's: the prologue's own rounding dominates both forms)
+            (ms, rs), (mn, rn) = errs[(0, M, K, N)], errs[(2, M, K, N)]
+            assert ms <= 1.5 * mn + 2.0 ** -24 and rs <= 1.15 * rn, f"split weight gradient less accurate M{M} K{K} N{N}: {ms:.3e}/{rs:.3e} vs {mn:.3e}/{rn:.3e}"
+    with pytest.raises(RuntimeError):      # bf16 argument: 0 fp32 (split), 1 bf16 operands, 2 fp32 on v_mfma_f32
+        call("mmd_wgrad_grouped_form", table, len(shapes), ni.value, nt.value, ws, 0, 0.0, 0.0, 3, 1)
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 24, 40), (4096, 16, 96), (1000, 528, 88), (130, 112, 180)])
 def test_pwconv_bwd(M, K, N):
     torch.manual_seed(M)
