@@ -73,7 +73,12 @@ __device__ __forceinline__ void pw_p5_acc_pre(const P5Coef& q, const float4& v, 
 #define PW_BK 32
 #define PW_LD 36
 #define PW_LDH 20      // bf16 mode: words per tile row (PW_BK / 2 data + 4 pad)
-#define PW_LD3 52      // split mode: three planes of PW_BK / 2 words + 4 pad (52 = 20 mod 32: the bf16 rows' bank pattern)
+// split mode: a tile row = three planes of PW_BK / 2 = 16 words, NO pad; the four 4-word groups of a plane are XOR-ed with (row >> 2) & 3.
+// Staging stores (8 lanes per row, one 64-bit store per plane): four consecutive rows cover banks 0 / 48 / 32 / 16 + 16 - all 64, no
+// conflict (the padded stride 52 overlapped neighbouring rows by 4 banks: 21 - 24 % of the LDS cycles were conflicts); fragment reads
+// (ds_read_b128, lane = row): rows with equal r & 3 share a 16-bank window and take different groups of it (tools/dev/lds_bank_model.py).
+// (Measured flat on the step: the LDS pipe is not what these kernels wait for.  Kept for the smaller tiles.)
+#define PW_LD3 48
 
 // NKL = 8-wide k groups of the LAST K tile that hold data (1..4): fp32 MFMA runs at the vector rate (64 cycles per
 // 32x32x2), so multiplying the zero padding of K = 112 / 48 / 24 ... is real time.  Compile-time so the hot loop keeps its schedule
@@ -226,6 +231,8 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[i] = mmd_ld4(wrow[i] + kc);
   };
+  // split mode: this thread's word offset inside a plane of its rows (rows lrow + 32 i share (row >> 2) & 3)
+  const int wofs3 = (((((tid & 7) >> 1) ^ (lrow >> 2)) & 3) << 2) + ((tid & 1) << 1);
   auto lstore = [&]() {
     if constexpr (PRO == 1) { if (a.bq_lds) bn_bwd_tab4(sBqTab, a.K, kcur, bq); }
 #pragma unroll
@@ -249,7 +256,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       }
       if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
       if constexpr (BF == 2) {
-        split3_store<PW_BK / 2>(&sAu[(lrow + i * 32) * PW_LD3 + (kq >> 1)], v);
+        split3_store<PW_BK / 2>(&sAu[(lrow + i * 32) * PW_LD3 + wofs3], v);
       } else if constexpr (BF) {
         // bf16 mode (round 6): the tile is stored as bf16 - rounded ONCE here (RNE, v_cvt_pk_bf16_f32) instead of by every lane in front of
         // every MFMA (12 converts + 6 ds_read_b128 per two MFMAs: the 16x faster pipe bought 24 %) - rows of PW_BK bf16 + 8 pad = 20 words
@@ -261,7 +268,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const float4 w4 = (kok && wok[i]) ? rb[i] : make_float4(0, 0, 0, 0);
-      if constexpr (BF == 2) split3_store<PW_BK / 2>(&sBu[(lrow + i * 32) * PW_LD3 + (kq >> 1)], w4);
+      if constexpr (BF == 2) split3_store<PW_BK / 2>(&sBu[(lrow + i * 32) * PW_LD3 + wofs3], w4);
       else if constexpr (BF) *reinterpret_cast<uint2*>(&sBu[(lrow + i * 32) * PW_LDH + (kq >> 1)]) = make_uint2(pk_bf16(w4.x, w4.y), pk_bf16(w4.z, w4.w));
       else *reinterpret_cast<float4*>(&sB[(lrow + i * 32) * PW_LD + kq]) = w4;
     }
@@ -295,14 +302,15 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
     }
   };
   // split mode: the three planes of both operands, six MFMAs per column slab - smallest partial products first
-  const unsigned* const pa3 = &sAu[(wm * 32 + r) * PW_LD3 + h * 4];
-  const unsigned* const pb3 = &sBu[(wn * NS * 32 + r) * PW_LD3 + h * 4];
+  const unsigned* const pa3 = &sAu[(wm * 32 + r) * PW_LD3];
+  const unsigned* const pb3 = &sBu[(wn * NS * 32 + r) * PW_LD3];
+  const int rofs3[2] = {((h ^ (r >> 2)) & 3) << 2, (((2 + h) ^ (r >> 2)) & 3) << 2};      // 16-deep group g, lane half h -> 4-word group 2 g + h, swizzled
   auto ldf = [](const unsigned* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(p)); };
   auto mma3 = [&](int g) {
-    const bf16x8 ah = ldf(pa3 + g * 8), am = ldf(pa3 + PW_BK / 2 + g * 8), al = ldf(pa3 + PW_BK + g * 8);
+    const bf16x8 ah = ldf(pa3 + rofs3[g]), am = ldf(pa3 + PW_BK / 2 + rofs3[g]), al = ldf(pa3 + PW_BK + rofs3[g]);
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      const unsigned* q = pb3 + j * 32 * PW_LD3 + g * 8;
+      const unsigned* q = pb3 + j * 32 * PW_LD3 + rofs3[g];
       const bf16x8 bh = ldf(q), bm = ldf(q + PW_BK / 2), bl = ldf(q + PW_BK);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
@@ -539,7 +547,10 @@ extern "C" int mmd_k_stamps(unsigned long long* out) { return hipMemcpyFromSymbo
 // its load latency: with PF = 2 the loads of K steps t+1 and t+2 are in flight while step t is multiplied (two register stages,
 // ~250 VGPRs - occupancy is irrelevant at these grid sizes).
 // (split form - common.h - tried here in round 6 and not kept: a block re-splits its 64 x 128 weight tile at every K step, 2/3 of the staging
-// VALU work, and the step measured 13.44 vs 13.44 ms with it)
+// VALU work, and the step measured 13.44 vs 13.44 ms with it.  With the weight tile copied from PRE-SPLIT bf16 planes instead - a per-store
+// mmd_split3_planes pass, three 8-byte loads per quad - this kernel and the LDS-tiled ones measured SLOWER, step 13.56 vs 13.23 ms, layer
+// by layer up to +16 %: three load instructions and 1.5x the bytes through the address path cost more than the 22 VALU instructions they
+// save.  profiles/r06_notes.md section 10.)
 template <bool BF, int PRO, int PF>
 __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
   __shared__ float sA[SK_BM * SK_LD];          // 16.5 KB
@@ -1244,7 +1255,7 @@ static int pw_dispatch(PwArgs& a, hipStream_t stream) {
       kern = plain ? pw_pick_lean<128, 64, 3, 5>(nkl, bfm) : gated ? pw_pick_lean<128, 64, 4, 5>(nkl, bfm) : pw_pick<128, 64, 0>(nkl, bfm);
     }
     a.nblk = ntm * a.ntn;
-    const size_t bql = pw_bq_lds(a, (const void*)kern, (bfm == 2 ? 40 : 28) * 1024);     // (sets a.bq_lds: before `a` is copied into the launch)
+    const size_t bql = pw_bq_lds(a, (const void*)kern, (bfm == 2 ? 37 : 28) * 1024);     // (sets a.bq_lds: before `a` is copied into the launch)
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(256), bql, stream, a);
   }
   if (a.stats_ws) mmd_stats_fold(a.stats, a.stats_ws, a.ws_slots, 2 * N, stream);
