@@ -4,7 +4,7 @@ Usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.c
 import collections, csv, sys
 
 FAM = {"pw_gemm": ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel", "pw_slab_kernel", "pw_slab_combine_kernel"),
-       "pw_wgrad": ("pw_wgrad_kernel", "wgrad_grouped_kernel", "wgrad_fold_kernel", "wgrad_grouped_rect_kernel", "wgrad_fold_rect_kernel"),
+       "pw_wgrad": ("pw_wgrad_kernel", "wgrad_grouped_kernel", "wgrad_fold_kernel", "wgrad_grouped_rect_kernel", "wgrad_fold_rect_kernel", "wgrad_grouped_split_kernel"),
        "dw_fwd": ("dw_fwd_kernel", "fuse_dw_fwd_kernel", "dw3_rows_kernel"), "dw_bwd": ("dw_wgrad_kernel", "dw_bwd_data_s2_kernel", "dw3_wgrad_rows_kernel"),
        "bn_bwd": ("bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"), "mbx": ("mbx_kernel", "bifpn_node_fused_kernel"),
        "se": ("se_hidden_kernel", "se_gate_kernel", "se_bwd_a_kernel", "se_bwd_b_kernel", "se_bwd_ab_kernel"), "node_bwd": ("fuse_dw_bwd_kernel",)}
