@@ -394,7 +394,7 @@ def main():
             roof["mfma_form"] = ("v_mfma_f32_32x32x2_f32 in every GEMM kernel (MMD_MFMA_F32=1)" if native else
                                  "split: LDS-tiled 1x1 kernels (K >= 64, N > 48) and the grouped weight gradient take each fp32 product as six "
                                  "v_mfma_f32_32x32x16_bf16 partial products of a three-way EXACT bf16 split of both operands, fp32 accumulate "
-                                 "(dropped terms <= 2^-26 |ab|; error vs float64 not above v_mfma_f32's: tests/test_gpu_kernels.py::"
+                                 "(dropped terms <= 2^-23 |ab|, 2^-27 rms - one fp32 rounding; 6 instead of 16 accumulator roundings per 16 k; error vs float64 not above v_mfma_f32's: tests/test_gpu_kernels.py::"
                                  "test_split3_precision); the other GEMM kernels use v_mfma_f32_32x32x2_f32")
             roof["peak_basis"] = ("157.3 TFLOP/s = dense v_mfma_f32 peak, the dtype's own pipe (MI355X_MICROARCH.md); the split form's own "
                                   "ceiling is 2516 / 6 = 419 TFLOP/s of fp32-equivalent flops on the bf16 pipe")

@@ -383,7 +383,7 @@ int mmd_pwconv_fwd_bf16(const float* x, const float* w, float* y, int M, int K, 
 // form | 16 (MMD_PW_FORM_NATIVE): fp32 products on v_mfma_f32_32x32x2_f32.  Without it the LDS-tiled kernels compute the SAME fp32 GEMM in the
 // split form where K >= 64 and N > 48 (csrc/common.h): each fp32 operand value is split exactly into three bf16 pieces (round to nearest:
 // x = h + m + l, both residuals exact), a * b is taken as the six largest of the nine partial products - each exact in fp32 - on
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulate; the three dropped ones are <= 2^-26 |a * b|, below the 2^-24 rounding of every fp32
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulate; the three dropped ones are at most 2^-23 |a * b| (2^-27 rms), the size of ONE 2^-24 rounding of an fp32
 // accumulate.  192 matrix-pipe cycles per 16-deep k group instead of 512.  Error against float64: not above the v_mfma_f32 chain's
 // (tests/test_gpu_kernels.py::test_split3_precision; measured lower on every shape).  Operands must be finite (Inf - Inf in a residual is NaN).
 // MMD_MFMA_F32=1 in the environment: the whole library on v_mfma_f32 (A/B timing, bisecting).

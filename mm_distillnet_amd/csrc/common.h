@@ -231,7 +231,9 @@ __device__ __forceinline__ float mmd_pool_get(long long q) { return (float)((dou
 // three bf16 pieces by round-to-nearest, x = h + m + l (x - h and (x - h) - m are exact in fp32; the last residual has at most 8 significant
 // bits), a bf16 x bf16 product is exact in fp32, so
 //     a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + [am*bl + al*bm + al*bl]
-// and the bracket is <= 2^-26 |a * b| - a quarter of the 2^-24 rounding EVERY fp32 accumulate makes anyway.  Six bf16 MFMAs (fp32 accumulate,
+// and the bracket - |m| <= 2^-8 |x|, |l| <= 2^-16 |x|: at most 2^-23 |a * b| when every residual sits at its maximum, 2^-24.2 at most and 2^-27.4
+// rms over 3 * 10^5 random pairs (tests/test_split3_math.py) - is the size of ONE fp32 rounding (<= 2^-24, 2^-25.3 rms) and is dropped: the form
+// then rounds the accumulator 6 times per 16 k where the v_mfma_f32 chain rounds it 16 times.  Six bf16 MFMAs (fp32 accumulate,
 // smallest terms first) per 16-deep k group = 192 cycles against 512 for eight v_mfma_f32_32x32x2_f32; the error against float64 measured
 // BELOW the fp32 MFMA chain's on every shape (fewer accumulator roundings: profiles/r06_notes.md section 10, test_split3_precision).
 // Not for Inf operands (Inf - Inf in the residual gives NaN where fp32 gives Inf) - activations and gradients here are finite.

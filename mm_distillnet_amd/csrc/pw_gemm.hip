@@ -254,7 +254,9 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
       if (a.gate) { v.x *= rg[i].x; v.y *= rg[i].y; v.z *= rg[i].z; v.w *= rg[i].w; }
       }
-      if (!(kok && rok[i])) v = make_float4(0, 0, 0, 0);
+      // (round 6) No mask on the A tile.  k >= K: the weight tile is zero there and the A value comes from a clamped - valid, finite -
+      // address, finite x 0 = 0; rows >= M: their outputs are neither stored nor summed.  16 v_cndmask per thread and K tile less.
+      // (The stem gather, PRO == 2, masks per element above: its out-of-image taps are real zeros of in-range rows.)
       if constexpr (BF == 2) {
         split3_store<PW_BK / 2>(&sAu[(lrow + i * 32) * PW_LD3 + wofs3], v);
       } else if constexpr (BF) {
@@ -420,7 +422,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
       if (cok && row < Mv) {
         float4 v = *reinterpret_cast<const float4*>(&smem[rl * LDC + cg * 4]);
         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        if (!a.xs.z) {
+        if (a.stats && !a.xs.z) {      // (frozen nets take no statistics: 8 VALU instructions per quad less)
           s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
           q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
         }
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
       if (a.in_act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
       if (a.gate) { v.x *= s.rg[i].x; v.y *= s.rg[i].y; v.z *= s.rg[i].z; v.w *= s.rg[i].w; }
       }
-      if (!(s.kok && rok[i])) v = make_float4(0, 0, 0, 0);
+      // (no mask on the A tile: k >= K meets the zeroed weight tile, rows >= M are never stored - see pw_gemm_body)
       if constexpr (BF) *reinterpret_cast<uint2*>(&sAu[(lrow + i * 8) * SK_LDH + (kq >> 1)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
       else *reinterpret_cast<float4*>(&sA[(lrow + i * 8) * SK_LD + kq]) = v;
     }
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
     }
     if (cok && row < Mv) {
       v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      if (!a.xs.z) {
+      if (a.stats && !a.xs.z) {
         s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
         q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
       }
