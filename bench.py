@@ -298,18 +298,23 @@ def main():
         if os.environ.get("MMD_PROF_DUMP"):
             for i, d in enumerate(dlls):
                 d.mmd_prof_dump_to((os.environ["MMD_PROF_DUMP"] + (".w16" if i else "")).encode())
-        for fam in FAMILIES:
-            for d in dlls:
-                d.mmd_prof_enable(fam, 1)
-        torch.cuda.synchronize()
         # one eager step on a single stream (teachers, weight-gradient and head side branches folded onto it), so that an
-        # event pair brackets one kernel running alone - the same condition as the serialised rocprofv3 kernel trace
+        # event pair brackets one kernel running alone - the same condition as the serialised rocprofv3 kernel trace.  Run twice, the
+        # counters switched on for the second: the single-stream form launches a few kernel variants the captured schedule does not, and a
+        # kernel's FIRST launch in a process uploads its code object inside the event pair (one 262 us "node backward" launch among four
+        # of 21 us in profiles/r06_notes.md section 10)
         conc = eng.concurrent_teachers
         eng.concurrent_teachers = False
         os.environ["MMD_NO_WG"] = "1"; os.environ["MMD_NO_SIDE"] = "1"
-        eng.step_body(batch if not use_graph else eng.static, eng.static["drop_scale"] if use_graph else eng.make_drop_scale(B))
-        eng.backward_tail()
-        torch.cuda.synchronize()
+        for leg in range(2):
+            if leg == 1:
+                for fam in FAMILIES:
+                    for d in dlls:
+                        d.mmd_prof_enable(fam, 1)
+            torch.cuda.synchronize()
+            eng.step_body(batch if not use_graph else eng.static, eng.static["drop_scale"] if use_graph else eng.make_drop_scale(B))
+            eng.backward_tail()
+            torch.cuda.synchronize()
         eng.concurrent_teachers = conc
         del os.environ["MMD_NO_WG"], os.environ["MMD_NO_SIDE"]
         import ctypes
