@@ -192,6 +192,27 @@ if getattr(eng, "pack", False):
         main.wait_stream(side)
 
     timeit("student + teacher pack, 2 streams", cap(student_and_real_pack))
+    if os.environ.get("MMD_DIAG_HALF"):
+        # the pack as two half batches (3 x 4 images each): do the smaller activations buy cache hits worth their doubled launch count?
+        def half_packs():
+            nets = [n for _, n in tn]
+            nets[0].begin_step()
+            for lo in (0, B // 2):
+                nets[0].forward([eng.static[m][lo:lo + B // 2].contiguous() for m, _ in tn], train=False, pack=nets)
+
+        timeit("teacher pack as two half batches", cap(half_packs))
+
+        def student_and_half_packs():
+            main = torch.cuda.current_stream()
+            ev = main.record_event()
+            student_fwd()
+            side = eng.side_streams[0]
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                half_packs()
+            main.wait_stream(side)
+
+        timeit("student + two half packs, 2 streams", cap(student_and_half_packs))
 if os.environ.get("MMD_DIAG_FWD_ONLY"):
     sys.exit(0)
 
