@@ -128,6 +128,27 @@ def launch_ranks(args, argv=None, runner=None):
     return (runner or subprocess.run)(cmd, env=env).returncode
 
 
+def alt_mfma_f32(args):
+    """The default fp32 workload once more in a child process with MMD_MFMA_F32=1 -> {ms_per_step, value, gemm family ms / frac} or {error}."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
+           "--size", str(args.size), "--coef", str(args.coef), "--precision", "fp32", "--no-cpu-baseline", "--no-alt"]
+    if args.no_graph:
+        cmd.append("--no-graph")
+    import subprocess
+    env = dict(os.environ, MMD_MFMA_F32="1")
+    env.pop("MMD_PROF_DUMP", None)
+    log("alt leg: the same workload with MMD_MFMA_F32=1 in a child process")
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+        rec = json.loads(out.stdout.decode().strip().splitlines()[-1])
+        r = rec.get("roofline") or {}
+        return {"what": "same command, MMD_MFMA_F32=1: every GEMM kernel on v_mfma_f32_32x32x2_f32 (child process, run before this one's GPU work)",
+                "ms_per_step": rec.get("ms_per_step"), "value": rec.get("value"), "unit": rec.get("unit"),
+                "gemm_family_ms_per_step": r.get("family_ms_per_step"), "gemm_family_frac": r.get("frac")}
+    except Exception as e:      # the record must not depend on the second leg
+        return {"error": repr(e)[:300]}
+
+
 def log(msg):
     print("[bench %6.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -145,6 +166,8 @@ def main():
                          "reference (the bf16_hbm storage mode was deleted in round 6: no faster for three rounds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the second measurement of the fp32 record (the same command in a child process with MMD_MFMA_F32=1: every GEMM on v_mfma_f32)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="images in the CPU baseline's batch (0 = the per-GPU batch)")
     ap.add_argument("--dev-timing", action="store_true",
                     help="run although work-skipping dev switches are set (MMD_DEV=1 + MMD_DEV_SKIP_CALLS / _SKIP_WG / _NO_BWD / MMD_ROWS_ABL): the record "
@@ -161,6 +184,17 @@ def main():
     rc = launch_ranks(args)
     if rc is not None:
         sys.exit(rc)
+    # The fp32 record's second number: the same command with every GEMM on v_mfma_f32_32x32x2_f32 (MMD_MFMA_F32=1) instead of the split form
+    # (fp32 products as six bf16 MFMAs on an exact three-way operand split, csrc/common.h).  The library reads the switch once per process, so
+    # the measurement runs as a child process - started and finished BEFORE this process touches the GPU - and its numbers ride in the record
+    # as `alt_mfma_f32`: whoever reads the line has both forms from one run on one box.
+    alt = None
+    # Only in the full-record mode (the CPU baseline leg on: the driver's plain `python bench.py`), never under a profiler: rocprofv3's
+    # preloaded library initialises the GPU before this program starts, and a process that has done so must not start another program.
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ)
+    if (args.precision == "fp32" and not args.no_alt and not args.no_cpu_baseline and not skipping and not profiled
+            and not os.environ.get("MMD_MFMA_F32") and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+        alt = alt_mfma_f32(args)
     # stdout carries exactly ONE line, the JSON record: RCCL prints its version banner to stdout when a communicator comes up, so
     # file descriptor 1 points at stderr for the whole run and the record goes out through a saved duplicate at the end
     sys.stdout.flush()
@@ -428,6 +462,8 @@ def main():
                            # every MMD_* variable this process saw (A/B knobs select kernels / schedules; the work-skipping ones are refused above)
                            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMD_")}},
                 "per_step": per_step, "roofline": roof, "cpu_baseline": cpu}
+        if alt is not None:
+            line["alt_mfma_f32"] = alt
         if skipping:        # --dev-timing: launches were skipped - not a measurement
             line["invalid"] = True
             line["invalid_reason"] = "work-skipping dev switches set: " + ", ".join(skipping)
