@@ -128,6 +128,13 @@ def launch_ranks(args, argv=None, runner=None):
     return (runner or subprocess.run)(cmd, env=env).returncode
 
 
+def alt_leg_wanted(args, env, skipping=()) -> bool:
+    """The second (v_mfma_f32) leg runs only for the plain full-record fp32 command of ONE process that no profiler has preloaded into."""
+    profiled = "rocprof" in env.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCP", "ROCPROF")) for k in env)
+    return bool(args.precision == "fp32" and not args.no_alt and not args.no_cpu_baseline and not skipping and not profiled
+                and not env.get("MMD_MFMA_F32") and int(env.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1)
+
+
 def alt_mfma_f32(args):
     """The default fp32 workload once more in a child process with MMD_MFMA_F32=1 -> {ms_per_step, value, gemm family ms / frac} or {error}."""
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
@@ -191,9 +198,7 @@ def main():
     alt = None
     # Only in the full-record mode (the CPU baseline leg on: the driver's plain `python bench.py`), never under a profiler: rocprofv3's
     # preloaded library initialises the GPU before this program starts, and a process that has done so must not start another program.
-    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ)
-    if (args.precision == "fp32" and not args.no_alt and not args.no_cpu_baseline and not skipping and not profiled
-            and not os.environ.get("MMD_MFMA_F32") and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+    if alt_leg_wanted(args, os.environ, skipping):
         alt = alt_mfma_f32(args)
     # stdout carries exactly ONE line, the JSON record: RCCL prints its version banner to stdout when a communicator comes up, so
     # file descriptor 1 points at stderr for the whole run and the record goes out through a saved duplicate at the end
