@@ -28,6 +28,13 @@ __device__ __forceinline__ float mmd_swish_grad(float x) {
 __device__ __forceinline__ float mmd_act(float x, int act) {
   return act == MMD_ACT_SWISH ? mmd_swish(x) : (act == MMD_ACT_SIGMOID ? mmd_sigmoid(x) : x);
 }
+// A quad through the activation behind ONE uniform branch per quad.  With mmd_act per element hipcc emitted a scalar compare + branch per
+// ELEMENT (act is a kernel argument) and, behind each, one element's mul -> exp -> add -> rcp -> mul chain alone: 32 dependent transcendental
+// chains in a row in a GEMM epilogue (round 6, ISA of pw_gemm_kernel_lean<128, 64, 2, 2, 3, 4>); four independent chains per branch interleave.
+__device__ __forceinline__ void mmd_act4(float4& v, int act) {
+  if (act == MMD_ACT_SWISH) { v.x = mmd_swish(v.x); v.y = mmd_swish(v.y); v.z = mmd_swish(v.z); v.w = mmd_swish(v.w); }
+  else if (act == MMD_ACT_SIGMOID) { v.x = mmd_sigmoid(v.x); v.y = mmd_sigmoid(v.y); v.z = mmd_sigmoid(v.z); v.w = mmd_sigmoid(v.w); }
+}
 __device__ __forceinline__ float4 mmd_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void mmd_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // 16-byte LDS read that stays ONE ds_read_b128.  Where the consumer is pairwise arithmetic (v_pk_fma_f32) hipcc splits a float4 LDS load

@@ -427,7 +427,7 @@ __device__ __forceinline__ void pw_gemm_body(const PwArgs& a) {
           q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
         }
         if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-        if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
+        if (a.out_act) mmd_act4(v, a.out_act);
         if (a.residual) { v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w; }
         mmd_stw4(a.y, offs[u], v, a.y16);
         if constexpr (PRO == 1) {
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void pw_gemm_skinny_kernel(PwArgs a) {
         q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
       }
       if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-      if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
+      if (a.out_act) mmd_act4(v, a.out_act);
       if (a.residual) { v.x += rr[i].x; v.y += rr[i].y; v.z += rr[i].z; v.w += rr[i].w; }
       mmd_stw4(a.y, offs[i], v, a.y16);
       if (a.xs.z) pw_xs_acc_pre(v, xz[i], xrs[i], xmu, xis, s4, q4);

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void pw_longk_kernel(PwArgs a) {
       s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
       q4.x += v.x * v.x; q4.y += v.y * v.y; q4.z += v.z * v.z; q4.w += v.w * v.w;
       if (a.out_scale) { v.x = v.x * osc.x + osh.x; v.y = v.y * osc.y + osh.y; v.z = v.z * osc.z + osh.z; v.w = v.w * osc.w + osh.w; }
-      if (a.out_act) { v.x = mmd_act(v.x, a.out_act); v.y = mmd_act(v.y, a.out_act); v.z = mmd_act(v.z, a.out_act); v.w = mmd_act(v.w, a.out_act); }
+      if (a.out_act) mmd_act4(v, a.out_act);
       const size_t off = (size_t)row * N + col;
       if (a.residual) { const float4 rr = mmd_ld4(a.residual + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
       mmd_st4(a.y + off, v);

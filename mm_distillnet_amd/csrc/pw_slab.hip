@@ -89,7 +89,7 @@ __device__ __forceinline__ void slab_epilogue(const PwArgs& a, int m0, int n0, i
         q4.x += u.x * u.x; q4.y += u.y * u.y; q4.z += u.z * u.z; q4.w += u.w * u.w;
       }
       if (a.out_scale) { u.x = u.x * osc.x + osh.x; u.y = u.y * osc.y + osh.y; u.z = u.z * osc.z + osh.z; u.w = u.w * osc.w + osh.w; }
-      if (a.out_act) { u.x = mmd_act(u.x, a.out_act); u.y = mmd_act(u.y, a.out_act); u.z = mmd_act(u.z, a.out_act); u.w = mmd_act(u.w, a.out_act); }
+      if (a.out_act) mmd_act4(u, a.out_act);
       if (a.residual) { u.x += rr[i].x; u.y += rr[i].y; u.z += rr[i].z; u.w += rr[i].w; }
       mmd_st4(a.y + (size_t)row * a.N + col, u);
       if (a.xs.z) {      // (pw_xs_acc's arithmetic on the prefetched z)
