@@ -48,11 +48,16 @@ __device__ __forceinline__ float bn_bwd_eval(float g, float z, float rs, int act
   if (act == MMD_ACT_SWISH) g *= mmd_swish_grad(z * a1 + sh);
   return a1 * g + a2 * (z - mu) + a3;
 }
+// (ONE uniform branch on `act` per quad: per element hipcc emits a scalar branch each and, behind it, one element's exp / rcp chain alone -
+// round 6, ISA of the GEMM epilogues' mmd_act, same pattern)
 __device__ __forceinline__ float4 bn_bwd_eval4(float4 g, float4 z, float rs, int act, const BnBwdCoef4& q) {
-  return make_float4(bn_bwd_eval(g.x, z.x, rs, act, q.a1.x, q.a2.x, q.a3.x, q.mu.x, q.sh.x),
-                     bn_bwd_eval(g.y, z.y, rs, act, q.a1.y, q.a2.y, q.a3.y, q.mu.y, q.sh.y),
-                     bn_bwd_eval(g.z, z.z, rs, act, q.a1.z, q.a2.z, q.a3.z, q.mu.z, q.sh.z),
-                     bn_bwd_eval(g.w, z.w, rs, act, q.a1.w, q.a2.w, q.a3.w, q.mu.w, q.sh.w));
+  g.x *= rs; g.y *= rs; g.z *= rs; g.w *= rs;
+  if (act == MMD_ACT_SWISH) {
+    g.x *= mmd_swish_grad(z.x * q.a1.x + q.sh.x); g.y *= mmd_swish_grad(z.y * q.a1.y + q.sh.y);
+    g.z *= mmd_swish_grad(z.z * q.a1.z + q.sh.z); g.w *= mmd_swish_grad(z.w * q.a1.w + q.sh.w);
+  }
+  return make_float4(q.a1.x * g.x + q.a2.x * (z.x - q.mu.x) + q.a3.x, q.a1.y * g.y + q.a2.y * (z.y - q.mu.y) + q.a3.y,
+                     q.a1.z * g.z + q.a2.z * (z.z - q.mu.z) + q.a3.z, q.a1.w * g.w + q.a2.w * (z.w - q.mu.w) + q.a3.w);
 }
 
 // Stem 3x3 / stride-2 TF-SAME convolution as an implicit GEMM: row m = output pixel (b, oh, ow), k = ci*9 + i*3 + j, the A
