@@ -32,6 +32,8 @@ def needs_build() -> bool:
         stamp = os.path.join(PKG, odir, "flags.stamp")
         if os.path.exists(stamp) and open(stamp).read() != _want_flags(extra):
             return True         # built with other flags (an A/B build): rebuild rather than silently reuse
+        if not os.path.exists(stamp) and os.environ.get("MMD_EXTRA_HIPCC_FLAGS"):
+            return True         # no record of the library's flags (e.g. a flagged build failed and cleared it): extra flags asked for -> build
     return False
 
 
