@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WG_RECT_WAV
 #define GW_LD3 52
 #define GW_MAXL3 255      // layers per launch on this kernel: its table copy must leave four 40 KB blocks per CU
 template <int WAVES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void wgrad_grouped_split_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void wgrad_grouped_split_kernel(const MmdWgradLayer* __restrict__ L, int nl, int nitems, float* __restrict__ ws, int xcd8) {
   __shared__ unsigned sD[128 * GW_LD3];
   __shared__ unsigned sX[64 * GW_LD3];
   __shared__ int sItem0[GW_MAXL3 + 1];
@@ -410,7 +410,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
   const int wn = wave >> 1, wk = wave & 1;
   const int c4x = (tid & 15) * 4, lx = tid >> 4;      // X tile: rows lx, lx + 16 of a step -> k slot lx
   int li = 0;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  // XCD-aware item order (round 6): blocks b, b + 8, ... share an XCD and its L2.  Consecutive items are the K tiles / N tiles of ONE row range -
+  // they re-read the same dY / X slabs - so each XCD takes runs of 2^xcd8 = 8 consecutive items inside every group of 64 blocks: the launch's
+  // HBM traffic 3.96 -> 2.67 GB per step (rocprofv3 FETCH_SIZE / WRITE_SIZE; 1.97x -> 1.33x its algorithmic bytes), step -0.05 .. -0.08 ms over
+  // ten alternating pairs.  (Round 4's XCD-aware walk gave every XCD one contiguous EIGHTH of the table and lost to the imbalance between the
+  // layers; runs of 8 keep every layer spread over all XCDs.  Runs of 4 / 16 / 32 measured the same within noise.  MMD_WG_XCD8=0: plain order.)
+  const int b0 = blockIdx.x;
+  const int rl = xcd8, gm = (8 << rl) - 1;      // run length 2^rl, group of 8 runs
+  const int vb = (rl && b0 < (int)(gridDim.x & ~(unsigned)gm)) ? ((b0 & ~gm) | ((b0 & 7) << rl) | ((b0 >> 3) & ((1 << rl) - 1))) : b0;      // (a trailing partial group keeps its order)
+  for (int item = vb; item < nitems; item += gridDim.x) {
     while (sItem0[li + 1] <= item) ++li;
     li = __builtin_amdgcn_readfirstlane(li);
     const MmdWgradLayer a = L[li];
@@ -710,8 +718,10 @@ static int wgrad_grouped_impl(const MmdWgradLayer* layers_dev, int n_layers, int
   if (wg_tile() == 0) {
     if (bf16 == 0 && rows32 && mmd_split_default() && n_layers <= GW_MAXL3) {
       static const int w3 = getenv("MMD_WG_SPLIT_W3") ? 1 : 0;
-      if (w3) hipLaunchKernelGGL(wgrad_grouped_split_kernel<3>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
-      else hipLaunchKernelGGL(wgrad_grouped_split_kernel<4>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
+      static const int xcd8_env = getenv("MMD_WG_XCD8") ? atoi(getenv("MMD_WG_XCD8")) : 3;      // log2 of the run length (3 = runs of 8, 0 = plain order)
+      const int xcd8 = xcd8_env;
+      if (w3) hipLaunchKernelGGL(wgrad_grouped_split_kernel<3>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws, xcd8);
+      else hipLaunchKernelGGL(wgrad_grouped_split_kernel<4>, dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws, xcd8);
     } else if (bf16 == 1) {
       if (rows32) hipLaunchKernelGGL((wgrad_grouped_rect_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
       else hipLaunchKernelGGL((wgrad_grouped_rect_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, layers_dev, n_layers, n_items, ws);
