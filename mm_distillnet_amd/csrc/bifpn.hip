@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void fuse_dw_fwd_kernel(FuseArgs a, const floa
   __shared__ float sIn[IH * IW * 64];
   __shared__ float sW[9 * 64];
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
+  // (XCD-aware order, round 6: blocks b, b + 8, ... share an XCD and its L2 - a contiguous eighth of the tiles per XCD keeps the neighbours
+  // whose halos overlap, and the channel chunks that restage one dz tile, behind one L2)
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int cc = bid % cchunks; bid /= cchunks;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
@@ -384,7 +386,9 @@ __global__ __launch_bounds__(FN_NT) void bifpn_node_fused_kernel(FuseArgs a, con
   float w[3];
   fuse_weights(a.theta, a.ntheta, w);
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
+  // (XCD-aware order, round 6: blocks b, b + 8, ... share an XCD and its L2 - a contiguous eighth of the tiles per XCD keeps the neighbours
+  // whose halos overlap, and the channel chunks that restage one dz tile, behind one L2)
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;
   const int b = bid, oh0 = th * 8, ow0 = tw * 8;
@@ -845,7 +849,9 @@ __global__ __launch_bounds__(256) void fuse_dw_bwd_kernel(FuseArgs a, const floa
   static_assert(IH * IW >= 4 * 9, "the weight-gradient reduction aliases the dzd tile");
   NODE_T(0);
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
+  // (XCD-aware order, round 6: blocks b, b + 8, ... share an XCD and its L2 - a contiguous eighth of the tiles per XCD keeps the neighbours
+  // whose halos overlap, and the channel chunks that restage one dz tile, behind one L2)
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int cc = bid % cchunks; bid /= cchunks;
   const int tw = bid % tiles_w; bid /= tiles_w;
   const int th = bid % tiles_h; bid /= tiles_h;

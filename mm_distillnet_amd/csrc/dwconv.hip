@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   MMD_DT(0);
   // XCD-aware order: blocks are dealt round-robin to the 8 XCDs; remap so that each XCD's L2 sees a contiguous run of tiles
   // (neighbouring tiles share halo rows / columns)
-  int bid = (a.pyr.n || a.noswz) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
+  int bid = (a.noswz) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   // pyramid launch (k=3, s=1): pick this block's level (unrolled selects: no dynamic indexing of the argument arrays)
   int H = a.H, W = a.W, OH = a.OH, OW = a.OW, tiles_h = a.tiles_h, tiles_w = a.tiles_w, lev = 0;
   size_t ro = 0;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void dw3_rows_kernel(DwArgs a, DwRowsGeom gm) 
   __shared__ float sRed[2 * 4 * CC];
   __shared__ float sRedW[WG ? 4 * 9 * CC : 1];
   const int tid = threadIdx.x, c4 = (tid & (LW - 1)) * 4, strip = tid / LW;
-  int bid = (a.noswz || a.pyr.n) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
+  int bid = (a.noswz) ? (int)blockIdx.x : mmd_xcd_swizzle(blockIdx.x, gridDim.x);
   // pyramid launch: this block's level (unrolled selects, as in dw_fwd_kernel); every level uses the same R and rows per block, a
   // level narrower than a block row simply leaves its right-hand strips idle (the 64^2 level is 75 % of the rows)
   int H = a.H, W = a.W, lev = 0, colblocks = gm.colblocks, rowblocks = gm.rowblocks;
