@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_sums_kernel(const float* _
   __shared__ float sW[K * K * 64];
   __shared__ float sWg[WG ? K * K * 64 : 1];
   const int tid = threadIdx.x, c4 = (tid & 15) * 4, pl_ = tid >> 4;      // 16 pixel lanes x 16 channel quads
-  int bid = blockIdx.x;
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);      // (XCD-aware order: neighbouring tiles, whose halos overlap, behind one L2)
   const int cc = bid % cchunks; bid /= cchunks;
   const int rb = bid % rowblocks; bid /= rowblocks;
   const int b = bid, c = cc * 64 + c4;
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgArgs a) {
   __shared__ float sIn[Cf::IH * Cf::IW * 64];
   float* sRed = sIn;                      // reused after the tile loop (behind a barrier)
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);      // (XCD-aware order: neighbouring tiles, whose halos overlap, behind one L2)
   int H = a.H, W = a.W, OH = a.OH, OW = a.OW, tiles_h = a.tiles_h, tiles_w = a.tiles_w, nsplit = a.nsplit, lev = 0;
   size_t ro = 0;
   if (a.pyr.n) {
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(256) void dw3_wgrad_rows_kernel(DwWgArgs a, DwRowsG
   constexpr int CC = 4 * LW;
   __shared__ float sRed[4 * 9 * CC];
   const int tid = threadIdx.x, c4 = (tid & (LW - 1)) * 4, strip = tid / LW;
-  int bid = blockIdx.x;
+  int bid = mmd_xcd_swizzle(blockIdx.x, gridDim.x);      // (XCD-aware order: neighbouring tiles, whose halos overlap, behind one L2)
   const int cc = bid % a.cchunks; bid /= a.cchunks;
   const int cb = bid % gm.colblocks; bid /= gm.colblocks;
   const int rb = bid % gm.rowblocks; bid /= gm.rowblocks;
