@@ -4,7 +4,8 @@ bytes - one line per pw_dispatch, in launch order).  FETCH_SIZE doubled (gfx950 
 Usage: pmc_by_shape.py <fetch counter_collection.csv> <write counter_collection.csv> <prof dump csv>"""
 import collections, csv, sys
 
-KEYS = ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel")
+KEYS = ("pw_gemm_kernel", "pw_gemm_skinny_kernel", "pw_stream_kernel", "pw_rows_kernel", "pw_longk_kernel", "mbconv_expand_bwd_kernel", "pw_slab_kernel")
+# (a K-sliced slab launch is two kernels under ONE tag: the combine kernel's bytes are added to the slab kernel's in front of it)
 
 
 def final_eager_step(rows):
@@ -28,7 +29,9 @@ def seq(path):
     out = []
     for r in final_eager_step(rows):
         n = r["Kernel_Name"]
-        if any(k in n for k in KEYS) and "false, 2>" not in n:      # PRO = 2 is the stem's implicit GEMM: launched outside pw_dispatch, no tag
+        if "pw_slab_combine_kernel" in n and out:
+            out[-1] = (out[-1][0], out[-1][1] + float(r["Counter_Value"]) * 1024.0)
+        elif any(k in n for k in KEYS) and "false, 2>" not in n and ", 0, 2>" not in n:      # PRO = 2 is the stem's implicit GEMM: launched outside pw_dispatch, no tag
             out.append((n.split("(")[0], float(r["Counter_Value"]) * 1024.0))
     return out
 
