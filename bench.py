@@ -146,7 +146,7 @@ def alt_mfma_f32(args):
     env.pop("MMD_PROF_DUMP", None)
     log("alt leg: the same workload with MMD_MFMA_F32=1 in a child process")
     try:
-        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
         rec = json.loads(out.stdout.decode().strip().splitlines()[-1])
         r = rec.get("roofline") or {}
         return {"what": "same command, MMD_MFMA_F32=1: every GEMM kernel on v_mfma_f32_32x32x2_f32 (child process, run before this one's GPU work)",
